@@ -1,0 +1,176 @@
+"""Independent dense PyTorch restatement of the rasterizer (tests only).
+
+Written from the mathematics (EWA splatting + front-to-back compositing), NOT by following the
+oracle's code, so that it cross-checks oracle/goi_oracle.cpp: the forward is evaluated densely
+(every pixel against every Gaussian, with tile-rectangle membership as a mask) and all gradients
+come from autograd.  The four places where the reference's backward is not the true derivative
+(hard part 3) are emulated where they matter:
+  * the 0.99 alpha clamp passes gradient straight through (CR/backward.cu:540,605,621);
+  * a frustum-clamped t.x / t.y is a constant for dL/dt.z and kills dL/dt.x (CR/backward.cu:168-176,262-264);
+  * 1/(denom^2 + 1e-7) differs from 1/denom^2 by < 1e-5 relative for det >= 0.09 -- ignored;
+  * T_final = 1 - alpha_out differs from the stored T by rounding only -- ignored.
+Runs in float64 by default; use small scenes (P of a few hundred, images of a few thousand pixels).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+SH_C0 = 0.28209479177387814
+SH_C1 = 0.4886025119029199
+SH_C2 = [1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792, 0.5462742152960396]
+SH_C3 = [-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154, -0.4570457994644658,
+         1.445305721320277, -0.5900435899266435]
+
+
+def sh_to_rgb(deg, sh, dirs):
+    """sh [P,M,3], dirs [P,3] unit -> rgb [P,3] (before +0.5 / clamp)."""
+    x, y, z = dirs[:, 0:1], dirs[:, 1:2], dirs[:, 2:3]
+    res = SH_C0 * sh[:, 0]
+    if deg > 0:
+        res = res - SH_C1 * y * sh[:, 1] + SH_C1 * z * sh[:, 2] - SH_C1 * x * sh[:, 3]
+    if deg > 1:
+        xx, yy, zz, xy, yz, xz = x * x, y * y, z * z, x * y, y * z, x * z
+        res = (res + SH_C2[0] * xy * sh[:, 4] + SH_C2[1] * yz * sh[:, 5] + SH_C2[2] * (2 * zz - xx - yy) * sh[:, 6]
+               + SH_C2[3] * xz * sh[:, 7] + SH_C2[4] * (xx - yy) * sh[:, 8])
+    if deg > 2:
+        res = (res + SH_C3[0] * y * (3 * xx - yy) * sh[:, 9] + SH_C3[1] * xy * z * sh[:, 10]
+               + SH_C3[2] * y * (4 * zz - xx - yy) * sh[:, 11] + SH_C3[3] * z * (2 * zz - 3 * xx - 3 * yy) * sh[:, 12]
+               + SH_C3[4] * x * (4 * zz - xx - yy) * sh[:, 13] + SH_C3[5] * z * (xx - yy) * sh[:, 14]
+               + SH_C3[6] * x * (xx - 3 * yy) * sh[:, 15])
+    return res
+
+
+def quat_to_rot(q):
+    r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = torch.stack([
+        1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+        2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+        2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], dim=-1).reshape(-1, 3, 3)
+    return R  # row-major rotation matrix, NOT normalising q (the op does not either)
+
+
+def render(means3D, opacities, semantics, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, W, H, bg,
+           shs=None, sh_degree=3, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None,
+           scale_modifier=1.0, means2D_sink=None):
+    """Returns dict(color[3,H,W], semantic[S,H,W], depth[1,H,W], alpha[1,H,W], radii[P], N).
+    All tensor inputs may require grad; viewmatrix/projmatrix are the transposed (row-vector) 4x4s."""
+    dt = means3D.dtype
+    P = means3D.shape[0]
+    V = viewmatrix.to(dt)
+    PM = projmatrix.to(dt)
+    ones = torch.ones(P, 1, dtype=dt)
+    hom = torch.cat([means3D, ones], 1)
+    p_view = hom @ V  # row-vector convention
+    p_hom = hom @ PM
+    p_w = 1.0 / (p_hom[:, 3] + 1e-7)
+    ndc_x, ndc_y = p_hom[:, 0] * p_w, p_hom[:, 1] * p_w
+    tz = p_view[:, 2]
+    in_front = tz > 0.2
+
+    # 3D covariance
+    if cov3D_precomp is None:
+        R = quat_to_rot(rotations)
+        Sm = torch.diag_embed(scale_modifier * scales)
+        L = R @ Sm
+        Sigma = L @ L.transpose(1, 2)
+    else:
+        c = cov3D_precomp
+        Sigma = torch.stack([c[:, 0], c[:, 1], c[:, 2], c[:, 1], c[:, 3], c[:, 4], c[:, 2], c[:, 4], c[:, 5]],
+                            -1).reshape(-1, 3, 3)
+
+    fx = W / (2.0 * tan_fovx)
+    fy = H / (2.0 * tan_fovy)
+    limx, limy = 1.3 * tan_fovx, 1.3 * tan_fovy
+    txtz, tytz = p_view[:, 0] / tz, p_view[:, 1] / tz
+    cx = (txtz < -limx) | (txtz > limx)
+    cy = (tytz < -limy) | (tytz > limy)
+    tx = torch.where(cx, (txtz.clamp(-limx, limx) * tz).detach(), p_view[:, 0])
+    ty = torch.where(cy, (tytz.clamp(-limy, limy) * tz).detach(), p_view[:, 1])
+    zero = torch.zeros_like(tz)
+    J = torch.stack([fx / tz, zero, -(fx * tx) / (tz * tz), zero, fy / tz, -(fy * ty) / (tz * tz)], -1).reshape(-1, 2, 3)
+    Wr = V[:3, :3].T  # world->camera rotation (row-major)
+    A = J @ Wr  # [P,2,3]
+    cov2 = A @ Sigma @ A.transpose(1, 2)
+    a = cov2[:, 0, 0] + 0.3
+    b = cov2[:, 0, 1]
+    c_ = cov2[:, 1, 1] + 0.3
+    det = a * c_ - b * b
+    con_a, con_b, con_c = c_ / det, -b / det, a / det
+    mid = 0.5 * (a + c_)
+    lam = mid + torch.sqrt(torch.clamp(mid * mid - det, min=0.1))
+    radius = torch.ceil(3.0 * torch.sqrt(lam)).detach()
+    px = ((ndc_x + 1.0) * W - 1.0) * 0.5
+    py = ((ndc_y + 1.0) * H - 1.0) * 0.5
+    if means2D_sink is not None:  # gradient sink in the reference's units (NDC * 0.5 * size)
+        px = px + 0.5 * W * means2D_sink[:, 0]
+        py = py + 0.5 * H * means2D_sink[:, 1]
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    pxd, pyd = px.detach(), py.detach()
+    rminx = torch.clamp(torch.trunc((pxd - radius) / 16), 0, gx)
+    rminy = torch.clamp(torch.trunc((pyd - radius) / 16), 0, gy)
+    rmaxx = torch.clamp(torch.trunc((pxd + radius + 15) / 16), 0, gx)
+    rmaxy = torch.clamp(torch.trunc((pyd + radius + 15) / 16), 0, gy)
+    touched = ((rmaxx - rminx) * (rmaxy - rminy)).to(torch.int64)
+    visible = in_front & (det != 0) & (touched > 0)
+    radii = torch.where(visible, radius, torch.zeros_like(radius)).to(torch.int32)
+    N = int(touched[visible].sum())
+
+    # colours
+    if colors_precomp is None:
+        d = means3D - campos.to(dt)[None]
+        d = d / d.norm(dim=1, keepdim=True)
+        rgb = torch.clamp_min(sh_to_rgb(sh_degree, shs, d) + 0.5, 0.0)
+    else:
+        rgb = colors_precomp
+
+    S = semantics.shape[1]
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=dt), torch.arange(W, dtype=dt), indexing="ij")
+    pixx, pixy = xs.reshape(-1), ys.reshape(-1)
+    tilex, tiley = torch.floor(pixx / 16), torch.floor(pixy / 16)
+    HW = W * H
+    T = torch.ones(HW, dtype=dt)
+    done = torch.zeros(HW, dtype=torch.bool)
+    C = torch.zeros(HW, 3, dtype=dt)
+    Cs = torch.zeros(HW, S, dtype=dt)
+    D = torch.zeros(HW, dtype=dt)
+    op = opacities.reshape(-1)
+    # front-to-back order: float32 depth bits, ties by index (stable sort)
+    order = torch.sort(tz.detach().to(torch.float32), stable=True).indices
+    for g in order.tolist():
+        if not bool(visible[g]):
+            continue
+        member = (tilex >= rminx[g]) & (tilex < rmaxx[g]) & (tiley >= rminy[g]) & (tiley < rmaxy[g]) & ~done
+        if not bool(member.any()):
+            continue
+        dx = px[g] - pixx
+        dy = py[g] - pixy
+        power = -0.5 * (con_a[g] * dx * dx + con_c[g] * dy * dy) - con_b[g] * dx * dy
+        valid = member & (power <= 0)
+        raw = op[g] * torch.exp(power)
+        alpha = raw + (torch.clamp(raw, max=0.99) - raw).detach()  # straight-through clamp
+        valid = valid & (alpha.detach() >= 1.0 / 255.0)
+        test_T = T * (1 - alpha)
+        newly_done = valid & (test_T.detach() < 1e-4)
+        done = done | newly_done
+        contrib = valid & ~newly_done
+        w = torch.where(contrib, alpha * T, torch.zeros_like(T))
+        C = C + w[:, None] * rgb[g][None]
+        Cs = Cs + w[:, None] * semantics[g][None]
+        D = D + w * tz[g]
+        T = torch.where(contrib, test_T, T)
+    color = (C + T[:, None] * bg.to(dt)[None]).T.reshape(3, H, W)
+    sem = Cs.T.reshape(S, H, W)
+    return dict(color=color, semantic=sem, depth=D.reshape(1, H, W), alpha=(1 - T).reshape(1, H, W), radii=radii,
+                N=N, conic=torch.stack([con_a, con_b, con_c], -1), means2D=torch.stack([px, py], -1), rgb=rgb,
+                tiles_touched=torch.where(visible, touched, torch.zeros_like(touched)))
+
+
+def covariance_from_scaling_rotation(scales, scale_modifier, rotations):
+    """pc.get_covariance restated: L = R(q/|q|) diag(s*mod), Sigma = L L^T, packed xx,xy,xz,yy,yz,zz
+    (scene/gaussian_model.py:33-37, utils/general_utils.py:70-122)."""
+    q = rotations / rotations.norm(dim=1, keepdim=True)
+    L = quat_to_rot(q) @ torch.diag_embed(scale_modifier * scales)
+    Sg = L @ L.transpose(1, 2)
+    return torch.stack([Sg[:, 0, 0], Sg[:, 0, 1], Sg[:, 0, 2], Sg[:, 1, 1], Sg[:, 1, 2], Sg[:, 2, 2]], -1)
