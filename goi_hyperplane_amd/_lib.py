@@ -1,0 +1,93 @@
+"""ctypes loader for libgoi_raster.so (the C ABI of include/goi_raster.h).
+
+The library is hand-written HIP for gfx950 and is the ONLY compute path of this package: there is
+no CPU or PyTorch fallback.  Loading fails loudly when the shared object is missing; calling a
+compute entry point without a GPU fails inside HIP with a clear error.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgoi_raster.so")
+
+ABI_VERSION = 1
+
+STAGES = ("preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges", "blend_fwd", "blend_bwd",
+          "preprocess_bwd")
+
+
+class GoiRasterScene(C.Structure):
+    """Mirror of `struct GoiRasterScene` (include/goi_raster.h)."""
+    _fields_ = [
+        ("P", C.c_int), ("D", C.c_int), ("M", C.c_int), ("S", C.c_int), ("W", C.c_int), ("H", C.c_int),
+        ("bg", C.c_void_p), ("means3D", C.c_void_p), ("shs", C.c_void_p), ("colors_precomp", C.c_void_p),
+        ("semantics", C.c_void_p), ("opacities", C.c_void_p), ("scales", C.c_void_p),
+        ("scale_modifier", C.c_float), ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p),
+        ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("campos", C.c_void_p),
+        ("tan_fovx", C.c_float), ("tan_fovy", C.c_float), ("prefiltered", C.c_int), ("debug", C.c_int),
+    ]
+
+
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+
+# name -> (restype, argtypes); every symbol include/goi_raster.h declares
+SYMBOLS = {
+    "goi_raster_abi_version": (C.c_int, []),
+    "goi_raster_last_error": (C.c_char_p, []),
+    "goi_raster_geom_bytes": (C.c_size_t, [C.c_int]),
+    "goi_raster_image_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "goi_raster_binning_bytes": (C.c_size_t, [C.c_int]),
+    "goi_raster_forward": (C.c_int, [C.POINTER(GoiRasterScene), C.c_void_p, C.c_void_p, ALLOC_FN, C.c_void_p]
+                           + [C.c_void_p] * 5 + [C.c_void_p]),
+    "goi_raster_backward": (C.c_int, [C.POINTER(GoiRasterScene), C.c_int] + [C.c_void_p] * 3 + [C.c_void_p] * 6
+                            + [C.c_void_p] * 11 + [C.c_void_p]),
+    "goi_raster_trace": (C.c_int, [C.POINTER(GoiRasterScene), C.c_void_p, C.c_void_p, C.c_void_p, ALLOC_FN,
+                                   C.c_void_p] + [C.c_void_p] * 4 + [C.c_void_p]),
+    "goi_raster_mark_visible": (C.c_int, [C.c_int] + [C.c_void_p] * 4 + [C.c_void_p]),
+    "goi_raster_profile_enable": (None, [C.c_int]),
+    "goi_raster_profile_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "goi_raster_debug_views": (C.c_int, [C.c_int] * 4 + [C.c_void_p] * 3 + [C.c_void_p] * 8 + [C.c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Returns the loaded library; raises if it has not been built (python -m goi_hyperplane_amd.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built. Run "
+                "`python -m goi_hyperplane_amd.build` (needs hipcc; cross-compiles for gfx950 without a GPU). "
+                "There is deliberately no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        got = lib.goi_raster_abi_version()
+        if got != ABI_VERSION:
+            raise ImportError(f"libgoi_raster.so ABI {got} != expected {ABI_VERSION}; rebuild")
+        _lib = lib
+    return _lib
+
+
+def last_error() -> str:
+    return load().goi_raster_last_error().decode("utf-8", "replace")
+
+
+def profile_enable(on: bool) -> None:
+    load().goi_raster_profile_enable(1 if on else 0)
+
+
+def profile_collect() -> dict:
+    """{stage: (milliseconds, launches)} accumulated since the previous collect."""
+    n = len(STAGES)
+    ms = (C.c_double * n)()
+    calls = (C.c_int * n)()
+    if load().goi_raster_profile_collect(ms, calls) < 0:
+        raise RuntimeError(last_error())
+    return {STAGES[i]: (ms[i], calls[i]) for i in range(n)}

@@ -1,0 +1,71 @@
+"""Builds libgoi_raster.so (hand-written HIP for gfx950) in-tree with hipcc.
+
+    python -m goi_hyperplane_amd.build [--force]
+
+One hipcc invocation per translation unit (parallel), then a link.  The library lands next to
+this file's package as goi_hyperplane_amd/lib/libgoi_raster.so so that it travels with the repo
+snapshot to the GPU box (it is git-ignored, not gpurun-ignored).
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libgoi_raster.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+
+COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
+          "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
+# per-file extra flags: the per-Gaussian kernels keep the reference's operation order
+UNITS = {
+    "api.hip": [],
+    "scan_sort.hip": [],
+    "preprocess.hip": ["-ffp-contract=off"],
+    "render.hip": [],
+}
+
+
+def _newer(src: str, dst: str) -> bool:
+    return (not os.path.exists(dst)) or os.path.getmtime(src) > os.path.getmtime(dst)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(LIBDIR, exist_ok=True)
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")] + [
+        os.path.join(ROOT, "include", "goi_raster.h")]
+    hdr_time = max(os.path.getmtime(h) for h in headers)
+
+    def compile_one(item):
+        name, extra = item
+        src = os.path.join(CSRC, name)
+        obj = os.path.join(objdir, name + ".o")
+        if force or _newer(src, obj) or hdr_time > os.path.getmtime(obj):
+            cmd = [HIPCC] + COMMON + extra + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+            return obj, True
+        return obj, False
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        results = list(ex.map(compile_one, UNITS.items()))
+    objs = [o for o, _ in results]
+    if force or any(c for _, c in results) or not os.path.exists(LIB):
+        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,394 @@
+// extern "C" entry points of libgoi_raster.so (see include/goi_raster.h): workspace layout,
+// stage orchestration on the caller's HIP stream, per-stage event timing.
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace goi {
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const char* where, hipError_t e) {
+    g_err = std::string(where) + ": " + hipGetErrorString(e);
+    return -1;
+}
+int fail(const std::string& msg) {
+    g_err = msg;
+    return -1;
+}
+
+#define GOI_HIP(call)                                       \
+    do {                                                    \
+        hipError_t e__ = (call);                            \
+        if (e__ != hipSuccess) return fail(#call, e__);     \
+    } while (0)
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+template <typename T>
+inline void carve(char*& p, T*& out, size_t count) {
+    p = reinterpret_cast<char*>(align_up(reinterpret_cast<size_t>(p), 256));
+    out = reinterpret_cast<T*>(p);
+    p += count * sizeof(T);
+}
+
+// ---- per-stage timing -------------------------------------------------------------------------
+struct StageEvents {
+    int stage;
+    hipEvent_t a, b;
+};
+bool g_profile = false;
+std::vector<StageEvents> g_events;
+std::vector<hipEvent_t> g_pool;
+
+hipEvent_t get_event() {
+    if (!g_pool.empty()) {
+        hipEvent_t e = g_pool.back();
+        g_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct StageTimer {
+    hipStream_t s;
+    bool on;
+    StageEvents ev{};
+    StageTimer(int stage, hipStream_t st) : s(st), on(g_profile) {
+        if (on) {
+            ev.stage = stage;
+            ev.a = get_event();
+            ev.b = get_event();
+            (void)hipEventRecord(ev.a, s);
+        }
+    }
+    ~StageTimer() {
+        if (on) {
+            (void)hipEventRecord(ev.b, s);
+            g_events.push_back(ev);
+        }
+    }
+};
+
+int check_stage(const GoiRasterScene& sc, hipStream_t s, const char* name) {
+    if (!sc.debug) return 0;
+    hipError_t e = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) return fail(name, e);
+    return 0;
+}
+
+int validate(const GoiRasterScene* sc, bool need_sem, bool need_opacity = true) {
+    if (!sc) return fail("scene is NULL");
+    if (sc->P < 0 || sc->W <= 0 || sc->H <= 0) return fail("bad P/W/H");
+    if (sc->S < 1 || sc->S > 32) return fail("semantic channels S must be in 1..32");
+    if (sc->P == 0) return 0;
+    if (need_opacity && !sc->opacities) return fail("opacities is NULL");
+    if (!sc->means3D || !sc->viewmatrix || !sc->projmatrix || !sc->campos || !sc->bg)
+        return fail("a required input pointer is NULL");
+    if (need_sem && !sc->semantics) return fail("semantics is required (the reference dereferences it unconditionally)");
+    if ((sc->shs == nullptr) == (sc->colors_precomp == nullptr))
+        return fail("Please provide excatly one of either SHs or precomputed colors!");
+    if (((sc->scales == nullptr || sc->rotations == nullptr) && sc->cov3D_precomp == nullptr) ||
+        ((sc->scales != nullptr || sc->rotations != nullptr) && sc->cov3D_precomp != nullptr))
+        return fail("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+    if (sc->shs && (sc->D < 0 || sc->D > 3 || sc->M < (sc->D + 1) * (sc->D + 1)))
+        return fail("SH degree must be 0..3 and M >= (D+1)^2");
+    return 0;
+}
+
+// Shared front end of forward and trace: preprocess -> depth sort -> scan -> emit -> tile sort ->
+// ranges.  Returns num_rendered (>= 0) and the final point list through *plist.
+int geometry_and_binning(const GoiRasterScene& sc, GeomView& g, ImageView& im, goi_alloc_fn alloc, void* user,
+                         int* radii, const uint32_t** plist, hipStream_t s) {
+    const int P = sc.P;
+    const int gx = (sc.W + TILE - 1) / TILE, gy = (sc.H + TILE - 1) / TILE;
+    GOI_HIP(hipMemsetAsync(g.counters, 0, 8 * sizeof(uint32_t), s));
+    {
+        StageTimer t(GOI_STAGE_PREPROCESS, s);
+        launch_preprocess_fwd(sc, g, radii, s);
+    }
+    if (check_stage(sc, s, "preprocess")) return -1;
+    int order_idx;
+    {
+        StageTimer t(GOI_STAGE_DEPTH_SORT, s);
+        order_idx = radix_sort_pairs(g.sort_keys, g.sort_vals, (size_t)P, 0, 32, g.scratch, s);
+    }
+    if (check_stage(sc, s, "depth sort")) return -1;
+    const uint32_t* order = g.sort_vals[order_idx];
+    uint32_t host_counters[2] = {0, 0};
+    {
+        StageTimer t(GOI_STAGE_SCAN, s);
+        exclusive_scan_u32(g.tiles_touched, order, g.offsets, (size_t)P, &g.counters[0], g.scratch, s);
+        GOI_HIP(hipMemcpyAsync(host_counters, g.counters, sizeof(host_counters), hipMemcpyDeviceToHost, s));
+        GOI_HIP(hipStreamSynchronize(s));
+    }
+    if (host_counters[1] != 0)
+        return fail("Point is filtered although prefiltered is set. This shouldn't happen!");
+    const int N = (int)host_counters[0];
+    if (N < 0) return fail("num_rendered overflows int32");
+    const size_t need = goi_raster_binning_bytes(N);
+    char* bin_mem = static_cast<char*>(alloc(user, need));
+    if (!bin_mem && need > 0) return fail("binning allocation callback returned NULL");
+    BinView bv;
+    binning_layout(N, bin_mem, &bv);
+    {
+        StageTimer t(GOI_STAGE_EMIT, s);
+        if (N > 0) launch_emit(P, sc.W, sc.H, g, order, radii, bv.keys[0], bv.vals[0], s);
+    }
+    if (check_stage(sc, s, "emit")) return -1;
+    int fin;
+    {
+        StageTimer t(GOI_STAGE_TILE_SORT, s);
+        fin = radix_sort_pairs(bv.keys, bv.vals, (size_t)N, 0, tile_key_bits((uint32_t)(gx * gy)), bv.scratch, s);
+    }
+    if (check_stage(sc, s, "tile sort")) return -1;
+    {
+        StageTimer t(GOI_STAGE_RANGES, s);
+        launch_ranges(N, bv.keys[fin], im.ranges, gx * gy, s);
+    }
+    if (check_stage(sc, s, "ranges")) return -1;
+    *plist = bv.vals[fin];
+    return N;
+}
+
+}  // namespace
+
+// Which ping-pong buffer holds the tile-sorted list: a pure function of the pass count, so the
+// backward can recompute it instead of storing it.
+static int tile_sort_result_index(int W, int H, int N) {
+    if (N <= 0) return 0;
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+    const int passes = (tile_key_bits((uint32_t)(gx * gy)) + 7) / 8;
+    return passes & 1;
+}
+
+size_t geom_layout(int P, char* base, GeomView* v) {
+    char* p = base;
+    const size_t n = (size_t)(P > 0 ? P : 1);
+    GeomView tmp;
+    GeomView& g = v ? *v : tmp;
+    carve(p, g.rec, n);
+    carve(p, g.cov3D, 6 * n);
+    carve(p, g.tiles_touched, n);
+    carve(p, g.clamped, n);
+    carve(p, g.sort_keys[0], n);
+    carve(p, g.sort_keys[1], n);
+    carve(p, g.sort_vals[0], n);
+    carve(p, g.sort_vals[1], n);
+    carve(p, g.offsets, n);
+    g.scratch_words = sort_scratch_words(n) + scan_scratch_words(n);
+    carve(p, g.scratch, g.scratch_words);
+    carve(p, g.counters, 8);
+    return (size_t)(p - base) + 256;
+}
+
+size_t image_layout(int W, int H, char* base, ImageView* v) {
+    char* p = base;
+    ImageView tmp;
+    ImageView& im = v ? *v : tmp;
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+    carve(p, im.n_contrib, (size_t)W * H);
+    carve(p, im.ranges, (size_t)gx * gy);
+    return (size_t)(p - base) + 256;
+}
+
+size_t binning_layout(int N, char* base, BinView* v) {
+    char* p = base;
+    const size_t n = (size_t)(N > 0 ? N : 1);
+    BinView tmp;
+    BinView& b = v ? *v : tmp;
+    carve(p, b.keys[0], n);
+    carve(p, b.keys[1], n);
+    carve(p, b.vals[0], n);
+    carve(p, b.vals[1], n);
+    b.scratch_words = sort_scratch_words(n) + 8;
+    carve(p, b.scratch, b.scratch_words);
+    return (size_t)(p - base) + 256;
+}
+
+}  // namespace goi
+
+using namespace goi;
+
+extern "C" {
+
+int goi_raster_abi_version(void) { return GOI_RASTER_ABI_VERSION; }
+const char* goi_raster_last_error(void) { return g_err.c_str(); }
+
+// Sizes are computed with a base that already has the strictest alignment, so they are upper
+// bounds for any 256-byte aligned buffer; +256 slack covers callers that hand over less.
+size_t goi_raster_geom_bytes(int P) { return geom_layout(P, nullptr, nullptr) + 256; }
+size_t goi_raster_image_bytes(int W, int H) { return image_layout(W, H, nullptr, nullptr) + 256; }
+size_t goi_raster_binning_bytes(int N) { return binning_layout(N, nullptr, nullptr) + 256; }
+
+int goi_raster_forward(const GoiRasterScene* scene, void* geom_buffer, void* image_buffer, goi_alloc_fn binning_alloc,
+                       void* alloc_user, float* out_color, float* out_semantic, float* out_depth, float* out_alpha,
+                       int* radii, void* stream) {
+    if (validate(scene, true)) return -1;
+    const GoiRasterScene& sc = *scene;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t HW = (size_t)sc.W * sc.H;
+    if (sc.P == 0) {  // zero-filled outputs, nothing launched (DGR/rasterize_points.cu:84-85)
+        GOI_HIP(hipMemsetAsync(out_color, 0, 3 * HW * sizeof(float), s));
+        GOI_HIP(hipMemsetAsync(out_semantic, 0, (size_t)sc.S * HW * sizeof(float), s));
+        GOI_HIP(hipMemsetAsync(out_depth, 0, HW * sizeof(float), s));
+        GOI_HIP(hipMemsetAsync(out_alpha, 0, HW * sizeof(float), s));
+        return 0;
+    }
+    if (!geom_buffer || !image_buffer || !binning_alloc) return fail("workspace pointer / allocator is NULL");
+    GeomView g;
+    ImageView im;
+    geom_layout(sc.P, static_cast<char*>(geom_buffer), &g);
+    image_layout(sc.W, sc.H, static_cast<char*>(image_buffer), &im);
+    const uint32_t* plist = nullptr;
+    const int N = geometry_and_binning(sc, g, im, binning_alloc, alloc_user, radii, &plist, s);
+    if (N < 0) return -1;
+    {
+        StageTimer t(GOI_STAGE_BLEND_FWD, s);
+        launch_render_fwd(sc, g, im, plist, out_color, out_semantic, out_depth, out_alpha, s);
+    }
+    if (check_stage(sc, s, "forward blend")) return -1;
+    GOI_HIP(hipGetLastError());
+    return N;
+}
+
+int goi_raster_trace(const GoiRasterScene* scene, const float* img_sem, void* geom_buffer, void* image_buffer,
+                     goi_alloc_fn binning_alloc, void* alloc_user, float* out_color, float* gau_sem, int* num_gsem,
+                     int* radii, void* stream) {
+    if (validate(scene, false)) return -1;
+    const GoiRasterScene& sc = *scene;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t HW = (size_t)sc.W * sc.H;
+    GOI_HIP(hipMemsetAsync(out_color, 0, 3 * HW * sizeof(float), s));
+    if (sc.P == 0) return 0;
+    if (!img_sem) return fail("img_sem is NULL");
+    if (!geom_buffer || !image_buffer || !binning_alloc) return fail("workspace pointer / allocator is NULL");
+    GOI_HIP(hipMemsetAsync(gau_sem, 0, (size_t)sc.P * sc.S * sizeof(float), s));
+    GOI_HIP(hipMemsetAsync(num_gsem, 0, (size_t)sc.P * sizeof(int), s));
+    GeomView g;
+    ImageView im;
+    geom_layout(sc.P, static_cast<char*>(geom_buffer), &g);
+    image_layout(sc.W, sc.H, static_cast<char*>(image_buffer), &im);
+    const uint32_t* plist = nullptr;
+    const int N = geometry_and_binning(sc, g, im, binning_alloc, alloc_user, radii, &plist, s);
+    if (N < 0) return -1;
+    launch_trace_fwd(sc, img_sem, g, im, plist, out_color, gau_sem, num_gsem, s);
+    if (check_stage(sc, s, "trace")) return -1;
+    GOI_HIP(hipGetLastError());
+    return N;
+}
+
+int goi_raster_backward(const GoiRasterScene* scene, int R, const void* geom_buffer, const void* binning_buffer,
+                        const void* image_buffer, const int* radii, const float* out_alpha, const float* dL_dout_color,
+                        const float* dL_dout_semantic, const float* dL_dout_depth, const float* dL_dout_alpha,
+                        float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dsemantic,
+                        float* dL_ddepth, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
+                        float* dL_drot, void* stream) {
+    if (validate(scene, true, false)) return -1;  // opacity lives in the forward's records
+    const GoiRasterScene& sc = *scene;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t P = (size_t)sc.P;
+    if (P == 0) return 0;
+    if (!geom_buffer || !image_buffer || (R > 0 && !binning_buffer)) return fail("workspace pointer is NULL");
+    GeomView g;
+    ImageView im;
+    BinView bv;
+    geom_layout(sc.P, const_cast<char*>(static_cast<const char*>(geom_buffer)), &g);
+    image_layout(sc.W, sc.H, const_cast<char*>(static_cast<const char*>(image_buffer)), &im);
+    // the accumulated (atomic) gradients start from zero
+    GOI_HIP(hipMemsetAsync(dL_dmean2D, 0, 3 * P * sizeof(float), s));
+    GOI_HIP(hipMemsetAsync(dL_dconic, 0, 4 * P * sizeof(float), s));
+    GOI_HIP(hipMemsetAsync(dL_dopacity, 0, P * sizeof(float), s));
+    GOI_HIP(hipMemsetAsync(dL_dcolor, 0, 3 * P * sizeof(float), s));
+    GOI_HIP(hipMemsetAsync(dL_dsemantic, 0, (size_t)sc.S * P * sizeof(float), s));
+    GOI_HIP(hipMemsetAsync(dL_ddepth, 0, P * sizeof(float), s));
+    if (R > 0) {
+        binning_layout(R, const_cast<char*>(static_cast<const char*>(binning_buffer)), &bv);
+        const int fin = tile_sort_result_index(sc.W, sc.H, R);
+        StageTimer t(GOI_STAGE_BLEND_BWD, s);
+        launch_render_bwd(sc, g, im, bv.vals[fin], out_alpha, dL_dout_color, dL_dout_semantic, dL_dout_depth,
+                          dL_dout_alpha, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dsemantic, dL_ddepth, s);
+    }
+    if (check_stage(sc, s, "backward blend")) return -1;
+    {
+        StageTimer t(GOI_STAGE_PREPROCESS_BWD, s);
+        launch_preprocess_bwd(sc, g, radii, dL_dmean2D, dL_dconic, dL_dcolor, dL_ddepth, dL_dmean3D, dL_dcov3D, dL_dsh,
+                              dL_dscale, dL_drot, s);
+    }
+    if (check_stage(sc, s, "backward preprocess")) return -1;
+    GOI_HIP(hipGetLastError());
+    return 0;
+}
+
+int goi_raster_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                            uint8_t* present, void* stream) {
+    (void)projmatrix;
+    if (P < 0) return fail("bad P");
+    if (P == 0) return 0;
+    if (!means3D || !viewmatrix || !present) return fail("NULL pointer");
+    launch_mark_visible(P, means3D, viewmatrix, present, static_cast<hipStream_t>(stream));
+    GOI_HIP(hipGetLastError());
+    return 0;
+}
+
+void goi_raster_profile_enable(int on) { g_profile = on != 0; }
+
+int goi_raster_profile_collect(double* ms, int* calls) {
+    for (auto& ev : g_events) {
+        GOI_HIP(hipEventSynchronize(ev.b));
+        float t = 0.f;
+        GOI_HIP(hipEventElapsedTime(&t, ev.a, ev.b));
+        if (ms) ms[ev.stage] += (double)t;
+        if (calls) calls[ev.stage] += 1;
+        g_pool.push_back(ev.a);
+        g_pool.push_back(ev.b);
+    }
+    g_events.clear();
+    return 0;
+}
+
+int goi_raster_debug_views(int P, int W, int H, int R, const void* geom_buffer, const void* binning_buffer,
+                           const void* image_buffer, float* depths, float* means2D, float* conic_opacity, float* rgb,
+                           uint32_t* tiles_touched, uint32_t* point_list, uint32_t* ranges, uint32_t* n_contrib,
+                           void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (P <= 0) return 0;
+    GeomView g;
+    ImageView im;
+    geom_layout(P, const_cast<char*>(static_cast<const char*>(geom_buffer)), &g);
+    image_layout(W, H, const_cast<char*>(static_cast<const char*>(image_buffer)), &im);
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+    // strided copies out of the 48-byte records
+    const char* rec = reinterpret_cast<const char*>(g.rec);
+    const size_t pitch = sizeof(GaussRec);
+    if (means2D) GOI_HIP(hipMemcpy2DAsync(means2D, 8, rec + 0, pitch, 8, P, hipMemcpyDeviceToDevice, s));
+    if (conic_opacity) {  // (a,b) then (c,o)
+        GOI_HIP(hipMemcpy2DAsync(conic_opacity, 16, rec + 8, pitch, 8, P, hipMemcpyDeviceToDevice, s));
+        GOI_HIP(hipMemcpy2DAsync(reinterpret_cast<char*>(conic_opacity) + 8, 16, rec + 16, pitch, 8, P,
+                                 hipMemcpyDeviceToDevice, s));
+    }
+    if (depths) GOI_HIP(hipMemcpy2DAsync(depths, 4, rec + 24, pitch, 4, P, hipMemcpyDeviceToDevice, s));
+    if (rgb) GOI_HIP(hipMemcpy2DAsync(rgb, 12, rec + 28, pitch, 12, P, hipMemcpyDeviceToDevice, s));
+    if (tiles_touched)
+        GOI_HIP(hipMemcpyAsync(tiles_touched, g.tiles_touched, sizeof(uint32_t) * P, hipMemcpyDeviceToDevice, s));
+    if (ranges) GOI_HIP(hipMemcpyAsync(ranges, im.ranges, sizeof(uint2) * gx * gy, hipMemcpyDeviceToDevice, s));
+    if (n_contrib)
+        GOI_HIP(hipMemcpyAsync(n_contrib, im.n_contrib, sizeof(uint32_t) * (size_t)W * H, hipMemcpyDeviceToDevice, s));
+    if (point_list && R > 0) {
+        BinView bv;
+        binning_layout(R, const_cast<char*>(static_cast<const char*>(binning_buffer)), &bv);
+        const int fin = tile_sort_result_index(W, H, R);
+        GOI_HIP(hipMemcpyAsync(point_list, bv.vals[fin], sizeof(uint32_t) * (size_t)R, hipMemcpyDeviceToDevice, s));
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,87 @@
+// Internal declarations shared by the HIP translation units of libgoi_raster.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "goi_raster.h"
+
+namespace goi {
+
+constexpr int TILE = 16;          // tile edge; part of the numerical contract (CR/config.h:16-17)
+constexpr int TILE_PIX = TILE * TILE;
+constexpr int WAVE = 64;
+
+// Per-Gaussian render record written by the forward preprocess: everything the blend kernels
+// need about a Gaussian except its semantic row, in three 16-byte words (48 B, one gather).
+//   q0 = (x, y, conic.a, conic.b)   q1 = (conic.c, opacity, depth, r)   q2 = (g, b, hx, hy)
+// hx / hy: half extents (pixels) of the axis-aligned box outside which alpha < 1/255 can be
+// proven; < 0 when the Gaussian can never reach 1/255, +inf when no bound is known.
+struct GaussRec {
+    float4 q0, q1, q2;
+};
+
+// ---- workspace layouts (opaque to callers; forward -> backward of one call must agree) -------
+struct GeomView {
+    GaussRec* rec;            // [P]
+    float* cov3D;             // [6P] (only when computed from scale/rotation)
+    uint32_t* tiles_touched;  // [P]
+    uint8_t* clamped;         // [P] bit0..2 = r,g,b clamped at 0
+    uint32_t* sort_keys[2];   // [P] depth bits (ping-pong)
+    uint32_t* sort_vals[2];   // [P] Gaussian ids (ping-pong); [final] = depth order
+    uint32_t* offsets;        // [P] exclusive prefix of tiles_touched in depth order
+    uint32_t* scratch;        // scan partials + radix histograms
+    uint32_t* counters;       // [8]: 0 = num_rendered, 1 = error flag
+    size_t scratch_words;
+};
+struct ImageView {
+    uint32_t* n_contrib;  // [HW]
+    uint2* ranges;        // [T]
+};
+struct BinView {
+    uint32_t* keys[2];  // [N] tile ids (ping-pong)
+    uint32_t* vals[2];  // [N] Gaussian ids (ping-pong)
+    uint32_t* scratch;
+    size_t scratch_words;
+};
+
+size_t geom_layout(int P, char* base, GeomView* v);
+size_t image_layout(int W, int H, char* base, ImageView* v);
+size_t binning_layout(int N, char* base, BinView* v);
+
+// ---- device-wide primitives (scan_sort.hip) ----------------------------------------------------
+size_t scan_scratch_words(size_t n);
+size_t sort_scratch_words(size_t n);
+// out[i] = sum_{j<i} f(j), f(j) = gather ? in[gather[j]] : in[j]; *total (device, may be NULL) = sum.
+void exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, size_t n, uint32_t* total,
+                        uint32_t* scratch, hipStream_t s);
+// Stable LSD radix sort of (key,val) pairs on key bits [lo, hi).  Data start in keys[0]/vals[0];
+// returns the index (0/1) of the buffers holding the sorted result.
+int radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], size_t n, int lo, int hi, uint32_t* scratch,
+                     hipStream_t s);
+
+// ---- stages ---------------------------------------------------------------------------------------
+void launch_preprocess_fwd(const GoiRasterScene& sc, const GeomView& g, int* radii, hipStream_t s);
+void launch_emit(int P, int W, int H, const GeomView& g, const uint32_t* order, const int* radii, uint32_t* keys,
+                 uint32_t* vals, hipStream_t s);
+void launch_ranges(int N, const uint32_t* sorted_keys, uint2* ranges, int T, hipStream_t s);
+void launch_render_fwd(const GoiRasterScene& sc, const GeomView& g, const ImageView& im, const uint32_t* point_list,
+                       float* out_color, float* out_sem, float* out_depth, float* out_alpha, hipStream_t s);
+void launch_trace_fwd(const GoiRasterScene& sc, const float* img_sem, const GeomView& g, const ImageView& im,
+                      const uint32_t* point_list, float* out_color, float* gau_sem, int* num_gsem, hipStream_t s);
+void launch_render_bwd(const GoiRasterScene& sc, const GeomView& g, const ImageView& im, const uint32_t* point_list,
+                       const float* out_alpha, const float* dL_dpix, const float* dL_dsem, const float* dL_ddepth,
+                       const float* dL_dalpha, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
+                       float* dL_dcolor, float* dL_dsemantic, float* dL_ddepths, hipStream_t s);
+void launch_preprocess_bwd(const GoiRasterScene& sc, const GeomView& g, const int* radii, const float* dL_dmean2D,
+                           const float* dL_dconic, float* dL_dcolor, const float* dL_ddepth, float* dL_dmean3D,
+                           float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, hipStream_t s);
+void launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
+
+// Number of key bits that cover every tile id < n_tiles (the reference sorts on
+// getHigherMsb(T) = floor(log2 T) + 1 tile bits, CR/rasterizer_impl.cu:35-50,304; any bit count
+// that covers the ids gives the same order).
+inline int tile_key_bits(uint32_t n_tiles) { return n_tiles <= 1 ? 1 : 32 - __builtin_clz(n_tiles); }
+
+}  // namespace goi

@@ -1,0 +1,563 @@
+// Per-Gaussian kernels: forward preprocess (project, EWA cov2D, conic, radius, tile rectangle,
+// SH -> RGB, render record) and its backward (conic -> cov3D/mean, projection, depth, SH, cov3D ->
+// scale/rotation).  Compiled with -ffp-contract=off: these stages are HBM-bound streaming, and
+// keeping the reference's operation order makes radii / tile rectangles / depth keys integer-exact.
+//
+// Behaviour restated from the reference (paths relative to submodules/diff-gaussian-rasterization/):
+//   forward : cuda_rasterizer/forward.cu:155-256 (+ :20-71 SH, :74-113 cov2D, :118-152 cov3D),
+//             cuda_rasterizer/auxiliary.h:41-56,139-164
+//   backward: cuda_rasterizer/backward.cu:144-274 (cov2D), :346-412 (projection/depth),
+//             :20-139 (SH), :278-341 (cov3D)
+// Layout is this library's own: one 48-byte GaussRec per Gaussian instead of five arrays, depth
+// keys for the per-Gaussian depth sort, 3 clamp bits in one byte.
+#include "common.h"
+#include "gmath.h"
+
+namespace goi {
+
+namespace {
+
+__device__ __forceinline__ float ndc_to_pix(float v, int S) { return (float)(((v + 1.0) * S - 1.0) * 0.5); }
+
+__device__ __forceinline__ void tile_rect(float px, float py, int r, int gx, int gy, int& x0, int& y0, int& x1,
+                                          int& y1) {
+    x0 = min(gx, max(0, (int)((px - r) / TILE)));
+    y0 = min(gy, max(0, (int)((py - r) / TILE)));
+    x1 = min(gx, max(0, (int)((px + r + TILE - 1) / TILE)));
+    y1 = min(gy, max(0, (int)((py + r + TILE - 1) / TILE)));
+}
+
+__device__ __forceinline__ M3 rotation_from_quat(float r, float x, float y, float z) {
+    return make_m3(1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
+                   2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
+                   2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y));
+}
+
+struct Cov2D {
+    M3 T, Vrk, W;
+    V3 t;
+    float txtz, tytz, limx, limy;
+    M3 cov;
+};
+
+__device__ __forceinline__ void ewa_cov2d(V3 mean, float fx, float fy, float tan_fovx, float tan_fovy,
+                                          const float* cov3D, const float* view, Cov2D& c) {
+    V3 t = xform_point_4x3(mean, view);
+    c.limx = 1.3f * tan_fovx;
+    c.limy = 1.3f * tan_fovy;
+    c.txtz = t.x / t.z;
+    c.tytz = t.y / t.z;
+    t.x = fminf(c.limx, fmaxf(-c.limx, c.txtz)) * t.z;
+    t.y = fminf(c.limy, fmaxf(-c.limy, c.tytz)) * t.z;
+    c.t = t;
+    M3 J = make_m3(fx / t.z, 0.0f, -(fx * t.x) / (t.z * t.z), 0.0f, fy / t.z, -(fy * t.y) / (t.z * t.z), 0.f, 0.f, 0.f);
+    c.W = make_m3(view[0], view[4], view[8], view[1], view[5], view[9], view[2], view[6], view[10]);
+    c.T = mul(c.W, J);
+    c.Vrk = make_m3(cov3D[0], cov3D[1], cov3D[2], cov3D[1], cov3D[3], cov3D[4], cov3D[2], cov3D[4], cov3D[5]);
+    c.cov = mul(mul(transpose(c.T), transpose(c.Vrk)), c.T);
+}
+
+struct PreArgs {
+    int P, D, M, W, H, gx, gy, prefiltered;
+    const float* means3D;
+    const float* shs;
+    const float* colors_precomp;
+    const float* opacities;
+    const float* scales;
+    const float* rotations;
+    const float* cov3D_precomp;
+    float scale_modifier, tan_fovx, tan_fovy, focal_x, focal_y;
+    const float* view_p;    // device, [16]
+    const float* proj_p;    // device, [16]
+    const float* campos_p;  // device, [3]
+};
+
+// The camera arrays are tiny, uniform device arrays: every thread reads them through the scalar
+// cache into registers once.
+struct Camera {
+    float view[16], proj[16], campos[3];
+};
+__device__ __forceinline__ Camera load_camera(const float* __restrict__ v, const float* __restrict__ p,
+                                              const float* __restrict__ c) {
+    Camera cam;
+#pragma unroll
+    for (int i = 0; i < 16; i++) cam.view[i] = v[i];
+#pragma unroll
+    for (int i = 0; i < 16; i++) cam.proj[i] = p[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) cam.campos[i] = c[i];
+    return cam;
+}
+
+__global__ __launch_bounds__(256) void preprocess_fwd_k(const PreArgs args, GaussRec* __restrict__ rec,
+                                                        float* __restrict__ cov3D_out,
+                                                        uint32_t* __restrict__ tiles_touched,
+                                                        uint8_t* __restrict__ clamped, uint32_t* __restrict__ sort_key,
+                                                        uint32_t* __restrict__ sort_val, int* __restrict__ radii,
+                                                        uint32_t* __restrict__ counters) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= args.P) return;
+    const Camera cam = load_camera(args.view_p, args.proj_p, args.campos_p);
+    struct : PreArgs {
+        const float *view, *proj, *campos;
+    } a;
+    static_cast<PreArgs&>(a) = args;
+    a.view = cam.view;
+    a.proj = cam.proj;
+    a.campos = cam.campos;
+    int my_radius_i = 0;
+    uint32_t touched = 0, key = 0xFFFFFFFFu;
+    uint8_t clamp_bits = 0;
+
+    const V3 p = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
+    const V3 p_view = xform_point_4x3(p, a.view);
+    do {
+        if (p_view.z <= 0.2f) {
+            if (a.prefiltered) atomicOr(&counters[1], 1u);  // the reference traps here
+            break;
+        }
+        const float4 p_hom = xform_point_4x4(p, a.proj);
+        const float p_w = 1.0f / (p_hom.w + 0.0000001f);
+        const float projx = p_hom.x * p_w, projy = p_hom.y * p_w;
+
+        float cov3D[6];
+        if (a.cov3D_precomp) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) cov3D[i] = a.cov3D_precomp[(size_t)6 * idx + i];
+        } else {
+            M3 S = make_m3(1, 0, 0, 0, 1, 0, 0, 0, 1);
+            S.c[0][0] = a.scale_modifier * a.scales[3 * idx];
+            S.c[1][1] = a.scale_modifier * a.scales[3 * idx + 1];
+            S.c[2][2] = a.scale_modifier * a.scales[3 * idx + 2];
+            const float4 q = reinterpret_cast<const float4*>(a.rotations)[idx];  // (r,x,y,z), not normalised
+            M3 R = rotation_from_quat(q.x, q.y, q.z, q.w);
+            M3 Mm = mul(S, R);
+            M3 Sg = mul(transpose(Mm), Mm);
+            cov3D[0] = Sg.c[0][0]; cov3D[1] = Sg.c[0][1]; cov3D[2] = Sg.c[0][2];
+            cov3D[3] = Sg.c[1][1]; cov3D[4] = Sg.c[1][2]; cov3D[5] = Sg.c[2][2];
+#pragma unroll
+            for (int i = 0; i < 6; i++) cov3D_out[(size_t)6 * idx + i] = cov3D[i];
+        }
+        Cov2D c2;
+        ewa_cov2d(p, a.focal_x, a.focal_y, a.tan_fovx, a.tan_fovy, cov3D, a.view, c2);
+        const float cx = c2.cov.c[0][0] + 0.3f, cy = c2.cov.c[0][1], cz = c2.cov.c[1][1] + 0.3f;
+        const float det = cx * cz - cy * cy;
+        if (det == 0.0f) break;
+        const float det_inv = 1.f / det;
+        const float con_a = cz * det_inv, con_b = -cy * det_inv, con_c = cx * det_inv;
+        const float mid = 0.5f * (cx + cz);
+        const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+        const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+        const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+        const float pix = ndc_to_pix(projx, a.W), piy = ndc_to_pix(projy, a.H);
+        int x0, y0, x1, y1;
+        tile_rect(pix, piy, (int)my_radius, a.gx, a.gy, x0, y0, x1, y1);
+        if ((x1 - x0) * (y1 - y0) == 0) break;
+
+        float cr, cg, cb;
+        if (a.colors_precomp) {
+            cr = a.colors_precomp[3 * idx];
+            cg = a.colors_precomp[3 * idx + 1];
+            cb = a.colors_precomp[3 * idx + 2];
+        } else {
+            const V3 campos = {a.campos[0], a.campos[1], a.campos[2]};
+            V3 dir = p - campos;
+            dir = dir / sqrtf(dot3(dir, dir));
+            const V3* sh = reinterpret_cast<const V3*>(a.shs) + (size_t)idx * a.M;
+            V3 res = kSH0 * sh[0];
+            if (a.D > 0) {
+                const float x = dir.x, y = dir.y, z = dir.z;
+                res = res - kSH1 * y * sh[1] + kSH1 * z * sh[2] - kSH1 * x * sh[3];
+                if (a.D > 1) {
+                    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                    res = res + kSH2[0] * xy * sh[4] + kSH2[1] * yz * sh[5] + kSH2[2] * (2.0f * zz - xx - yy) * sh[6] +
+                          kSH2[3] * xz * sh[7] + kSH2[4] * (xx - yy) * sh[8];
+                    if (a.D > 2) {
+                        res = res + kSH3[0] * y * (3.0f * xx - yy) * sh[9] + kSH3[1] * xy * z * sh[10] +
+                              kSH3[2] * y * (4.0f * zz - xx - yy) * sh[11] +
+                              kSH3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * sh[12] +
+                              kSH3[4] * x * (4.0f * zz - xx - yy) * sh[13] + kSH3[5] * z * (xx - yy) * sh[14] +
+                              kSH3[6] * x * (xx - 3.0f * yy) * sh[15];
+                    }
+                }
+            }
+            res = res + V3{0.5f, 0.5f, 0.5f};
+            clamp_bits = (uint8_t)((res.x < 0 ? 1 : 0) | (res.y < 0 ? 2 : 0) | (res.z < 0 ? 4 : 0));
+            cr = fmaxf(res.x, 0.0f);
+            cg = fmaxf(res.y, 0.0f);
+            cb = fmaxf(res.z, 0.0f);
+        }
+        // Box outside which alpha = min(0.99, o*exp(power)) < 1/255 is certain (see DESIGN.md,
+        // "exact contribution box"): the ellipse power >= -tau of the COMPUTED conic, tau inflated.
+        const float o = a.opacities[idx];
+        float hx = -1.f, hy = -1.f;
+        if (o >= 1.0f / 255.0f) {
+            const double tau = log(255.0 * (double)o) * 1.01 + 0.01;
+            const double detc = (double)con_a * (double)con_c - (double)con_b * (double)con_b;
+            if (detc > 0.0 && con_a > 0.f && con_c > 0.f) {
+                hx = (float)(sqrt(2.0 * tau * (double)con_c / detc) * 1.000001) + 1e-3f;
+                hy = (float)(sqrt(2.0 * tau * (double)con_a / detc) * 1.000001) + 1e-3f;
+                if (!(hx == hx) || !(hy == hy)) hx = hy = __builtin_inff();
+            } else {
+                hx = hy = __builtin_inff();
+            }
+        }
+        GaussRec r;
+        r.q0 = make_float4(pix, piy, con_a, con_b);
+        r.q1 = make_float4(con_c, o, p_view.z, cr);
+        r.q2 = make_float4(cg, cb, hx, hy);
+        rec[idx] = r;
+        my_radius_i = (int)my_radius;
+        touched = (uint32_t)((y1 - y0) * (x1 - x0));
+        key = __float_as_uint(p_view.z);
+    } while (false);
+
+    radii[idx] = my_radius_i;
+    tiles_touched[idx] = touched;
+    clamped[idx] = clamp_bits;
+    sort_key[idx] = key;
+    sort_val[idx] = (uint32_t)idx;
+}
+
+struct BwdArgs {
+    int P, D, M, W, H;
+    const float* means3D;
+    const float* shs;
+    const float* scales;
+    const float* rotations;
+    const float* cov3D;  // precomputed or the forward's
+    float scale_modifier, tan_fovx, tan_fovy, focal_x, focal_y;
+    const float* view_p;
+    const float* proj_p;
+    const float* campos_p;
+};
+
+__global__ __launch_bounds__(256) void preprocess_bwd_k(const BwdArgs args, const int* __restrict__ radii,
+                                                        const uint8_t* __restrict__ clamped,
+                                                        const float* __restrict__ dL_dmean2D,
+                                                        const float* __restrict__ dL_dconic,
+                                                        const float* __restrict__ dL_dcolor,
+                                                        const float* __restrict__ dL_ddepth,
+                                                        float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D,
+                                                        float* __restrict__ dL_dsh, float* __restrict__ dL_dscale,
+                                                        float* __restrict__ dL_drot) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= args.P) return;
+    const Camera cam = load_camera(args.view_p, args.proj_p, args.campos_p);
+    struct : BwdArgs {
+        const float *view, *proj, *campos;
+    } a;
+    static_cast<BwdArgs&>(a) = args;
+    a.view = cam.view;
+    a.proj = cam.proj;
+    a.campos = cam.campos;
+    V3 gmean = {0, 0, 0};
+    float gcov[6] = {0, 0, 0, 0, 0, 0};
+    V3 gscale = {0, 0, 0};
+    float4 grot = make_float4(0, 0, 0, 0);
+    const bool visible = radii[idx] > 0;
+    V3* dsh = dL_dsh ? reinterpret_cast<V3*>(dL_dsh) + (size_t)idx * a.M : nullptr;
+
+    if (visible) {
+        const V3 mean = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
+        // ---- conic -> cov2D -> cov3D and the covariance path of the mean gradient
+        {
+            float cov3D[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) cov3D[i] = a.cov3D[(size_t)6 * idx + i];
+            const float dca = dL_dconic[4 * idx], dcb = dL_dconic[4 * idx + 1], dcc = dL_dconic[4 * idx + 3];
+            Cov2D c;
+            ewa_cov2d(mean, a.focal_x, a.focal_y, a.tan_fovx, a.tan_fovy, cov3D, a.view, c);
+            const float x_grad_mul = (c.txtz < -c.limx || c.txtz > c.limx) ? 0.f : 1.f;
+            const float y_grad_mul = (c.tytz < -c.limy || c.tytz > c.limy) ? 0.f : 1.f;
+            const auto& T = c.T.c;
+            const auto& Vrk = c.Vrk.c;
+            const auto& Wm = c.W.c;
+            const float ca = c.cov.c[0][0] + 0.3f, cb = c.cov.c[0][1], cc = c.cov.c[1][1] + 0.3f;
+            const float denom = ca * cc - cb * cb;
+            float dL_da = 0, dL_db = 0, dL_dc = 0;
+            const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+            if (denom2inv != 0) {
+                dL_da = denom2inv * (-cc * cc * dca + 2 * cb * cc * dcb + (denom - ca * cc) * dcc);
+                dL_dc = denom2inv * (-ca * ca * dcc + 2 * ca * cb * dcb + (denom - ca * cc) * dca);
+                dL_db = denom2inv * 2 * (cb * cc * dca - (denom + 2 * cb * cb) * dcb + ca * cb * dcc);
+                gcov[0] = (T[0][0] * T[0][0] * dL_da + T[0][0] * T[1][0] * dL_db + T[1][0] * T[1][0] * dL_dc);
+                gcov[3] = (T[0][1] * T[0][1] * dL_da + T[0][1] * T[1][1] * dL_db + T[1][1] * T[1][1] * dL_dc);
+                gcov[5] = (T[0][2] * T[0][2] * dL_da + T[0][2] * T[1][2] * dL_db + T[1][2] * T[1][2] * dL_dc);
+                gcov[1] = 2 * T[0][0] * T[0][1] * dL_da + (T[0][0] * T[1][1] + T[0][1] * T[1][0]) * dL_db +
+                          2 * T[1][0] * T[1][1] * dL_dc;
+                gcov[2] = 2 * T[0][0] * T[0][2] * dL_da + (T[0][0] * T[1][2] + T[0][2] * T[1][0]) * dL_db +
+                          2 * T[1][0] * T[1][2] * dL_dc;
+                gcov[4] = 2 * T[0][2] * T[0][1] * dL_da + (T[0][1] * T[1][2] + T[0][2] * T[1][1]) * dL_db +
+                          2 * T[1][1] * T[1][2] * dL_dc;
+            }
+            const float r0a = T[0][0] * Vrk[0][0] + T[0][1] * Vrk[0][1] + T[0][2] * Vrk[0][2];
+            const float r0b = T[0][0] * Vrk[1][0] + T[0][1] * Vrk[1][1] + T[0][2] * Vrk[1][2];
+            const float r0c = T[0][0] * Vrk[2][0] + T[0][1] * Vrk[2][1] + T[0][2] * Vrk[2][2];
+            const float r1a = T[1][0] * Vrk[0][0] + T[1][1] * Vrk[0][1] + T[1][2] * Vrk[0][2];
+            const float r1b = T[1][0] * Vrk[1][0] + T[1][1] * Vrk[1][1] + T[1][2] * Vrk[1][2];
+            const float r1c = T[1][0] * Vrk[2][0] + T[1][1] * Vrk[2][1] + T[1][2] * Vrk[2][2];
+            const float dL_dT00 = 2 * r0a * dL_da + r1a * dL_db;
+            const float dL_dT01 = 2 * r0b * dL_da + r1b * dL_db;
+            const float dL_dT02 = 2 * r0c * dL_da + r1c * dL_db;
+            const float dL_dT10 = 2 * r1a * dL_dc + r0a * dL_db;
+            const float dL_dT11 = 2 * r1b * dL_dc + r0b * dL_db;
+            const float dL_dT12 = 2 * r1c * dL_dc + r0c * dL_db;
+            const float dL_dJ00 = Wm[0][0] * dL_dT00 + Wm[0][1] * dL_dT01 + Wm[0][2] * dL_dT02;
+            const float dL_dJ02 = Wm[2][0] * dL_dT00 + Wm[2][1] * dL_dT01 + Wm[2][2] * dL_dT02;
+            const float dL_dJ11 = Wm[1][0] * dL_dT10 + Wm[1][1] * dL_dT11 + Wm[1][2] * dL_dT12;
+            const float dL_dJ12 = Wm[2][0] * dL_dT10 + Wm[2][1] * dL_dT11 + Wm[2][2] * dL_dT12;
+            const float tz = 1.f / c.t.z;
+            const float tz2 = tz * tz;
+            const float tz3 = tz2 * tz;
+            const float dL_dtx = x_grad_mul * -a.focal_x * tz2 * dL_dJ02;
+            const float dL_dty = y_grad_mul * -a.focal_y * tz2 * dL_dJ12;
+            const float dL_dtz = -a.focal_x * tz2 * dL_dJ00 - a.focal_y * tz2 * dL_dJ11 +
+                                 (2 * a.focal_x * c.t.x) * tz3 * dL_dJ02 + (2 * a.focal_y * c.t.y) * tz3 * dL_dJ12;
+            gmean = xform_vec_4x3_t({dL_dtx, dL_dty, dL_dtz}, a.view);
+        }
+        // ---- projection and depth paths of the mean gradient
+        {
+            const float* proj = a.proj;
+            const float* view = a.view;
+            const float4 m_hom = xform_point_4x4(mean, proj);
+            const float m_w = 1.0f / (m_hom.w + 0.0000001f);
+            const float mul1 = (proj[0] * mean.x + proj[4] * mean.y + proj[8] * mean.z + proj[12]) * m_w * m_w;
+            const float mul2 = (proj[1] * mean.x + proj[5] * mean.y + proj[9] * mean.z + proj[13]) * m_w * m_w;
+            const float d2x = dL_dmean2D[3 * idx], d2y = dL_dmean2D[3 * idx + 1];
+            V3 g1;
+            g1.x = (proj[0] * m_w - proj[3] * mul1) * d2x + (proj[1] * m_w - proj[3] * mul2) * d2y;
+            g1.y = (proj[4] * m_w - proj[7] * mul1) * d2x + (proj[5] * m_w - proj[7] * mul2) * d2y;
+            g1.z = (proj[8] * m_w - proj[11] * mul1) * d2x + (proj[9] * m_w - proj[11] * mul2) * d2y;
+            gmean = gmean + g1;
+            const float mul3 = view[2] * mean.x + view[6] * mean.y + view[10] * mean.z + view[14];
+            const float dd = dL_ddepth[idx];
+            V3 g2;
+            g2.x = (view[2] - view[3] * mul3) * dd;
+            g2.y = (view[6] - view[7] * mul3) * dd;
+            g2.z = (view[10] - view[11] * mul3) * dd;
+            gmean = gmean + g2;
+        }
+        // ---- SH backward (colour gradient -> SH coefficients and view-direction path of the mean)
+        if (a.shs) {
+            const V3 campos = {a.campos[0], a.campos[1], a.campos[2]};
+            const V3 dir_orig = mean - campos;
+            const V3 dir = dir_orig / sqrtf(dot3(dir_orig, dir_orig));
+            const V3* sh = reinterpret_cast<const V3*>(a.shs) + (size_t)idx * a.M;
+            const uint8_t cl = clamped[idx];
+            V3 g = {dL_dcolor[3 * idx], dL_dcolor[3 * idx + 1], dL_dcolor[3 * idx + 2]};
+            g.x *= (cl & 1) ? 0.f : 1.f;
+            g.y *= (cl & 2) ? 0.f : 1.f;
+            g.z *= (cl & 4) ? 0.f : 1.f;
+            V3 dRGBdx = {0, 0, 0}, dRGBdy = {0, 0, 0}, dRGBdz = {0, 0, 0};
+            const float x = dir.x, y = dir.y, z = dir.z;
+            const int ncoef = (a.D + 1) * (a.D + 1);
+            for (int k = ncoef; k < a.M; k++) dsh[k] = V3{0, 0, 0};
+            dsh[0] = kSH0 * g;
+            if (a.D > 0) {
+                dsh[1] = (-kSH1 * y) * g;
+                dsh[2] = (kSH1 * z) * g;
+                dsh[3] = (-kSH1 * x) * g;
+                dRGBdx = -kSH1 * sh[3];
+                dRGBdy = -kSH1 * sh[1];
+                dRGBdz = kSH1 * sh[2];
+                if (a.D > 1) {
+                    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                    dsh[4] = (kSH2[0] * xy) * g;
+                    dsh[5] = (kSH2[1] * yz) * g;
+                    dsh[6] = (kSH2[2] * (2.f * zz - xx - yy)) * g;
+                    dsh[7] = (kSH2[3] * xz) * g;
+                    dsh[8] = (kSH2[4] * (xx - yy)) * g;
+                    dRGBdx = dRGBdx + (kSH2[0] * y * sh[4] + kSH2[2] * 2.f * -x * sh[6] + kSH2[3] * z * sh[7] +
+                                       kSH2[4] * 2.f * x * sh[8]);
+                    dRGBdy = dRGBdy + (kSH2[0] * x * sh[4] + kSH2[1] * z * sh[5] + kSH2[2] * 2.f * -y * sh[6] +
+                                       kSH2[4] * 2.f * -y * sh[8]);
+                    dRGBdz = dRGBdz + (kSH2[1] * y * sh[5] + kSH2[2] * 2.f * 2.f * z * sh[6] + kSH2[3] * x * sh[7]);
+                    if (a.D > 2) {
+                        dsh[9] = (kSH3[0] * y * (3.f * xx - yy)) * g;
+                        dsh[10] = (kSH3[1] * xy * z) * g;
+                        dsh[11] = (kSH3[2] * y * (4.f * zz - xx - yy)) * g;
+                        dsh[12] = (kSH3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy)) * g;
+                        dsh[13] = (kSH3[4] * x * (4.f * zz - xx - yy)) * g;
+                        dsh[14] = (kSH3[5] * z * (xx - yy)) * g;
+                        dsh[15] = (kSH3[6] * x * (xx - 3.f * yy)) * g;
+                        dRGBdx = dRGBdx + (kSH3[0] * sh[9] * 3.f * 2.f * xy + kSH3[1] * sh[10] * yz +
+                                           kSH3[2] * sh[11] * -2.f * xy + kSH3[3] * sh[12] * -3.f * 2.f * xz +
+                                           kSH3[4] * sh[13] * (-3.f * xx + 4.f * zz - yy) +
+                                           kSH3[5] * sh[14] * 2.f * xz + kSH3[6] * sh[15] * 3.f * (xx - yy));
+                        dRGBdy = dRGBdy + (kSH3[0] * sh[9] * 3.f * (xx - yy) + kSH3[1] * sh[10] * xz +
+                                           kSH3[2] * sh[11] * (-3.f * yy + 4.f * zz - xx) +
+                                           kSH3[3] * sh[12] * -3.f * 2.f * yz + kSH3[4] * sh[13] * -2.f * xy +
+                                           kSH3[5] * sh[14] * -2.f * yz + kSH3[6] * sh[15] * -3.f * 2.f * xy);
+                        dRGBdz = dRGBdz + (kSH3[1] * sh[10] * xy + kSH3[2] * sh[11] * 4.f * 2.f * yz +
+                                           kSH3[3] * sh[12] * 3.f * (2.f * zz - xx - yy) +
+                                           kSH3[4] * sh[13] * 4.f * 2.f * xz + kSH3[5] * sh[14] * (xx - yy));
+                    }
+                }
+            }
+            const V3 dL_ddir = {dot3(dRGBdx, g), dot3(dRGBdy, g), dot3(dRGBdz, g)};
+            const V3 v = dir_orig;
+            const float sum2 = v.x * v.x + v.y * v.y + v.z * v.z;
+            const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+            V3 dm;
+            dm.x = ((+sum2 - v.x * v.x) * dL_ddir.x - v.y * v.x * dL_ddir.y - v.z * v.x * dL_ddir.z) * invsum32;
+            dm.y = (-v.x * v.y * dL_ddir.x + (sum2 - v.y * v.y) * dL_ddir.y - v.z * v.y * dL_ddir.z) * invsum32;
+            dm.z = (-v.x * v.z * dL_ddir.x - v.y * v.z * dL_ddir.y + (sum2 - v.z * v.z) * dL_ddir.z) * invsum32;
+            gmean = gmean + dm;
+        }
+        // ---- cov3D -> scale / rotation
+        if (a.scales) {
+            const float4 q = reinterpret_cast<const float4*>(a.rotations)[idx];
+            const float r = q.x, x = q.y, y = q.z, z = q.w;
+            const M3 R = rotation_from_quat(r, x, y, z);
+            M3 S = make_m3(1, 0, 0, 0, 1, 0, 0, 0, 1);
+            const V3 s = a.scale_modifier * V3{a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]};
+            S.c[0][0] = s.x;
+            S.c[1][1] = s.y;
+            S.c[2][2] = s.z;
+            const M3 Mm = mul(S, R);
+            const M3 dSig = make_m3(gcov[0], 0.5f * gcov[1], 0.5f * gcov[2], 0.5f * gcov[1], gcov[3], 0.5f * gcov[4],
+                                    0.5f * gcov[2], 0.5f * gcov[4], gcov[5]);
+            M3 M2 = Mm;
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) M2.c[i][j] = Mm.c[i][j] * 2.0f;
+            const M3 dL_dM = mul(M2, dSig);
+            const M3 Rt = transpose(R);
+            M3 dMt = transpose(dL_dM);
+            gscale.x = dot3(column(Rt, 0), column(dMt, 0));
+            gscale.y = dot3(column(Rt, 1), column(dMt, 1));
+            gscale.z = dot3(column(Rt, 2), column(dMt, 2));
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                dMt.c[0][j] *= s.x;
+                dMt.c[1][j] *= s.y;
+                dMt.c[2][j] *= s.z;
+            }
+            const auto& A = dMt.c;
+            grot.x = 2 * z * (A[0][1] - A[1][0]) + 2 * y * (A[2][0] - A[0][2]) + 2 * x * (A[1][2] - A[2][1]);
+            grot.y = 2 * y * (A[1][0] + A[0][1]) + 2 * z * (A[2][0] + A[0][2]) + 2 * r * (A[1][2] - A[2][1]) -
+                     4 * x * (A[2][2] + A[1][1]);
+            grot.z = 2 * x * (A[1][0] + A[0][1]) + 2 * r * (A[2][0] - A[0][2]) + 2 * z * (A[1][2] + A[2][1]) -
+                     4 * y * (A[2][2] + A[0][0]);
+            grot.w = 2 * r * (A[0][1] - A[1][0]) + 2 * x * (A[2][0] + A[0][2]) + 2 * y * (A[1][2] + A[2][1]) -
+                     4 * z * (A[1][1] + A[0][0]);
+        }
+    } else if (dsh) {
+        for (int k = 0; k < a.M; k++) dsh[k] = V3{0, 0, 0};
+    }
+    dL_dmean3D[3 * idx] = gmean.x;
+    dL_dmean3D[3 * idx + 1] = gmean.y;
+    dL_dmean3D[3 * idx + 2] = gmean.z;
+#pragma unroll
+    for (int i = 0; i < 6; i++) dL_dcov3D[(size_t)6 * idx + i] = gcov[i];
+    dL_dscale[3 * idx] = gscale.x;
+    dL_dscale[3 * idx + 1] = gscale.y;
+    dL_dscale[3 * idx + 2] = gscale.z;
+    reinterpret_cast<float4*>(dL_drot)[idx] = grot;
+}
+
+__global__ __launch_bounds__(256) void mark_visible_k(int P, const float* __restrict__ means3D, const float* view,
+                                                      uint8_t* __restrict__ present) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P) return;
+    const V3 p = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
+    float m[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) m[i] = view[i];
+    present[idx] = xform_point_4x3(p, m).z > 0.2f ? 1 : 0;
+}
+
+// Emits the (tile id, Gaussian id) instances of every visible Gaussian, walking the Gaussians in
+// depth order so that a stable sort by tile alone reproduces the reference's (tile, depth, id)
+// order (CR/rasterizer_impl.cu:70-111 emits 64-bit tile|depth keys in id order instead).
+__global__ __launch_bounds__(256) void emit_k(int P, int gx, int gy, const GaussRec* __restrict__ rec,
+                                              const int* __restrict__ radii, const uint32_t* __restrict__ order,
+                                              const uint32_t* __restrict__ offsets, uint32_t* __restrict__ keys,
+                                              uint32_t* __restrict__ vals) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const uint32_t g = order[i];
+    const int r = radii[g];
+    if (r <= 0) return;
+    const float4 q0 = rec[g].q0;
+    int x0, y0, x1, y1;
+    tile_rect(q0.x, q0.y, r, gx, gy, x0, y0, x1, y1);
+    uint32_t off = offsets[i];
+    for (int y = y0; y < y1; y++)
+        for (int x = x0; x < x1; x++) {
+            keys[off] = (uint32_t)(y * gx + x);
+            vals[off] = g;
+            off++;
+        }
+}
+
+// Per-tile [start,end) from the tile-sorted key list (CR/rasterizer_impl.cu:116-138).
+__global__ __launch_bounds__(256) void ranges_k(int N, const uint32_t* __restrict__ keys, uint2* __restrict__ ranges) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const uint32_t cur = keys[i];
+    if (i == 0)
+        ranges[cur].x = 0;
+    else {
+        const uint32_t prev = keys[i - 1];
+        if (cur != prev) {
+            ranges[prev].y = i;
+            ranges[cur].x = i;
+        }
+    }
+    if (i == N - 1) ranges[cur].y = N;
+}
+
+}  // namespace
+
+void launch_preprocess_fwd(const GoiRasterScene& sc, const GeomView& g, int* radii, hipStream_t s) {
+    PreArgs a;
+    a.P = sc.P; a.D = sc.D; a.M = sc.M; a.W = sc.W; a.H = sc.H;
+    a.gx = (sc.W + TILE - 1) / TILE;
+    a.gy = (sc.H + TILE - 1) / TILE;
+    a.prefiltered = sc.prefiltered;
+    a.means3D = sc.means3D; a.shs = sc.shs; a.colors_precomp = sc.colors_precomp; a.opacities = sc.opacities;
+    a.scales = sc.scales; a.rotations = sc.rotations; a.cov3D_precomp = sc.cov3D_precomp;
+    a.scale_modifier = sc.scale_modifier; a.tan_fovx = sc.tan_fovx; a.tan_fovy = sc.tan_fovy;
+    a.focal_y = sc.H / (2.0f * sc.tan_fovy);
+    a.focal_x = sc.W / (2.0f * sc.tan_fovx);
+    a.view_p = sc.viewmatrix; a.proj_p = sc.projmatrix; a.campos_p = sc.campos;
+    preprocess_fwd_k<<<dim3((sc.P + 255) / 256), dim3(256), 0, s>>>(a, g.rec, g.cov3D, g.tiles_touched, g.clamped,
+                                                                   g.sort_keys[0], g.sort_vals[0], radii, g.counters);
+}
+
+void launch_preprocess_bwd(const GoiRasterScene& sc, const GeomView& g, const int* radii, const float* dL_dmean2D,
+                           const float* dL_dconic, float* dL_dcolor, const float* dL_ddepth, float* dL_dmean3D,
+                           float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, hipStream_t s) {
+    BwdArgs a;
+    a.P = sc.P; a.D = sc.D; a.M = sc.M; a.W = sc.W; a.H = sc.H;
+    a.means3D = sc.means3D; a.shs = sc.shs; a.scales = sc.scales; a.rotations = sc.rotations;
+    a.cov3D = sc.cov3D_precomp ? sc.cov3D_precomp : g.cov3D;
+    a.scale_modifier = sc.scale_modifier; a.tan_fovx = sc.tan_fovx; a.tan_fovy = sc.tan_fovy;
+    a.focal_y = sc.H / (2.0f * sc.tan_fovy);
+    a.focal_x = sc.W / (2.0f * sc.tan_fovx);
+    a.view_p = sc.viewmatrix; a.proj_p = sc.projmatrix; a.campos_p = sc.campos;
+    preprocess_bwd_k<<<dim3((sc.P + 255) / 256), dim3(256), 0, s>>>(a, radii, g.clamped, dL_dmean2D, dL_dconic, dL_dcolor,
+                                                                   dL_ddepth, dL_dmean3D, dL_dcov3D,
+                                                                   (sc.shs && sc.M > 0) ? dL_dsh : nullptr, dL_dscale,
+                                                                   dL_drot);
+}
+
+void launch_emit(int P, int W, int H, const GeomView& g, const uint32_t* order, const int* radii, uint32_t* keys,
+                 uint32_t* vals, hipStream_t s) {
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+    emit_k<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, gx, gy, g.rec, radii, order, g.offsets, keys, vals);
+}
+
+void launch_ranges(int N, const uint32_t* sorted_keys, uint2* ranges, int T, hipStream_t s) {
+    (void)hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)T, s);
+    if (N > 0) ranges_k<<<dim3((N + 255) / 256), dim3(256), 0, s>>>(N, sorted_keys, ranges);
+}
+
+void launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s) {
+    mark_visible_k<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, means3D, view, present);
+}
+
+}  // namespace goi

@@ -1,0 +1,157 @@
+"""Python operator API of the rasterizer: the names, parameter order, defaults, return tuples and
+error messages of the reference's `diff_gaussian_rasterization` package
+(submodules/diff-gaussian-rasterization/diff_gaussian_rasterization/__init__.py), so that
+gaussian_renderer/__init__.py:14,36-95 and gui/gs_renderer.py:10-13,263-334 run unchanged.
+
+    GaussianRasterizationSettings   NamedTuple of per-view constants           (ref :246-258)
+    GaussianRasterizer              nn.Module: forward / trace / markVisible   (ref :260-349)
+    rasterize_gaussians, trace_gaussians                                        (ref :21-69)
+    _RasterizeGaussians             torch.autograd.Function                     (ref :71-244)
+
+Differences, all behind the same surface:
+  * compute goes through goi_hyperplane_amd._C (C ABI of libgoi_raster.so, hand-written HIP);
+  * the backward is gated on ctx.needs_input_grad only for what Python returns (the kernels always
+    produce the full gradient set in this version);
+  * the number of semantic channels S is read from `semantics.shape[1]` at run time (the reference
+    compiles SEM_CHANNELS = 10 in, cuda_rasterizer/config.h:18).
+"""
+from __future__ import annotations
+
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from . import _C
+
+
+def _cpu_snapshot(args):
+    return tuple(a.detach().cpu().clone() if isinstance(a, torch.Tensor) else a for a in args)
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def _forward_args(rs, means3D, colors_precomp, payload, opacities, scales, rotations, cov3Ds_precomp, sh):
+    """Argument order of _C.rasterize_gaussians / _C.rasterize_gaussians_trace (ext.cpp:15-20)."""
+    return (rs.bg, means3D, colors_precomp, payload, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+            rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree,
+            rs.campos, rs.prefiltered, rs.debug)
+
+
+def _call_with_snapshot(fn, args, debug, dump_name, what):
+    """debug=True: keep a CPU copy of the arguments and dump it if the call raises (ref :112-119,165-172)."""
+    if not debug:
+        return fn(*args)
+    snapshot = _cpu_snapshot(args)
+    try:
+        return fn(*args)
+    except Exception:
+        torch.save(snapshot, dump_name)
+        print(f"\nAn error occured in {what}. Please forward {dump_name} for debugging.")
+        raise
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, semantics, opacities, scales, rotations, cov3Ds_precomp,
+                raster_settings):
+        args = _forward_args(raster_settings, means3D, colors_precomp, semantics, opacities, scales, rotations,
+                             cov3Ds_precomp, sh)
+        (num_rendered, color, semant, depth, alpha, radii, geomBuffer, binningBuffer, imgBuffer) = _call_with_snapshot(
+            _C.rasterize_gaussians, args, raster_settings.debug, "snapshot_fw.dump", "forward")
+        ctx.raster_settings = raster_settings
+        ctx.num_rendered = num_rendered
+        ctx.save_for_backward(colors_precomp, semantics, means3D, scales, rotations, cov3Ds_precomp, radii, sh,
+                              geomBuffer, binningBuffer, imgBuffer, alpha)
+        ctx.mark_non_differentiable(radii)
+        return color, semant, radii, depth, alpha
+
+    @staticmethod
+    def backward(ctx, grad_out_color, grad_out_sem, grad_out_radii, grad_depth, grad_alpha):
+        rs = ctx.raster_settings
+        (colors_precomp, semantics, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer,
+         imgBuffer, alpha) = ctx.saved_tensors
+        args = (rs.bg, means3D, radii, colors_precomp, semantics, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+                rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, grad_out_sem, grad_depth,
+                grad_alpha, sh, rs.sh_degree, rs.campos, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, alpha,
+                rs.debug)
+        (grad_means2D, grad_colors_precomp, grad_semantics, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
+         grad_scales, grad_rotations) = _call_with_snapshot(_C.rasterize_gaussians_backward, args, rs.debug,
+                                                            "snapshot_bw.dump", "backward")
+        # input order: means3D, means2D, sh, colors_precomp, semantics, opacities, scales, rotations, cov3Ds_precomp
+        return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_semantics, grad_opacities, grad_scales,
+                grad_rotations, grad_cov3Ds_precomp, None)
+
+    @staticmethod
+    def trace(means3D, means2D, sh, colors_precomp, img_sem, opacities, scales, rotations, cov3Ds_precomp,
+              raster_settings):
+        args = _forward_args(raster_settings, means3D, colors_precomp, img_sem, opacities, scales, rotations,
+                             cov3Ds_precomp, sh)
+        (num_rendered, color, gau_sem, num_gsem, geomBuffer, binningBuffer, imgBuffer) = _call_with_snapshot(
+            _C.rasterize_gaussians_trace, args, raster_settings.debug, "snapshot_fw.dump", "forward")
+        return color, gau_sem, num_gsem
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, semantics, opacities, scales, rotations, cov3Ds_precomp,
+                        raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, semantics, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings)
+
+
+def trace_gaussians(means3D, means2D, sh, colors_precomp, img_sem, opacities, scales, rotations, cov3Ds_precomp,
+                    raster_settings):
+    return _RasterizeGaussians.trace(means3D, means2D, sh, colors_precomp, img_sem, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings)
+
+
+def _check_exclusive(shs, colors_precomp, scales, rotations, cov3D_precomp):
+    if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+        raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+    if ((scales is None or rotations is None) and cov3D_precomp is None) or (
+            (scales is not None or rotations is not None) and cov3D_precomp is not None):
+        raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+
+
+def _absent_to_empty(*tensors):
+    """None -> an empty CPU tensor, the reference's marker for an absent optional input (ref :286-297)."""
+    return tuple(torch.Tensor([]) if t is None else t for t in tensors)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        with torch.no_grad():
+            rs = self.raster_settings
+            return _C.mark_visible(positions, rs.viewmatrix, rs.projmatrix)
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, semantics=None, scales=None,
+                rotations=None, cov3D_precomp=None):
+        _check_exclusive(shs, colors_precomp, scales, rotations, cov3D_precomp)
+        shs, colors_precomp, semantics, scales, rotations, cov3D_precomp = _absent_to_empty(
+            shs, colors_precomp, semantics, scales, rotations, cov3D_precomp)
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, semantics, opacities, scales, rotations,
+                                   cov3D_precomp, self.raster_settings)
+
+    def trace(self, means3D, means2D, opacities, shs=None, colors_precomp=None, img_sem=None, scales=None,
+              rotations=None, cov3D_precomp=None):
+        _check_exclusive(shs, colors_precomp, scales, rotations, cov3D_precomp)
+        shs, colors_precomp, img_sem, scales, rotations, cov3D_precomp = _absent_to_empty(
+            shs, colors_precomp, img_sem, scales, rotations, cov3D_precomp)
+        return trace_gaussians(means3D, means2D, shs, colors_precomp, img_sem, opacities, scales, rotations,
+                               cov3D_precomp, self.raster_settings)

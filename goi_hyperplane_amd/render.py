@@ -1,0 +1,160 @@
+"""Render harness: the build's equivalent of gaussian_renderer.render (reference
+gaussian_renderer/__init__.py:18-105) and of gui/gs_renderer.py:231-348's Renderer.render, working on
+a minimal Gaussian container instead of scene.GaussianModel (which needs plyfile / simple_knn).
+
+Same settings construction, same choice between SH / precomputed colours and scale+rotation /
+precomputed covariance, same output dictionary keys.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import torch
+
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+
+SH_C0 = 0.28209479177387814
+SH_C1 = 0.4886025119029199
+SH_C2 = (1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792, 0.5462742152960396)
+SH_C3 = (-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154, -0.4570457994644658,
+         1.445305721320277, -0.5900435899266435)
+
+
+@dataclass
+class PipelineParams:
+    """arguments/__init__.py:56-62"""
+    convert_SHs_python: bool = False
+    compute_cov3D_python: bool = False
+    debug: bool = False
+
+
+class GaussianSet(torch.nn.Module):
+    """The accessor surface of scene.GaussianModel that render() touches
+    (get_xyz / get_opacity / get_scaling / get_rotation / get_features / get_semantics /
+    get_covariance, scene/gaussian_model.py:90-127), holding already-activated tensors."""
+
+    def __init__(self, means3D, scales, rotations, opacities, shs, semantics, sh_degree=3, max_sh_degree=3):
+        super().__init__()
+        P = torch.nn.Parameter
+        self._xyz = P(means3D)
+        self._scaling = P(scales)
+        self._rotation = P(rotations)
+        self._opacity = P(opacities)
+        self._features = P(shs)
+        self._semantics = P(semantics)
+        self.active_sh_degree = sh_degree
+        self.max_sh_degree = max_sh_degree
+        self._semantics_masks = None
+
+    @classmethod
+    def from_scene(cls, scene, device):
+        t = lambda a: torch.tensor(a, dtype=torch.float32, device=device)  # noqa: E731
+        return cls(t(scene.means3D), t(scene.scales), t(scene.rotations), t(scene.opacities), t(scene.shs),
+                   t(scene.semantics), scene.sh_degree)
+
+    get_xyz = property(lambda self: self._xyz)
+    get_scaling = property(lambda self: self._scaling)
+    get_rotation = property(lambda self: self._rotation)
+    get_opacity = property(lambda self: self._opacity)
+    get_features = property(lambda self: self._features)
+
+    @property
+    def get_semantics(self):  # scene/gaussian_model.py:108-113
+        return self._semantics if self._semantics_masks is None else self._semantics * self._semantics_masks
+
+    def set_semantic_masks(self, masks=None):  # scene/gaussian_model.py:119-123
+        self._semantics_masks = None if masks is None else masks.unsqueeze(1)
+
+    def get_covariance(self, scaling_modifier=1.0):  # scene/gaussian_model.py:33-37,125-126
+        return covariance_from_scaling_rotation(self._scaling, scaling_modifier, self._rotation)
+
+
+def covariance_from_scaling_rotation(scaling, scaling_modifier, rotation):
+    """L = R(q/|q|) diag(s*mod); Sigma = L L^T; packed xx,xy,xz,yy,yz,zz (utils/general_utils.py:70-122)."""
+    q = rotation / rotation.norm(dim=1, keepdim=True)
+    r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                     2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                     2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], dim=-1).reshape(-1, 3, 3)
+    L = R * (scaling_modifier * scaling)[:, None, :]
+    S = L @ L.transpose(1, 2)
+    return torch.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], dim=-1)
+
+
+def eval_sh(deg, sh, dirs):
+    """sh [P,3,(deg+1)^2...], dirs [P,3] unit -> [P,3]; the polynomial form of utils/sh_utils.py:57-112."""
+    res = SH_C0 * sh[..., 0]
+    if deg > 0:
+        x, y, z = dirs[..., 0:1], dirs[..., 1:2], dirs[..., 2:3]
+        res = res - SH_C1 * y * sh[..., 1] + SH_C1 * z * sh[..., 2] - SH_C1 * x * sh[..., 3]
+        if deg > 1:
+            xx, yy, zz, xy, yz, xz = x * x, y * y, z * z, x * y, y * z, x * z
+            res = (res + SH_C2[0] * xy * sh[..., 4] + SH_C2[1] * yz * sh[..., 5]
+                   + SH_C2[2] * (2.0 * zz - xx - yy) * sh[..., 6] + SH_C2[3] * xz * sh[..., 7]
+                   + SH_C2[4] * (xx - yy) * sh[..., 8])
+            if deg > 2:
+                res = (res + SH_C3[0] * y * (3 * xx - yy) * sh[..., 9] + SH_C3[1] * xy * z * sh[..., 10]
+                       + SH_C3[2] * y * (4 * zz - xx - yy) * sh[..., 11]
+                       + SH_C3[3] * z * (2 * zz - 3 * xx - 3 * yy) * sh[..., 12]
+                       + SH_C3[4] * x * (4 * zz - xx - yy) * sh[..., 13] + SH_C3[5] * z * (xx - yy) * sh[..., 14]
+                       + SH_C3[6] * x * (xx - 3 * yy) * sh[..., 15])
+    return res
+
+
+class TorchCamera:
+    """Device-side view constants (scene/cameras.py:17-48 fields that render() reads)."""
+
+    def __init__(self, cam, device):
+        self.image_width, self.image_height = cam.image_width, cam.image_height
+        self.FoVx, self.FoVy = cam.FoVx, cam.FoVy
+        self.world_view_transform = torch.tensor(cam.world_view_transform, device=device)
+        self.full_proj_transform = torch.tensor(cam.full_proj_transform, device=device)
+        self.camera_center = torch.tensor(cam.camera_center, device=device)
+
+
+def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, gaussian_mask=None):
+    """gaussian_renderer.render; `gaussian_mask` adds gui/gs_renderer.py:315-321's index-select."""
+    dev = pc.get_xyz.device
+    screenspace_points = torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True, device=dev) + 0
+    try:
+        screenspace_points.retain_grad()
+    except Exception:
+        pass
+    raster_settings = GaussianRasterizationSettings(
+        image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
+        tanfovx=math.tan(viewpoint_camera.FoVx * 0.5), tanfovy=math.tan(viewpoint_camera.FoVy * 0.5), bg=bg_color,
+        scale_modifier=scaling_modifier, viewmatrix=viewpoint_camera.world_view_transform,
+        projmatrix=viewpoint_camera.full_proj_transform, sh_degree=pc.active_sh_degree,
+        campos=viewpoint_camera.camera_center, prefiltered=False, debug=pipe.debug)
+    rasterizer = GaussianRasterizer(raster_settings=raster_settings)
+
+    means3D, means2D, opacity = pc.get_xyz, screenspace_points, pc.get_opacity
+    scales = rotations = cov3D_precomp = None
+    if pipe.compute_cov3D_python:
+        cov3D_precomp = pc.get_covariance(scaling_modifier)
+    else:
+        scales, rotations = pc.get_scaling, pc.get_rotation
+    shs = colors_precomp = None
+    if override_color is None:
+        if pipe.convert_SHs_python:
+            shs_view = pc.get_features.transpose(1, 2).view(-1, 3, (pc.max_sh_degree + 1) ** 2)
+            dir_pp = pc.get_xyz - viewpoint_camera.camera_center.repeat(pc.get_features.shape[0], 1)
+            dir_pp_normalized = dir_pp / dir_pp.norm(dim=1, keepdim=True)
+            colors_precomp = torch.clamp_min(eval_sh(pc.active_sh_degree, shs_view, dir_pp_normalized) + 0.5, 0.0)
+        else:
+            shs = pc.get_features
+    else:
+        colors_precomp = override_color
+    semantics = pc.get_semantics
+
+    if gaussian_mask is not None:
+        sel = lambda t: None if t is None else t[gaussian_mask]  # noqa: E731
+        semantics, means3D, scales, rotations, opacity, shs = map(sel, (semantics, means3D, scales, rotations, opacity, shs))
+        cov3D_precomp, colors_precomp, means2D = sel(cov3D_precomp), sel(colors_precomp), sel(means2D)
+
+    rendered_image, rendered_sem, radii, depth, alpha = rasterizer(
+        means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, semantics=semantics,
+        opacities=opacity, scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
+    return {"render": rendered_image, "semantics": rendered_sem, "depth": depth, "alpha": alpha,
+            "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii}

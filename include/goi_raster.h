@@ -1,0 +1,140 @@
+/*
+ * include/goi_raster.h -- C ABI of libgoi_raster.so, the MI355X (gfx950) differentiable Gaussian
+ * rasterizer with a per-Gaussian semantic-feature channel.
+ *
+ * This is the drop-in boundary for the reference's rasterizer hot path.  Each entry point replaces
+ * one C++ entry of the reference (paths relative to submodules/diff-gaussian-rasterization/):
+ *
+ *   goi_raster_forward      <- CudaRasterizer::Rasterizer::forward   cuda_rasterizer/rasterizer.h:20-46,
+ *                              called from RasterizeGaussiansCUDA    rasterize_points.cu:35-123
+ *   goi_raster_backward     <- CudaRasterizer::Rasterizer::backward  cuda_rasterizer/rasterizer.h:75-111,
+ *                              called from RasterizeGaussiansBackwardCUDA rasterize_points.cu:213-306
+ *   goi_raster_trace        <- CudaRasterizer::Rasterizer::trace     cuda_rasterizer/rasterizer.h:48-73,
+ *                              called from TraceGaussiansCUDA        rasterize_points.cu:125-211
+ *   goi_raster_mark_visible <- CudaRasterizer::Rasterizer::markVisible cuda_rasterizer/rasterizer.h:13-18,
+ *                              called from markVisible               rasterize_points.cu:308-327
+ *   goi_raster_*_bytes      <- required<GeometryState/ImageState/BinningState>() cuda_rasterizer/rasterizer_impl.h:67-73
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (torch tensors in the Python binding);
+ *     no torch types cross this boundary; inputs are never written;
+ *   - an absent optional input is NULL (the reference's "empty tensor => nullptr", rasterize_points.cu:98-111);
+ *   - all arrays are contiguous fp32 unless stated; matrices are 16 floats in the reference's
+ *     transposed (row-vector) convention (cuda_rasterizer/auxiliary.h:58-77);
+ *   - the three workspaces are opaque bytes sized by goi_raster_*_bytes(); the binning workspace
+ *     size depends on num_rendered, which is only known mid-call, so the caller passes an
+ *     allocation callback (the reference's std::function<char*(size_t)>, rasterize_points.cu:27-33);
+ *   - outputs need not be initialised by the caller; every element is written;
+ *   - `stream` is a hipStream_t (NULL = the default stream); all work is enqueued on it; the only
+ *     host synchronisation is the read-back of num_rendered inside forward/trace (the reference
+ *     has the same one, cuda_rasterizer/rasterizer_impl.cu:285);
+ *   - return value: >= 0 on success (forward/trace: num_rendered), < 0 on error with the message
+ *     available from goi_raster_last_error() (thread-local).
+ *   - supported S (semantic channels): any 1..32; fast paths are instantiated for 10 and 16.
+ */
+#ifndef GOI_RASTER_H
+#define GOI_RASTER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GOI_RASTER_ABI_VERSION 1
+
+typedef struct GoiRasterScene {
+    int P;                       /* number of Gaussians */
+    int D;                       /* active SH degree, 0..3 */
+    int M;                       /* SH coefficients per colour channel held in shs (0 if shs == NULL) */
+    int S;                       /* semantic channels */
+    int W, H;                    /* image width, height */
+    const float* bg;             /* [3] */
+    const float* means3D;        /* [P,3] */
+    const float* shs;            /* [P,M,3] or NULL */
+    const float* colors_precomp; /* [P,3] or NULL */
+    const float* semantics;      /* [P,S] (forward/backward) */
+    const float* opacities;      /* [P] */
+    const float* scales;         /* [P,3] or NULL */
+    float scale_modifier;
+    const float* rotations;      /* [P,4] (r,x,y,z) or NULL */
+    const float* cov3D_precomp;  /* [P,6] or NULL */
+    const float* viewmatrix;     /* [16] */
+    const float* projmatrix;     /* [16] */
+    const float* campos;         /* [3] */
+    float tan_fovx, tan_fovy;
+    int prefiltered;
+    int debug;                   /* synchronise and check after every stage */
+} GoiRasterScene;
+
+/* Device-memory allocation callback: must return a device pointer to at least `bytes` bytes that
+ * stays valid until the matching backward has run (NULL = failure). */
+typedef void* (*goi_alloc_fn)(void* user, size_t bytes);
+
+int goi_raster_abi_version(void);
+const char* goi_raster_last_error(void);
+
+size_t goi_raster_geom_bytes(int P);
+size_t goi_raster_image_bytes(int W, int H);
+size_t goi_raster_binning_bytes(int num_rendered);
+
+/* Forward: color[3,H,W], semantic[S,H,W], depth[H,W], alpha[H,W], radii[P] (int32). */
+int goi_raster_forward(const GoiRasterScene* scene, void* geom_buffer, void* image_buffer,
+                       goi_alloc_fn binning_alloc, void* alloc_user,
+                       float* out_color, float* out_semantic, float* out_depth, float* out_alpha,
+                       int* radii, void* stream);
+
+/* Backward of the forward that filled the three workspaces.  R = that forward's return value.
+ * dL_dconic is [P,4] (x: a, y: b, z: unused, w: c), dL_dsh [P,M,3] (may be NULL when M == 0). */
+int goi_raster_backward(const GoiRasterScene* scene, int R,
+                        const void* geom_buffer, const void* binning_buffer, const void* image_buffer,
+                        const int* radii, const float* out_alpha,
+                        const float* dL_dout_color, const float* dL_dout_semantic,
+                        const float* dL_dout_depth, const float* dL_dout_alpha,
+                        float* dL_dmean2D /*[P,3]*/, float* dL_dconic /*[P,4]*/, float* dL_dopacity /*[P]*/,
+                        float* dL_dcolor /*[P,3]*/, float* dL_dsemantic /*[P,S]*/, float* dL_ddepth /*[P]*/,
+                        float* dL_dmean3D /*[P,3]*/, float* dL_dcov3D /*[P,6]*/, float* dL_dsh /*[P,M,3]*/,
+                        float* dL_dscale /*[P,3]*/, float* dL_drot /*[P,4]*/, void* stream);
+
+/* Trace: scene->semantics is ignored; img_sem[S,H,W] is scattered onto the Gaussians it meets
+ * with alpha > 0.005.  out_color[3,H,W], gau_sem[P,S], num_gsem[P] (int32), radii[P]. */
+int goi_raster_trace(const GoiRasterScene* scene, const float* img_sem, void* geom_buffer, void* image_buffer,
+                     goi_alloc_fn binning_alloc, void* alloc_user,
+                     float* out_color, float* gau_sem, int* num_gsem, int* radii, void* stream);
+
+/* present[P] (bytes, 0/1): view-space z > 0.2. */
+int goi_raster_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                            uint8_t* present, void* stream);
+
+/* ---- measurement hooks (bench.py): per-stage HIP-event timing on the launch stream ---------- */
+enum {
+    GOI_STAGE_PREPROCESS = 0,   /* forward per-Gaussian kernel */
+    GOI_STAGE_DEPTH_SORT,       /* radix sort of Gaussians by depth */
+    GOI_STAGE_SCAN,             /* prefix sum of tiles_touched + num_rendered read-back */
+    GOI_STAGE_EMIT,             /* (tile, Gaussian) instance emission */
+    GOI_STAGE_TILE_SORT,        /* stable radix sort of instances by tile */
+    GOI_STAGE_RANGES,           /* per-tile [start,end) */
+    GOI_STAGE_BLEND_FWD,        /* forward alpha blend */
+    GOI_STAGE_BLEND_BWD,        /* backward alpha blend */
+    GOI_STAGE_PREPROCESS_BWD,   /* cov2D + projection + SH + cov3D backward */
+    GOI_STAGE_COUNT
+};
+/* on != 0: record events around every stage of subsequent calls (adds event overhead). */
+void goi_raster_profile_enable(int on);
+/* Synchronises the recorded events and ADDS each stage's elapsed milliseconds and launch count
+ * since the last reset into ms[GOI_STAGE_COUNT] / calls[GOI_STAGE_COUNT]; then resets. */
+int goi_raster_profile_collect(double* ms, int* calls);
+
+/* Inspection of the opaque workspaces (tests only): copies device -> caller DEVICE buffers.
+ * Any pointer may be NULL.  point_list is in final sorted order. */
+int goi_raster_debug_views(int P, int W, int H, int R, const void* geom_buffer, const void* binning_buffer,
+                           const void* image_buffer,
+                           float* depths /*[P]*/, float* means2D /*[P,2]*/, float* conic_opacity /*[P,4]*/,
+                           float* rgb /*[P,3]*/, uint32_t* tiles_touched /*[P]*/, uint32_t* point_list /*[R]*/,
+                           uint32_t* ranges /*[T,2]*/, uint32_t* n_contrib /*[H*W]*/, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
