@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""bench.py -- training views/s (+ render ms/frame) of the rasterizer hot path on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W                         # one GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W          # N GPUs (driver launches this)
+
+Workload (BASELINE.json metric): 1M Gaussians, 1600x1056, RGB from SH degree 3 + 16-d semantic
+feature, fp32; synthetic scene of SURVEY.md 8(d) (goi_hyperplane_amd.scene.HEADLINE).
+A "step" = one training view on every rank: rasterizer forward + backward through the reference-
+shaped autograd operator (loss = (sum colour + sum semantics)/HW), then -- when N > 1 -- the sum
+all-reduce of the Gaussian gradients over RCCL.  Views are independent, so ranks shard them
+(weak scaling: one view per rank per step); value = N*K / max-over-ranks time.
+
+The JSON line also carries
+  roofline     : for the dominant kernel (largest share of the timed region): achieved =
+                 algorithmic bytes per launch (DESIGN.md / SURVEY.md 8(d)) / average duration
+                 measured with HIP events on the launch stream inside the timed region;
+  cpu_baseline : the CPU oracle ("port": oracle/goi_oracle.cpp, OpenMP) timed on rank 0 at N = 1
+                 on a bounded sample of the same workload;
+  stages       : per-stage average ms and algorithmic GB/s (every stage, not only the dominant).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def stage_bytes(P, V, N, T, HW, S):
+    """Algorithmic (compulsory) bytes per view and stage, fp32, every array touched once
+    (SURVEY.md 8(d) derivation; the per-stage split sums to B_fwd / B_bwd)."""
+    C = 3
+    return {
+        "preprocess": 60 * P + 259 * V,
+        "depth_sort": 16 * V,                 # this build's extra stage: (key,id) read + write once
+        "scan": 8 * P,
+        "emit": 12 * V + 12 * N,
+        "tile_sort": 24 * N,
+        "ranges": 8 * N + 24 * T,
+        "blend_fwd": (4 + 24 + 4 * (C + S + 1)) * N + 4 * (6 + S) * HW,
+        "blend_bwd": (84 + 8 * S) * N + 4 * (7 + S) * HW,
+        "preprocess_bwd": 4 * (76 + S) * P + 627 * V,
+    }
+
+
+def survey_bytes(P, V, N, T, HW, S):
+    b_fwd = 68 * P + 271 * V + (72 + 4 * (4 + S)) * N + 4 * (6 + S) * HW + 24 * T
+    b_bwd = 4 * (76 + S) * P + 627 * V + (84 + 8 * S) * N + 4 * (7 + S) * HW
+    return b_fwd, b_bwd
+
+
+def cpu_baseline(args, n_full_per_view):
+    """Times the CPU oracle (forward + backward, all host threads) on a bounded sample: the first
+    P_sample Gaussians of the same scene at the full resolution; linear extrapolation in N."""
+    from goi_hyperplane_amd.scene import HEADLINE, make_camera, make_scene
+    from oracle import oracle
+    oracle.build()
+    cores = os.cpu_count() or 1
+    Ps = min(args.P, args.cpu_sample_P)
+    sc = make_scene(Ps, S=args.S, sh_degree=3, seed=0, extent=HEADLINE["extent"], log_scale_mean=args.mu,
+                    log_scale_std=HEADLINE["log_scale_std"])
+    cam = make_camera(args.W, args.H, fovx=HEADLINE["fovx"])
+    o = oracle.from_scene(sc, cam, threads=cores)
+    HW = args.W * args.H
+    t0 = time.perf_counter()
+    f = o.forward()
+    t1 = time.perf_counter()
+    o.backward(np.full((3, args.H, args.W), 1.0 / HW, np.float32), np.full((args.S, args.H, args.W), 1.0 / HW, np.float32))
+    t2 = time.perf_counter()
+    sample_s = t2 - t0
+    scale = max(n_full_per_view, 1) / max(f.num_rendered, 1)
+    return {
+        "value": 1.0 / (sample_s * scale), "unit": "views/s", "cores": cores, "kind": "port",
+        "sample": f"oracle fwd+bwd on the first {Ps} of {args.P} Gaussians at {args.W}x{args.H}, S={args.S}: "
+                  f"N={f.num_rendered}, fwd {t1 - t0:.2f} s + bwd {t2 - t1:.2f} s; value extrapolated linearly in N "
+                  f"to N={n_full_per_view}",
+        "sample_seconds": sample_s, "sample_num_rendered": int(f.num_rendered),
+    }
+
+
+def main():
+    from goi_hyperplane_amd.scene import HEADLINE
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--P", type=int, default=HEADLINE["P"])
+    ap.add_argument("--S", type=int, default=HEADLINE["S"])
+    ap.add_argument("--W", type=int, default=HEADLINE["W"])
+    ap.add_argument("--H", type=int, default=HEADLINE["H"])
+    ap.add_argument("--mu", type=float, default=HEADLINE["log_scale_mean"], help="log-scale mean of the generator")
+    ap.add_argument("--views", type=int, default=16, help="distinct cameras cycled through")
+    ap.add_argument("--grads", choices=["all", "semantics"], default="all",
+                    help="which Gaussian gradients are all-reduced when --gpus > 1")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-P", type=int, default=100_000)
+    ap.add_argument("--no-stage-timing", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a ROCm GPU; there is no CPU fallback"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from goi_hyperplane_amd import _lib
+    from goi_hyperplane_amd.dist import allreduce_gradients
+    from goi_hyperplane_amd.render import GaussianSet, PipelineParams, TorchCamera, render
+    from goi_hyperplane_amd.scene import make_camera, make_scene
+    _lib.load()
+
+    sc = make_scene(args.P, S=args.S, sh_degree=3, seed=0, extent=HEADLINE["extent"], log_scale_mean=args.mu,
+                    log_scale_std=HEADLINE["log_scale_std"])  # identical replica on every rank
+    pc = GaussianSet.from_scene(sc, dev)
+    params = [pc._xyz, pc._features, pc._semantics, pc._opacity, pc._scaling, pc._rotation]
+    reduce_params = params if args.grads == "all" else [pc._semantics]
+    cams = [TorchCamera(make_camera(args.W, args.H, fovx=HEADLINE["fovx"], yaw=0.02 * (i - args.views / 2),
+                                    pitch=0.01 * ((i * 7) % 5 - 2)), dev) for i in range(args.views)]
+    bg = torch.zeros(3, device=dev)
+    pipe = PipelineParams()
+    HW = args.W * args.H
+    T = ((args.W + 15) // 16) * ((args.H + 15) // 16)
+    inv_hw = 1.0 / HW
+    stats = {"V": 0, "N": 0, "views": 0}
+
+    def step(i, record=False):
+        cam = cams[(i * world + rank) % len(cams)]  # rank r takes views r, r+G, ... of the cycle
+        for p in params:
+            p.grad = None
+        out = render(cam, pc, pipe, bg)
+        loss = (out["render"].sum() + out["semantics"].sum()) * inv_hw
+        loss.backward()
+        if world > 1:
+            allreduce_gradients(reduce_params, dist)
+        if record:
+            stats["radii"] = out["radii"]
+        return out
+
+    for i in range(args.warmup):
+        step(i)
+    # workload statistics of the views this rank will time (outside the timed region)
+    with torch.no_grad():
+        from goi_hyperplane_amd import _C
+        for i in range(min(args.steps, len(cams))):
+            cam = cams[((args.warmup + i) * world + rank) % len(cams)]
+            n, *_r = _C.rasterize_gaussians(bg, pc._xyz, torch.Tensor([]), pc._semantics, pc._opacity, pc._scaling,
+                                            pc._rotation, 1.0, torch.Tensor([]), cam.world_view_transform,
+                                            cam.full_proj_transform, np.tan(cam.FoVx * 0.5), np.tan(cam.FoVy * 0.5),
+                                            args.H, args.W, pc._features, 3, cam.camera_center, False, False)
+            stats["N"] += n
+            stats["V"] += int((_r[4] > 0).sum())
+            stats["views"] += 1
+            del _r
+    V = stats["V"] / stats["views"]
+    N = stats["N"] / stats["views"]
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    timing = not args.no_stage_timing
+    if timing:
+        _lib.profile_collect()  # drop anything recorded so far
+        _lib.profile_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    stages = {}
+    if timing:
+        _lib.profile_enable(False)
+        stages = _lib.profile_collect()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # render ms/frame: forward only, no_grad (the GUI path, gui/main.py:556-602), outside the step timing
+    with torch.no_grad():
+        for i in range(2):
+            render(cams[i % len(cams)], pc, pipe, bg)
+        barrier()
+        r0 = time.perf_counter()
+        nfr = max(5, min(args.steps, 50))
+        for i in range(nfr):
+            render(cams[(i * world + rank) % len(cams)], pc, pipe, bg)
+        barrier()
+        render_ms = (time.perf_counter() - r0) / nfr * 1e3
+
+    if rank == 0:
+        sb = stage_bytes(args.P, V, N, T, HW, args.S)
+        b_fwd, b_bwd = survey_bytes(args.P, V, N, T, HW, args.S)
+        stage_out = {}
+        dominant, dom_ms = None, -1.0
+        for name, (ms, calls) in stages.items():
+            if calls == 0:
+                continue
+            avg = ms / calls
+            gbs = sb[name] / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
+            stage_out[name] = {"ms": round(avg, 4), "launches": calls, "alg_MB": round(sb[name] / 1e6, 2),
+                               "alg_GBps": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4)}
+            if ms > dom_ms:
+                dominant, dom_ms = name, ms
+        roofline = None
+        if dominant:
+            d = stage_out[dominant]
+            roofline = {"bound": "hbm", "kernel": dominant, "achieved": d["alg_GBps"], "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": d["hbm_frac"], "traffic": None,
+                        "bytes_per_launch": sb[dominant], "avg_ms": d["ms"]}
+        gpu_ms = sum(v["ms"] for v in stage_out.values())
+        ms_per_step = elapsed / args.steps * 1e3
+        res = {
+            "metric": "training views/sec (rasterizer fwd+bwd), 1M Gaussians @1600x1056 RGB+16-d feat",
+            "value": args.steps * world / elapsed, "unit": "views/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.P} Gaussians @{args.W}x{args.H}, SH deg 3 RGB + {args.S}-d semantic, fwd+bwd"
+                                   f"{' + RCCL all-reduce(' + args.grads + ' grads)' if world > 1 else ''}",
+                       "P": args.P, "V": V, "N_per_view": N, "tiles": T, "HW": HW, "S": args.S,
+                       "views_per_step": world, "parallelism": f"views sharded x{world}",
+                       "allreduce_bytes": int(sum(p.numel() for p in reduce_params) * 4) if world > 1 else 0},
+            "render_ms_per_frame": render_ms,
+            "roofline": roofline,
+            "whole_view": {"alg_bytes_fwd": b_fwd, "alg_bytes_bwd": b_bwd,
+                           "alg_GBps_over_step": (b_fwd + b_bwd) / (ms_per_step * 1e-3) / 1e9,
+                           "hbm_frac_over_step": (b_fwd + b_bwd) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "gpu_stage_ms_sum": gpu_ms},
+            "stages": stage_out,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(args, int(N))
+        else:
+            res["cpu_baseline"] = None
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -222,13 +222,15 @@ def test_trace_matches_oracle(oracle_mod, dev):
     tc = TorchCamera(cam, dev)
     img = np.random.default_rng(1).normal(size=(10, 64, 96)).astype(np.float32)
     o = oracle_mod.from_scene(sc, cam)
+    ok = o.forward().fragile == 0  # same colour path: mask pixels that sit on a blend guard
     n, color, gau_sem, num = o.trace(img)
     rs = GaussianRasterizationSettings(64, 96, cam.tanfovx, cam.tanfovy, torch.zeros(3, device=dev), 1.0,
                                        tc.world_view_transform, tc.full_proj_transform, 3, tc.camera_center, False, False)
     t = lambda a: torch.tensor(a, device=dev)  # noqa: E731
     c2, g2, n2 = GaussianRasterizer(rs).trace(t(sc.means3D), None, t(sc.opacities), shs=t(sc.shs), img_sem=t(img),
                                               scales=t(sc.scales), rotations=t(sc.rotations))
-    assert np.abs(c2.cpu().numpy() - color).max() < 2e-4
+    assert ok.mean() > 0.98
+    assert np.abs(c2.cpu().numpy() - color)[:, ok].max() < FWD_TOL
     # hits with alpha within rounding of 0.005 may flip: compare counts loosely, sums relative to scale
     dn = np.abs(n2.cpu().numpy() - num)
     assert (dn > 0).mean() < 0.02
