@@ -21,14 +21,15 @@ LIB = os.path.join(LIBDIR, "libgoi_raster.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
-COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
+COMMON = ["--offload-arch=" + ARCH] + os.environ.get("GOI_EXTRA_FLAGS", "").split() + ["-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
           "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
 # per-file extra flags: the per-Gaussian kernels keep the reference's operation order
 UNITS = {
     "api.hip": [],
     "scan_sort.hip": [],
     "preprocess.hip": ["-ffp-contract=off"],
-    "render.hip": [],
+    "render_fwd.hip": [],
+    "render_bwd.hip": [],
 }
 
 
