@@ -54,6 +54,39 @@ __device__ __forceinline__ TileGeom tile_geom(int W, int H, int gx) {
     return t;
 }
 
+// Wave-per-quadrant geometry: one 64-thread workgroup per 8x8 quadrant.  Hardware deals
+// workgroup b to XCD b % 8, so quadrant index tq = (b % 8) * per + b / 8 gives every XCD a
+// contiguous band of tiles (all four quadrants of a tile and its neighbours share one L2).
+struct QuadGeom {
+    int tile, q, tx, ty, lane, px, py;
+    bool inside;
+    float pxf, pyf, QX0, QY0;
+};
+__device__ __forceinline__ QuadGeom quad_geom(int W, int H, int gx, int n_quads) {
+    QuadGeom t;
+    const int per = (int)(gridDim.x >> 3);
+    const int tq = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    t.lane = threadIdx.x & 63;
+    if (tq >= n_quads) {
+        t.tile = -1;
+        return t;
+    }
+    t.tile = tq >> 2;
+    t.q = tq & 3;
+    t.tx = t.tile % gx;
+    t.ty = t.tile / gx;
+    const int qx0 = t.tx * TILE + (t.q & 1) * 8, qy0 = t.ty * TILE + (t.q >> 1) * 8;
+    t.px = qx0 + (t.lane & 7);
+    t.py = qy0 + (t.lane >> 3);
+    t.inside = t.px < W && t.py < H;
+    t.pxf = (float)t.px;
+    t.pyf = (float)t.py;
+    t.QX0 = (float)qx0;
+    t.QY0 = (float)qy0;
+    return t;
+}
+inline int quad_grid(int n_quads) { return 8 * ((n_quads + 7) / 8); }
+
 __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long m) {
     return ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(m >> 32)) << 32) |
            (unsigned int)__builtin_amdgcn_readfirstlane((int)(m & 0xFFFFFFFFull));
