@@ -48,6 +48,7 @@ SYMBOLS = {
     "goi_raster_mark_visible": (C.c_int, [C.c_int] + [C.c_void_p] * 4 + [C.c_void_p]),
     "goi_raster_profile_enable": (None, [C.c_int]),
     "goi_raster_profile_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "goi_raster_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     "goi_raster_debug_views": (C.c_int, [C.c_int] * 4 + [C.c_void_p] * 3 + [C.c_void_p] * 8 + [C.c_void_p]),
 }
 
@@ -77,6 +78,11 @@ def load():
 
 def last_error() -> str:
     return load().goi_raster_last_error().decode("utf-8", "replace")
+
+
+def set_option(name: str, value: int) -> None:
+    if load().goi_raster_set_option(name.encode(), int(value)) < 0:
+        raise RuntimeError(last_error())
 
 
 def profile_enable(on: bool) -> None:

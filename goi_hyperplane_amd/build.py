@@ -30,6 +30,7 @@ UNITS = {
     "preprocess.hip": ["-ffp-contract=off"],
     "render_fwd.hip": [],
     "render_bwd.hip": [],
+    "render_bwd_tile.hip": [],
 }
 
 

@@ -161,6 +161,8 @@ int geometry_and_binning(const GoiRasterScene& sc, GeomView& g, ImageView& im, g
 
 }  // namespace
 
+Options g_options;
+
 // Which ping-pong buffer holds the tile-sorted list: a pure function of the pass count, so the
 // backward can recompute it instead of storing it.
 static int tile_sort_result_index(int W, int H, int N) {
@@ -340,6 +342,14 @@ int goi_raster_mark_visible(int P, const float* means3D, const float* viewmatrix
 }
 
 void goi_raster_profile_enable(int on) { g_profile = on != 0; }
+
+int goi_raster_set_option(const char* name, int value) {
+    if (!name) return fail("option name is NULL");
+    if (!strcmp(name, "fwd_variant")) g_options.fwd_variant = value;
+    else if (!strcmp(name, "bwd_variant")) g_options.bwd_variant = value;
+    else return fail(std::string("unknown option ") + name);
+    return 0;
+}
 
 int goi_raster_profile_collect(double* ms, int* calls) {
     for (auto& ev : g_events) {

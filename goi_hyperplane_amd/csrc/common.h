@@ -50,6 +50,13 @@ size_t geom_layout(int P, char* base, GeomView* v);
 size_t image_layout(int W, int H, char* base, ImageView* v);
 size_t binning_layout(int N, char* base, BinView* v);
 
+// Tuning / experiment switches (goi_raster_set_option); defaults are the shipped configuration.
+struct Options {
+    int fwd_variant = 0;  // 0: LDS-staged pair loop, 1: scalar-load pair loop
+    int bwd_variant = 0;  // 0: workgroup-per-tile backward, 1: wave-per-quadrant backward
+};
+extern Options g_options;
+
 // ---- device-wide primitives (scan_sort.hip) ----------------------------------------------------
 size_t scan_scratch_words(size_t n);
 size_t sort_scratch_words(size_t n);
@@ -74,6 +81,11 @@ void launch_render_bwd(const GoiRasterScene& sc, const GeomView& g, const ImageV
                        const float* out_alpha, const float* dL_dpix, const float* dL_dsem, const float* dL_ddepth,
                        const float* dL_dalpha, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
                        float* dL_dcolor, float* dL_dsemantic, float* dL_ddepths, hipStream_t s);
+void launch_render_bwd_tile(const GoiRasterScene& sc, const GeomView& g, const ImageView& im,
+                            const uint32_t* point_list, const float* out_alpha, const float* dL_dpix,
+                            const float* dL_dsem, const float* dL_ddepth, const float* dL_dalpha, float* dL_dmean2D,
+                            float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dsemantic,
+                            float* dL_ddepths, hipStream_t s);
 void launch_preprocess_bwd(const GoiRasterScene& sc, const GeomView& g, const int* radii, const float* dL_dmean2D,
                            const float* dL_dconic, float* dL_dcolor, const float* dL_ddepth, float* dL_dmean3D,
                            float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, hipStream_t s);

@@ -33,6 +33,14 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// experiment: flags & 2 -> workgroup-scope (L2-local) atomics
+__device__ __forceinline__ void gadd(float* p, float v, int flags) {
+    if (flags & 2)
+        (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else
+        atomicAdd(p, v);
+}
+
 constexpr int GROUP = 16;    // contributing Gaussians per MFMA group (the M of 16x16x4)
 constexpr int TSTRIDE = 66;  // row stride (floats) of the transposition buffers: conflict-free A reads
 
@@ -51,7 +59,7 @@ __global__ __launch_bounds__(64) void render_bwd_k(
     const float* __restrict__ out_alpha, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
     const float* __restrict__ dL_dpixsem, const float* __restrict__ dL_dpixdepth, const float* __restrict__ dL_dalphas,
     float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
-    float* __restrict__ dL_dcolor, float* __restrict__ dL_dsemantic, float* __restrict__ dL_ddepths) {
+    float* __restrict__ dL_dcolor, float* __restrict__ dL_dsemantic, float* __restrict__ dL_ddepths, int exp_flags) {
     using Cfg = BwdCfg<S4>;
     constexpr int NF4 = Cfg::NF4, NSEM = Cfg::NSEM, NCH = Cfg::NCH, NB = Cfg::NB;
     __shared__ float4 s_geo[64];          // x, y, conic a, b
@@ -168,24 +176,24 @@ __global__ __launch_bounds__(64) void render_bwd_k(
         for (int r = 0; r < 4; r++) {
             const int row = 4 * kq + r;
             if (mm < 8) s_wt[row * 8 + mm] = accm[r];  // moments -> exchange area (aliases the w buffer)
-            if (row < cnt) {
+            if (row < cnt && !(exp_flags & 1)) {
                 const uint32_t gid = __float_as_uint(s_gmeta[row * 2 + 1].z);
 #pragma unroll
                 for (int nb = 0; nb < NB; nb++) {
                     const int ch = nb * 16 + mm;
                     if (ch < NSEM) {
-                        if (ch < S) atomicAdd(&dL_dsemantic[(size_t)gid * S + ch], acc[nb][r]);
+                        if (ch < S) gadd(&dL_dsemantic[(size_t)gid * S + ch], acc[nb][r], exp_flags);
                     } else if (ch < NSEM + 3) {
-                        atomicAdd(&dL_dcolor[(size_t)gid * 3 + (ch - NSEM)], acc[nb][r]);
+                        gadd(&dL_dcolor[(size_t)gid * 3 + (ch - NSEM)], acc[nb][r], exp_flags);
                     } else if (ch == NSEM + 3) {
-                        atomicAdd(&dL_ddepths[gid], acc[nb][r]);
+                        gadd(&dL_ddepths[gid], acc[nb][r], exp_flags);
                     }
                 }
             }
         }
         __builtin_amdgcn_wave_barrier();
         // moments -> (mean2D.x, mean2D.y, conic a, b, c, opacity): one lane per group member
-        if (lane < cnt) {
+        if (lane < cnt && !(exp_flags & 1)) {
             const float4 m03 = *reinterpret_cast<const float4*>(&s_wt[lane * 8]);
             const float2 m45 = *reinterpret_cast<const float2*>(&s_wt[lane * 8 + 4]);
             const float4 g = s_gmeta[lane * 2];
@@ -199,12 +207,12 @@ __global__ __launch_bounds__(64) void render_bwd_k(
             const float sxy = Dx * Dy * m0 - Dx * mv - Dy * mu + muv;  // sum h dx dy
             const float syy = Dy * Dy * m0 - 2.f * Dy * mv + mvv;      // sum h dy^2
             const float o = g2.y;
-            atomicAdd(&dL_dmean2D[(size_t)gid * 3 + 0], -o * half_W * (g.z * sx + g.w * sy));
-            atomicAdd(&dL_dmean2D[(size_t)gid * 3 + 1], -o * half_H * (g2.x * sy + g.w * sx));
-            atomicAdd(&dL_dconic[(size_t)gid * 4 + 0], -0.5f * o * sxx);
-            atomicAdd(&dL_dconic[(size_t)gid * 4 + 1], -0.5f * o * sxy);
-            atomicAdd(&dL_dconic[(size_t)gid * 4 + 3], -0.5f * o * syy);
-            atomicAdd(&dL_dopacity[gid], m0);
+            gadd(&dL_dmean2D[(size_t)gid * 3 + 0], -o * half_W * (g.z * sx + g.w * sy), exp_flags);
+            gadd(&dL_dmean2D[(size_t)gid * 3 + 1], -o * half_H * (g2.x * sy + g.w * sx), exp_flags);
+            gadd(&dL_dconic[(size_t)gid * 4 + 0], -0.5f * o * sxx, exp_flags);
+            gadd(&dL_dconic[(size_t)gid * 4 + 1], -0.5f * o * sxy, exp_flags);
+            gadd(&dL_dconic[(size_t)gid * 4 + 3], -0.5f * o * syy, exp_flags);
+            gadd(&dL_dopacity[gid], m0, exp_flags);
         }
         __builtin_amdgcn_wave_barrier();
     };
@@ -296,7 +304,8 @@ void launch_bwd_s4(const GoiRasterScene& sc, const GeomView& g, const ImageView&
     const int n_quads = gx * gy * 4;
     render_bwd_k<S4><<<dim3(quad_grid(n_quads)), dim3(64), 0, s>>>(
         im.ranges, point_list, sc.W, sc.H, gx, n_quads, sc.S, g.rec, sc.semantics, sc.bg, out_alpha, im.n_contrib, dL_dpix,
-        dL_dsem, dL_ddepth, dL_dalpha, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dsemantic, dL_ddepths);
+        dL_dsem, dL_ddepth, dL_dalpha, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dsemantic, dL_ddepths,
+        g_options.bwd_variant >> 4);
 }
 
 }  // namespace
@@ -305,6 +314,11 @@ void launch_render_bwd(const GoiRasterScene& sc, const GeomView& g, const ImageV
                        const float* out_alpha, const float* dL_dpix, const float* dL_dsem, const float* dL_ddepth,
                        const float* dL_dalpha, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
                        float* dL_dcolor, float* dL_dsemantic, float* dL_ddepths, hipStream_t s) {
+    if (g_options.bwd_variant == 0) {  // default: workgroup-per-tile kernel (fewer L2 atomics)
+        launch_render_bwd_tile(sc, g, im, point_list, out_alpha, dL_dpix, dL_dsem, dL_ddepth, dL_dalpha, dL_dmean2D,
+                               dL_dconic, dL_dopacity, dL_dcolor, dL_dsemantic, dL_ddepths, s);
+        return;
+    }
 #define GOI_CALL(N)                                                                                              \
     launch_bwd_s4<N>(sc, g, im, point_list, out_alpha, dL_dpix, dL_dsem, dL_ddepth, dL_dalpha, dL_dmean2D, dL_dconic, \
                      dL_dopacity, dL_dcolor, dL_dsemantic, dL_ddepths, s)

@@ -170,6 +170,7 @@ __global__ __launch_bounds__(64) void render_fwd_k(const uint2* __restrict__ ran
     }
 }
 
+
 template <int S4>
 void launch_fwd_s4(const GoiRasterScene& sc, const GeomView& g, const ImageView& im, const uint32_t* point_list,
                    float* out_color, float* out_sem, float* out_depth, float* out_alpha, hipStream_t s) {

@@ -126,6 +126,9 @@ void goi_raster_profile_enable(int on);
  * since the last reset into ms[GOI_STAGE_COUNT] / calls[GOI_STAGE_COUNT]; then resets. */
 int goi_raster_profile_collect(double* ms, int* calls);
 
+/* Tuning / experiment switches ("fwd_variant", "bwd_variant"); defaults are the shipped kernels. */
+int goi_raster_set_option(const char* name, int value);
+
 /* Inspection of the opaque workspaces (tests only): copies device -> caller DEVICE buffers.
  * Any pointer may be NULL.  point_list is in final sorted order. */
 int goi_raster_debug_views(int P, int W, int H, int R, const void* geom_buffer, const void* binning_buffer,
