@@ -120,7 +120,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("GOI_BENCH_FORCE_DIST") == "1"  # exercise the RCCL path with a single rank
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=dev)
@@ -152,7 +153,7 @@ def main():
         out = render(cam, pc, pipe, bg)
         loss = (out["render"].sum() + out["semantics"].sum()) * inv_hw
         loss.backward()
-        if world > 1:
+        if dist is not None:
             allreduce_gradients(reduce_params, dist)
         if record:
             stats["radii"] = out["radii"]
@@ -178,7 +179,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if dist is not None:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -196,7 +197,7 @@ def main():
     if timing:
         _lib.profile_enable(False)
         stages = _lib.profile_collect()
-    if world > 1:
+    if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -258,7 +259,7 @@ def main():
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res))
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -73,6 +73,11 @@ def load():
         if got != ABI_VERSION:
             raise ImportError(f"libgoi_raster.so ABI {got} != expected {ABI_VERSION}; rebuild")
         _lib = lib
+        # experiment switches, e.g. GOI_OPTIONS="sort_variant=1,bwd_variant=1"
+        for item in filter(None, os.environ.get("GOI_OPTIONS", "").split(",")):
+            name, _, value = item.partition("=")
+            if lib.goi_raster_set_option(name.strip().encode(), int(value)) < 0:
+                raise RuntimeError(lib.goi_raster_last_error().decode())
     return _lib
 
 

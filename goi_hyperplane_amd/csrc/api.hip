@@ -347,6 +347,7 @@ int goi_raster_set_option(const char* name, int value) {
     if (!name) return fail("option name is NULL");
     if (!strcmp(name, "fwd_variant")) g_options.fwd_variant = value;
     else if (!strcmp(name, "bwd_variant")) g_options.bwd_variant = value;
+    else if (!strcmp(name, "sort_variant")) g_options.sort_variant = value;
     else return fail(std::string("unknown option ") + name);
     return 0;
 }

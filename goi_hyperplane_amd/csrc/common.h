@@ -52,8 +52,9 @@ size_t binning_layout(int N, char* base, BinView* v);
 
 // Tuning / experiment switches (goi_raster_set_option); defaults are the shipped configuration.
 struct Options {
-    int fwd_variant = 0;  // 0: LDS-staged pair loop, 1: scalar-load pair loop
+    int fwd_variant = 1;  // 0: one candidate per loop trip, 1: two candidates per trip (default)
     int bwd_variant = 0;  // 0: workgroup-per-tile backward, 1: wave-per-quadrant backward
+    int sort_variant = 1;  // 0: histogram / scan / scatter per pass, 1: onesweep (decoupled look-back, default)
 };
 extern Options g_options;
 

@@ -23,7 +23,7 @@ namespace goi {
 
 namespace {
 
-template <int S4, bool TRACE>
+template <int S4, bool TRACE, bool UNROLL2>
 __global__ __launch_bounds__(64) void render_fwd_k(const uint2* __restrict__ ranges,
                                                    const uint32_t* __restrict__ point_list, int W, int H, int gx,
                                                    int n_quads, int S, const GaussRec* __restrict__ rec,
@@ -109,13 +109,9 @@ __global__ __launch_bounds__(64) void render_fwd_k(const uint2* __restrict__ ran
         __builtin_amdgcn_wave_barrier();  // single-wave workgroup: LDS is in order, only the compiler must not reorder
 
         // ---- pair loop over the hits, front to back
-        while (m) {
-            const int j = __builtin_ctzll(m);
-            m &= m - 1;
-            const float4 g = s_geo[j];
-            const float2 g2 = s_geo2[j];
-            const PairEval e = eval_pair(g.x, g.y, g.z, g.w, g2.x, g2.y, t.pxf, t.pyf);
-            bool c = !done && e.hit;
+        // applies one candidate to the per-pixel state (sequential part) and accumulates its features
+        auto apply = [&](int j, const PairEval& e, bool valid) {
+            bool c = valid && !done && e.hit;
             const float test_T = T * (1.f - e.alpha);
             if (c && test_T < kTMin) {
                 done = true;
@@ -150,7 +146,34 @@ __global__ __launch_bounds__(64) void render_fwd_k(const uint2* __restrict__ ran
                     last_contributor = (uint32_t)(b * 64 + j + 1);
                 }
             }
-            if (__all(done)) m = 0;
+        };
+        if constexpr (UNROLL2) {
+            // two candidates per trip: their alpha evaluations are independent (ILP, half the
+            // branches); the state update stays strictly in list order
+            while (m) {
+                const int j0 = __builtin_ctzll(m);
+                m &= m - 1;
+                const bool has1 = m != 0;
+                const int j1 = has1 ? __builtin_ctzll(m) : j0;
+                if (has1) m &= m - 1;
+                const float4 ga = s_geo[j0], gb = s_geo[j1];
+                const float2 ha = s_geo2[j0], hb = s_geo2[j1];
+                const PairEval e0 = eval_pair(ga.x, ga.y, ga.z, ga.w, ha.x, ha.y, t.pxf, t.pyf);
+                const PairEval e1 = eval_pair(gb.x, gb.y, gb.z, gb.w, hb.x, hb.y, t.pxf, t.pyf);
+                apply(j0, e0, true);
+                apply(j1, e1, has1);
+                if (__all(done)) m = 0;
+            }
+        } else {
+            while (m) {
+                const int j = __builtin_ctzll(m);
+                m &= m - 1;
+                const float4 g = s_geo[j];
+                const float2 g2 = s_geo2[j];
+                const PairEval e = eval_pair(g.x, g.y, g.z, g.w, g2.x, g2.y, t.pxf, t.pyf);
+                apply(j, e, true);
+                if (__all(done)) m = 0;
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -176,9 +199,14 @@ void launch_fwd_s4(const GoiRasterScene& sc, const GeomView& g, const ImageView&
                    float* out_color, float* out_sem, float* out_depth, float* out_alpha, hipStream_t s) {
     const int gx = (sc.W + TILE - 1) / TILE, gy = (sc.H + TILE - 1) / TILE;
     const int n_quads = gx * gy * 4;
-    render_fwd_k<S4, false><<<dim3(quad_grid(n_quads)), dim3(64), 0, s>>>(
-        im.ranges, point_list, sc.W, sc.H, gx, n_quads, sc.S, g.rec, sc.semantics, sc.bg, out_color, out_sem, out_depth,
-        out_alpha, im.n_contrib, nullptr, nullptr, nullptr);
+    if (g_options.fwd_variant == 1)
+        render_fwd_k<S4, false, true><<<dim3(quad_grid(n_quads)), dim3(64), 0, s>>>(
+            im.ranges, point_list, sc.W, sc.H, gx, n_quads, sc.S, g.rec, sc.semantics, sc.bg, out_color, out_sem,
+            out_depth, out_alpha, im.n_contrib, nullptr, nullptr, nullptr);
+    else
+        render_fwd_k<S4, false, false><<<dim3(quad_grid(n_quads)), dim3(64), 0, s>>>(
+            im.ranges, point_list, sc.W, sc.H, gx, n_quads, sc.S, g.rec, sc.semantics, sc.bg, out_color, out_sem,
+            out_depth, out_alpha, im.n_contrib, nullptr, nullptr, nullptr);
 }
 
 }  // namespace
@@ -194,7 +222,7 @@ void launch_trace_fwd(const GoiRasterScene& sc, const float* img_sem, const Geom
                       const uint32_t* point_list, float* out_color, float* gau_sem, int* num_gsem, hipStream_t s) {
     const int gx = (sc.W + TILE - 1) / TILE, gy = (sc.H + TILE - 1) / TILE;
     const int n_quads = gx * gy * 4;
-    render_fwd_k<1, true><<<dim3(quad_grid(n_quads)), dim3(64), 0, s>>>(
+    render_fwd_k<1, true, false><<<dim3(quad_grid(n_quads)), dim3(64), 0, s>>>(
         im.ranges, point_list, sc.W, sc.H, gx, n_quads, sc.S, g.rec, nullptr, sc.bg, out_color, nullptr, nullptr, nullptr,
         im.n_contrib, img_sem, gau_sem, num_gsem);
 }

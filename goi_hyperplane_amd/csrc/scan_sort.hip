@@ -204,6 +204,184 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_k(const uint32_t* 
     }
 }
 
+// ---- single-pass-per-digit radix sort ("onesweep") -----------------------------------------------
+// One kernel per digit: every block ranks its 4096 elements, publishes its per-digit counts, obtains
+// the counts of all earlier blocks by decoupled look-back over per-(block, digit) status words, and
+// scatters through LDS so that each digit's elements leave as one contiguous run.  A prologue kernel
+// computes the global digit histograms of every pass in one read of the keys.
+//
+// Inter-workgroup protocol (MI355X: per-XCD L2s are not coherent): a status word is ONE aligned
+// 32-bit granule {2-bit state, 30-bit count} written and read with relaxed AGENT-scope atomics
+// (write-through / L1-bypassing), so the data is its own flag and no fence is needed; block ids
+// come from a ticket counter so a block only ever waits for blocks that have already started;
+// every spin is bounded and reports through an error word instead of hanging the device.
+constexpr uint32_t ST_EMPTY = 0u, ST_AGGREGATE = 1u << 30, ST_PREFIX = 2u << 30, ST_MASK = 3u << 30;
+constexpr uint32_t ST_VALUE = (1u << 30) - 1u;
+constexpr int MAX_PASSES = 4;
+
+struct SweepPlan {
+    int passes;
+    int shift[MAX_PASSES];
+    int nbits[MAX_PASSES];
+};
+
+__global__ __launch_bounds__(SORT_THREADS) void sweep_hist_k(const uint32_t* __restrict__ keys, size_t n, SweepPlan plan,
+                                                             uint32_t* __restrict__ ghist) {
+    __shared__ uint32_t h[MAX_PASSES][RADIX_MAX];
+    for (int i = threadIdx.x; i < MAX_PASSES * RADIX_MAX; i += SORT_THREADS) (&h[0][0])[i] = 0;
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * SORT_TILE;
+#pragma unroll 4
+    for (int k = 0; k < SORT_ITEMS; k++) {
+        size_t i = base + (size_t)k * SORT_THREADS + threadIdx.x;
+        if (i < n) {
+            const uint32_t key = keys[i];
+            for (int p = 0; p < plan.passes; p++)
+                atomicAdd(&h[p][(key >> plan.shift[p]) & ((1u << plan.nbits[p]) - 1u)], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < plan.passes * RADIX_MAX; i += SORT_THREADS) {
+        const uint32_t v = (&h[0][0])[i];
+        if (v) atomicAdd(&ghist[i], v);
+    }
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void sweep_pass_k(const uint32_t* __restrict__ keys_in,
+                                                             const uint32_t* __restrict__ vals_in,
+                                                             uint32_t* __restrict__ keys_out,
+                                                             uint32_t* __restrict__ vals_out, size_t n, int shift,
+                                                             int nbits, const uint32_t* __restrict__ ghist,
+                                                             uint32_t* status, uint32_t* ticket, uint32_t* error) {
+    __shared__ uint32_t cnt[SORT_WAVES][RADIX_MAX];  // per-wave digit counts -> per-wave local offsets
+    __shared__ uint32_t gbase[RADIX_MAX];            // global position of this block's first element of digit d
+    __shared__ uint32_t lbase[RADIX_MAX];            // local (in-block) exclusive offset of digit d
+    __shared__ uint32_t s_keys[SORT_TILE];
+    __shared__ uint32_t s_vals[SORT_TILE];
+    __shared__ uint32_t s_bid;
+    const uint32_t radix = 1u << nbits, mask = radix - 1u;
+    if (threadIdx.x == 0) s_bid = atomicAdd(ticket, 1u);
+    for (int i = threadIdx.x; i < SORT_WAVES * RADIX_MAX; i += SORT_THREADS) (&cnt[0][0])[i] = 0;
+    __syncthreads();
+    const uint32_t bid = s_bid;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    const size_t tile_base = (size_t)bid * SORT_TILE;
+    const size_t wbase = tile_base + (size_t)w * SORT_WAVE_ITEMS;
+    uint32_t key[SORT_ITEMS], val[SORT_ITEMS], rank[SORT_ITEMS];
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; r++) {
+        size_t i = wbase + (size_t)r * WAVE + lane;
+        const bool ok = i < n;
+        key[r] = ok ? keys_in[i] : 0xFFFFFFFFu;
+        val[r] = ok ? vals_in[i] : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; r++) {
+        size_t i = wbase + (size_t)r * WAVE + lane;
+        const bool ok = i < n;
+        const uint32_t d = (key[r] >> shift) & mask;
+        uint64_t peers = __ballot(ok);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            if (b < nbits) {
+                const bool bit = (d >> b) & 1u;
+                const uint64_t bal = __ballot(bit);
+                peers &= bit ? bal : ~bal;
+            }
+        }
+        const uint32_t prev = ok ? cnt[w][d] : 0u;
+        const uint32_t below = (uint32_t)__popcll(peers & lt);
+        rank[r] = prev + below;
+        __builtin_amdgcn_wave_barrier();
+        if (ok && below == 0) cnt[w][d] = prev + (uint32_t)__popcll(peers);
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    // ---- per digit: block count, wave offsets, publish, look back, global base
+    uint32_t my_total = 0;
+    if (threadIdx.x < radix) {
+        const uint32_t d = threadIdx.x;
+        uint32_t run = 0;
+#pragma unroll
+        for (int ww = 0; ww < SORT_WAVES; ww++) {
+            const uint32_t t = cnt[ww][d];
+            cnt[ww][d] = run;  // exclusive offset of wave ww inside the block's run of digit d
+            run += t;
+        }
+        my_total = run;
+        uint32_t* st = status + (size_t)d;  // status[block][digit], digit-minor
+        __hip_atomic_store(st + (size_t)bid * RADIX_MAX, ST_AGGREGATE | my_total, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t excl = 0;
+        for (int64_t pb = (int64_t)bid - 1; pb >= 0; pb--) {
+            uint32_t v;
+            uint32_t spins = 0;
+            do {
+                v = __hip_atomic_load(st + (size_t)pb * RADIX_MAX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((v & ST_MASK) == ST_EMPTY && ++spins > (1u << 24)) {
+                    atomicOr(error, 2u);  // never hang the device: report and carry on with garbage
+                    v = ST_PREFIX;
+                }
+                if ((v & ST_MASK) == ST_EMPTY) __builtin_amdgcn_s_sleep(1);
+            } while ((v & ST_MASK) == ST_EMPTY);
+            excl += v & ST_VALUE;
+            if ((v & ST_MASK) == ST_PREFIX) break;
+        }
+        __hip_atomic_store(st + (size_t)bid * RADIX_MAX, ST_PREFIX | ((excl + my_total) & ST_VALUE), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        gbase[d] = excl;  // + global digit base, added after the scan below
+        lbase[d] = my_total;
+    }
+    __syncthreads();
+    // exclusive scans over the digits: global digit base (from ghist) and local base (from lbase)
+    if (threadIdx.x < 64) {
+        // one wave scans up to 256 digits: 4 per lane
+        uint32_t g[4], l[4], gs = 0, ls = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t d = threadIdx.x * 4 + k;
+            g[k] = d < radix ? ghist[d] : 0u;
+            l[k] = d < radix ? lbase[d] : 0u;
+            gs += g[k];
+            ls += l[k];
+        }
+        const uint32_t gi = wave_inclusive_scan(gs, lane) - gs, li = wave_inclusive_scan(ls, lane) - ls;
+        uint32_t gr = gi, lr = li;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t d = threadIdx.x * 4 + k;
+            if (d < radix) {
+                gbase[d] += gr;
+                lbase[d] = lr;
+            }
+            gr += g[k];
+            lr += l[k];
+        }
+    }
+    __syncthreads();
+    // ---- reorder through LDS: element -> local position lbase[d] + wave offset + rank
+#pragma unroll
+    for (int r = 0; r < SORT_ITEMS; r++) {
+        size_t i = wbase + (size_t)r * WAVE + lane;
+        if (i < n) {
+            const uint32_t d = (key[r] >> shift) & mask;
+            const uint32_t lp = lbase[d] + cnt[w][d] + rank[r];
+            s_keys[lp] = key[r];
+            s_vals[lp] = val[r];
+        }
+    }
+    __syncthreads();
+    const uint32_t count = (uint32_t)(tile_base + SORT_TILE <= n ? SORT_TILE : (n > tile_base ? n - tile_base : 0));
+    for (uint32_t i = threadIdx.x; i < count; i += SORT_THREADS) {
+        const uint32_t k = s_keys[i];
+        const uint32_t d = (k >> shift) & mask;
+        const uint32_t pos = gbase[d] + (i - lbase[d]);
+        keys_out[pos] = k;
+        vals_out[pos] = s_vals[i];
+    }
+}
+
 inline size_t div_up(size_t a, size_t b) { return (a + b - 1) / b; }
 
 }  // namespace
@@ -213,7 +391,9 @@ size_t scan_scratch_words(size_t n) { return div_up(n, SCAN_CHUNK) + 16; }
 size_t sort_scratch_words(size_t n) {
     size_t nblk = div_up(n, SORT_TILE);
     size_t table = (size_t)RADIX_MAX * nblk;
-    return table + scan_scratch_words(table) + 16;
+    size_t three_kernel = table + scan_scratch_words(table) + 16;
+    size_t onesweep = (size_t)MAX_PASSES * table + (size_t)MAX_PASSES * RADIX_MAX + 64;
+    return three_kernel > onesweep ? three_kernel : onesweep;
 }
 
 void exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, size_t n, uint32_t* total,
@@ -239,6 +419,33 @@ int radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], size_t n, int lo, int
     const int bits = hi - lo;
     const int passes = (bits + 7) / 8;
     int shift = lo;
+    if (g_options.sort_variant == 1 && passes <= MAX_PASSES) {
+        // scratch: [passes][nblk][256] status words | [passes][256] global histograms | tickets | error
+        const size_t st_words = (size_t)passes * nblk * RADIX_MAX;
+        uint32_t* status = scratch;
+        uint32_t* ghist = scratch + (size_t)MAX_PASSES * nblk * RADIX_MAX;
+        uint32_t* ticket = ghist + MAX_PASSES * RADIX_MAX;
+        uint32_t* error = ticket + MAX_PASSES;
+        (void)hipMemsetAsync(status, 0, st_words * sizeof(uint32_t), s);
+        (void)hipMemsetAsync(ghist, 0, (MAX_PASSES * RADIX_MAX + MAX_PASSES + 1) * sizeof(uint32_t), s);
+        SweepPlan plan;
+        plan.passes = passes;
+        int sh = lo;
+        for (int p = 0; p < passes; p++) {
+            plan.nbits[p] = (bits - (sh - lo) + (passes - p) - 1) / (passes - p);
+            plan.shift[p] = sh;
+            sh += plan.nbits[p];
+        }
+        for (int p = passes; p < MAX_PASSES; p++) plan.shift[p] = plan.nbits[p] = 0;
+        sweep_hist_k<<<dim3(nblk), dim3(SORT_THREADS), 0, s>>>(keys[0], n, plan, ghist);
+        for (int p = 0; p < passes; p++) {
+            sweep_pass_k<<<dim3(nblk), dim3(SORT_THREADS), 0, s>>>(
+                keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, plan.shift[p], plan.nbits[p],
+                ghist + (size_t)p * RADIX_MAX, status + (size_t)p * nblk * RADIX_MAX, ticket + p, error);
+            cur ^= 1;
+        }
+        return cur;
+    }
     for (int p = 0; p < passes; p++) {
         const int nbits = (bits - (shift - lo) + (passes - p) - 1) / (passes - p);
         const uint32_t mask = (1u << nbits) - 1u;

@@ -46,4 +46,4 @@ for rnd in range(6):
                 if n:
                     res[v].setdefault(k, []).append(ms / n)
 for v in values:
-    print("variant", v, "checksums", ref[v], {k: round(float(np.median(x)), 4) for k, x in res[v].items() if k.startswith("blend")})
+    print("variant", v, "checksums", ref[v], {k: round(float(np.median(x)), 4) for k, x in res[v].items()})
