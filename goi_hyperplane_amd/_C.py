@@ -162,12 +162,13 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, semantics, 
             sc = _scene(P, S, H, W, ten["bg"], ten["means3D"], ten["sh"], ten["colors"], ten["semantics"], None,
                         ten["scales"], ten["rotations"], scale_modifier, ten["cov3D"], ten["viewmatrix"],
                         ten["projmatrix"], tan_fovx, tan_fovy, degree, ten["campos"], False, debug)
+            scratch = torch.empty(lib.goi_raster_backward_scratch_bytes(int(R), S), dtype=torch.uint8, device=dev)
             r = lib.goi_raster_backward(
                 C.byref(sc), int(R), _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(ten["radii"]),
                 _ptr(ten["alphas"]), _ptr(ten["g_c"]), _ptr(ten["g_s"]), _ptr(ten["g_d"]), _ptr(ten["g_a"]),
                 _ptr(dL_dmeans2D), _ptr(dL_dconic), _ptr(dL_dopacity), _ptr(dL_dcolors), _ptr(dL_dsemantics),
                 _ptr(dL_ddepths), _ptr(dL_dmeans3D), _ptr(dL_dcov3D), _ptr(dL_dsh), _ptr(dL_dscales),
-                _ptr(dL_drotations), _stream(dev))
+                _ptr(dL_drotations), _ptr(scratch), _stream(dev))
             if r < 0:
                 raise RuntimeError(_lib.last_error())
     return (dL_dmeans2D, dL_dcolors, dL_dsemantics, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales,

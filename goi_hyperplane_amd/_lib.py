@@ -39,10 +39,11 @@ SYMBOLS = {
     "goi_raster_geom_bytes": (C.c_size_t, [C.c_int]),
     "goi_raster_image_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "goi_raster_binning_bytes": (C.c_size_t, [C.c_int]),
+    "goi_raster_backward_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "goi_raster_forward": (C.c_int, [C.POINTER(GoiRasterScene), C.c_void_p, C.c_void_p, ALLOC_FN, C.c_void_p]
                            + [C.c_void_p] * 5 + [C.c_void_p]),
     "goi_raster_backward": (C.c_int, [C.POINTER(GoiRasterScene), C.c_int] + [C.c_void_p] * 3 + [C.c_void_p] * 6
-                            + [C.c_void_p] * 11 + [C.c_void_p]),
+                            + [C.c_void_p] * 11 + [C.c_void_p, C.c_void_p]),
     "goi_raster_trace": (C.c_int, [C.POINTER(GoiRasterScene), C.c_void_p, C.c_void_p, C.c_void_p, ALLOC_FN,
                                    C.c_void_p] + [C.c_void_p] * 4 + [C.c_void_p]),
     "goi_raster_mark_visible": (C.c_int, [C.c_int] + [C.c_void_p] * 4 + [C.c_void_p]),

@@ -186,6 +186,7 @@ size_t geom_layout(int P, char* base, GeomView* v) {
     carve(p, g.sort_vals[0], n);
     carve(p, g.sort_vals[1], n);
     carve(p, g.offsets, n);
+    carve(p, g.goff, n);
     g.scratch_words = sort_scratch_words(n) + scan_scratch_words(n);
     carve(p, g.scratch, g.scratch_words);
     carve(p, g.counters, 8);
@@ -199,6 +200,16 @@ size_t image_layout(int W, int H, char* base, ImageView* v) {
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     carve(p, im.n_contrib, (size_t)W * H);
     carve(p, im.ranges, (size_t)gx * gy);
+    return (size_t)(p - base) + 256;
+}
+
+size_t bwd_scratch_layout(int N, int S, char* base, BwdScratchView* v) {
+    char* p = base;
+    const size_t n = (size_t)(N > 0 ? N : 1) * 4;
+    BwdScratchView tmp;
+    BwdScratchView& b = v ? *v : tmp;
+    carve(p, b.rows, n * (size_t)bwd_row_floats(S));
+    carve(p, b.flags, n);
     return (size_t)(p - base) + 256;
 }
 
@@ -230,6 +241,7 @@ const char* goi_raster_last_error(void) { return g_err.c_str(); }
 size_t goi_raster_geom_bytes(int P) { return geom_layout(P, nullptr, nullptr) + 256; }
 size_t goi_raster_image_bytes(int W, int H) { return image_layout(W, H, nullptr, nullptr) + 256; }
 size_t goi_raster_binning_bytes(int N) { return binning_layout(N, nullptr, nullptr) + 256; }
+size_t goi_raster_backward_scratch_bytes(int N, int S) { return bwd_scratch_layout(N, S, nullptr, nullptr) + 256; }
 
 int goi_raster_forward(const GoiRasterScene* scene, void* geom_buffer, void* image_buffer, goi_alloc_fn binning_alloc,
                        void* alloc_user, float* out_color, float* out_semantic, float* out_depth, float* out_alpha,
@@ -293,7 +305,7 @@ int goi_raster_backward(const GoiRasterScene* scene, int R, const void* geom_buf
                         const float* dL_dout_semantic, const float* dL_dout_depth, const float* dL_dout_alpha,
                         float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dsemantic,
                         float* dL_ddepth, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
-                        float* dL_drot, void* stream) {
+                        float* dL_drot, void* scratch, void* stream) {
     if (validate(scene, true, false)) return -1;  // opacity lives in the forward's records
     const GoiRasterScene& sc = *scene;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -305,22 +317,41 @@ int goi_raster_backward(const GoiRasterScene* scene, int R, const void* geom_buf
     BinView bv;
     geom_layout(sc.P, const_cast<char*>(static_cast<const char*>(geom_buffer)), &g);
     image_layout(sc.W, sc.H, const_cast<char*>(static_cast<const char*>(image_buffer)), &im);
-    // the accumulated (atomic) gradients start from zero
-    GOI_HIP(hipMemsetAsync(dL_dmean2D, 0, 3 * P * sizeof(float), s));
-    GOI_HIP(hipMemsetAsync(dL_dconic, 0, 4 * P * sizeof(float), s));
-    GOI_HIP(hipMemsetAsync(dL_dopacity, 0, P * sizeof(float), s));
-    GOI_HIP(hipMemsetAsync(dL_dcolor, 0, 3 * P * sizeof(float), s));
-    GOI_HIP(hipMemsetAsync(dL_dsemantic, 0, (size_t)sc.S * P * sizeof(float), s));
-    GOI_HIP(hipMemsetAsync(dL_ddepth, 0, P * sizeof(float), s));
-    if (R > 0) {
-        binning_layout(R, const_cast<char*>(static_cast<const char*>(binning_buffer)), &bv);
-        const int fin = tile_sort_result_index(sc.W, sc.H, R);
-        StageTimer t(GOI_STAGE_BLEND_BWD, s);
-        launch_render_bwd(sc, g, im, bv.vals[fin], out_alpha, dL_dout_color, dL_dout_semantic, dL_dout_depth,
-                          dL_dout_alpha, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dsemantic, dL_ddepth, s);
-    }
-    if (check_stage(sc, s, "backward blend")) return -1;
-    {
+    const int fin = tile_sort_result_index(sc.W, sc.H, R);
+    if (R > 0) binning_layout(R, const_cast<char*>(static_cast<const char*>(binning_buffer)), &bv);
+    const bool rows_path = scratch != nullptr && g_options.bwd_variant == 0;
+    if (rows_path) {
+        // atomic-free path: (quadrant, Gaussian) partial rows + validity bytes, then a fixed-order sum
+        BwdScratchView scr;
+        bwd_scratch_layout(R, sc.S, static_cast<char*>(scratch), &scr);
+        {
+            StageTimer t(GOI_STAGE_BLEND_BWD, s);
+            if (R > 0) {
+                GOI_HIP(hipMemsetAsync(scr.flags, 0, (size_t)R * 4, s));
+                launch_render_bwd_rows(sc, g, im, bv.vals[fin], radii, out_alpha, dL_dout_color, dL_dout_semantic,
+                                       dL_dout_depth, dL_dout_alpha, scr, s);
+            }
+        }
+        if (check_stage(sc, s, "backward blend")) return -1;
+        StageTimer t(GOI_STAGE_PREPROCESS_BWD, s);
+        launch_reduce_rows(sc, g, scr, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dsemantic, dL_ddepth, s);
+        launch_preprocess_bwd(sc, g, radii, dL_dmean2D, dL_dconic, dL_dcolor, dL_ddepth, dL_dmean3D, dL_dcov3D, dL_dsh,
+                              dL_dscale, dL_drot, s);
+    } else {
+        // atomic path: the accumulated gradients start from zero
+        GOI_HIP(hipMemsetAsync(dL_dmean2D, 0, 3 * P * sizeof(float), s));
+        GOI_HIP(hipMemsetAsync(dL_dconic, 0, 4 * P * sizeof(float), s));
+        GOI_HIP(hipMemsetAsync(dL_dopacity, 0, P * sizeof(float), s));
+        GOI_HIP(hipMemsetAsync(dL_dcolor, 0, 3 * P * sizeof(float), s));
+        GOI_HIP(hipMemsetAsync(dL_dsemantic, 0, (size_t)sc.S * P * sizeof(float), s));
+        GOI_HIP(hipMemsetAsync(dL_ddepth, 0, P * sizeof(float), s));
+        if (R > 0) {
+            StageTimer t(GOI_STAGE_BLEND_BWD, s);
+            launch_render_bwd_tile(sc, g, im, bv.vals[fin], out_alpha, dL_dout_color, dL_dout_semantic, dL_dout_depth,
+                                   dL_dout_alpha, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dsemantic,
+                                   dL_ddepth, s);
+        }
+        if (check_stage(sc, s, "backward blend")) return -1;
         StageTimer t(GOI_STAGE_PREPROCESS_BWD, s);
         launch_preprocess_bwd(sc, g, radii, dL_dmean2D, dL_dconic, dL_dcolor, dL_ddepth, dL_dmean3D, dL_dcov3D, dL_dsh,
                               dL_dscale, dL_drot, s);

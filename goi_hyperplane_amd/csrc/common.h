@@ -31,6 +31,7 @@ struct GeomView {
     uint32_t* sort_keys[2];   // [P] depth bits (ping-pong)
     uint32_t* sort_vals[2];   // [P] Gaussian ids (ping-pong); [final] = depth order
     uint32_t* offsets;        // [P] exclusive prefix of tiles_touched in depth order
+    uint32_t* goff;           // [P] the same prefix indexed by Gaussian id = first emit-order instance of g
     uint32_t* scratch;        // scan partials + radix histograms
     uint32_t* counters;       // [8]: 0 = num_rendered, 1 = error flag
     size_t scratch_words;
@@ -39,6 +40,16 @@ struct ImageView {
     uint32_t* n_contrib;  // [HW]
     uint2* ranges;        // [T]
 };
+// Backward scratch (goi_raster_backward_scratch_bytes): one 128-byte partial-gradient row per
+// (emit-order instance, quadrant) and one validity byte per row.
+// row = [sem 0..4*ceil(S/4)) | r g b depth | mean2D.x .y conic.a .b .c opacity | pad], 64-byte multiple
+inline int bwd_row_floats(int S) { return ((4 * ((S + 3) / 4) + 4 + 6 + 15) / 16) * 16; }
+struct BwdScratchView {
+    float* rows;     // [4N][bwd_row_floats(S)]: slot = (emit-order instance) * 4 + quadrant
+    uint8_t* flags;  // [4N] validity bytes
+};
+size_t bwd_scratch_layout(int N, int S, char* base, BwdScratchView* v);
+
 struct BinView {
     uint32_t* keys[2];  // [N] tile ids (ping-pong)
     uint32_t* vals[2];  // [N] Gaussian ids (ping-pong)
@@ -53,7 +64,7 @@ size_t binning_layout(int N, char* base, BinView* v);
 // Tuning / experiment switches (goi_raster_set_option); defaults are the shipped configuration.
 struct Options {
     int fwd_variant = 1;  // 0: one candidate per loop trip, 1: two candidates per trip (default)
-    int bwd_variant = 0;  // 0: workgroup-per-tile backward, 1: wave-per-quadrant backward
+    int bwd_variant = 0;  // 0: atomic-free wave-per-quadrant backward (needs scratch), 1: workgroup-per-tile + atomics
     int sort_variant = 1;  // 0: histogram / scan / scatter per pass, 1: onesweep (decoupled look-back, default)
 };
 extern Options g_options;
@@ -78,10 +89,15 @@ void launch_render_fwd(const GoiRasterScene& sc, const GeomView& g, const ImageV
                        float* out_color, float* out_sem, float* out_depth, float* out_alpha, hipStream_t s);
 void launch_trace_fwd(const GoiRasterScene& sc, const float* img_sem, const GeomView& g, const ImageView& im,
                       const uint32_t* point_list, float* out_color, float* gau_sem, int* num_gsem, hipStream_t s);
-void launch_render_bwd(const GoiRasterScene& sc, const GeomView& g, const ImageView& im, const uint32_t* point_list,
-                       const float* out_alpha, const float* dL_dpix, const float* dL_dsem, const float* dL_ddepth,
-                       const float* dL_dalpha, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
-                       float* dL_dcolor, float* dL_dsemantic, float* dL_ddepths, hipStream_t s);
+// atomic-free backward blend: partial rows + flags into the scratch (render_bwd.hip)
+void launch_render_bwd_rows(const GoiRasterScene& sc, const GeomView& g, const ImageView& im,
+                            const uint32_t* point_list, const int* radii, const float* out_alpha, const float* dL_dpix,
+                            const float* dL_dsem, const float* dL_ddepth, const float* dL_dalpha,
+                            const BwdScratchView& scr, hipStream_t s);
+// sums every Gaussian's partial rows (fixed order) into the six blend-gradient arrays; writes all P rows
+void launch_reduce_rows(const GoiRasterScene& sc, const GeomView& g, const BwdScratchView& scr, float* dL_dmean2D,
+                        float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dsemantic, float* dL_ddepth,
+                        hipStream_t s);
 void launch_render_bwd_tile(const GoiRasterScene& sc, const GeomView& g, const ImageView& im,
                             const uint32_t* point_list, const float* out_alpha, const float* dL_dpix,
                             const float* dL_dsem, const float* dL_ddepth, const float* dL_dalpha, float* dL_dmean2D,
@@ -91,6 +107,18 @@ void launch_preprocess_bwd(const GoiRasterScene& sc, const GeomView& g, const in
                            const float* dL_dconic, float* dL_dcolor, const float* dL_ddepth, float* dL_dmean3D,
                            float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, hipStream_t s);
 void launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
+
+// Tile rectangle of a Gaussian (restates getRect, CR/auxiliary.h:46-56: float divide, truncation).
+__device__ __forceinline__ void tile_rect(float px, float py, int r, int gx, int gy, int& x0, int& y0, int& x1,
+                                          int& y1) {
+    x0 = min(gx, max(0, (int)((px - r) / TILE)));
+    y0 = min(gy, max(0, (int)((py - r) / TILE)));
+    x1 = min(gx, max(0, (int)((px + r + TILE - 1) / TILE)));
+    y1 = min(gy, max(0, (int)((py + r + TILE - 1) / TILE)));
+}
+
+// The depth sort runs ceil(32/8) = 4 ping-pong passes from buffer 0, so its result is in buffer 0.
+inline int depth_sort_result_index() { return ((32 + 7) / 8) & 1; }
 
 // Number of key bits that cover every tile id < n_tiles (the reference sorts on
 // getHigherMsb(T) = floor(log2 T) + 1 tile bits, CR/rasterizer_impl.cu:35-50,304; any bit count

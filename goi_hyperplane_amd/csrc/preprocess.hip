@@ -19,14 +19,6 @@ namespace {
 
 __device__ __forceinline__ float ndc_to_pix(float v, int S) { return (float)(((v + 1.0) * S - 1.0) * 0.5); }
 
-__device__ __forceinline__ void tile_rect(float px, float py, int r, int gx, int gy, int& x0, int& y0, int& x1,
-                                          int& y1) {
-    x0 = min(gx, max(0, (int)((px - r) / TILE)));
-    y0 = min(gy, max(0, (int)((py - r) / TILE)));
-    x1 = min(gx, max(0, (int)((px + r + TILE - 1) / TILE)));
-    y1 = min(gy, max(0, (int)((py + r + TILE - 1) / TILE)));
-}
-
 __device__ __forceinline__ M3 rotation_from_quat(float r, float x, float y, float z) {
     return make_m3(1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
                    2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
@@ -469,16 +461,102 @@ __global__ __launch_bounds__(256) void mark_visible_k(int P, const float* __rest
     present[idx] = xform_point_4x3(p, m).z > 0.2f ? 1 : 0;
 }
 
+// Sums the partial-gradient rows of every Gaussian (written by render_bwd_rows_k, one row per
+// (emit-order instance, quadrant) slot, a Gaussian's slots contiguous) in a fixed order and writes
+// the six blend-gradient arrays for ALL Gaussians (zeros where nothing contributed): no memsets, no
+// atomics, bit-reproducible.  A quarter wave (16 lanes) owns one Gaussian.  Memory-level parallelism
+// is what matters here: the lanes fetch 16 instances x 4 validity bytes in one load, the flagged
+// slots of the chunk are packed into a 64-bit mask (quadrant-major), and up to 16 rows are requested
+// back to back before the first is consumed (lane e reads row elements e, e+16, ...: coalesced).
+template <int K>  // K = row_floats / 16
+__global__ __launch_bounds__(256) void reduce_rows_k(int P, int S, int nch, const uint32_t* __restrict__ order,
+                                                     const uint32_t* __restrict__ offsets,
+                                                     const uint32_t* __restrict__ tiles_touched,
+                                                     const float* __restrict__ rows, const uint8_t* __restrict__ flags,
+                                                     float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic,
+                                                     float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor,
+                                                     float* __restrict__ dL_dsemantic, float* __restrict__ dL_ddepth) {
+    constexpr int RF = 16 * K;
+    constexpr int INFLIGHT = 16;
+    const int lane = threadIdx.x & 63, quarter = lane >> 4, e = lane & 15;
+    // Gaussians are visited in DEPTH order: that is the order of the slot space, so consecutive quarter
+    // waves stream through rows[] and flags[] front to back (DRAM-page and TLB friendly); only the
+    // per-Gaussian outputs are scattered
+    const int i = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool live = i < P;
+    const uint32_t g = live ? order[i] : 0u;
+    const uint32_t cnt = live ? tiles_touched[g] : 0u;
+    const size_t inst0 = cnt ? (size_t)offsets[i] : 0;
+    const uint32_t* flags32 = reinterpret_cast<const uint32_t*>(flags);
+    float sum[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) sum[k] = 0.f;
+    // every lane of the wave must reach the ballots: loop to the wave's largest count
+    uint32_t cmax = cnt;
+#pragma unroll
+    for (int d = 32; d >= 16; d >>= 1) cmax = max(cmax, (uint32_t)__shfl_xor((int)cmax, d, 64));
+    for (uint32_t c = 0; c < cmax; c += 16) {
+        const uint32_t w = (c + e < cnt) ? flags32[inst0 + c + e] : 0u;  // 4 quadrant bytes of instance c+e
+        unsigned long long m = 0;  // bit 16q + i: quadrant q of instance c+i is valid
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const unsigned long long bal = __ballot(((w >> (8 * q)) & 0xFFu) != 0);
+            m |= ((bal >> (16 * quarter)) & 0xFFFFull) << (16 * q);
+        }
+        const float* chunk = rows + (inst0 + c) * 4 * RF;
+        while (m) {
+            float v[INFLIGHT][K];
+#pragma unroll
+            for (int i = 0; i < INFLIGHT; i++) {
+                const bool have = m != 0;
+                const int bit = have ? __builtin_ctzll(m) : 0;
+                if (have) m &= m - 1;
+                const float* r = chunk + (size_t)((bit & 15) * 4 + (bit >> 4)) * RF;
+#pragma unroll
+                for (int k = 0; k < K; k++) v[i][k] = have ? r[e + 16 * k] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < INFLIGHT; i++)
+#pragma unroll
+                for (int k = 0; k < K; k++) sum[k] += v[i][k];
+        }
+    }
+    if (!live) return;
+    const int nsem = nch - 4;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const float v = sum[k];
+        const int el = e + 16 * k;
+        if (el < nsem) {
+            if (el < S) dL_dsemantic[(size_t)g * S + el] = v;
+        } else if (el < nsem + 3) {
+            dL_dcolor[(size_t)g * 3 + (el - nsem)] = v;
+        } else if (el == nsem + 3) {
+            dL_ddepth[g] = v;
+        } else if (el < nch + 2) {
+            dL_dmean2D[(size_t)g * 3 + (el - nch)] = v;
+            if (el == nch + 1) dL_dmean2D[(size_t)g * 3 + 2] = 0.f;
+        } else if (el < nch + 5) {
+            const int c = el - nch - 2;  // a, b, c -> x, y, w of the [P,2,2] conic gradient
+            dL_dconic[(size_t)g * 4 + (c == 2 ? 3 : c)] = v;
+            if (c == 2) dL_dconic[(size_t)g * 4 + 2] = 0.f;
+        } else if (el == nch + 5) {
+            dL_dopacity[g] = v;
+        }
+    }
+}
+
 // Emits the (tile id, Gaussian id) instances of every visible Gaussian, walking the Gaussians in
 // depth order so that a stable sort by tile alone reproduces the reference's (tile, depth, id)
 // order (CR/rasterizer_impl.cu:70-111 emits 64-bit tile|depth keys in id order instead).
 __global__ __launch_bounds__(256) void emit_k(int P, int gx, int gy, const GaussRec* __restrict__ rec,
                                               const int* __restrict__ radii, const uint32_t* __restrict__ order,
-                                              const uint32_t* __restrict__ offsets, uint32_t* __restrict__ keys,
-                                              uint32_t* __restrict__ vals) {
+                                              const uint32_t* __restrict__ offsets, uint32_t* __restrict__ goff,
+                                              uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
     const uint32_t g = order[i];
+    goff[g] = offsets[i];
     const int r = radii[g];
     if (r <= 0) return;
     const float4 q0 = rec[g].q0;
@@ -545,10 +623,27 @@ void launch_preprocess_bwd(const GoiRasterScene& sc, const GeomView& g, const in
                                                                    dL_drot);
 }
 
+void launch_reduce_rows(const GoiRasterScene& sc, const GeomView& g, const BwdScratchView& scr, float* dL_dmean2D,
+                        float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dsemantic, float* dL_ddepth,
+                        hipStream_t s) {
+    const int rf = bwd_row_floats(sc.S), nch = 4 * ((sc.S + 3) / 4) + 4;
+    const dim3 grid((sc.P + 15) / 16);
+    const uint32_t* order = g.sort_vals[depth_sort_result_index()];
+    if (rf == 32)
+        reduce_rows_k<2><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, order, g.offsets, g.tiles_touched, scr.rows, scr.flags,
+                                                    dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dsemantic, dL_ddepth);
+    else if (rf == 16)
+        reduce_rows_k<1><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, order, g.offsets, g.tiles_touched, scr.rows, scr.flags,
+                                                    dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dsemantic, dL_ddepth);
+    else
+        reduce_rows_k<3><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, order, g.offsets, g.tiles_touched, scr.rows, scr.flags,
+                                                    dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dsemantic, dL_ddepth);
+}
+
 void launch_emit(int P, int W, int H, const GeomView& g, const uint32_t* order, const int* radii, uint32_t* keys,
                  uint32_t* vals, hipStream_t s) {
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
-    emit_k<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, gx, gy, g.rec, radii, order, g.offsets, keys, vals);
+    emit_k<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, gx, gy, g.rec, radii, order, g.offsets, g.goff, keys, vals);
 }
 
 void launch_ranges(int N, const uint32_t* sorted_keys, uint2* ranges, int T, hipStream_t s) {

@@ -1,4 +1,4 @@
-// Backward tile blend for gfx950.  Restates the reference's backward renderCUDA
+// Backward tile blend for gfx950 -- ATOMIC-FREE, deterministic.  Restates the reference's backward renderCUDA
 // (cuda_rasterizer/backward.cu:415-625): per pixel, back-to-front over the tile's sorted list
 // starting at the forward's last contributor, same guards, T recovered as T_final / prod(1-alpha),
 // gradients w.r.t. colour, semantics, depth, 2D mean (NDC units), conic (a, b, c) and opacity with
@@ -22,9 +22,13 @@
 //     and opacity gradients are exact linear combinations of the six moments, expanded around the
 //     Gaussian's centre right after the MFMA.  16 contributing Gaussians form a group; their w and h
 //     columns are transposed through LDS into the MFMA A-operand layout.
-//  5. One global atomic per (quadrant, Gaussian, quantity) leaves the wave -- 64x fewer than the
-//     reference's one per (pixel, Gaussian, quantity); the 16 semantic channels of a Gaussian go out
-//     as one 64-byte-contiguous wave-level atomic.
+//  5. NO ATOMICS.  The reference adds one float atomic per (pixel, Gaussian, quantity); on MI355X L2
+//     atomics retire about one dword per clock per channel and would dominate this kernel.  Instead
+//     every (quadrant, Gaussian) pair owns one row of a scratch buffer, addressed by the Gaussian's
+//     EMIT-ORDER instance index (Gaussian-major: goff[g] + tile offset inside g's rectangle) times 4
+//     plus the quadrant.  Rows are written once with plain stores plus a validity byte;
+//     reduce_rows_k then sums each Gaussian's rows, which are contiguous in slot space, in a fixed
+//     order.  Gradients are bit-reproducible run to run.
 #include "blend_common.h"
 
 namespace goi {
@@ -32,14 +36,6 @@ namespace goi {
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-// experiment: flags & 2 -> workgroup-scope (L2-local) atomics
-__device__ __forceinline__ void gadd(float* p, float v, int flags) {
-    if (flags & 2)
-        (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    else
-        atomicAdd(p, v);
-}
 
 constexpr int GROUP = 16;    // contributing Gaussians per MFMA group (the M of 16x16x4)
 constexpr int TSTRIDE = 66;  // row stride (floats) of the transposition buffers: conflict-free A reads
@@ -53,22 +49,21 @@ struct BwdCfg {
 };
 
 template <int S4>
-__global__ __launch_bounds__(64) void render_bwd_k(
-    const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int gx, int n_quads,
-    int S, const GaussRec* __restrict__ rec, const float* __restrict__ semantics, const float* __restrict__ bg,
+__global__ __launch_bounds__(64) void render_bwd_rows_k(
+    const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int gx, int gy,
+    int n_quads, int S, const GaussRec* __restrict__ rec, const float* __restrict__ semantics,
+    const int* __restrict__ radii, const uint32_t* __restrict__ goff, const float* __restrict__ bg,
     const float* __restrict__ out_alpha, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
     const float* __restrict__ dL_dpixsem, const float* __restrict__ dL_dpixdepth, const float* __restrict__ dL_dalphas,
-    float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
-    float* __restrict__ dL_dcolor, float* __restrict__ dL_dsemantic, float* __restrict__ dL_ddepths, int exp_flags) {
+    float* __restrict__ rows, uint8_t* __restrict__ flags, int row_floats) {
     using Cfg = BwdCfg<S4>;
     constexpr int NF4 = Cfg::NF4, NSEM = Cfg::NSEM, NCH = Cfg::NCH, NB = Cfg::NB;
     __shared__ float4 s_geo[64];          // x, y, conic a, b
-    __shared__ float2 s_geo2[64];         // conic c, opacity
+    __shared__ float4 s_geo2[64];         // conic c, opacity, slot index (bits), -
     __shared__ float4 s_feat[64 * NF4];   // semantics..., then (r,g,b,depth) in word 0
-    __shared__ uint32_t s_id[64];
     __shared__ float s_wt[GROUP * TSTRIDE];  // w columns, [slot][pixel]
     __shared__ float s_ht[GROUP * TSTRIDE];  // h columns
-    __shared__ float4 s_gmeta[GROUP * 2];    // per group member: (x, y, a, b), (c, opacity, id bits, -)
+    __shared__ float4 s_gmeta[GROUP * 2];    // per group member: (x, y, a, b), (c, opacity, slot bits, -)
 
     const QuadGeom t = quad_geom(W, H, gx, n_quads);
     if (t.tile < 0) return;
@@ -150,7 +145,7 @@ __global__ __launch_bounds__(64) void render_bwd_k(
 
     int nslot = 0;  // filled slots of the current MFMA group (wave-uniform)
 
-    // flushes `cnt` filled slots: D = [w]^T dL (NB blocks) and [h]^T basis, then global atomics
+    // flushes `cnt` filled slots: D = [w]^T dL (NB blocks) and [h]^T basis, then one row per member
     auto flush_group = [&](int cnt) {
         f32x4 acc[NB];
         f32x4 accm = {0.f, 0.f, 0.f, 0.f};
@@ -176,30 +171,24 @@ __global__ __launch_bounds__(64) void render_bwd_k(
         for (int r = 0; r < 4; r++) {
             const int row = 4 * kq + r;
             if (mm < 8) s_wt[row * 8 + mm] = accm[r];  // moments -> exchange area (aliases the w buffer)
-            if (row < cnt && !(exp_flags & 1)) {
-                const uint32_t gid = __float_as_uint(s_gmeta[row * 2 + 1].z);
+            if (row < cnt) {
+                float* dst = rows + (size_t)__float_as_uint(s_gmeta[row * 2 + 1].z) * row_floats;
 #pragma unroll
                 for (int nb = 0; nb < NB; nb++) {
                     const int ch = nb * 16 + mm;
-                    if (ch < NSEM) {
-                        if (ch < S) gadd(&dL_dsemantic[(size_t)gid * S + ch], acc[nb][r], exp_flags);
-                    } else if (ch < NSEM + 3) {
-                        gadd(&dL_dcolor[(size_t)gid * 3 + (ch - NSEM)], acc[nb][r], exp_flags);
-                    } else if (ch == NSEM + 3) {
-                        gadd(&dL_ddepths[gid], acc[nb][r], exp_flags);
-                    }
+                    if (ch < NCH) dst[ch] = acc[nb][r];
                 }
             }
         }
         __builtin_amdgcn_wave_barrier();
         // moments -> (mean2D.x, mean2D.y, conic a, b, c, opacity): one lane per group member
-        if (lane < cnt && !(exp_flags & 1)) {
+        if (lane < cnt) {
             const float4 m03 = *reinterpret_cast<const float4*>(&s_wt[lane * 8]);
             const float2 m45 = *reinterpret_cast<const float2*>(&s_wt[lane * 8 + 4]);
             const float4 g = s_gmeta[lane * 2];
             const float4 g2 = s_gmeta[lane * 2 + 1];
-            const uint32_t gid = __float_as_uint(g2.z);
-            const float Dx = g.x - QCX, Dy = g.y - QCY;  // dx = Dx - u, dy = Dy - v
+            const uint32_t slot = __float_as_uint(g2.z);  // (emit-order instance) * 4 + quadrant
+            const float Dx = g.x - QCX, Dy = g.y - QCY;   // dx = Dx - u, dy = Dy - v
             const float m0 = m03.x, mu = m03.y, mv = m03.z, muu = m03.w, muv = m45.x, mvv = m45.y;
             const float sx = Dx * m0 - mu;                             // sum h dx
             const float sy = Dy * m0 - mv;                             // sum h dy
@@ -207,12 +196,14 @@ __global__ __launch_bounds__(64) void render_bwd_k(
             const float sxy = Dx * Dy * m0 - Dx * mv - Dy * mu + muv;  // sum h dx dy
             const float syy = Dy * Dy * m0 - 2.f * Dy * mv + mvv;      // sum h dy^2
             const float o = g2.y;
-            gadd(&dL_dmean2D[(size_t)gid * 3 + 0], -o * half_W * (g.z * sx + g.w * sy), exp_flags);
-            gadd(&dL_dmean2D[(size_t)gid * 3 + 1], -o * half_H * (g2.x * sy + g.w * sx), exp_flags);
-            gadd(&dL_dconic[(size_t)gid * 4 + 0], -0.5f * o * sxx, exp_flags);
-            gadd(&dL_dconic[(size_t)gid * 4 + 1], -0.5f * o * sxy, exp_flags);
-            gadd(&dL_dconic[(size_t)gid * 4 + 3], -0.5f * o * syy, exp_flags);
-            gadd(&dL_dopacity[gid], m0, exp_flags);
+            float* dst = rows + (size_t)slot * row_floats + NCH;
+            dst[0] = -o * half_W * (g.z * sx + g.w * sy);   // dL/dmean2D.x (NDC units)
+            dst[1] = -o * half_H * (g2.x * sy + g.w * sx);  // dL/dmean2D.y
+            dst[2] = -0.5f * o * sxx;                       // dL/dconic a
+            dst[3] = -0.5f * o * sxy;                       // dL/dconic b
+            dst[4] = -0.5f * o * syy;                       // dL/dconic c
+            dst[5] = m0;                                    // dL/dopacity = sum G dL/dalpha
+            flags[slot] = 1;
         }
         __builtin_amdgcn_wave_barrier();
     };
@@ -228,10 +219,12 @@ __global__ __launch_bounds__(64) void render_bwd_k(
         if (hit) {
             const float4* r4 = reinterpret_cast<const float4*>(rec + id);
             const float4 q1 = r4[1];
+            int x0, y0, x1, y1;
+            tile_rect(q0.x, q0.y, radii[id], gx, gy, x0, y0, x1, y1);
+            const uint32_t inst = goff[id] + (uint32_t)((t.ty - y0) * (x1 - x0) + (t.tx - x0));
             s_geo[lane] = q0;
-            s_geo2[lane] = make_float2(q1.x, q1.y);
+            s_geo2[lane] = make_float4(q1.x, q1.y, __uint_as_float(inst * 4u + (uint32_t)t.q), 0.f);
             s_feat[lane * NF4] = make_float4(q1.w, q2.x, q2.y, q1.z);
-            s_id[lane] = id;
             const float* srow = semantics + (size_t)id * S;
             if ((S & 3) == 0) {
 #pragma unroll
@@ -255,7 +248,7 @@ __global__ __launch_bounds__(64) void render_bwd_k(
             m &= m - 1;
             const int pos0 = n_proc - 1 - (b * 64 + j);  // 0-based list position
             const float4 g = s_geo[j];
-            const float2 g2 = s_geo2[j];
+            const float4 g2 = s_geo2[j];
             const PairEval e = eval_pair(g.x, g.y, g.z, g.w, g2.x, g2.y, t.pxf, t.pyf);
             const bool c = (pos0 < last_contributor) && e.hit;
             if (!__any(c)) continue;
@@ -282,7 +275,7 @@ __global__ __launch_bounds__(64) void render_bwd_k(
             s_ht[nslot * TSTRIDE + lane] = hval;
             if (lane == 0) {  // group members may outlive this batch's staging slots: keep their metadata
                 s_gmeta[nslot * 2] = g;
-                s_gmeta[nslot * 2 + 1] = make_float4(g2.x, g2.y, __uint_as_float(s_id[j]), 0.f);
+                s_gmeta[nslot * 2 + 1] = g2;
             }
             nslot++;
             if (nslot == GROUP) {
@@ -296,32 +289,24 @@ __global__ __launch_bounds__(64) void render_bwd_k(
 }
 
 template <int S4>
-void launch_bwd_s4(const GoiRasterScene& sc, const GeomView& g, const ImageView& im, const uint32_t* point_list,
-                   const float* out_alpha, const float* dL_dpix, const float* dL_dsem, const float* dL_ddepth,
-                   const float* dL_dalpha, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
-                   float* dL_dsemantic, float* dL_ddepths, hipStream_t s) {
+void launch_bwd_rows_s4(const GoiRasterScene& sc, const GeomView& g, const ImageView& im, const uint32_t* point_list,
+                        const int* radii, const float* out_alpha, const float* dL_dpix, const float* dL_dsem,
+                        const float* dL_ddepth, const float* dL_dalpha, const BwdScratchView& scr, hipStream_t s) {
     const int gx = (sc.W + TILE - 1) / TILE, gy = (sc.H + TILE - 1) / TILE;
     const int n_quads = gx * gy * 4;
-    render_bwd_k<S4><<<dim3(quad_grid(n_quads)), dim3(64), 0, s>>>(
-        im.ranges, point_list, sc.W, sc.H, gx, n_quads, sc.S, g.rec, sc.semantics, sc.bg, out_alpha, im.n_contrib, dL_dpix,
-        dL_dsem, dL_ddepth, dL_dalpha, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dsemantic, dL_ddepths,
-        g_options.bwd_variant >> 4);
+    render_bwd_rows_k<S4><<<dim3(quad_grid(n_quads)), dim3(64), 0, s>>>(
+        im.ranges, point_list, sc.W, sc.H, gx, gy, n_quads, sc.S, g.rec, sc.semantics, radii, g.goff, sc.bg, out_alpha,
+        im.n_contrib, dL_dpix, dL_dsem, dL_ddepth, dL_dalpha, scr.rows, scr.flags, bwd_row_floats(sc.S));
 }
 
 }  // namespace
 
-void launch_render_bwd(const GoiRasterScene& sc, const GeomView& g, const ImageView& im, const uint32_t* point_list,
-                       const float* out_alpha, const float* dL_dpix, const float* dL_dsem, const float* dL_ddepth,
-                       const float* dL_dalpha, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
-                       float* dL_dcolor, float* dL_dsemantic, float* dL_ddepths, hipStream_t s) {
-    if (g_options.bwd_variant == 0) {  // default: workgroup-per-tile kernel (fewer L2 atomics)
-        launch_render_bwd_tile(sc, g, im, point_list, out_alpha, dL_dpix, dL_dsem, dL_ddepth, dL_dalpha, dL_dmean2D,
-                               dL_dconic, dL_dopacity, dL_dcolor, dL_dsemantic, dL_ddepths, s);
-        return;
-    }
-#define GOI_CALL(N)                                                                                              \
-    launch_bwd_s4<N>(sc, g, im, point_list, out_alpha, dL_dpix, dL_dsem, dL_ddepth, dL_dalpha, dL_dmean2D, dL_dconic, \
-                     dL_dopacity, dL_dcolor, dL_dsemantic, dL_ddepths, s)
+void launch_render_bwd_rows(const GoiRasterScene& sc, const GeomView& g, const ImageView& im,
+                            const uint32_t* point_list, const int* radii, const float* out_alpha, const float* dL_dpix,
+                            const float* dL_dsem, const float* dL_ddepth, const float* dL_dalpha,
+                            const BwdScratchView& scr, hipStream_t s) {
+#define GOI_CALL(N) \
+    launch_bwd_rows_s4<N>(sc, g, im, point_list, radii, out_alpha, dL_dpix, dL_dsem, dL_ddepth, dL_dalpha, scr, s)
     GOI_DISPATCH_S4(sc.S, GOI_CALL)
 #undef GOI_CALL
 }

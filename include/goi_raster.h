@@ -78,6 +78,7 @@ const char* goi_raster_last_error(void);
 size_t goi_raster_geom_bytes(int P);
 size_t goi_raster_image_bytes(int W, int H);
 size_t goi_raster_binning_bytes(int num_rendered);
+size_t goi_raster_backward_scratch_bytes(int num_rendered, int S);
 
 /* Forward: color[3,H,W], semantic[S,H,W], depth[H,W], alpha[H,W], radii[P] (int32). */
 int goi_raster_forward(const GoiRasterScene* scene, void* geom_buffer, void* image_buffer,
@@ -95,7 +96,10 @@ int goi_raster_backward(const GoiRasterScene* scene, int R,
                         float* dL_dmean2D /*[P,3]*/, float* dL_dconic /*[P,4]*/, float* dL_dopacity /*[P]*/,
                         float* dL_dcolor /*[P,3]*/, float* dL_dsemantic /*[P,S]*/, float* dL_ddepth /*[P]*/,
                         float* dL_dmean3D /*[P,3]*/, float* dL_dcov3D /*[P,6]*/, float* dL_dsh /*[P,M,3]*/,
-                        float* dL_dscale /*[P,3]*/, float* dL_drot /*[P,4]*/, void* stream);
+                        float* dL_dscale /*[P,3]*/, float* dL_drot /*[P,4]*/,
+                        void* scratch /* goi_raster_backward_scratch_bytes(R, S) bytes, uninitialised; NULL selects
+                                         the float-atomic accumulation path (not bit-reproducible) */,
+                        void* stream);
 
 /* Trace: scene->semantics is ignored; img_sem[S,H,W] is scattered onto the Gaussians it meets
  * with alpha > 0.005.  out_color[3,H,W], gau_sem[P,S], num_gsem[P] (int32), radii[P]. */
