@@ -549,26 +549,45 @@ __global__ __launch_bounds__(256) void reduce_rows_k(int P, int S, int nch, cons
 // Emits the (tile id, Gaussian id) instances of every visible Gaussian, walking the Gaussians in
 // depth order so that a stable sort by tile alone reproduces the reference's (tile, depth, id)
 // order (CR/rasterizer_impl.cu:70-111 emits 64-bit tile|depth keys in id order instead).
+// Wave-cooperative: each lane prepares one Gaussian (rectangle, output offset), then the wave walks
+// its 64 Gaussians one at a time and all lanes write that Gaussian's instances side by side, so every
+// store instruction covers one contiguous run instead of 64 scattered words.
 __global__ __launch_bounds__(256) void emit_k(int P, int gx, int gy, const GaussRec* __restrict__ rec,
                                               const int* __restrict__ radii, const uint32_t* __restrict__ order,
                                               const uint32_t* __restrict__ offsets, uint32_t* __restrict__ goff,
                                               uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
-    const uint32_t g = order[i];
-    goff[g] = offsets[i];
-    const int r = radii[g];
-    if (r <= 0) return;
-    const float4 q0 = rec[g].q0;
-    int x0, y0, x1, y1;
-    tile_rect(q0.x, q0.y, r, gx, gy, x0, y0, x1, y1);
-    uint32_t off = offsets[i];
-    for (int y = y0; y < y1; y++)
-        for (int x = x0; x < x1; x++) {
-            keys[off] = (uint32_t)(y * gx + x);
-            vals[off] = g;
-            off++;
+    const int lane = threadIdx.x & 63;
+    uint32_t g = 0, off = 0;
+    int x0 = 0, y0 = 0, w = 1, cnt = 0;
+    if (i < P) {
+        g = order[i];
+        off = offsets[i];
+        goff[g] = off;
+        const int r = radii[g];
+        if (r > 0) {
+            const float4 q0 = rec[g].q0;
+            int x1, y1;
+            tile_rect(q0.x, q0.y, r, gx, gy, x0, y0, x1, y1);
+            w = x1 - x0;
+            cnt = w * (y1 - y0);
         }
+    }
+    unsigned long long todo = __ballot(cnt > 0);
+    while (todo) {
+        const int j = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int cj = __builtin_amdgcn_readlane(cnt, j);
+        const int wj = __builtin_amdgcn_readlane(w, j);
+        const int xj = __builtin_amdgcn_readlane(x0, j), yj = __builtin_amdgcn_readlane(y0, j);
+        const uint32_t oj = (uint32_t)__builtin_amdgcn_readlane((int)off, j);
+        const uint32_t gj = (uint32_t)__builtin_amdgcn_readlane((int)g, j);
+        for (int k = lane; k < cj; k += 64) {
+            const int row = k / wj, col = k - row * wj;
+            keys[oj + k] = (uint32_t)((yj + row) * gx + xj + col);
+            vals[oj + k] = gj;
+        }
+    }
 }
 
 // Per-tile [start,end) from the tile-sorted key list (CR/rasterizer_impl.cu:116-138).
