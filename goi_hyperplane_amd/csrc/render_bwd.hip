@@ -37,7 +37,14 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#if defined(GOI_BWD_WAVES)
+#define GOI_BWD_LAUNCH_BOUNDS __launch_bounds__(64, GOI_BWD_WAVES)
+#else
+#define GOI_BWD_LAUNCH_BOUNDS __launch_bounds__(64)
+#endif
+
 constexpr int GROUP = 16;    // contributing Gaussians per MFMA group (the M of 16x16x4)
+constexpr int BATCH = 32;    // list entries examined / staged per round (lanes 0..31): LDS, not lanes, is scarce
 constexpr int TSTRIDE = 66;  // row stride (floats) of the transposition buffers: conflict-free A reads
 
 template <int S4>
@@ -49,18 +56,18 @@ struct BwdCfg {
 };
 
 template <int S4>
-__global__ __launch_bounds__(64) void render_bwd_rows_k(
+__global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int gx, int gy,
     int n_quads, int S, const GaussRec* __restrict__ rec, const float* __restrict__ semantics,
     const int* __restrict__ radii, const uint32_t* __restrict__ goff, const float* __restrict__ bg,
     const float* __restrict__ out_alpha, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
     const float* __restrict__ dL_dpixsem, const float* __restrict__ dL_dpixdepth, const float* __restrict__ dL_dalphas,
-    float* __restrict__ rows, uint8_t* __restrict__ flags, int row_floats) {
+    float* __restrict__ rows, uint8_t* __restrict__ flags, int row_floats, int exp_flags) {
     using Cfg = BwdCfg<S4>;
     constexpr int NF4 = Cfg::NF4, NSEM = Cfg::NSEM, NCH = Cfg::NCH, NB = Cfg::NB;
-    __shared__ float4 s_geo[64];          // x, y, conic a, b
-    __shared__ float4 s_geo2[64];         // conic c, opacity, slot index (bits), -
-    __shared__ float4 s_feat[64 * NF4];   // semantics..., then (r,g,b,depth) in word 0
+    __shared__ float4 s_geo[BATCH];       // x, y, conic a, b
+    __shared__ float4 s_geo2[BATCH];      // conic c, opacity, slot index (bits), -
+    __shared__ float4 s_feat[BATCH * NF4];  // (r,g,b,depth), semantics...
     __shared__ float s_wt[GROUP * TSTRIDE];  // w columns, [slot][pixel]
     __shared__ float s_ht[GROUP * TSTRIDE];  // h columns
     __shared__ float4 s_gmeta[GROUP * 2];    // per group member: (x, y, a, b), (c, opacity, slot bits, -)
@@ -79,7 +86,7 @@ __global__ __launch_bounds__(64) void render_bwd_rows_k(
     for (int d = 32; d >= 1; d >>= 1) n_proc = max(n_proc, __shfl_xor(n_proc, d, 64));
     n_proc = __builtin_amdgcn_readfirstlane(n_proc);
     if (n_proc == 0) return;  // nothing was composited in this quadrant
-    const int rounds = (n_proc + 63) / 64;
+    const int rounds = (n_proc + BATCH - 1) / BATCH;
 
     // ---- per-pixel upstream gradients, channel order (sem0.., r, g, b, depth)
     const float T_final = t.inside ? (1.f - out_alpha[pix_id]) : 0.f;
@@ -132,9 +139,9 @@ __global__ __launch_bounds__(64) void render_bwd_rows_k(
     uint32_t id_n = 0;
     float4 q0_n = make_float4(0, 0, 0, 0), q2_n = make_float4(0, 0, -1.f, -1.f);
     auto prefetch = [&](int b) {
-        const int k = b * 64 + lane;  // list position n_proc-1-k, walking back to front
+        const int k = b * BATCH + lane;  // list position n_proc-1-k, walking back to front
         q2_n.z = -1.f;
-        if (k < n_proc) {
+        if (lane < BATCH && k < n_proc) {
             id_n = point_list[range.x + (n_proc - 1 - k)];
             const float4* r4 = reinterpret_cast<const float4*>(rec + id_n);
             q0_n = r4[0];
@@ -147,6 +154,7 @@ __global__ __launch_bounds__(64) void render_bwd_rows_k(
 
     // flushes `cnt` filled slots: D = [w]^T dL (NB blocks) and [h]^T basis, then one row per member
     auto flush_group = [&](int cnt) {
+        if (exp_flags & 1) return;
         f32x4 acc[NB];
         f32x4 accm = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -171,7 +179,7 @@ __global__ __launch_bounds__(64) void render_bwd_rows_k(
         for (int r = 0; r < 4; r++) {
             const int row = 4 * kq + r;
             if (mm < 8) s_wt[row * 8 + mm] = accm[r];  // moments -> exchange area (aliases the w buffer)
-            if (row < cnt) {
+            if (row < cnt && !(exp_flags & 2)) {
                 float* dst = rows + (size_t)__float_as_uint(s_gmeta[row * 2 + 1].z) * row_floats;
 #pragma unroll
                 for (int nb = 0; nb < NB; nb++) {
@@ -182,7 +190,7 @@ __global__ __launch_bounds__(64) void render_bwd_rows_k(
         }
         __builtin_amdgcn_wave_barrier();
         // moments -> (mean2D.x, mean2D.y, conic a, b, c, opacity): one lane per group member
-        if (lane < cnt) {
+        if (lane < cnt && !(exp_flags & 2)) {
             const float4 m03 = *reinterpret_cast<const float4*>(&s_wt[lane * 8]);
             const float2 m45 = *reinterpret_cast<const float2*>(&s_wt[lane * 8 + 4]);
             const float4 g = s_gmeta[lane * 2];
@@ -246,7 +254,7 @@ __global__ __launch_bounds__(64) void render_bwd_rows_k(
         while (m) {
             const int j = __builtin_ctzll(m);
             m &= m - 1;
-            const int pos0 = n_proc - 1 - (b * 64 + j);  // 0-based list position
+            const int pos0 = n_proc - 1 - (b * BATCH + j);  // 0-based list position
             const float4 g = s_geo[j];
             const float4 g2 = s_geo2[j];
             const PairEval e = eval_pair(g.x, g.y, g.z, g.w, g2.x, g2.y, t.pxf, t.pyf);
@@ -296,7 +304,7 @@ void launch_bwd_rows_s4(const GoiRasterScene& sc, const GeomView& g, const Image
     const int n_quads = gx * gy * 4;
     render_bwd_rows_k<S4><<<dim3(quad_grid(n_quads)), dim3(64), 0, s>>>(
         im.ranges, point_list, sc.W, sc.H, gx, gy, n_quads, sc.S, g.rec, sc.semantics, radii, g.goff, sc.bg, out_alpha,
-        im.n_contrib, dL_dpix, dL_dsem, dL_ddepth, dL_dalpha, scr.rows, scr.flags, bwd_row_floats(sc.S));
+        im.n_contrib, dL_dpix, dL_dsem, dL_ddepth, dL_dalpha, scr.rows, scr.flags, bwd_row_floats(sc.S), g_options.bwd_variant >> 4);
 }
 
 }  // namespace
