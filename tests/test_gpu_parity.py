@@ -255,3 +255,64 @@ def test_api_errors(dev):
     with pytest.raises(RuntimeError, match="semantics"):
         r(m, m, z(4, 1, device=dev), colors_precomp=z(4, 3, device=dev), scales=z(4, 3, device=dev),
           rotations=z(4, 4, device=dev))
+
+
+def test_full_size_properties(dev):
+    """BASELINE.json's full size (1M Gaussians, 1600x1056, S=16) -- too big for the oracle, so the
+    checks are size-independent properties of the operator:
+      * forward and backward are bit-reproducible (the backward has no atomics);
+      * semantics enter linearly: render(s1 + s2) == render(s1) + render(s2), colour/alpha unchanged;
+      * with loss = sum of semantic channel c, dL/dsemantics[g][c'] = delta(c,c') * sum_pix w[pix,g],
+        so the columns agree and the total gradient mass equals the sum of alpha over the image
+        (sum_g w[pix,g] = 1 - T[pix]) -- a checksum tying the backward to the forward."""
+    from goi_hyperplane_amd.render import GaussianSet, PipelineParams, TorchCamera, render
+    from goi_hyperplane_amd.scene import HEADLINE, make_camera, make_headline_scene
+    sc = make_headline_scene()
+    cam = TorchCamera(make_camera(HEADLINE["W"], HEADLINE["H"], fovx=HEADLINE["fovx"], yaw=0.03), dev)
+    pc = GaussianSet.from_scene(sc, dev)
+    bg = torch.zeros(3, device=dev)
+    pipe = PipelineParams()
+
+    def fwd_bwd(loss_fn):
+        for p in pc.parameters():
+            p.grad = None
+        out = render(cam, pc, pipe, bg)
+        loss_fn(out).backward()
+        return out, {n: p.grad.clone() for n, p in pc.named_parameters()}
+
+    inv = 1.0 / (HEADLINE["W"] * HEADLINE["H"])
+    loss = lambda o: (o["render"].sum() + o["semantics"].sum()) * inv  # noqa: E731
+    o1, g1 = fwd_bwd(loss)
+    o2, g2 = fwd_bwd(loss)
+    for k in ("render", "semantics", "depth", "alpha"):
+        assert torch.equal(o1[k], o2[k]), f"forward {k} not reproducible"
+    for k in g1:
+        assert torch.equal(g1[k], g2[k]), f"gradient {k} not bit-reproducible"
+        assert torch.isfinite(g1[k]).all()
+    assert int((o1["radii"] > 0).sum()) > 400_000 and float(o1["alpha"].mean()) > 0.9
+
+    # linearity in the semantic features
+    with torch.no_grad():
+        s_orig = pc._semantics.detach().clone()
+        s_a = torch.randn_like(s_orig)
+        s_b = torch.randn_like(s_orig)
+        pc._semantics.copy_(s_a)
+        ra = render(cam, pc, pipe, bg)
+        pc._semantics.copy_(s_b)
+        rb = render(cam, pc, pipe, bg)
+        pc._semantics.copy_(s_a + s_b)
+        rab = render(cam, pc, pipe, bg)
+        pc._semantics.copy_(s_orig)
+        assert torch.equal(ra["render"], rb["render"]) and torch.equal(ra["alpha"], rb["alpha"])
+        err = (rab["semantics"] - (ra["semantics"] + rb["semantics"])).abs().max().item()
+        assert err < 1e-4, err
+
+    # gradient mass == alpha mass, column by column
+    o3, g3 = fwd_bwd(lambda o: o["semantics"][3].sum())
+    gs = g3["_semantics"].double()
+    alpha_mass = o3["alpha"].double().sum().item()
+    assert abs(gs[:, 3].sum().item() - alpha_mass) < 1e-4 * alpha_mass
+    other = torch.cat([gs[:, :3], gs[:, 4:]], 1).abs().max().item()
+    assert other == 0.0
+    o4, g4 = fwd_bwd(lambda o: o["semantics"][11].sum())
+    assert (g4["_semantics"][:, 11] - g3["_semantics"][:, 3]).abs().max().item() <= 1e-6 * g3["_semantics"][:, 3].abs().max().item() + 1e-9
