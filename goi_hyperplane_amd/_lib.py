@@ -49,6 +49,8 @@ SYMBOLS = {
     "goi_raster_mark_visible": (C.c_int, [C.c_int] + [C.c_void_p] * 4 + [C.c_void_p]),
     "goi_raster_profile_enable": (None, [C.c_int]),
     "goi_raster_profile_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "goi_semantic_decode": (C.c_int, [C.c_void_p, C.c_int, C.c_longlong, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                      C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "goi_raster_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     "goi_raster_debug_views": (C.c_int, [C.c_int] * 4 + [C.c_void_p] * 3 + [C.c_void_p] * 8 + [C.c_void_p]),
 }

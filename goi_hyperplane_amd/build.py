@@ -31,6 +31,7 @@ UNITS = {
     "render_fwd.hip": [],
     "render_bwd.hip": [],
     "render_bwd_tile.hip": [],
+    "semantic_head.hip": [],
 }
 
 

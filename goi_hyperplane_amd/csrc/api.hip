@@ -372,6 +372,19 @@ int goi_raster_mark_visible(int P, const float* means3D, const float* viewmatrix
     return 0;
 }
 
+int goi_semantic_decode(const float* sem, int S, long long HW, const float* W, const float* bias, int n_codes,
+                        const float* code_score, float thresh, float* sim_out, int* idx_out, uint8_t* bg_mask_out,
+                        void* stream) {
+    if (!sem || !W || !bias) return fail("goi_semantic_decode: NULL input");
+    if (S < 1 || S > 32 || n_codes < 1 || HW < 0) return fail("goi_semantic_decode: need 1 <= S <= 32, n_codes >= 1");
+    if (HW == 0) return 0;
+    if (launch_semantic_decode(sem, S, HW, W, bias, n_codes, code_score, thresh, sim_out, idx_out, bg_mask_out,
+                               static_cast<hipStream_t>(stream)) < 0)
+        return fail("goi_semantic_decode: code book too large for LDS");
+    GOI_HIP(hipGetLastError());
+    return 0;
+}
+
 void goi_raster_profile_enable(int on) { g_profile = on != 0; }
 
 int goi_raster_set_option(const char* name, int value) {

@@ -106,6 +106,9 @@ void launch_render_bwd_tile(const GoiRasterScene& sc, const GeomView& g, const I
 void launch_preprocess_bwd(const GoiRasterScene& sc, const GeomView& g, const int* radii, const float* dL_dmean2D,
                            const float* dL_dconic, float* dL_dcolor, const float* dL_ddepth, float* dL_dmean3D,
                            float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, hipStream_t s);
+int launch_semantic_decode(const float* sem, int S, long long HW, const float* W, const float* bias, int n_codes,
+                           const float* code_score, float thresh, float* sim_out, int* idx_out, uint8_t* bg_mask_out,
+                           hipStream_t s);
 void launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
 
 // Tile rectangle of a Gaussian (restates getRect, CR/auxiliary.h:46-56: float divide, truncation).

@@ -1,0 +1,142 @@
+// Fused semantic-head decode for gfx950 (the inference half of SURVEY.md row a23).
+//
+// Reference behaviour (gui/main.py:364-386 with scene/semantic_model.py:13-50 used as ONE
+// Linear(S -> n_codes, bias) -- train.py:64 -- and a code book LUT[n_codes, 256]):
+//     dec   = MLP(f)                       f = rendered semantic feature of a pixel, [S]
+//     idx   = argmax softmax(10 * dec)     (= argmax dec)
+//     feat  = LUT[idx] / |LUT[idx]|
+//     sim   = sigmoid(LinearSVM(feat))  or  vlm similarity(feat)
+//     sim[sim < thresh] = 0
+// Everything after the argmax depends on the code index only, so the host folds it into a table
+// code_score[n_codes]; the per-pixel work is the dense contraction F[HW,S] x W^T[S,n_codes] + b and an
+// argmax.  That contraction runs on the matrix cores in exact fp32 (v_mfma_f32_16x16x4_f32: M = 16
+// pixels, N = 16 codes, K = 4 channels per instruction) and never materialises the [HW, n_codes]
+// logits, the [HW, 256] gathered features or the permuted [HW, S] copy of the rasterizer output:
+// the kernel reads the rasterizer's channel-major [S, H, W] tensor directly (A operand: 16
+// consecutive pixels of one channel = one 64-byte segment) and writes 4-8 bytes per pixel.
+#include "common.h"
+
+namespace goi {
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int MAX_K4 = 8;  // S <= 32
+
+// (value, index) max with lowest-index tie break across the 16 lanes of a DPP row
+__device__ __forceinline__ void row_argmax(float& v, int& i) {
+#define GOI_STEP(ctrl)                                                                                  \
+    {                                                                                                   \
+        const float ov = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), ctrl, 0xF, 0xF, false)); \
+        const int oi = __builtin_amdgcn_update_dpp(i, i, ctrl, 0xF, 0xF, false);                        \
+        const bool take = (ov > v) || (ov == v && oi < i);                                              \
+        v = take ? ov : v;                                                                              \
+        i = take ? oi : i;                                                                              \
+    }
+    GOI_STEP(0xB1)   // quad_perm [1,0,3,2]
+    GOI_STEP(0x4E)   // quad_perm [2,3,0,1]
+    GOI_STEP(0x141)  // row_half_mirror
+    GOI_STEP(0x140)  // row_mirror
+#undef GOI_STEP
+}
+
+template <int K4>
+__global__ __launch_bounds__(256) void semantic_decode_k(const float* __restrict__ sem, int S, long long HW,
+                                                         const float* __restrict__ Wm, const float* __restrict__ bias,
+                                                         int n_codes, const float* __restrict__ code_score, float thresh,
+                                                         float* __restrict__ sim_out, int* __restrict__ idx_out,
+                                                         uint8_t* __restrict__ bg_mask_out) {
+    extern __shared__ __attribute__((aligned(16))) float s_w[];  // W^T padded: [4*K4][ncp], then bias[ncp]
+    const int nblk = (n_codes + 15) / 16, ncp = nblk * 16;
+    float* s_b = s_w + (size_t)4 * K4 * ncp;
+    for (int i = threadIdx.x; i < 4 * K4 * ncp; i += 256) {
+        const int ch = i / ncp, code = i - ch * ncp;
+        s_w[i] = (ch < S && code < n_codes) ? Wm[(size_t)code * S + ch] : 0.f;
+    }
+    for (int i = threadIdx.x; i < ncp; i += 256) s_b[i] = i < n_codes ? bias[i] : -__builtin_inff();
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kq = lane >> 4, mm = lane & 15;
+    const long long n_groups = (HW + 63) / 64;
+    for (long long grp = (long long)blockIdx.x * 4 + wave; grp < n_groups; grp += (long long)gridDim.x * 4) {
+        const long long pix0 = grp * 64;
+#pragma unroll 1
+        for (int mb = 0; mb < 4; mb++) {
+            // A fragments: pixel pix0 + 16 mb + mm, channels 4 s + kq
+            const long long pa = pix0 + 16 * mb + mm;
+            float a[K4];
+#pragma unroll
+            for (int s = 0; s < K4; s++) {
+                const int ch = 4 * s + kq;
+                a[s] = (ch < S && pa < HW) ? sem[(size_t)ch * HW + pa] : 0.f;
+            }
+            float bv[4] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+            int bi[4] = {0, 0, 0, 0};
+            for (int nb = 0; nb < nblk; nb++) {
+                const float b0 = s_b[nb * 16 + mm];
+                f32x4 acc = {b0, b0, b0, b0};
+#pragma unroll
+                for (int s = 0; s < K4; s++)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], s_w[(size_t)(4 * s + kq) * ncp + nb * 16 + mm], acc, 0,
+                                                               0, 0);
+                const int code = nb * 16 + mm;
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    if (acc[r] > bv[r]) {  // strict: earlier (lower) codes win ties
+                        bv[r] = acc[r];
+                        bi[r] = code;
+                    }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) row_argmax(bv[r], bi[r]);
+            if (mm == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const long long p = pix0 + 16 * mb + 4 * kq + r;  // D row = 4*kq + r
+                    if (p < HW) {
+                        const int code = bi[r];
+                        float sc = code_score ? code_score[code] : 0.f;
+                        const bool bg = sc < thresh;
+                        if (bg) sc = 0.f;
+                        if (sim_out) sim_out[p] = sc;
+                        if (idx_out) idx_out[p] = code;
+                        if (bg_mask_out) bg_mask_out[p] = bg ? 1 : 0;
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+int launch_semantic_decode(const float* sem, int S, long long HW, const float* W, const float* bias, int n_codes,
+                           const float* code_score, float thresh, float* sim_out, int* idx_out, uint8_t* bg_mask_out,
+                           hipStream_t s) {
+    const int K4 = (S + 3) / 4;
+    const int ncp = ((n_codes + 15) / 16) * 16;
+    const size_t lds = ((size_t)4 * K4 * ncp + ncp) * sizeof(float);
+    if (lds > 160 * 1024) return -1;
+    const long long n_groups = (HW + 63) / 64;
+    long long blocks = (n_groups + 3) / 4;
+    if (blocks > 256 * 8) blocks = 256 * 8;  // grid-stride: W^T is staged into LDS once per workgroup
+    if (blocks < 1) blocks = 1;
+#define GOI_CASE(N)                                                                                            \
+    case N:                                                                                                    \
+        if (lds > 64 * 1024)                                                                                   \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(semantic_decode_k<N>),                     \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
+        semantic_decode_k<N><<<dim3((unsigned)blocks), dim3(256), lds, s>>>(sem, S, HW, W, bias, n_codes, code_score, \
+                                                                             thresh, sim_out, idx_out, bg_mask_out); \
+        break;
+    switch (K4) {
+        GOI_CASE(1) GOI_CASE(2) GOI_CASE(3) GOI_CASE(4) GOI_CASE(5) GOI_CASE(6) GOI_CASE(7) GOI_CASE(8)
+        default: return -1;
+    }
+#undef GOI_CASE
+    return 0;
+}
+
+}  // namespace goi

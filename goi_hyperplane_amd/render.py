@@ -158,3 +158,15 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
         opacities=opacity, scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
     return {"render": rendered_image, "semantics": rendered_sem, "depth": depth, "alpha": alpha,
             "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii}
+
+
+def render_gui(viewpoint_camera, pc, bg_color, scaling_modifier=1.0, override_color=None, compute_cov3D_python=False,
+               convert_SHs_python=False, gaussian_mask=None):
+    """gui/gs_renderer.py:231-348 (Renderer.render): same rasterizer call as render(), optional
+    `gaussian_mask` index-select of every per-Gaussian tensor (:315-321), image clamped to [0,1] (:336),
+    result keyed "image" instead of "render"."""
+    pipe = PipelineParams(convert_SHs_python=convert_SHs_python, compute_cov3D_python=compute_cov3D_python)
+    out = render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier, override_color, gaussian_mask)
+    return {"image": out["render"].clamp(0, 1), "semantics": out["semantics"], "depth": out["depth"],
+            "alpha": out["alpha"], "viewspace_points": out["viewspace_points"],
+            "visibility_filter": out["visibility_filter"], "radii": out["radii"]}

@@ -111,6 +111,17 @@ int goi_raster_trace(const GoiRasterScene* scene, const float* img_sem, void* ge
 int goi_raster_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                             uint8_t* present, void* stream);
 
+/* ---- semantic head, inference decode ----------------------------------------
+ * Replaces, per pixel, gui/main.py:364-386 of the reference with scene/semantic_model.py used as one
+ * Linear(S -> n_codes, bias):  idx = argmax_c (W[c,:] . f + b[c]);  sim = code_score[idx];
+ * sim < thresh -> background (sim = 0).  `sem` is the rasterizer's semantic output [S, HW]
+ * (channel-major, no permute); W is [n_codes, S] row-major (torch Linear.weight); code_score[n_codes]
+ * is the host-folded tail (LUT lookup -> L2 normalise -> LinearSVM/VLM score).  Any of sim_out[HW],
+ * idx_out[HW] (int32), bg_mask_out[HW] (bytes) may be NULL.  S <= 32. */
+int goi_semantic_decode(const float* sem, int S, long long HW, const float* W, const float* bias, int n_codes,
+                        const float* code_score, float thresh, float* sim_out, int* idx_out, uint8_t* bg_mask_out,
+                        void* stream);
+
 /* ---- measurement hooks (bench.py): per-stage HIP-event timing on the launch stream ---------- */
 enum {
     GOI_STAGE_PREPROCESS = 0,   /* forward per-Gaussian kernel */

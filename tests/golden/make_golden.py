@@ -94,6 +94,60 @@ def ref_python_pins():
     print("wrote ref_python_pins.npz", {k: v.shape for k, v in out.items()})
 
 
+def semantic_pins():
+    """Semantic head: outputs of the REFERENCE's SemanticModel class
+    (scene/semantic_model.py, loaded by file path because the `scene` package imports clip) and a
+    checkpoint written by its own save(); the gui/main.py:364-386 decode and the train.py:142-163
+    losses are evaluated here with that model (those two files cannot be imported: dearpygui / cv2)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_semantic_model", os.path.join(REF, "scene", "semantic_model.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    torch.manual_seed(7)
+    S, TAB, APE, HW = 10, 300, 256, 24 * 16
+    mlp = mod.SemanticModel(dim_in=S, dim_out=TAB, num_layer=1, use_bias=True, device="cpu")
+    with torch.no_grad():
+        mlp.layers[0].bias.normal_(0, 0.1)
+    mlp.save(os.path.join(HERE, "ref_semantic_mlp.pt"))
+    feats = torch.randn(HW, S)
+    lut = torch.rand(TAB, APE) * 0.03 + 0.01 * torch.randn(TAB, APE)
+    svm_w = torch.randn(1, APE) * 0.5
+    svm_b = torch.tensor([0.3])
+    with torch.no_grad():
+        dec = mlp(feats)
+        sem_logit = torch.softmax(dec * 10, dim=-1).argmax(dim=-1)            # gui/main.py:366
+        sem_feature = lut[sem_logit]                                          # :367
+        normed = sem_feature / sem_feature.norm(dim=-1, keepdim=True)         # :370
+        logit = torch.nn.functional.linear(normed / 0.3438, svm_w, svm_b).squeeze()  # networks.py:56-57
+        sim = logit.sigmoid()                                                 # :374
+        bg = sim < 0.5                                                        # :379
+        sim_out = sim.clone()
+        sim_out[bg] = 0                                                       # :382
+    # training losses, train.py:142-163, iteration < 1000
+    gtl = torch.randn(HW, APE)
+    lutp = lut.clone().requires_grad_(True)
+    f = feats.clone().requires_grad_(True)
+    sem_label = torch.softmax(mlp(f), dim=-1)
+    g = gtl / gtl.norm(dim=1, keepdim=True)
+    lut1 = lutp / lutp.norm(dim=1, keepdim=True)
+    simm = g @ lut1.T
+    sim_val = simm.max(dim=1, keepdim=True)[0]
+    label = (simm == sim_val).float().detach()
+    lab = torch.nn.MSELoss()(sem_label, label) * 50
+    sl = (1 - sim_val.mean())
+    recc = 1 - torch.nn.functional.cosine_similarity(lutp[sem_label.argmax(-1)], g, dim=-1).mean()
+    b = torch.softmax(simm * 1, dim=1) * torch.log_softmax(simm * 1, dim=1)
+    sl1 = -1.0 * b.sum(dim=-1).mean()
+    loss = lab + sl + 0.3 * sl1 + recc
+    loss.backward()
+    np.savez_compressed(os.path.join(HERE, "ref_semantic_pins.npz"), feats=feats.numpy(), lut=lut.numpy(),
+                        svm_w=svm_w.numpy(), svm_b=svm_b.numpy(), dec=dec.numpy(), idx=sem_logit.numpy(),
+                        sim=sim_out.numpy(), bg=bg.numpy(), gtl=gtl.numpy(), loss=loss.item(),
+                        terms=np.array([lab.item(), sl.item(), sl1.item(), recc.item()]),
+                        grad_feats=f.grad.numpy(), grad_lut=lutp.grad.numpy())
+    print("wrote ref_semantic_pins.npz, ref_semantic_mlp.pt; loss", loss.item())
+
+
 ORACLE_CASES = {
     # name: (P, S, W, H, log_scale_mean, kwargs)
     "s10_sh3": dict(P=1500, S=10, W=128, H=96, mu=-2.8, deg=3),
@@ -138,4 +192,5 @@ def oracle_goldens():
 
 if __name__ == "__main__":
     ref_python_pins()
+    semantic_pins()
     oracle_goldens()

@@ -316,3 +316,43 @@ def test_full_size_properties(dev):
     assert other == 0.0
     o4, g4 = fwd_bwd(lambda o: o["semantics"][11].sum())
     assert (g4["_semantics"][:, 11] - g3["_semantics"][:, 3]).abs().max().item() <= 1e-6 * g3["_semantics"][:, 3].abs().max().item() + 1e-9
+
+
+def test_fused_semantic_decode_matches_unfused_reference(dev):
+    """csrc/semantic_head.hip (MFMA contraction + argmax + score lookup) vs the unfused restatement of
+    gui/main.py:364-386, on the committed reference pins and at full frame size."""
+    from goi_hyperplane_amd.semantic import (LinearSVM, SemanticModel, compute_similarity,
+                                             compute_similarity_reference, svm_score_fn)
+    pins = np.load(os.path.join(GOLD, "ref_semantic_pins.npz"))
+    mlp = SemanticModel.load(os.path.join(GOLD, "ref_semantic_mlp.pt"), map_location="cpu").to(dev)
+    svm = LinearSVM().to(dev)
+    with torch.no_grad():
+        svm.linear.weight.copy_(torch.tensor(pins["svm_w"]))
+        svm.linear.bias.copy_(torch.tensor(pins["svm_b"]))
+    lut = torch.tensor(pins["lut"], device=dev)
+    feats = torch.tensor(pins["feats"], device=dev)                 # [HW, S]
+    sem_chw = feats.T.reshape(10, 24, 16).contiguous()
+    bg = torch.zeros(feats.shape[0], dtype=torch.bool, device=dev)
+    sim, idx = compute_similarity(sem_chw, mlp, lut, svm_score_fn(svm), 0.5, out_bg_mask=bg, return_index=True)
+    assert (idx.cpu().numpy() == pins["idx"]).all()
+    assert (bg.cpu().numpy() == pins["bg"]).all()
+    np.testing.assert_allclose(sim.cpu().numpy(), pins["sim"], rtol=1e-5, atol=1e-6)
+
+    # full frame, S = 16, 300 codes: argmax may differ from the GEMM-based reference only on near ties
+    torch.manual_seed(0)
+    S, H, W = 16, 1056, 1600
+    mlp16 = SemanticModel(dim_in=S, dim_out=300, num_layer=1, use_bias=True, device=dev)
+    lut16 = torch.rand(300, 256, device=dev)
+    sem = torch.randn(S, H, W, device=dev)
+    sim_f, idx_f = compute_similarity(sem, mlp16, lut16, svm_score_fn(svm), 0.5, return_index=True)
+    sim_r, idx_r = compute_similarity_reference(sem.permute(1, 2, 0).reshape(-1, S), mlp16, lut16, svm_score_fn(svm), 0.5)
+    agree = (idx_f.long() == idx_r)
+    assert agree.float().mean().item() > 0.9999
+    assert (sim_f[agree] - sim_r[agree]).abs().max().item() < 1e-6
+    # odd sizes: HW not a multiple of 64, S not a multiple of 4, n_codes not a multiple of 16
+    mlp7 = SemanticModel(dim_in=7, dim_out=37, num_layer=1, use_bias=True, device=dev)
+    lut7 = torch.rand(37, 256, device=dev)
+    sem7 = torch.randn(7, 13, 11, device=dev)
+    s7, i7 = compute_similarity(sem7, mlp7, lut7, svm_score_fn(svm), 0.5, return_index=True)
+    r7, j7 = compute_similarity_reference(sem7.permute(1, 2, 0).reshape(-1, 7), mlp7, lut7, svm_score_fn(svm), 0.5)
+    assert (i7.long() == j7).all() and (s7 - r7).abs().max().item() < 1e-6

@@ -1,0 +1,58 @@
+"""CPU pins of the semantic head against vectors produced by the REFERENCE's own
+SemanticModel class and its checkpoint format (tests/golden/make_golden.py:semantic_pins)."""
+import os
+
+import numpy as np
+import torch
+
+from goi_hyperplane_amd.semantic import (LinearSVM, SemanticModel, codebook_losses, compute_similarity_reference,
+                                         svm_score_fn)
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _load():
+    pins = np.load(os.path.join(GOLD, "ref_semantic_pins.npz"))
+    mlp = SemanticModel.load(os.path.join(GOLD, "ref_semantic_mlp.pt"), map_location="cpu")  # written by the reference class
+    return pins, mlp
+
+
+def _svm(pins):
+    svm = LinearSVM()
+    with torch.no_grad():
+        svm.linear.weight.copy_(torch.tensor(pins["svm_w"]))
+        svm.linear.bias.copy_(torch.tensor(pins["svm_b"]))
+    return svm
+
+
+def test_reference_checkpoint_loads_and_matches():
+    pins, mlp = _load()
+    assert mlp.args["dim_in"] == 10 and mlp.args["dim_out"] == 300 and mlp.num_layer == 1
+    with torch.no_grad():
+        dec = mlp(torch.tensor(pins["feats"]))
+    np.testing.assert_allclose(dec.numpy(), pins["dec"], rtol=1e-5, atol=1e-6)
+
+
+def test_decode_restatement_matches_reference_lines():
+    pins, mlp = _load()
+    bg = torch.zeros(pins["feats"].shape[0], dtype=torch.bool)
+    sim, idx = compute_similarity_reference(torch.tensor(pins["feats"]), mlp, torch.tensor(pins["lut"]),
+                                            svm_score_fn(_svm(pins)), 0.5, out_bg_mask=bg)
+    assert (idx.numpy() == pins["idx"]).all()
+    assert (bg.numpy() == pins["bg"]).all()
+    np.testing.assert_allclose(sim.numpy(), pins["sim"], rtol=1e-5, atol=1e-6)
+
+
+def test_training_losses_match_reference_lines():
+    pins, mlp = _load()
+    S, H, W = 10, 24, 16
+    f = torch.tensor(pins["feats"]).T.reshape(S, H, W).clone().requires_grad_(True)
+    lut = torch.tensor(pins["lut"]).clone().requires_grad_(True)
+    gtl = torch.tensor(pins["gtl"]).T.reshape(256, H, W)
+    loss, terms = codebook_losses(f, mlp, lut, gtl, iteration=1)
+    loss.backward()
+    assert abs(loss.item() - float(pins["loss"])) < 1e-5
+    np.testing.assert_allclose([terms[k].item() for k in ("lab", "sl", "sl1", "recc")], pins["terms"], rtol=1e-5, atol=1e-6)
+    gf = f.grad.reshape(S, -1).T.numpy()
+    np.testing.assert_allclose(gf, pins["grad_feats"], rtol=1e-4, atol=1e-8)
+    np.testing.assert_allclose(lut.grad.numpy(), pins["grad_lut"], rtol=1e-4, atol=1e-8)
