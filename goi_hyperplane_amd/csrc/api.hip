@@ -42,7 +42,7 @@ struct StageEvents {
     int stage;
     hipEvent_t a, b;
 };
-bool g_profile = false;
+unsigned g_profile_mask = 0;  // bit i = record HIP events around GOI_STAGE_i
 std::vector<StageEvents> g_events;
 std::vector<hipEvent_t> g_pool;
 
@@ -61,7 +61,7 @@ struct StageTimer {
     hipStream_t s;
     bool on;
     StageEvents ev{};
-    StageTimer(int stage, hipStream_t st) : s(st), on(g_profile) {
+    StageTimer(int stage, hipStream_t st) : s(st), on((g_profile_mask >> stage) & 1u) {
         if (on) {
             ev.stage = stage;
             ev.a = get_event();
@@ -385,7 +385,9 @@ int goi_semantic_decode(const float* sem, int S, long long HW, const float* W, c
     return 0;
 }
 
-void goi_raster_profile_enable(int on) { g_profile = on != 0; }
+void goi_raster_profile_enable(int on) { g_profile_mask = on ? ~0u : 0u; }
+
+void goi_raster_profile_stages(unsigned stage_mask) { g_profile_mask = stage_mask; }
 
 int goi_raster_set_option(const char* name, int value) {
     if (!name) return fail("option name is NULL");

@@ -137,6 +137,9 @@ enum {
 };
 /* on != 0: record events around every stage of subsequent calls (adds event overhead). */
 void goi_raster_profile_enable(int on);
+/* Same, restricted to the stages whose bit (1u << GOI_STAGE_x) is set; 0 turns profiling off.  Timing
+ * one stage costs two event records per call instead of two per stage. */
+void goi_raster_profile_stages(unsigned stage_mask);
 /* Synchronises the recorded events and ADDS each stage's elapsed milliseconds and launch count
  * since the last reset into ms[GOI_STAGE_COUNT] / calls[GOI_STAGE_COUNT]; then resets. */
 int goi_raster_profile_collect(double* ms, int* calls);
