@@ -47,6 +47,8 @@ SYMBOLS = {
     "goi_raster_trace": (C.c_int, [C.POINTER(GoiRasterScene), C.c_void_p, C.c_void_p, C.c_void_p, ALLOC_FN,
                                    C.c_void_p] + [C.c_void_p] * 4 + [C.c_void_p]),
     "goi_raster_mark_visible": (C.c_int, [C.c_int] + [C.c_void_p] * 4 + [C.c_void_p]),
+    "goi_knn_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "goi_knn_dist2": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "goi_raster_profile_enable": (None, [C.c_int]),
     "goi_raster_profile_stages": (None, [C.c_uint]),
     "goi_raster_profile_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int)]),

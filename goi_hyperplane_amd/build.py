@@ -32,6 +32,7 @@ UNITS = {
     "render_bwd.hip": [],
     "render_bwd_tile.hip": [],
     "semantic_head.hip": [],
+    "knn.hip": ["-ffp-contract=off"],
 }
 
 

@@ -385,6 +385,18 @@ int goi_semantic_decode(const float* sem, int S, long long HW, const float* W, c
     return 0;
 }
 
+size_t goi_knn_workspace_bytes(int P) { return P > 0 ? knn_workspace_bytes(P) : 0; }
+
+int goi_knn_dist2(int P, const float* points, float* mean_dist2, void* workspace, void* stream) {
+    if (P < 0) return fail("goi_knn_dist2: bad P");
+    if (P == 0) return 0;
+    if (!points || !mean_dist2 || !workspace) return fail("goi_knn_dist2: a required pointer is NULL");
+    if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail("goi_knn_dist2: workspace must be 256-byte aligned");
+    launch_knn(P, points, mean_dist2, workspace, static_cast<hipStream_t>(stream));
+    GOI_HIP(hipGetLastError());
+    return 0;
+}
+
 void goi_raster_profile_enable(int on) { g_profile_mask = on ? ~0u : 0u; }
 
 void goi_raster_profile_stages(unsigned stage_mask) { g_profile_mask = stage_mask; }

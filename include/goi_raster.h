@@ -147,6 +147,15 @@ int goi_raster_profile_collect(double* ms, int* calls);
 /* Tuning / experiment switches ("fwd_variant", "bwd_variant"); defaults are the shipped kernels. */
 int goi_raster_set_option(const char* name, int value);
 
+/* ---- simple_knn._C.distCUDA2 (submodules/simple-knn/ext.cpp:15-17, spatial.cu:15-26,
+ * simple_knn.cu:170-221): mean squared distance of every point to its 3 nearest OTHER points,
+ * mean_dist2[i] = (d0 + d1 + d2) / 3 in fp32.  points [P,3] and mean_dist2 [P] are device pointers;
+ * workspace holds goi_knn_workspace_bytes(P) bytes of device memory (256-byte aligned).  With fewer
+ * than 4 points the missing neighbours count as FLT_MAX, as in the reference.  Asynchronous on
+ * `stream`; no host read-back. */
+size_t goi_knn_workspace_bytes(int P);
+int goi_knn_dist2(int P, const float* points, float* mean_dist2, void* workspace, void* stream);
+
 /* Inspection of the opaque workspaces (tests only): copies device -> caller DEVICE buffers.
  * Any pointer may be NULL.  point_list is in final sorted order. */
 int goi_raster_debug_views(int P, int W, int H, int R, const void* geom_buffer, const void* binning_buffer,

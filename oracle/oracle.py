@@ -28,7 +28,7 @@ class _Scene(C.Structure):
 
 def build(force: bool = False) -> None:
     """Compile liboracle.so / liboracle_fma.so with the committed Makefile (g++ only)."""
-    if force or not os.path.exists(os.path.join(_HERE, "liboracle.so")):
+    if force or not all(os.path.exists(os.path.join(_HERE, n)) for n in ("liboracle.so", "libknn_oracle.so")):
         subprocess.check_call(["make", "-C", _HERE, "all"], stdout=subprocess.DEVNULL)
 
 
@@ -203,3 +203,24 @@ def from_scene(scene, cam, bg=(0.0, 0.0, 0.0), **kw) -> Oracle:
                 sh_degree=scene.sh_degree)
     args.update(kw)
     return Oracle(**args)
+
+
+def knn_mean_dist2(points, fma: bool = True, brute: bool = False):
+    """distCUDA2 oracle (oracle/knn_oracle.cpp): points [P,3] float32 -> mean squared distance to the
+    3 nearest other points, [P] float32.  brute=True runs the O(P^2) definition instead of the
+    restated Morton/box search."""
+    path = os.path.join(_HERE, "libknn_oracle.so")
+    if not os.path.exists(path):
+        build(force=True)
+    if "knn" not in _libs:
+        lib = C.CDLL(path)
+        for fn in (lib.goi_knn_oracle, lib.goi_knn_oracle_brute):
+            fn.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+            fn.restype = None
+        _libs["knn"] = lib
+    lib = _libs["knn"]
+    pts = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 3)
+    out = np.zeros(pts.shape[0], dtype=np.float32)
+    fn = lib.goi_knn_oracle_brute if brute else lib.goi_knn_oracle
+    fn(pts.shape[0], pts.ctypes.data, out.ctypes.data, 1 if fma else 0)
+    return out

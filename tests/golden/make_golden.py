@@ -190,7 +190,21 @@ def oracle_goldens():
         print("wrote", name, "N", f.num_rendered, "fragile", int(f.fragile.sum()))
 
 
+def knn_golden():
+    """distCUDA2 has no reference-side vectors (CUDA-only implementation, no tests); the fixture is an
+    independent exact answer: float64 k-d tree, k = 4 including the point itself."""
+    from scipy.spatial import cKDTree
+
+    rng = np.random.default_rng(11)
+    c = rng.standard_normal((12, 3)) * 3
+    pts = (c[rng.integers(0, 12, 3000)] + 0.2 * rng.standard_normal((3000, 3))).astype(np.float32)
+    d, _ = cKDTree(pts.astype(np.float64)).query(pts.astype(np.float64), k=4)
+    np.savez_compressed(os.path.join(HERE, "knn_kdtree64.npz"), points=pts, mean_dist2=(d[:, 1:] ** 2).mean(1))
+    print("wrote knn_kdtree64")
+
+
 if __name__ == "__main__":
+    knn_golden()
     ref_python_pins()
     semantic_pins()
     oracle_goldens()
