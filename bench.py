@@ -8,8 +8,9 @@
 Workload (BASELINE.json metric): 1M Gaussians, 1600x1056, RGB from SH degree 3 + 16-d semantic
 feature, fp32; synthetic scene of SURVEY.md 8(d) (goi_hyperplane_amd.scene.HEADLINE).
 A "step" = one training view on every rank: rasterizer forward + backward through the reference-
-shaped autograd operator (loss = (sum colour + sum semantics)/HW), then -- when N > 1 -- the sum
-all-reduce of the Gaussian gradients over RCCL.  Views are independent, so ranks shard them
+shaped autograd operator (render() -> torch.autograd.backward with dense upstream gradients
+dL/dcolour [3,H,W], dL/dsemantics [S,H,W]; the image-space loss itself is not part of the metric),
+then -- when N > 1 -- the sum all-reduce of the Gaussian gradients over RCCL.  Views are independent, so ranks shard them
 (weak scaling: one view per rank per step); value = N*K / max-over-ranks time.
 
 The JSON line also carries
@@ -145,14 +146,17 @@ def main():
     T = ((args.W + 15) // 16) * ((args.H + 15) // 16)
     inv_hw = 1.0 / HW
     stats = {"V": 0, "N": 0, "views": 0}
+    # upstream gradients of a dense image-space loss (fixed, so that no loss kernels sit in the step)
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    g_color = torch.randn((3, args.H, args.W), device=dev, generator=gen) * inv_hw
+    g_sem = torch.randn((args.S, args.H, args.W), device=dev, generator=gen) * inv_hw
 
     def step(i, record=False):
         cam = cams[(i * world + rank) % len(cams)]  # rank r takes views r, r+G, ... of the cycle
         for p in params:
             p.grad = None
         out = render(cam, pc, pipe, bg)
-        loss = (out["render"].sum() + out["semantics"].sum()) * inv_hw
-        loss.backward()
+        torch.autograd.backward((out["render"], out["semantics"]), (g_color, g_sem))
         if dist is not None:
             allreduce_gradients(reduce_params, dist)
         if record:

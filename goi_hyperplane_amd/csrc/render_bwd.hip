@@ -20,8 +20,12 @@
 //         moments[j][m]      = sum_pix h[pix][j] * basis[pix][m],           h = G * dL/dalpha
 //     with basis = (1, u, v, u^2, uv, v^2) in quadrant-centred pixel coordinates; the 2D-mean, conic
 //     and opacity gradients are exact linear combinations of the six moments, expanded around the
-//     Gaussian's centre right after the MFMA.  16 contributing Gaussians form a group; their w and h
-//     columns are transposed through LDS into the MFMA A-operand layout.
+//     Gaussian's centre right after the MFMA.  8 contributing Gaussians form a group; their w columns
+//     (rows 0..7) and h columns (rows 8..15) are STACKED along M of one A operand and transposed
+//     through a single LDS buffer; the B operand of the last block carries (r, g, b, depth) in columns
+//     0..3 and the six basis functions in columns 4..9, so one MFMA yields the colour/depth gradients
+//     (upper half of D) and the moments (lower half) at once.  The halves of D that pair w with the
+//     basis or h with dL are never read.
 //  5. NO ATOMICS.  The reference adds one float atomic per (pixel, Gaussian, quantity); on MI355X L2
 //     atomics retire about one dword per clock per channel and would dominate this kernel.  Instead
 //     every (quadrant, Gaussian) pair owns one row of a scratch buffer, addressed by the Gaussian's
@@ -36,23 +40,28 @@ namespace goi {
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-#if defined(GOI_BWD_WAVES)
-#define GOI_BWD_LAUNCH_BOUNDS __launch_bounds__(64, GOI_BWD_WAVES)
-#else
-#define GOI_BWD_LAUNCH_BOUNDS __launch_bounds__(64)
+// Up to 16 semantic channels the kernel fits 128 VGPRs without spilling and 8 KB of LDS per wave:
+// 4 waves per SIMD.  Wider features (17..32 channels) need ~200 VGPRs: 2 waves per SIMD.
+#if !defined(GOI_BWD_WAVES)
+#define GOI_BWD_WAVES 4
 #endif
+#define GOI_BWD_LAUNCH_BOUNDS __launch_bounds__(64, (S4 <= 4 ? GOI_BWD_WAVES : 2))
 
-constexpr int GROUP = 16;    // contributing Gaussians per MFMA group (the M of 16x16x4)
+#ifndef GOI_TSTRIDE
+#define GOI_TSTRIDE 66
+#endif
+constexpr int GROUP = 8;     // contributing Gaussians per MFMA group: rows 0..7 = w, rows 8..15 = h of 16x16x4
 constexpr int BATCH = 32;    // list entries examined / staged per round (lanes 0..31): LDS, not lanes, is scarce
-constexpr int TSTRIDE = 66;  // row stride (floats) of the transposition buffers: conflict-free A reads
+constexpr int TSTRIDE = GOI_TSTRIDE;  // row stride (floats) of the transposition buffer
 
 template <int S4>
 struct BwdCfg {
     static constexpr int NF4 = 1 + S4;          // staged float4 words per Gaussian
     static constexpr int NSEM = 4 * S4;         // padded semantic channels
     static constexpr int NCH = NSEM + 4;        // channel order: sem0.., r, g, b, depth
-    static constexpr int NB = (NCH + 15) / 16;  // 16-column MFMA blocks for the feature gradient
+    static constexpr int NB = (NSEM + 15) / 16;  // 16-column MFMA blocks of semantic channels (+ 1 mixed block)
 };
 
 template <int S4>
@@ -68,8 +77,7 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
     __shared__ float4 s_geo[BATCH];       // x, y, conic a, b
     __shared__ float4 s_geo2[BATCH];      // conic c, opacity, slot index (bits), -
     __shared__ float4 s_feat[BATCH * NF4];  // (r,g,b,depth), semantics...
-    __shared__ float s_wt[GROUP * TSTRIDE];  // w columns, [slot][pixel]
-    __shared__ float s_ht[GROUP * TSTRIDE];  // h columns
+    __shared__ float s_t[2 * GROUP * TSTRIDE];  // [row][pixel]: rows 0..7 = w of slot, rows 8..15 = h of slot
     __shared__ float4 s_gmeta[GROUP * 2];    // per group member: (x, y, a, b), (c, opacity, slot bits, -)
 
     const QuadGeom t = quad_geom(W, H, gx, n_quads);
@@ -107,31 +115,47 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
     }
     const float bg_dot = bg[0] * dLch[NSEM] + bg[1] * dLch[NSEM + 1] + bg[2] * dLch[NSEM + 2];
     float R = 0.f;
+    f32x2 dL2[NCH / 2];  // the same gradients as register pairs for the packed dot product
+#pragma unroll
+    for (int i = 0; i < NCH / 2; i++) dL2[i] = f32x2{dLch[2 * i], dLch[2 * i + 1]};
+    const f32x4* s_feat4 = reinterpret_cast<const f32x4*>(s_feat);
 
     // ---- MFMA B operands (fixed for the whole kernel), built once through LDS:
     //      bfrag[nb][s] = dL[pixel 4s + (lane>>4)][channel 16 nb + (lane&15)]
     const int kq = lane >> 4, mm = lane & 15;
-    float bfrag[NB][16];
+    float bfrag[NB][16];  // semantic blocks
+    float bmix[16];       // mixed block: columns 0..3 = dL/d(r, g, b, depth), 4..9 = moment basis
     {
-        static_assert(64 * 16 <= GROUP * TSTRIDE, "staging region too small");
+        static_assert(64 * 16 <= 2 * GROUP * TSTRIDE, "staging region too small");
 #pragma unroll
         for (int nb = 0; nb < NB; nb++) {
 #pragma unroll
             for (int c = 0; c < 16; c++) {
                 const int ch = nb * 16 + c;
-                s_wt[lane * 16 + c] = ch < NCH ? dLch[ch] : 0.f;
+                s_t[lane * 16 + c] = ch < NSEM ? dLch[ch] : 0.f;
             }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int s = 0; s < 16; s++) bfrag[nb][s] = s_wt[(4 * s + kq) * 16 + mm];
+            for (int s = 0; s < 16; s++) bfrag[nb][s] = s_t[(4 * s + kq) * 16 + mm];
             __builtin_amdgcn_wave_barrier();
         }
+#pragma unroll
+        for (int c = 0; c < 4; c++) s_t[lane * 4 + c] = dLch[NSEM + c];
+        __builtin_amdgcn_wave_barrier();
+        // basis_m(pixel 4s + kq) in quadrant-centred coordinates u, v in [-3.5, 3.5]
+        // (pixel 4s+kq = column 4(s&1)+kq, row s>>1); m = mm - 4: 1, u, v, u^2, uv, v^2
+        const float u_even = (float)kq - 3.5f;
+        const float k1 = mm == 4 ? 1.f : 0.f, ku = mm == 5 ? 1.f : 0.f, kv = mm == 6 ? 1.f : 0.f;
+        const float kuu = mm == 7 ? 1.f : 0.f, kuv = mm == 8 ? 1.f : 0.f, kvv = mm == 9 ? 1.f : 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; s++) {
+            const float u = u_even + (float)(4 * (s & 1));
+            const float v = (float)(s >> 1) - 3.5f;
+            const float bm = k1 + ku * u + kv * v + kuu * (u * u) + kuv * (u * v) + kvv * (v * v);
+            bmix[s] = mm < 4 ? s_t[(4 * s + kq) * 4 + mm] : bm;
+        }
+        __builtin_amdgcn_wave_barrier();
     }
-    // moment basis B operand, generated on the fly: lane (kq, mm) needs basis_mm(pixel 4s + kq) in
-    // quadrant-centred coordinates u, v in [-3.5, 3.5] (pixel 4s+kq = column 4(s&1)+kq, row s>>1)
-    const float u_even = (float)kq - 3.5f;
-    const float k1 = mm == 0 ? 1.f : 0.f, ku = mm == 1 ? 1.f : 0.f, kv = mm == 2 ? 1.f : 0.f;
-    const float kuu = mm == 3 ? 1.f : 0.f, kuv = mm == 4 ? 1.f : 0.f, kvv = mm == 5 ? 1.f : 0.f;
     const float QCX = t.QX0 + 3.5f, QCY = t.QY0 + 3.5f;  // quadrant centre (pixel coordinates)
     const float half_W = 0.5f * W, half_H = 0.5f * H;
 
@@ -156,43 +180,39 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
     auto flush_group = [&](int cnt) {
         if (exp_flags & 1) return;
         f32x4 acc[NB];
-        f32x4 accm = {0.f, 0.f, 0.f, 0.f};
+        f32x4 accx = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int nb = 0; nb < NB; nb++) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int s = 0; s < 16; s++) {
-            const int off = mm * TSTRIDE + 4 * s + kq;
-            const float aw = s_wt[off];
-            const float ah = s_ht[off];
-            const float u = u_even + (float)(4 * (s & 1));
-            const float v = (float)(s >> 1) - 3.5f;
-            const float bm = k1 + ku * u + kv * v + kuu * (u * u) + kuv * (u * v) + kvv * (v * v);
+            const float a = s_t[mm * TSTRIDE + 4 * s + kq];
 #pragma unroll
             for (int nb = 0; nb < NB; nb++)
-                acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw, bfrag[nb][s], acc[nb], 0, 0, 0);
-            accm = __builtin_amdgcn_mfma_f32_16x16x4f32(ah, bm, accm, 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bfrag[nb][s], acc[nb], 0, 0, 0);
+            accx = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bmix[s], accx, 0, 0, 0);
         }
-        // D[row = 4*kq + r][col = mm]: row = group slot, col = channel / moment
+        // D[row = 4*kq + r][col = mm]: rows 0..7 = w of slot `row` (x dL), rows 8..15 = h of slot row-8 (x basis)
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int row = 4 * kq + r;
-            if (mm < 8) s_wt[row * 8 + mm] = accm[r];  // moments -> exchange area (aliases the w buffer)
+            if (row >= GROUP && mm >= 4 && mm < 12) s_t[(row - GROUP) * 8 + (mm - 4)] = accx[r];  // moments -> exchange area
             if (row < cnt && !(exp_flags & 2)) {
                 float* dst = rows + (size_t)__float_as_uint(s_gmeta[row * 2 + 1].z) * row_floats;
 #pragma unroll
                 for (int nb = 0; nb < NB; nb++) {
                     const int ch = nb * 16 + mm;
-                    if (ch < NCH) dst[ch] = acc[nb][r];
+                    if (ch < NSEM) dst[ch] = acc[nb][r];
                 }
+                if (mm < 4) dst[NSEM + mm] = accx[r];
             }
         }
         __builtin_amdgcn_wave_barrier();
         // moments -> (mean2D.x, mean2D.y, conic a, b, c, opacity): one lane per group member
         if (lane < cnt && !(exp_flags & 2)) {
-            const float4 m03 = *reinterpret_cast<const float4*>(&s_wt[lane * 8]);
-            const float2 m45 = *reinterpret_cast<const float2*>(&s_wt[lane * 8 + 4]);
+            const float4 m03 = *reinterpret_cast<const float4*>(&s_t[lane * 8]);
+            const float2 m45 = *reinterpret_cast<const float2*>(&s_t[lane * 8 + 4]);
             const float4 g = s_gmeta[lane * 2];
             const float4 g2 = s_gmeta[lane * 2 + 1];
             const uint32_t slot = __float_as_uint(g2.z);  // (emit-order instance) * 4 + quadrant
@@ -261,13 +281,22 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
             const bool c = (pos0 < last_contributor) && e.hit;
             if (!__any(c)) continue;
 
-            const float4 f0 = s_feat[j * NF4];  // r, g, b, depth
-            float dotv = f0.x * dLch[NSEM] + f0.y * dLch[NSEM + 1] + f0.z * dLch[NSEM + 2] + f0.w * dLch[NSEM + 3] + dLa;
+            // <feature, dL/dpixel> as packed fp32 FMAs (v_pk_fma_f32: two channels per instruction)
+            f32x2 dot2 = {0.f, 0.f};
+            if (!(exp_flags & 4)) {
+                const f32x4 f0 = s_feat4[j * NF4];  // r, g, b, depth
+                f32x2 da = f0.xy * dL2[NSEM / 2];
+                f32x2 db = f0.zw * dL2[NSEM / 2 + 1];
 #pragma unroll
-            for (int i = 0; i < S4; i++) {
-                const float4 f = s_feat[j * NF4 + 1 + i];
-                dotv += f.x * dLch[4 * i + 0] + f.y * dLch[4 * i + 1] + f.z * dLch[4 * i + 2] + f.w * dLch[4 * i + 3];
+                for (int i = 0; i < S4; i++) {
+                    const f32x4 f = s_feat4[j * NF4 + 1 + i];
+                    da = __builtin_elementwise_fma(f.xy, dL2[2 * i], da);
+                    db = __builtin_elementwise_fma(f.zw, dL2[2 * i + 1], db);
+                }
+                dot2 = da + db;
             }
+            float dotv = (dot2.x + dot2.y) + dLa;
+            if (exp_flags & 4) dotv = dLa;  // experiment: no feature reads / dot product
             const float one_m_a = 1.f - e.alpha;
             const float inv = __builtin_amdgcn_rcpf(one_m_a);
             const float Tn = T * inv;
@@ -279,8 +308,8 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
                 wgt = e.alpha * Tn;
                 hval = e.G * dL_dopa;
             }
-            s_wt[nslot * TSTRIDE + lane] = wgt;
-            s_ht[nslot * TSTRIDE + lane] = hval;
+            s_t[nslot * TSTRIDE + lane] = wgt;
+            s_t[(GROUP + nslot) * TSTRIDE + lane] = hval;
             if (lane == 0) {  // group members may outlive this batch's staging slots: keep their metadata
                 s_gmeta[nslot * 2] = g;
                 s_gmeta[nslot * 2 + 1] = g2;
@@ -302,9 +331,9 @@ void launch_bwd_rows_s4(const GoiRasterScene& sc, const GeomView& g, const Image
                         const float* dL_ddepth, const float* dL_dalpha, const BwdScratchView& scr, hipStream_t s) {
     const int gx = (sc.W + TILE - 1) / TILE, gy = (sc.H + TILE - 1) / TILE;
     const int n_quads = gx * gy * 4;
-    render_bwd_rows_k<S4><<<dim3(quad_grid(n_quads)), dim3(64), 0, s>>>(
+    render_bwd_rows_k<S4><<<dim3(quad_grid(n_quads)), dim3(64), (size_t)((g_options.bwd_variant >> 8) & 0xFF) * 1024, s>>>(
         im.ranges, point_list, sc.W, sc.H, gx, gy, n_quads, sc.S, g.rec, sc.semantics, radii, g.goff, sc.bg, out_alpha,
-        im.n_contrib, dL_dpix, dL_dsem, dL_ddepth, dL_dalpha, scr.rows, scr.flags, bwd_row_floats(sc.S), g_options.bwd_variant >> 4);
+        im.n_contrib, dL_dpix, dL_dsem, dL_ddepth, dL_dalpha, scr.rows, scr.flags, bwd_row_floats(sc.S), (g_options.bwd_variant >> 4) & 0xF);
 }
 
 }  // namespace
