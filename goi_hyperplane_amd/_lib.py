@@ -47,6 +47,7 @@ SYMBOLS = {
     "goi_raster_trace": (C.c_int, [C.POINTER(GoiRasterScene), C.c_void_p, C.c_void_p, C.c_void_p, ALLOC_FN,
                                    C.c_void_p] + [C.c_void_p] * 4 + [C.c_void_p]),
     "goi_raster_mark_visible": (C.c_int, [C.c_int] + [C.c_void_p] * 4 + [C.c_void_p]),
+    "goi_adam_step": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
     "goi_knn_workspace_bytes": (C.c_size_t, [C.c_int]),
     "goi_knn_dist2": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "goi_raster_profile_enable": (None, [C.c_int]),
@@ -89,6 +90,15 @@ def load():
 
 def last_error() -> str:
     return load().goi_raster_last_error().decode("utf-8", "replace")
+
+
+class GoiAdamGroup(C.Structure):
+    """include/goi_raster.h: GoiAdamGroup"""
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("numel", C.c_longlong), ("row_len", C.c_int), ("step_size", C.c_float), ("bc2_sqrt", C.c_float)]
+
+
+ADAM_MAX_GROUPS = 8
 
 
 def set_option(name: str, value: int) -> None:

@@ -33,6 +33,7 @@ UNITS = {
     "render_bwd_tile.hip": [],
     "semantic_head.hip": [],
     "knn.hip": ["-ffp-contract=off"],
+    "adam.hip": ["-ffp-contract=off"],
 }
 
 

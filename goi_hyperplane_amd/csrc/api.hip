@@ -385,6 +385,24 @@ int goi_semantic_decode(const float* sem, int S, long long HW, const float* W, c
     return 0;
 }
 
+int goi_adam_step(const GoiAdamGroup* groups, int n_groups, double beta1, double beta2, double eps,
+                  const unsigned char* nograd_mask, void* stream) {
+    if (n_groups < 0 || n_groups > GOI_ADAM_MAX_GROUPS) return fail("goi_adam_step: n_groups must be 0..8");
+    if (n_groups && !groups) return fail("goi_adam_step: groups is NULL");
+    for (int i = 0; i < n_groups; i++) {
+        const GoiAdamGroup& g = groups[i];
+        if (g.numel < 0 || g.row_len < 1) return fail("goi_adam_step: bad numel / row_len");
+        if (g.numel == 0) continue;
+        if (!g.param || !g.grad || !g.exp_avg || !g.exp_avg_sq) return fail("goi_adam_step: a tensor pointer is NULL");
+        if ((reinterpret_cast<uintptr_t>(g.param) | reinterpret_cast<uintptr_t>(g.grad) |
+             reinterpret_cast<uintptr_t>(g.exp_avg) | reinterpret_cast<uintptr_t>(g.exp_avg_sq)) & 15)
+            return fail("goi_adam_step: tensors must be 16-byte aligned");
+    }
+    launch_adam_step(groups, n_groups, beta1, beta2, eps, nograd_mask, static_cast<hipStream_t>(stream));
+    GOI_HIP(hipGetLastError());
+    return 0;
+}
+
 size_t goi_knn_workspace_bytes(int P) { return P > 0 ? knn_workspace_bytes(P) : 0; }
 
 int goi_knn_dist2(int P, const float* points, float* mean_dist2, void* workspace, void* stream) {

@@ -399,7 +399,7 @@ size_t sort_scratch_words(size_t n) {
 void exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, size_t n, uint32_t* total,
                         uint32_t* scratch, hipStream_t s) {
     if (n == 0) {
-        if (total) hipMemsetAsync(total, 0, sizeof(uint32_t), s);
+        if (total) (void)hipMemsetAsync(total, 0, sizeof(uint32_t), s);
         return;
     }
     const size_t nb = div_up(n, SCAN_CHUNK);

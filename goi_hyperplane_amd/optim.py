@@ -1,0 +1,84 @@
+"""Fused Adam for the Gaussian parameter groups.
+
+`FusedAdam` takes the same constructor arguments, keeps the same `param_groups` / `state` layout and
+therefore the same `state_dict()` format as `torch.optim.Adam`, which is what the reference builds in
+scene/gaussian_model.py:163-253 (`torch.optim.Adam(l, lr=0.0, eps=1e-15)` over named groups) and
+serialises in `capture()` / `restore()`: checkpoints move in both directions.  `step()` runs ONE HIP
+kernel over every group (csrc/adam.hip) instead of torch's ~10 foreach kernels per state tensor;
+`step(nograd_mask=...)` also applies gui/main.py:480-513's per-Gaussian gradient mask on the fly.
+
+Not supported (the reference uses none of them): weight_decay, amsgrad, maximize, capturable,
+differentiable.  fp32 CUDA (ROCm) tensors only; there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False):
+        if weight_decay != 0 or amsgrad:
+            raise NotImplementedError("FusedAdam covers the reference's configuration: no weight decay, no amsgrad")
+        if not 0.0 <= lr or not 0.0 <= eps or not (0.0 <= betas[0] < 1.0) or not (0.0 <= betas[1] < 1.0):
+            raise ValueError("invalid Adam hyper-parameter")
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False, maximize=False, foreach=None,
+                        capturable=False, differentiable=False, fused=None)
+        super().__init__(params, defaults)
+
+    @torch.no_grad()
+    def step(self, closure=None, nograd_mask: torch.Tensor | None = None):
+        """One Adam update of every parameter that has a gradient.  nograd_mask: optional [P] bool/uint8
+        tensor; Gaussians with a non-zero entry are updated as if their gradient rows were zero."""
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = _lib.load()
+        launches = {}  # (beta1, beta2, eps, device) -> list of GoiAdamGroup
+        keep = []
+        for group in self.param_groups:
+            beta1, beta2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if not p.is_cuda:
+                    raise RuntimeError("FusedAdam: parameters must live on a ROCm GPU; there is no CPU fallback")
+                if p.dtype != torch.float32 or p.grad.dtype != torch.float32 or p.grad.is_sparse:
+                    raise TypeError("FusedAdam: dense float32 parameters and gradients only")
+                if not p.is_contiguous():
+                    raise RuntimeError("FusedAdam: parameters must be contiguous")
+                state = self.state[p]
+                if len(state) == 0:
+                    state["step"] = torch.tensor(0.0, dtype=torch.float32)  # torch keeps a host-side fp32 scalar
+                    state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                state["step"] += 1
+                t = float(state["step"])
+                grad = p.grad.contiguous()
+                keep.append(grad)
+                step_size = group["lr"] / (1.0 - beta1 ** t)
+                bc2_sqrt = math.sqrt(1.0 - beta2 ** t)
+                row_len = p.numel() // p.shape[0] if p.dim() > 0 and p.shape[0] > 0 else 1
+                if nograd_mask is not None and p.shape[0] != nograd_mask.shape[0]:
+                    raise ValueError("nograd_mask must have one entry per Gaussian (parameter rows)")
+                launches.setdefault((beta1, beta2, group["eps"], p.device), []).append(_lib.GoiAdamGroup(
+                    p.data_ptr(), grad.data_ptr(), state["exp_avg"].data_ptr(), state["exp_avg_sq"].data_ptr(),
+                    p.numel(), max(row_len, 1), step_size, bc2_sqrt))
+        mask = None
+        if nograd_mask is not None:
+            mask = nograd_mask.to(torch.uint8).contiguous()
+        for (beta1, beta2, eps, dev), groups in launches.items():
+            with torch.cuda.device(dev):
+                stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+                for i in range(0, len(groups), _lib.ADAM_MAX_GROUPS):
+                    chunk = groups[i:i + _lib.ADAM_MAX_GROUPS]
+                    arr = (_lib.GoiAdamGroup * len(chunk))(*chunk)
+                    mp = C.c_void_p(mask.data_ptr()) if mask is not None else None
+                    if lib.goi_adam_step(arr, len(chunk), beta1, beta2, eps, mp, stream) < 0:
+                        raise RuntimeError(_lib.last_error())
+        return loss

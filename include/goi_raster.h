@@ -156,6 +156,26 @@ int goi_raster_set_option(const char* name, int value);
 size_t goi_knn_workspace_bytes(int P);
 int goi_knn_dist2(int P, const float* points, float* mean_dist2, void* workspace, void* stream);
 
+/* ---- fused Adam step over the Gaussian parameter groups (scene/gaussian_model.py:163-253:
+ * torch.optim.Adam(lr=0.0, eps=1e-15) over xyz / f_dc / f_rest / semantics / opacity / scaling /
+ * rotation; train.py:193 optimizer.step()) with the optional per-Gaussian gradient mask of
+ * gui/main.py:480-513 (clear_noralative_gs_grad: rows with mask != 0 see a zero gradient).
+ * One launch for up to GOI_ADAM_MAX_GROUPS tensors.  All pointers are device pointers to fp32,
+ * 16-byte aligned; numel = P * row_len. */
+#define GOI_ADAM_MAX_GROUPS 8
+typedef struct GoiAdamGroup {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    long long numel;
+    int row_len;      /* elements per Gaussian (mask granularity); >= 1 */
+    float step_size;  /* lr / (1 - beta1^t), rounded to fp32 once */
+    float bc2_sqrt;   /* sqrt(1 - beta2^t) */
+} GoiAdamGroup;
+int goi_adam_step(const GoiAdamGroup* groups, int n_groups, double beta1, double beta2, double eps,
+                  const unsigned char* nograd_mask /*[P] or NULL*/, void* stream);
+
 /* Inspection of the opaque workspaces (tests only): copies device -> caller DEVICE buffers.
  * Any pointer may be NULL.  point_list is in final sorted order. */
 int goi_raster_debug_views(int P, int W, int H, int R, const void* geom_buffer, const void* binning_buffer,

@@ -224,3 +224,22 @@ def knn_mean_dist2(points, fma: bool = True, brute: bool = False):
     fn = lib.goi_knn_oracle_brute if brute else lib.goi_knn_oracle
     fn(pts.shape[0], pts.ctypes.data, out.ctypes.data, 1 if fma else 0)
     return out
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, nograd_rows=None):
+    """numpy fp32 restatement of one torch.optim.Adam update as the reference runs it on the GPU
+    (torch/optim/adam.py _multi_tensor_adam, non-capturable: _foreach_lerp_, _foreach_mul_ +
+    _foreach_addcmul_, sqrt / bias_correction2_sqrt + eps, _foreach_addcdiv_), one rounding per op.
+    `step` is the 1-based step count.  nograd_rows: optional bool [P]; masked rows see grad = 0
+    (gui/main.py:480-513).  Returns (param, exp_avg, exp_avg_sq)."""
+    f = np.float32
+    p, g, m, v = (np.array(a, dtype=np.float32, copy=True) for a in (param, grad, exp_avg, exp_avg_sq))
+    if nograd_rows is not None:
+        g[np.asarray(nograd_rows, dtype=bool)] = 0
+    m = m + (g - m) * f(1.0 - beta1)
+    v = v * f(beta2) + (f(1.0 - beta2) * g) * g
+    bc1 = 1.0 - beta1 ** step
+    bc2_sqrt = (1.0 - beta2 ** step) ** 0.5
+    den = np.sqrt(v) / f(bc2_sqrt) + f(eps)
+    p = p + f(-(lr / bc1)) * (m / den)
+    return p, m, v

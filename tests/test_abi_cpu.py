@@ -28,7 +28,7 @@ def lib():
 
 def test_library_exports_every_declared_symbol(lib):
     hdr = open(os.path.join(ROOT, "include", "goi_raster.h")).read()
-    declared = set(re.findall(r"\b(goi_(?:raster|semantic|knn)_[a-z_0-9]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(goi_(?:raster|semantic|knn|adam)_[a-z_0-9]+)\s*\(", hdr))
     assert {"goi_raster_forward", "goi_raster_backward", "goi_raster_trace", "goi_raster_mark_visible",
             "goi_raster_geom_bytes", "goi_raster_image_bytes", "goi_raster_binning_bytes",
             "goi_raster_last_error", "goi_raster_abi_version"} <= declared
@@ -54,6 +54,22 @@ def test_scene_struct_layout_matches_c(tmp_path):
     for f in fields:
         assert getattr(GoiRasterScene, f).offset == int(out[f]), f
     assert C.sizeof(GoiRasterScene) == int(out["sizeof"])
+
+
+def test_adam_group_struct_layout_matches_c(tmp_path):
+    import subprocess
+    from goi_hyperplane_amd._lib import GoiAdamGroup
+    fields = [f[0] for f in GoiAdamGroup._fields_]
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "goi_raster.h"\nint main(void){\n'
+                   + "".join(f'printf("{f} %zu\\n", offsetof(GoiAdamGroup, {f}));\n' for f in fields)
+                   + 'printf("sizeof %zu\\n", sizeof(GoiAdamGroup));return 0;}\n')
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    for f in fields:
+        assert getattr(GoiAdamGroup, f).offset == int(out[f]), f
+    assert C.sizeof(GoiAdamGroup) == int(out["sizeof"])
 
 
 def test_workspace_sizes(lib):
