@@ -53,6 +53,15 @@ class GaussianSet(torch.nn.Module):
         return cls(t(scene.means3D), t(scene.scales), t(scene.rotations), t(scene.opacities), t(scene.shs),
                    t(scene.semantics), scene.sh_degree)
 
+    @classmethod
+    def from_ply(cls, path, device, sh_degree=3, semantic_dim=16):
+        """A scene saved by the reference (point_cloud.ply with sem_* columns, scene/gaussian_model.py:308-358),
+        activated the way its get_* properties do."""
+        from . import io as gio
+        a = gio.activate(gio.load_ply(path, max_sh_degree=sh_degree, semantic_dim=semantic_dim))
+        return cls(*(a[k].to(device) for k in ("means3D", "scales", "rotations", "opacities", "shs", "semantics")),
+                   sh_degree=sh_degree, max_sh_degree=sh_degree)
+
     get_xyz = property(lambda self: self._xyz)
     get_scaling = property(lambda self: self._scaling)
     get_rotation = property(lambda self: self._rotation)

@@ -203,8 +203,32 @@ def knn_golden():
     print("wrote knn_kdtree64")
 
 
+def kmeans_pins():
+    """Runs the reference's kmeans (train.py:36-56; the function only -- the module itself imports the
+    CUDA extensions) on a small seeded input and stores input, seed and resulting centres."""
+    import ast
+
+    src = open(os.path.join(REF, "train.py")).read()
+    fn = next(n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "kmeans")
+    ns = {"torch": torch}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "train.py:kmeans", "exec"), ns)
+    g = torch.Generator().manual_seed(5)
+    base = torch.randn(24, 32, generator=g)
+    x = base[torch.randint(0, 24, (900,), generator=g)] + 0.15 * torch.randn(900, 32, generator=g)
+    out = {}
+    for name, k in (("k16", 16), ("k40_dead", 40)):
+        xin = x.clone()
+        torch.manual_seed(1234)
+        c = ns["kmeans"](xin, k)
+        out[name + "_centers"] = c.numpy()
+        out[name + "_x_after"] = xin.numpy()
+    np.savez_compressed(os.path.join(HERE, "ref_kmeans_pins.npz"), x=x.numpy(), seed=1234, **out)
+    print("wrote ref_kmeans_pins")
+
+
 if __name__ == "__main__":
     knn_golden()
+    kmeans_pins()
     ref_python_pins()
     semantic_pins()
     oracle_goldens()
