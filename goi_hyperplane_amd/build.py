@@ -34,6 +34,7 @@ UNITS = {
     "semantic_head.hip": [],
     "knn.hip": ["-ffp-contract=off"],
     "adam.hip": ["-ffp-contract=off"],
+    "codebook_loss.hip": [],
 }
 
 

@@ -385,6 +385,21 @@ int goi_semantic_decode(const float* sem, int S, long long HW, const float* W, c
     return 0;
 }
 
+int goi_codebook_loss_partial_rows(void) { return codebook_loss_waves(); }
+
+int goi_codebook_loss_rows(const float* sim_raw, const float* inv_gnorm, const float* sem, const float* W,
+                           const float* bias, long long HW, int C, int S, float t, float* dsim, float* dsem,
+                           float* partials, void* stream) {
+    if (HW < 0) return fail("goi_codebook_loss_rows: bad HW");
+    if (!sim_raw || !inv_gnorm || !sem || !W || !dsim || !dsem || !partials)
+        return fail("goi_codebook_loss_rows: a required pointer is NULL");
+    if (launch_codebook_rows(sim_raw, inv_gnorm, sem, W, bias, HW, C, S, t, dsim, dsem, partials,
+                             static_cast<hipStream_t>(stream)) < 0)
+        return fail("goi_codebook_loss_rows: supported sizes are 1 <= S <= 16, 1 <= C <= 512");
+    GOI_HIP(hipGetLastError());
+    return 0;
+}
+
 int goi_adam_step(const GoiAdamGroup* groups, int n_groups, double beta1, double beta2, double eps,
                   const unsigned char* nograd_mask, void* stream) {
     if (n_groups < 0 || n_groups > GOI_ADAM_MAX_GROUPS) return fail("goi_adam_step: n_groups must be 0..8");

@@ -109,6 +109,9 @@ void launch_preprocess_bwd(const GoiRasterScene& sc, const GeomView& g, const in
 int launch_semantic_decode(const float* sem, int S, long long HW, const float* W, const float* bias, int n_codes,
                            const float* code_score, float thresh, float* sim_out, int* idx_out, uint8_t* bg_mask_out,
                            hipStream_t s);
+int codebook_loss_waves();
+int launch_codebook_rows(const float* sim, const float* inv_gnorm, const float* sem, const float* W, const float* bias,
+                         long long HW, int C, int S, float t, float* dsim, float* dsem, float* partials, hipStream_t s);
 int launch_adam_step(const GoiAdamGroup* groups, int n_groups, double beta1, double beta2, double eps,
                      const uint8_t* nograd_mask, hipStream_t s);
 size_t knn_workspace_bytes(int P);

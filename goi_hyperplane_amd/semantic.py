@@ -11,12 +11,16 @@ checkpoints load unchanged:
 
 Inference (`compute_similarity`) is the hot part at GUI frame rate: it runs as ONE fused HIP kernel
 (csrc/semantic_head.hip: fp32 MFMA contraction + argmax + per-code score lookup) that reads the
-rasterizer's [S, H, W] output directly.  The training losses are restated in PyTorch: their dense
-contraction gtl[HW,256] x lut^T[256,300] is a plain library GEMM (hipBLASLt through torch.matmul).
+rasterizer's [S, H, W] output directly.  The training losses exist twice: `codebook_losses` restates
+train.py line by line in PyTorch (the parity reference: ~40 kernels over [HW,300] tensors, 109 ms
+and 21 GB at 1600x1056 on MI355X); `fused_codebook_losses` is the product path: two library GEMMs
+(hipBLASLt through torch.matmul, on transposed views of the [256,H,W] map) around ONE HIP kernel
+(csrc/codebook_loss.hip) that produces the four loss terms and every gradient in a single pass.
 """
 from __future__ import annotations
 
 import ctypes as C
+import ctypes as C_
 
 import torch
 import torch.nn.functional as F
@@ -163,3 +167,69 @@ def codebook_losses(sem_feature_chw: torch.Tensor, semantic_mlp: SemanticModel, 
     sl1 = -1.0 * (torch.softmax(anneal, dim=1) * torch.log_softmax(anneal, dim=1)).sum(dim=-1).mean()
     loss = lab + sl + 0.3 * sl1 + recc
     return loss, {"lab": lab, "sl": sl, "sl1": sl1, "recc": recc}
+
+
+class _FusedCodebookLoss(torch.autograd.Function):
+    """loss = lab + sl + 0.3 sl1 + recc of train.py:142-163, with all gradients produced in the forward
+    (the loss is a scalar: backward only scales them)."""
+
+    @staticmethod
+    def forward(ctx, sem_chw, weight, bias, lut1, gtl_chw, t):
+        lib = _lib.load()
+        if not sem_chw.is_cuda:
+            raise RuntimeError("goi_hyperplane_amd.semantic: tensors must live on a ROCm GPU; there is no CPU fallback")
+        dev = sem_chw.device
+        S = int(sem_chw.shape[0])
+        HW = int(sem_chw[0].numel())
+        C, D = int(lut1.shape[0]), int(lut1.shape[1])
+        sem = sem_chw.detach().contiguous().float().view(S, HW)
+        g = gtl_chw.detach().contiguous().float().view(D, HW)  # [D, HW]: used as g^T through views, never copied
+        w = weight.detach().contiguous().float()
+        b = None if bias is None else bias.detach().contiguous().float()
+        l1 = lut1.detach().contiguous().float()
+        with torch.cuda.device(dev):
+            inv_gnorm = torch.linalg.vector_norm(g, dim=0).reciprocal_()            # [HW]
+            sim_raw = torch.matmul(g.t(), l1.t())                                     # [HW, C]  (matrix cores)
+            dsim = torch.empty_like(sim_raw)
+            dsem = torch.empty((S, HW), dtype=torch.float32, device=dev)
+            rows = lib.goi_codebook_loss_partial_rows()
+            partials = torch.empty((rows, C * (S + 1) + 4), dtype=torch.float32, device=dev)
+            p = lambda x: None if x is None else C_.c_void_p(x.data_ptr())  # noqa: E731
+            r = lib.goi_codebook_loss_rows(p(sim_raw), p(inv_gnorm), p(sem), p(w), p(b), HW, C, S, float(t), p(dsim),
+                                           p(dsem), p(partials), C_.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+            if r < 0:
+                raise RuntimeError(_lib.last_error())
+            del sim_raw
+            tot = partials.sum(dim=0)                                                 # fixed order: reproducible
+            dWb = tot[: C * (S + 1)].view(C, S + 1)
+            sums = tot[C * (S + 1):]
+            lab = sums[0] * (50.0 / (HW * C))
+            sl = 1.0 - sums[1] / HW
+            sl1 = sums[2] / HW
+            recc = 1.0 - sums[3] / HW
+            dl1 = torch.matmul(dsim.t(), g.t())                                       # [C, D]   (matrix cores)
+        ctx.save_for_backward(dsem.view_as(sem_chw), dWb[:, :S].contiguous(), dWb[:, S].contiguous(), dl1)
+        ctx.has_bias = bias is not None
+        terms = torch.stack([lab, sl, sl1, recc])
+        ctx.mark_non_differentiable(terms)
+        return lab + sl + 0.3 * sl1 + recc, terms
+
+    @staticmethod
+    def backward(ctx, grad_loss, _grad_terms):
+        dsem, dW, db, dl1 = ctx.saved_tensors
+        return (grad_loss * dsem, grad_loss * dW, (grad_loss * db) if ctx.has_bias else None, grad_loss * dl1, None, None)
+
+
+def fused_codebook_losses(sem_feature_chw: torch.Tensor, semantic_mlp: SemanticModel, lut: torch.Tensor,
+                          gtl_chw: torch.Tensor, iteration: int):
+    """Drop-in for `codebook_losses` (same arguments, same (loss, dict) result, same gradients into the
+    rasterizer output, the decoder and the code book) running on the GPU as described in
+    csrc/codebook_loss.hip.  Covers the reference's configuration: one Linear(S -> tab_len) decoder,
+    S <= 16, tab_len <= 512."""
+    if semantic_mlp.num_layer != 1:
+        raise NotImplementedError("the fused losses cover the reference's configuration: one Linear(S -> tab_len)")
+    lin = semantic_mlp.layers[0]
+    lut1 = lut / lut.norm(dim=1, keepdim=True)  # differentiable: the kernel returns dL/dlut1
+    t = 1.0 if iteration < 1000 else 2.0
+    loss, terms = _FusedCodebookLoss.apply(sem_feature_chw, lin.weight, lin.bias, lut1, gtl_chw, t)
+    return loss, {"lab": terms[0], "sl": terms[1], "sl1": terms[2], "recc": terms[3]}

@@ -156,6 +156,19 @@ int goi_raster_set_option(const char* name, int value);
 size_t goi_knn_workspace_bytes(int P);
 int goi_knn_dist2(int P, const float* points, float* mean_dist2, void* workspace, void* stream);
 
+/* ---- training losses of the semantic head, row pass (train.py:142-163; see csrc/codebook_loss.hip).
+ * Inputs: sim_raw [HW][C] = <g_p, LUT_c/|LUT_c|> with g NOT normalised, inv_gnorm [HW] = 1/|g_p|,
+ * sem [S][HW] (the rasterizer's channel-major feature map), decoder W [C][S] and bias [C] (or NULL),
+ * anneal factor t (1 or 2).  Outputs: dsim [HW][C] = dL/dsim_raw, dsem [S][HW] = dL/dsem, and
+ * partials [goi_codebook_loss_partial_rows()][C*(S+1)+4]: per persistent wave the dL/dW rows (S
+ * values then dL/db per code) followed by the sums over its pixels of (sum_c (P-label)^2, max sim,
+ * entropy, sim at the decoder's argmax); the caller adds the rows up.  L = lab + sl + 0.3 sl1 + recc
+ * with upstream gradient 1.  1 <= S <= 16, 1 <= C <= 512.  All pointers are device pointers. */
+int goi_codebook_loss_partial_rows(void);
+int goi_codebook_loss_rows(const float* sim_raw, const float* inv_gnorm, const float* sem, const float* W,
+                           const float* bias, long long HW, int C, int S, float t, float* dsim, float* dsem,
+                           float* partials, void* stream);
+
 /* ---- fused Adam step over the Gaussian parameter groups (scene/gaussian_model.py:163-253:
  * torch.optim.Adam(lr=0.0, eps=1e-15) over xyz / f_dc / f_rest / semantics / opacity / scaling /
  * rotation; train.py:193 optimizer.step()) with the optional per-Gaussian gradient mask of

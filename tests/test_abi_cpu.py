@@ -28,7 +28,7 @@ def lib():
 
 def test_library_exports_every_declared_symbol(lib):
     hdr = open(os.path.join(ROOT, "include", "goi_raster.h")).read()
-    declared = set(re.findall(r"\b(goi_(?:raster|semantic|knn|adam)_[a-z_0-9]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(goi_(?:raster|semantic|knn|adam|codebook)_[a-z_0-9]+)\s*\(", hdr))
     assert {"goi_raster_forward", "goi_raster_backward", "goi_raster_trace", "goi_raster_mark_visible",
             "goi_raster_geom_bytes", "goi_raster_image_bytes", "goi_raster_binning_bytes",
             "goi_raster_last_error", "goi_raster_abi_version"} <= declared
