@@ -137,18 +137,38 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, semantics, 
     M = 0 if (sh is None or sh.numel() == 0) else int(sh.size(1))
     f32 = dict(dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        # every element is written by the library (atomically accumulated ones are zeroed there)
-        dL_dmeans3D = torch.empty((P, 3), **f32)
+        # every element is written by the library (atomically accumulated ones are zeroed there).
+        # The gradients of the six Gaussian parameter tensors are views of ONE flat buffer (256-byte
+        # aligned sections): autograd hands these views to the leaves as .grad, so the data-parallel
+        # exchange can be a single all-reduce over the buffer instead of one per tensor (dist.py).
+        sections = (("means3D", (P, 3)), ("sh", (P, M, 3)), ("semantics", (P, S)), ("opacity", (P, 1)),
+                    ("scales", (P, 3)), ("rotations", (P, 4)))
+        offs, total = {}, 0
+        for name, shape in sections:
+            offs[name] = total
+            n = 1
+            for d in shape:
+                n *= d
+            total += (n + 63) // 64 * 64
+        flat = torch.empty((total,), **f32)
+
+        def view(name, shape):
+            n = 1
+            for d in shape:
+                n *= d
+            return flat[offs[name]:offs[name] + n].view(shape)
+        dL_dmeans3D = view("means3D", (P, 3))
+        dL_dsh = view("sh", (P, M, 3))
+        dL_dsemantics = view("semantics", (P, S))
+        dL_dopacity = view("opacity", (P, 1))
+        dL_dscales = view("scales", (P, 3))
+        dL_drotations = view("rotations", (P, 4))
+        del flat
         dL_dmeans2D = torch.empty((P, 3), **f32)
         dL_dcolors = torch.empty((P, 3), **f32)
-        dL_dsemantics = torch.empty((P, S), **f32)
         dL_ddepths = torch.empty((P, 1), **f32)
         dL_dconic = torch.empty((P, 2, 2), **f32)
-        dL_dopacity = torch.empty((P, 1), **f32)
         dL_dcov3D = torch.empty((P, 6), **f32)
-        dL_dsh = torch.empty((P, M, 3), **f32)
-        dL_dscales = torch.empty((P, 3), **f32)
-        dL_drotations = torch.empty((P, 4), **f32)
         if P != 0:
             ten = dict(bg=_prep(background, "background", dev), means3D=_prep(means3D, "means3D", dev),
                        sh=_prep(sh, "sh", dev), colors=_prep(colors, "colors_precomp", dev),

@@ -21,6 +21,30 @@ def shard_views(num_views: int, rank: int, world: int, epoch: int = 0, seed: int
     return perm[rank::world]
 
 
+def coalesce_shared_storage(grads, max_waste: float = 0.25):
+    """Gradients that are views of one buffer (the rasterizer's backward writes the six parameter
+    gradients into a single flat allocation, _C.rasterize_gaussians_backward) are exchanged as ONE
+    tensor spanning them: xGMI rings are per-link bound, so one 300 MB collective beats six smaller
+    ones.  Tensors that do not share storage -- or whose span would be mostly foreign bytes -- are
+    returned unchanged."""
+    groups = {}
+    for g in grads:
+        key = (g.untyped_storage().data_ptr(), g.dtype, g.device) if g.is_contiguous() else id(g)
+        groups.setdefault(key, []).append(g)
+    out = []
+    for key, gs in groups.items():
+        if len(gs) == 1 or not isinstance(key, tuple):
+            out.extend(gs)
+            continue
+        lo = min(g.storage_offset() for g in gs)
+        hi = max(g.storage_offset() + g.numel() for g in gs)
+        if sum(g.numel() for g in gs) < (1.0 - max_waste) * (hi - lo):
+            out.extend(gs)
+            continue
+        out.append(torch.as_strided(gs[0], (hi - lo,), (1,), lo))
+    return out
+
+
 def allreduce_gradients(params, dist, bucket_bytes: int = 0):
     """Sum-all-reduce `.grad` of every parameter in place.
 
@@ -32,7 +56,7 @@ def allreduce_gradients(params, dist, bucket_bytes: int = 0):
     if not grads:
         return
     if bucket_bytes <= 0:
-        works = [dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True) for g in grads]
+        works = [dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True) for g in coalesce_shared_storage(grads)]
         for w in works:
             w.wait()
         return

@@ -42,15 +42,36 @@ def _worker(rank, world, port, bucket_bytes, q):
     g = o.backward(np.full((3, 48, 64), 1 / HW, np.float32), np.full((10, 48, 64), 1 / HW, np.float32))
     names = ["means3D", "sh", "semantics", "opacity", "scales", "rotations"]
     params = []
+    flat = torch.empty(sum((g[n].size + 63) // 64 * 64 for n in names))  # the layout of _C.rasterize_gaussians_backward
+    off = 0
     for n in names:
         p = torch.nn.Parameter(torch.zeros(g[n].shape))
-        p.grad = torch.tensor(g[n])
+        v = flat[off:off + g[n].size].view(g[n].shape)
+        v.copy_(torch.tensor(g[n]))
+        p.grad = v
+        off += (g[n].size + 63) // 64 * 64
         params.append(p)
     local = [p.grad.clone() for p in params]
     allreduce_gradients(params, dist, bucket_bytes=bucket_bytes)
     q.put((rank, views[0], [x.numpy() for x in local], [p.grad.numpy() for p in params]))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def test_views_of_one_buffer_are_exchanged_as_one_tensor():
+    from goi_hyperplane_amd.dist import coalesce_shared_storage
+    flat = torch.arange(64 * 5, dtype=torch.float32)
+    a, b, c = flat[0:30].view(10, 3), flat[64:64 + 40].view(10, 4), flat[128:128 + 160].view(10, 16)
+    lone = torch.zeros(7)
+    out = coalesce_shared_storage([a, lone, b, c])
+    assert len(out) == 2 and any(o is lone for o in out)
+    span = next(o for o in out if o is not lone)
+    assert span.numel() == 128 + 160 and span.data_ptr() == flat.data_ptr()
+    span.mul_(2)  # what an in-place all-reduce does: the views see it
+    assert float(b[0, 0]) == 128.0 and float(c[9, 15]) == 2 * (128 + 159)
+    # a mostly-foreign span is not coalesced
+    big = torch.zeros(10000)
+    assert len(coalesce_shared_storage([big[0:10], big[9000:9010]])) == 2
 
 
 def _run(bucket_bytes):

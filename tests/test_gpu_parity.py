@@ -356,3 +356,26 @@ def test_fused_semantic_decode_matches_unfused_reference(dev):
     s7, i7 = compute_similarity(sem7, mlp7, lut7, svm_score_fn(svm), 0.5, return_index=True)
     r7, j7 = compute_similarity_reference(sem7.permute(1, 2, 0).reshape(-1, 7), mlp7, lut7, svm_score_fn(svm), 0.5)
     assert (i7.long() == j7).all() and (s7 - r7).abs().max().item() < 1e-6
+
+
+def test_parameter_gradients_share_one_buffer_for_a_single_allreduce():
+    """The six Gaussian parameter gradients come back as views of one allocation and autograd keeps
+    them as the leaves' .grad: dist.allreduce_gradients then issues one collective."""
+    from goi_hyperplane_amd.dist import coalesce_shared_storage
+    from goi_hyperplane_amd.render import GaussianSet, PipelineParams, TorchCamera, render
+    from goi_hyperplane_amd.scene import make_camera, make_scene
+    dev = torch.device("cuda")
+    sc = make_scene(3000, S=16, sh_degree=3, seed=3, log_scale_mean=-2.5)
+    pc = GaussianSet.from_scene(sc, dev)
+    cam = TorchCamera(make_camera(160, 112), dev)
+    out = render(cam, pc, PipelineParams(), torch.zeros(3, device=dev))
+    (out["render"].sum() + out["semantics"].sum()).backward()
+    params = [pc._xyz, pc._features, pc._semantics, pc._opacity, pc._scaling, pc._rotation]
+    grads = [p.grad for p in params]
+    assert len({g.untyped_storage().data_ptr() for g in grads}) == 1
+    span = coalesce_shared_storage(grads)
+    assert len(span) == 1 and span[0].numel() >= sum(g.numel() for g in grads)
+    before = [g.clone() for g in grads]
+    span[0].mul_(2)
+    for g, b in zip(grads, before):
+        assert torch.equal(g, 2 * b)
