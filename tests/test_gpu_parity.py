@@ -379,3 +379,45 @@ def test_parameter_gradients_share_one_buffer_for_a_single_allreduce():
     span[0].mul_(2)
     for g, b in zip(grads, before):
         assert torch.equal(g, 2 * b)
+
+
+@pytest.mark.parametrize("P,S,masked", [(3_000_000, 16, False), (6_000_000, 16, True)])
+def test_larger_scene_configs_properties(dev, P, S, masked):
+    """BASELINE.json configs 2 and 5 by size (3 M Gaussians forward + backward; 6 M Gaussians with a
+    hyperplane-masked render): reproducibility, the gradient-mass checksum, and -- for the masked render --
+    equality with the render of the kept subset (gui/gs_renderer.py:315-321 index-selects the tensors)."""
+    from goi_hyperplane_amd.render import GaussianSet, PipelineParams, TorchCamera, render
+    from goi_hyperplane_amd.scene import HEADLINE, make_camera, make_scene
+    sc = make_scene(P, S=S, sh_degree=3, seed=1, extent=HEADLINE["extent"],  # same volume: 3x / 6x the density
+                    log_scale_mean=HEADLINE["log_scale_mean"], log_scale_std=HEADLINE["log_scale_std"])
+    cam = TorchCamera(make_camera(HEADLINE["W"], HEADLINE["H"], fovx=HEADLINE["fovx"], yaw=-0.05), dev)
+    pc = GaussianSet.from_scene(sc, dev)
+    del sc
+    bg = torch.zeros(3, device=dev)
+    pipe = PipelineParams()
+    mask = None
+    if masked:
+        g = torch.Generator(device=dev).manual_seed(0)
+        mask = torch.rand(P, device=dev, generator=g) < 0.6
+
+    def fwd_bwd():
+        for p in pc.parameters():
+            p.grad = None
+        out = render(cam, pc, pipe, bg, gaussian_mask=mask)
+        out["semantics"][5].sum().backward()
+        return out, pc._semantics.grad.clone(), pc._xyz.grad.clone()
+
+    o1, gs1, gx1 = fwd_bwd()
+    o2, gs2, gx2 = fwd_bwd()
+    assert torch.equal(o1["render"], o2["render"]) and torch.equal(o1["semantics"], o2["semantics"])
+    assert torch.equal(gs1, gs2) and torch.equal(gx1, gx2) and torch.isfinite(gx1).all()
+    alpha_mass = o1["alpha"].double().sum().item()
+    assert alpha_mass > 0.5 * HEADLINE["W"] * HEADLINE["H"]
+    assert abs(gs1[:, 5].double().sum().item() - alpha_mass) < 1e-4 * alpha_mass
+    if masked:
+        assert float(gs1[~mask].abs().max()) == 0.0 and float(gx1[~mask].abs().max()) == 0.0
+        with torch.no_grad():
+            sub = GaussianSet(pc._xyz[mask], pc._scaling[mask], pc._rotation[mask], pc._opacity[mask],
+                              pc._features[mask], pc._semantics[mask])
+            o3 = render(cam, sub, pipe, bg)
+        assert torch.equal(o3["render"], o1["render"]) and torch.equal(o3["semantics"], o1["semantics"])
