@@ -400,6 +400,16 @@ int goi_codebook_loss_rows(const float* sim_raw, const float* inv_gnorm, const f
     return 0;
 }
 
+int goi_codebook_dlut_partial_blocks(void) { return codebook_dlut_blocks(); }
+
+int goi_codebook_dlut(const float* dsim, const float* g, long long HW, int C, int D, float* partial, void* stream) {
+    if (!dsim || !g || !partial || HW < 0) return fail("goi_codebook_dlut: bad arguments");
+    if (launch_codebook_dlut(dsim, g, HW, C, D, partial, static_cast<hipStream_t>(stream)) < 0)
+        return fail("goi_codebook_dlut: supported shape is D = 256, 288 < C <= 304, HW % 4 = 0");
+    GOI_HIP(hipGetLastError());
+    return 0;
+}
+
 int goi_adam_step(const GoiAdamGroup* groups, int n_groups, double beta1, double beta2, double eps,
                   const unsigned char* nograd_mask, void* stream) {
     if (n_groups < 0 || n_groups > GOI_ADAM_MAX_GROUPS) return fail("goi_adam_step: n_groups must be 0..8");

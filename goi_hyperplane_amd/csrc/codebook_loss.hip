@@ -264,6 +264,111 @@ __global__ __launch_bounds__(CBL_THREADS, (CPL <= 5 ? 2 : 1)) void codebook_rows
     }
 }
 
+
+// ---- dL/dL1 = dsim^T [C x HW] * g^T [HW x 256]: split-K fp32 MFMA GEMM --------------------------
+// The reduction runs over the PIXEL axis (K = HW = 1.7 M) and the output is only C x 256, so the
+// classic output tiling leaves the chip idle (hipBLASLt: 5.0 ms = 52 TFLOP/s).  Here every CU owns a
+// contiguous pixel range and keeps a FULL 304 x 256 partial result in the accumulators of its 8
+// waves (wave w: all 19 code blocks x one feature block = 76 VGPRs; two workgroups split the 256 columns): no atomics, no output traffic
+// until the final 311 KB per CU, summed afterwards in a fixed order.
+//   A[m = code][k = pixel]: the dsim tile of 32 pixels x 304 codes is shared by the 8 waves through
+//       LDS (row stride 308 floats: the four k lanes of a fragment read land 16 banks apart);
+//   B[k = pixel][n = feature]: each lane loads one float4 = 4 consecutive pixels of ITS feature row
+//       straight from the channel-major map (64 B contiguous per row across the 4 k lanes) and uses
+//       register r as the B operand of k-step r: the k <-> pixel assignment (16 jj + 4 kq + r) is a
+//       permutation of the tile, applied to A's addressing as well.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int DL_KP = 32;       // pixels per LDS stage
+constexpr int DL_THREADS = 512;  // 8 waves: a workgroup owns 128 of the 256 feature columns, wave w one block of 16
+
+template <int NCB>
+__global__ __launch_bounds__(DL_THREADS) void codebook_dlut_k(const float* __restrict__ dsim, const float* __restrict__ g,
+                                                              long long HW, int C, float* __restrict__ partial) {
+    constexpr int NC = NCB * 16, LDW = NC + 4;
+    constexpr int PER_T = (DL_KP * NC + DL_THREADS - 1) / DL_THREADS;
+    extern __shared__ __attribute__((aligned(16))) float s_tile[];  // [2][DL_KP][LDW]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, kq = lane >> 4, mm = lane & 15;
+    const int dh = blockIdx.x & 1, nrange = gridDim.x >> 1, range = blockIdx.x >> 1;
+    const long long per = ((HW + nrange - 1) / nrange + DL_KP - 1) / DL_KP * DL_KP;
+    const long long pb = (long long)range * per;
+    const long long pe = min(HW, pb + per);
+    const int nst = pe > pb ? (int)((pe - pb + DL_KP - 1) / DL_KP) : 0;
+    const int dcol = 128 * dh + 16 * w + mm;
+    const float* grow = g + (size_t)dcol * HW;
+
+    f32x4 acc[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    float stage[PER_T];
+    auto fetch_tile = [&](int st) {  // global -> registers (coalesced: the tile is one contiguous block of rows)
+        const long long p0 = pb + (long long)st * DL_KP;
+#pragma unroll
+        for (int i = 0; i < PER_T; i++) {
+            const int idx = tid + i * DL_THREADS;
+            const int row = idx / NC, col = idx - row * NC;
+            const long long p = p0 + row;
+            stage[i] = (idx < DL_KP * NC && p < pe && col < C) ? dsim[(size_t)p * C + col] : 0.f;
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < PER_T; i++) {
+            const int idx = tid + i * DL_THREADS;
+            const int row = idx / NC, col = idx - row * NC;
+            if (idx < DL_KP * NC) s_tile[(buf * DL_KP + row) * LDW + col] = stage[i];
+        }
+    };
+    float4 bq[2], bn[2];
+    auto fetch_b = [&](int st, float4* dst) {
+        const long long p0 = pb + (long long)st * DL_KP;
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++) {
+            const long long p = p0 + 16 * jj + 4 * kq;  // pe and p are multiples of 4 (HW % 4 == 0, ranges of 32)
+            dst[jj] = p < pe ? *reinterpret_cast<const float4*>(grow + p) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+
+    if (nst > 0) {
+        fetch_tile(0);
+        fetch_b(0, bq);
+        store_tile(0);
+    }
+    __syncthreads();
+    for (int st = 0; st < nst; st++) {
+        const int buf = st & 1;
+        if (st + 1 < nst) {  // next stage's loads fly while this stage's MFMAs run
+            fetch_tile(st + 1);
+            fetch_b(st + 1, bn);
+        }
+        const float* tile = s_tile + buf * DL_KP * LDW;
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++) {
+            const float bv[4] = {bq[jj].x, bq[jj].y, bq[jj].z, bq[jj].w};
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float* arow = tile + (16 * jj + 4 * kq + r) * LDW + mm;
+#pragma unroll
+                for (int cb = 0; cb < NCB; cb++)
+                    acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[16 * cb], bv[r], acc[cb], 0, 0, 0);
+            }
+        }
+        if (st + 1 < nst) {
+            store_tile(buf ^ 1);
+            bq[0] = bn[0];
+            bq[1] = bn[1];
+        }
+        __syncthreads();
+    }
+    // D[row = code 16 cb + 4 kq + r][col = feature 16 w + mm]
+    float* out = partial + (size_t)range * NC * 256;
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) out[(size_t)(16 * cb + 4 * kq + r) * 256 + dcol] = acc[cb][r];
+}
+
 }  // namespace
 
 int codebook_loss_waves() { return 256 * 8; }  // persistent: 8 waves per CU (2 per SIMD at ~230 VGPRs)
@@ -291,4 +396,19 @@ int launch_codebook_rows(const float* sim, const float* inv_gnorm, const float* 
     return 0;
 }
 
+}  // namespace goi
+
+namespace goi {
+int codebook_dlut_blocks() { return 256; }  // pixel ranges; two workgroups (column halves) per range
+// partial: [codebook_dlut_blocks()][304][256]; returns -1 when the shape is not the kernel's (C in 289..304,
+// D = 256, HW % 4 = 0): the caller then uses a library GEMM
+int launch_codebook_dlut(const float* dsim, const float* g, long long HW, int C, int D, float* partial, hipStream_t s) {
+    constexpr int NCB = 19;
+    if (D != 256 || C > NCB * 16 || C <= (NCB - 1) * 16 || (HW & 3) != 0) return -1;
+    const size_t lds = (size_t)2 * DL_KP * (NCB * 16 + 4) * sizeof(float);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(codebook_dlut_k<NCB>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    codebook_dlut_k<NCB><<<dim3(2 * codebook_dlut_blocks()), dim3(DL_THREADS), lds, s>>>(dsim, g, HW, C, partial);
+    return 0;
+}
 }  // namespace goi

@@ -112,6 +112,8 @@ int launch_semantic_decode(const float* sem, int S, long long HW, const float* W
 int codebook_loss_waves();
 int launch_codebook_rows(const float* sim, const float* inv_gnorm, const float* sem, const float* W, const float* bias,
                          long long HW, int C, int S, float t, float* dsim, float* dsem, float* partials, hipStream_t s);
+int codebook_dlut_blocks();
+int launch_codebook_dlut(const float* dsim, const float* g, long long HW, int C, int D, float* partial, hipStream_t s);
 int launch_adam_step(const GoiAdamGroup* groups, int n_groups, double beta1, double beta2, double eps,
                      const uint8_t* nograd_mask, hipStream_t s);
 size_t knn_workspace_bytes(int P);

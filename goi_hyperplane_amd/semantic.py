@@ -13,9 +13,10 @@ Inference (`compute_similarity`) is the hot part at GUI frame rate: it runs as O
 (csrc/semantic_head.hip: fp32 MFMA contraction + argmax + per-code score lookup) that reads the
 rasterizer's [S, H, W] output directly.  The training losses exist twice: `codebook_losses` restates
 train.py line by line in PyTorch (the parity reference: ~40 kernels over [HW,300] tensors, 109 ms
-and 21 GB at 1600x1056 on MI355X); `fused_codebook_losses` is the product path: two library GEMMs
-(hipBLASLt through torch.matmul, on transposed views of the [256,H,W] map) around ONE HIP kernel
-(csrc/codebook_loss.hip) that produces the four loss terms and every gradient in a single pass.
+and 21 GB at 1600x1056 on MI355X); `fused_codebook_losses` is the product path (8 ms, 8 GB): a library
+GEMM for sim (hipBLASLt through torch.matmul, on a transposed view of the [256,H,W] map), ONE HIP row
+kernel producing the four loss terms and every per-pixel gradient, and a split-K MFMA GEMM for
+dL/dLUT (both in csrc/codebook_loss.hip).
 """
 from __future__ import annotations
 
@@ -207,7 +208,16 @@ class _FusedCodebookLoss(torch.autograd.Function):
             sl = 1.0 - sums[1] / HW
             sl1 = sums[2] / HW
             recc = 1.0 - sums[3] / HW
-            dl1 = torch.matmul(dsim.t(), g.t())                                       # [C, D]   (matrix cores)
+            if D == 256 and 288 < C <= 304 and HW % 4 == 0:
+                # split-K MFMA GEMM over the pixel axis with a persistent [304, 256] accumulator per CU
+                blocks = lib.goi_codebook_dlut_partial_blocks()
+                part = torch.empty((blocks, 304, D), dtype=torch.float32, device=dev)
+                if lib.goi_codebook_dlut(p(dsim), p(g), HW, C, D, p(part),
+                                         C_.c_void_p(torch.cuda.current_stream(dev).cuda_stream)) < 0:
+                    raise RuntimeError(_lib.last_error())
+                dl1 = part.sum(dim=0)[:C].contiguous()
+            else:
+                dl1 = torch.matmul(dsim.t(), g.t())                                   # [C, D]   (library GEMM)
         ctx.save_for_backward(dsem.view_as(sem_chw), dWb[:, :S].contiguous(), dWb[:, S].contiguous(), dl1)
         ctx.has_bias = bias is not None
         terms = torch.stack([lab, sl, sl1, recc])

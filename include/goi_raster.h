@@ -169,6 +169,14 @@ int goi_codebook_loss_rows(const float* sim_raw, const float* inv_gnorm, const f
                            const float* bias, long long HW, int C, int S, float t, float* dsim, float* dsem,
                            float* partials, void* stream);
 
+/* dL/dL1 [C][D] = dsim^T * g^T as a split-K fp32 MFMA GEMM over the pixel axis (csrc/codebook_loss.hip):
+ * dsim [HW][C] (from goi_codebook_loss_rows), g [D][HW] (the channel-major ground-truth map).  Writes
+ * partial [goi_codebook_dlut_partial_blocks()][304][D]; the caller sums over the first axis and keeps
+ * rows < C.  Supported shape: D = 256, 288 < C <= 304, HW % 4 = 0; returns < 0 otherwise (use a
+ * library GEMM then). */
+int goi_codebook_dlut_partial_blocks(void);
+int goi_codebook_dlut(const float* dsim, const float* g, long long HW, int C, int D, float* partial, void* stream);
+
 /* ---- fused Adam step over the Gaussian parameter groups (scene/gaussian_model.py:163-253:
  * torch.optim.Adam(lr=0.0, eps=1e-15) over xyz / f_dc / f_rest / semantics / opacity / scaling /
  * rotation; train.py:193 optimizer.step()) with the optional per-Gaussian gradient mask of
