@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-P", type=int, default=100_000)
     ap.add_argument("--no-stage-timing", action="store_true")
+    ap.add_argument("--no-semantic-finetune", action="store_true",
+                    help="skip the secondary semantics-only-training figure")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -228,6 +230,45 @@ def main():
         barrier()
         render_ms = (time.perf_counter() - r0) / nfr * 1e3
 
+    # Secondary figure: the reference's DEFAULT training configuration optimises only the semantic features
+    # (arguments/__init__.py:85-90).  With every other parameter frozen the feature-gradient-only backward
+    # applies (goi_raster_backward_semantics, bit-identical dL/dsemantics); not part of `value`.
+    sem_only = None
+    if not args.no_semantic_finetune:
+        from goi_hyperplane_amd import rasterizer
+        rasterizer.set_backward_mode(semantics_only=True)
+        for p in params:
+            p.requires_grad_(False)
+            p.grad = None
+        pc._semantics.requires_grad_(True)
+
+        def sem_step(i):
+            cam = cams[(i * world + rank) % len(cams)]
+            pc._semantics.grad = None
+            out = render(cam, pc, pipe, bg)
+            torch.autograd.backward((out["semantics"],), (g_sem,))
+            if dist is not None:
+                allreduce_gradients([pc._semantics], dist)
+        for i in range(2):
+            sem_step(i)
+        barrier()
+        s0 = time.perf_counter()
+        nss = max(5, min(args.steps, 50))
+        for i in range(nss):
+            sem_step(i)
+        barrier()
+        sem_elapsed = time.perf_counter() - s0
+        if dist is not None:
+            tt = torch.tensor([sem_elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            sem_elapsed = float(tt.item())
+        sem_only = {"views_per_s": nss * world / sem_elapsed, "ms_per_step": sem_elapsed / nss * 1e3, "steps": nss,
+                    "what": "only the semantic features trainable (the reference's default): forward + "
+                            "feature-gradient-only backward" + (" + RCCL all-reduce of dL/dsemantics" if world > 1 else "")}
+        rasterizer.set_backward_mode(semantics_only=False)
+        for p in params:
+            p.requires_grad_(True)
+
     if rank == 0:
         sb = stage_bytes(args.P, V, N, T, HW, args.S)
         b_fwd, b_bwd = survey_bytes(args.P, V, N, T, HW, args.S)
@@ -273,6 +314,7 @@ def main():
                        "views_per_step": world, "parallelism": f"views sharded x{world}",
                        "allreduce_bytes": int(sum(p.numel() for p in reduce_params) * 4) if world > 1 else 0},
             "render_ms_per_frame": render_ms,
+            "semantic_finetune": sem_only,
             "roofline": roofline,
             "whole_view": {"alg_bytes_fwd": b_fwd, "alg_bytes_bwd": b_bwd,
                            "alg_GBps_over_step": (b_fwd + b_bwd) / (ms_per_step * 1e-3) / 1e9,

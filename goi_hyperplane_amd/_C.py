@@ -66,6 +66,24 @@ class _BinningAllocator:
             return None
 
 
+_SCRATCH = {}
+
+
+def _backward_scratch(nbytes: int, dev) -> torch.Tensor:
+    """Grow-only backward scratch per (device, stream): the buffer is 4*R*129 bytes (4 GB at the headline
+    size) and R changes with every view, so going through the caching allocator each step leaves it
+    hunting for a block of a new size -- an occasional 4 GB hipMalloc inside a training step.  The
+    scratch is dead when goi_raster_backward returns (same stream), so one buffer serves all calls."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    buf = _SCRATCH.get(key)
+    if buf is None or buf.numel() < nbytes:
+        _SCRATCH.pop(key, None)
+        buf = None
+        buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=dev)
+        _SCRATCH[key] = buf
+    return buf
+
+
 def _scene(P, S, H, W, bg, means3D, sh, colors, semantics, opacity, scales, rotations, scale_modifier, cov3D,
            viewmatrix, projmatrix, tan_fovx, tan_fovy, degree, campos, prefiltered, debug):
     M = 0 if (sh is None or sh.numel() == 0) else int(sh.size(1))
@@ -182,7 +200,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, semantics, 
             sc = _scene(P, S, H, W, ten["bg"], ten["means3D"], ten["sh"], ten["colors"], ten["semantics"], None,
                         ten["scales"], ten["rotations"], scale_modifier, ten["cov3D"], ten["viewmatrix"],
                         ten["projmatrix"], tan_fovx, tan_fovy, degree, ten["campos"], False, debug)
-            scratch = torch.empty(lib.goi_raster_backward_scratch_bytes(int(R), S), dtype=torch.uint8, device=dev)
+            scratch = _backward_scratch(lib.goi_raster_backward_scratch_bytes(int(R), S), dev)
             r = lib.goi_raster_backward(
                 C.byref(sc), int(R), _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(ten["radii"]),
                 _ptr(ten["alphas"]), _ptr(ten["g_c"]), _ptr(ten["g_s"]), _ptr(ten["g_d"]), _ptr(ten["g_a"]),
@@ -193,6 +211,40 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, semantics, 
                 raise RuntimeError(_lib.last_error())
     return (dL_dmeans2D, dL_dcolors, dL_dsemantics, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales,
             dL_drotations)
+
+
+def rasterize_gaussians_backward_semantics(background, means3D, radii, semantics, viewmatrix, projmatrix, tan_fovx,
+                                           tan_fovy, dL_dout_semantic, campos, geomBuffer, R, binningBuffer,
+                                           imageBuffer, alphas, sh_degree=0, debug=False):
+    """-> dL_dsemantics[P,S] only (not in the reference's pybind module): the feature-gradient-only
+    backward behind goi_raster_backward_semantics, for training runs that optimise only the semantic
+    features (the reference's default, arguments/__init__.py:85-90).  Bit-identical to the
+    dL_dsemantics of rasterize_gaussians_backward."""
+    lib = _lib.load()
+    dev = _check_device(means3D)
+    P = int(means3D.size(0))
+    S = int(dL_dout_semantic.size(0))
+    H, W = int(dL_dout_semantic.size(1)), int(dL_dout_semantic.size(2))
+    with torch.cuda.device(dev):
+        dL_dsemantics = torch.empty((P, S), dtype=torch.float32, device=dev)
+        if P != 0:
+            ten = dict(bg=_prep(background, "background", dev), means3D=_prep(means3D, "means3D", dev),
+                       semantics=_prep(semantics, "semantics", dev), viewmatrix=_prep(viewmatrix, "viewmatrix", dev),
+                       projmatrix=_prep(projmatrix, "projmatrix", dev), campos=_prep(campos, "campos", dev),
+                       radii=_prep(radii, "radii", dev, torch.int32), alphas=_prep(alphas, "alphas", dev),
+                       g_s=_prep(dL_dout_semantic, "dL_dout_semantic", dev))
+            # the geometry inputs are not read by this path (everything it needs is in the forward's
+            # workspaces); the scene only has to pass validation
+            sc = _scene(P, S, H, W, ten["bg"], ten["means3D"], None, ten["means3D"], ten["semantics"], None,
+                        None, None, 1.0, ten["means3D"], ten["viewmatrix"], ten["projmatrix"], tan_fovx, tan_fovy,
+                        sh_degree, ten["campos"], False, debug)
+            scratch = _backward_scratch(lib.goi_raster_backward_scratch_bytes(int(R), S), dev)
+            r = lib.goi_raster_backward_semantics(C.byref(sc), int(R), _ptr(geomBuffer), _ptr(binningBuffer),
+                                                  _ptr(imageBuffer), _ptr(ten["radii"]), _ptr(ten["alphas"]),
+                                                  _ptr(ten["g_s"]), _ptr(dL_dsemantics), _ptr(scratch), _stream(dev))
+            if r < 0:
+                raise RuntimeError(_lib.last_error())
+    return dL_dsemantics
 
 
 def rasterize_gaussians_trace(background, means3D, colors, img_sem, opacity, scales, rotations, scale_modifier,

@@ -31,6 +31,7 @@ UNITS = {
     "render_fwd.hip": [],
     "render_bwd.hip": [],
     "render_bwd_tile.hip": [],
+    "render_bwd_sem.hip": [],
     "semantic_head.hip": [],
     "knn.hip": ["-ffp-contract=off"],
     "adam.hip": ["-ffp-contract=off"],

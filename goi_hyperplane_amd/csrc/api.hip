@@ -361,6 +361,41 @@ int goi_raster_backward(const GoiRasterScene* scene, int R, const void* geom_buf
     return 0;
 }
 
+int goi_raster_backward_semantics(const GoiRasterScene* scene, int R, const void* geom_buffer, const void* binning_buffer,
+                                  const void* image_buffer, const int* radii, const float* out_alpha,
+                                  const float* dL_dout_semantic, float* dL_dsemantic, void* scratch, void* stream) {
+    if (validate(scene, true, false)) return -1;
+    const GoiRasterScene& sc = *scene;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (sc.P == 0) return 0;
+    if (!geom_buffer || !image_buffer || (R > 0 && !binning_buffer)) return fail("workspace pointer is NULL");
+    if (!scratch) return fail("goi_raster_backward_semantics needs the scratch of goi_raster_backward_scratch_bytes");
+    if (!dL_dout_semantic || !dL_dsemantic || !out_alpha || !radii) return fail("a required pointer is NULL");
+    GeomView g;
+    ImageView im;
+    BinView bv;
+    geom_layout(sc.P, const_cast<char*>(static_cast<const char*>(geom_buffer)), &g);
+    image_layout(sc.W, sc.H, const_cast<char*>(static_cast<const char*>(image_buffer)), &im);
+    const int fin = tile_sort_result_index(sc.W, sc.H, R);
+    if (R > 0) binning_layout(R, const_cast<char*>(static_cast<const char*>(binning_buffer)), &bv);
+    BwdScratchView scr;  // same allocation as the full backward; rows are narrower here
+    bwd_scratch_layout(R, sc.S, static_cast<char*>(scratch), &scr);
+    const int row_floats = ((4 * ((sc.S + 3) / 4) + 15) / 16) * 16;
+    {
+        StageTimer t(GOI_STAGE_BLEND_BWD, s);
+        if (R > 0) {
+            GOI_HIP(hipMemsetAsync(scr.flags, 0, (size_t)R * 4, s));
+            launch_render_bwd_sem(sc, g, im, bv.vals[fin], radii, out_alpha, dL_dout_semantic, scr.rows, scr.flags,
+                                  row_floats, s);
+        }
+    }
+    if (check_stage(sc, s, "backward blend (semantics)")) return -1;
+    StageTimer t(GOI_STAGE_PREPROCESS_BWD, s);
+    launch_reduce_sem_rows(sc, g, scr.rows, scr.flags, row_floats, dL_dsemantic, s);
+    GOI_HIP(hipGetLastError());
+    return 0;
+}
+
 int goi_raster_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                             uint8_t* present, void* stream) {
     (void)projmatrix;

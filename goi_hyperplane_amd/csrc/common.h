@@ -94,6 +94,12 @@ void launch_render_bwd_rows(const GoiRasterScene& sc, const GeomView& g, const I
                             const uint32_t* point_list, const int* radii, const float* out_alpha, const float* dL_dpix,
                             const float* dL_dsem, const float* dL_ddepth, const float* dL_dalpha,
                             const BwdScratchView& scr, hipStream_t s);
+// feature-gradient-only backward blend (render_bwd_sem.hip) and its row reduction: dL/dsemantics only
+void launch_render_bwd_sem(const GoiRasterScene& sc, const GeomView& g, const ImageView& im, const uint32_t* point_list,
+                           const int* radii, const float* out_alpha, const float* dL_dsem, float* rows, uint8_t* flags,
+                           int row_floats, hipStream_t s);
+void launch_reduce_sem_rows(const GoiRasterScene& sc, const GeomView& g, const float* rows, const uint8_t* flags,
+                            int row_floats, float* dL_dsemantic, hipStream_t s);
 // sums every Gaussian's partial rows (fixed order) into the six blend-gradient arrays; writes all P rows
 void launch_reduce_rows(const GoiRasterScene& sc, const GeomView& g, const BwdScratchView& scr, float* dL_dmean2D,
                         float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dsemantic, float* dL_ddepth,

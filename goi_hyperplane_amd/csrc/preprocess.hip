@@ -659,6 +659,20 @@ void launch_reduce_rows(const GoiRasterScene& sc, const GeomView& g, const BwdSc
                                                     dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dsemantic, dL_ddepth);
 }
 
+void launch_reduce_sem_rows(const GoiRasterScene& sc, const GeomView& g, const float* rows, const uint8_t* flags,
+                            int row_floats, float* dL_dsemantic, hipStream_t s) {
+    // rows hold semantic channels only: with nch = row_floats + 4 every element index is a semantic one
+    const int nch = row_floats + 4;
+    const dim3 grid((sc.P + 15) / 16);
+    const uint32_t* order = g.sort_vals[depth_sort_result_index()];
+    if (row_floats == 16)
+        reduce_rows_k<1><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, order, g.offsets, g.tiles_touched, rows, flags, nullptr,
+                                                    nullptr, nullptr, nullptr, dL_dsemantic, nullptr);
+    else
+        reduce_rows_k<2><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, order, g.offsets, g.tiles_touched, rows, flags, nullptr,
+                                                    nullptr, nullptr, nullptr, dL_dsemantic, nullptr);
+}
+
 void launch_emit(int P, int W, int H, const GeomView& g, const uint32_t* order, const int* radii, uint32_t* keys,
                  uint32_t* vals, hipStream_t s) {
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;

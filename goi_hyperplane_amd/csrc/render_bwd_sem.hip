@@ -1,0 +1,182 @@
+// Feature-gradient-only backward blend for gfx950.
+//
+// The reference's training script optimises ONLY the per-Gaussian semantic features by default
+// (arguments/__init__.py:85-90: semantic_finetune = True, every other *_finetune = False;
+// scene/gaussian_model.py:185-246 freezes the rest), yet its backward kernel always computes every
+// gradient (cuda_rasterizer/backward.cu:415-625).  dL/dsemantics needs none of the alpha-gradient
+// machinery:
+//     dL/dsem[g][ch] = sum_pix w[pix][g] * dL/dpixel_sem[pix][ch],      w = alpha * T
+// so this kernel keeps the structure of render_bwd_rows_k (one wave = one 8x8 quadrant, lane-parallel
+// staging of box-test hits, back-to-front walk from the wave's own last contributor, T recovered as
+// T_final / prod(1 - alpha), MFMA reduction over the 64 pixels, one scratch row per (quadrant,
+// Gaussian), no atomics) and drops the rest: no feature rows are staged, there is no <feature, dL>
+// product, no dL/dalpha recurrence, no moments; 16 members form a group and all 16 MFMA rows carry w.
+// The w values, the k-order of the MFMA and the reduce order are those of the full kernel, so the
+// result is bit-identical to the dL/dsemantics of the full backward.
+#include "blend_common.h"
+
+namespace goi {
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SGROUP = 16;
+constexpr int SBATCH = 32;
+constexpr int STSTRIDE = 66;
+
+template <int S4>
+__global__ __launch_bounds__(64) void render_bwd_sem_k(
+    const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int gx, int gy,
+    int n_quads, int S, const GaussRec* __restrict__ rec, const int* __restrict__ radii,
+    const uint32_t* __restrict__ goff, const float* __restrict__ out_alpha, const uint32_t* __restrict__ n_contrib,
+    const float* __restrict__ dL_dpixsem, float* __restrict__ rows, uint8_t* __restrict__ flags, int row_floats) {
+    constexpr int NSEM = 4 * S4, NB = (NSEM + 15) / 16;
+    __shared__ float4 s_geo[SBATCH];          // x, y, conic a, b
+    __shared__ float4 s_geo2[SBATCH];         // conic c, opacity, slot index (bits), -
+    __shared__ float s_t[SGROUP * STSTRIDE];  // w columns, [member][pixel]
+    __shared__ uint32_t s_slot[SGROUP];
+
+    const QuadGeom t = quad_geom(W, H, gx, n_quads);
+    if (t.tile < 0) return;
+    const int lane = t.lane;
+    const uint2 range = ranges[t.tile];
+    const size_t HW = (size_t)W * H;
+    const size_t pix_id = (size_t)W * t.py + t.px;
+    const int last_contributor = t.inside ? (int)n_contrib[pix_id] : 0;
+    int n_proc = last_contributor;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) n_proc = max(n_proc, __shfl_xor(n_proc, d, 64));
+    n_proc = __builtin_amdgcn_readfirstlane(n_proc);
+    if (n_proc == 0) return;
+    const int rounds = (n_proc + SBATCH - 1) / SBATCH;
+    float T = t.inside ? (1.f - out_alpha[pix_id]) : 0.f;
+
+    // MFMA B operands: bfrag[nb][s] = dL[pixel 4s + (lane>>4)][channel 16 nb + (lane&15)]
+    const int kq = lane >> 4, mm = lane & 15;
+    float bfrag[NB][16];
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++) {
+#pragma unroll
+        for (int c = 0; c < 16; c++) {
+            const int ch = nb * 16 + c;
+            s_t[lane * 16 + c] = (t.inside && ch < S) ? dL_dpixsem[ch * HW + pix_id] : 0.f;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s = 0; s < 16; s++) bfrag[nb][s] = s_t[(4 * s + kq) * 16 + mm];
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    uint32_t id_n = 0;
+    float4 q0_n = make_float4(0, 0, 0, 0), q2_n = make_float4(0, 0, -1.f, -1.f);
+    auto prefetch = [&](int b) {
+        const int k = b * SBATCH + lane;
+        q2_n.z = -1.f;
+        if (lane < SBATCH && k < n_proc) {
+            id_n = point_list[range.x + (n_proc - 1 - k)];
+            const float4* r4 = reinterpret_cast<const float4*>(rec + id_n);
+            q0_n = r4[0];
+            q2_n = r4[2];
+        }
+    };
+    prefetch(0);
+    int nslot = 0;
+
+    auto flush_group = [&](int cnt) {
+        f32x4 acc[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s = 0; s < 16; s++) {
+            const float a = s_t[mm * STSTRIDE + 4 * s + kq];
+#pragma unroll
+            for (int nb = 0; nb < NB; nb++)
+                acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bfrag[nb][s], acc[nb], 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = 4 * kq + r;  // D[row = member][col = channel]
+            if (row < cnt) {
+                float* dst = rows + (size_t)s_slot[row] * row_floats;
+#pragma unroll
+                for (int nb = 0; nb < NB; nb++) {
+                    const int ch = nb * 16 + mm;
+                    if (ch < NSEM) dst[ch] = acc[nb][r];
+                }
+            }
+        }
+        if (lane < cnt) flags[s_slot[lane]] = 1;
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    for (int b = 0; b < rounds; b++) {
+        const uint32_t id = id_n;
+        const float4 q0 = q0_n, q2 = q2_n;
+        const bool hit = box_hits_quadrant(q0.x, q0.y, q2.z, q2.w, t.QX0, t.QY0);
+        if (b + 1 < rounds) prefetch(b + 1);
+        unsigned long long m = __ballot(hit);
+        if (m == 0) continue;
+        if (hit) {
+            const float4 q1 = reinterpret_cast<const float4*>(rec + id)[1];
+            int x0, y0, x1, y1;
+            tile_rect(q0.x, q0.y, radii[id], gx, gy, x0, y0, x1, y1);
+            const uint32_t inst = goff[id] + (uint32_t)((t.ty - y0) * (x1 - x0) + (t.tx - x0));
+            s_geo[lane] = q0;
+            s_geo2[lane] = make_float4(q1.x, q1.y, __uint_as_float(inst * 4u + (uint32_t)t.q), 0.f);
+        }
+        __builtin_amdgcn_wave_barrier();
+        while (m) {
+            const int j = __builtin_ctzll(m);
+            m &= m - 1;
+            const int pos0 = n_proc - 1 - (b * SBATCH + j);
+            const float4 g = s_geo[j];
+            const float4 g2 = s_geo2[j];
+            const PairEval e = eval_pair(g.x, g.y, g.z, g.w, g2.x, g2.y, t.pxf, t.pyf);
+            const bool c = (pos0 < last_contributor) && e.hit;
+            if (!__any(c)) continue;
+            const float one_m_a = 1.f - e.alpha;
+            const float inv = __builtin_amdgcn_rcpf(one_m_a);
+            const float Tn = T * inv;
+            float wgt = 0.f;
+            if (c) {
+                T = Tn;
+                wgt = e.alpha * Tn;
+            }
+            s_t[nslot * STSTRIDE + lane] = wgt;
+            if (lane == 0) s_slot[nslot] = __float_as_uint(g2.z);
+            nslot++;
+            if (nslot == SGROUP) {
+                flush_group(SGROUP);
+                nslot = 0;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (nslot > 0) flush_group(nslot);
+}
+
+template <int S4>
+void launch_bwd_sem_s4(const GoiRasterScene& sc, const GeomView& g, const ImageView& im, const uint32_t* point_list,
+                       const int* radii, const float* out_alpha, const float* dL_dsem, float* rows, uint8_t* flags,
+                       int row_floats, hipStream_t s) {
+    const int gx = (sc.W + TILE - 1) / TILE, gy = (sc.H + TILE - 1) / TILE;
+    const int n_quads = gx * gy * 4;
+    render_bwd_sem_k<S4><<<dim3(quad_grid(n_quads)), dim3(64), 0, s>>>(im.ranges, point_list, sc.W, sc.H, gx, gy, n_quads,
+                                                                        sc.S, g.rec, radii, g.goff, out_alpha, im.n_contrib,
+                                                                        dL_dsem, rows, flags, row_floats);
+}
+
+}  // namespace
+
+// rows: [4N][row_floats] with row_floats = 16 * ceil(4*ceil(S/4) / 16); flags [4N] zeroed by the caller
+void launch_render_bwd_sem(const GoiRasterScene& sc, const GeomView& g, const ImageView& im, const uint32_t* point_list,
+                           const int* radii, const float* out_alpha, const float* dL_dsem, float* rows, uint8_t* flags,
+                           int row_floats, hipStream_t s) {
+#define GOI_CALL(N) launch_bwd_sem_s4<N>(sc, g, im, point_list, radii, out_alpha, dL_dsem, rows, flags, row_floats, s)
+    GOI_DISPATCH_S4(sc.S, GOI_CALL)
+#undef GOI_CALL
+}
+
+}  // namespace goi

@@ -17,6 +17,8 @@ Differences, all behind the same surface:
 """
 from __future__ import annotations
 
+import os
+
 from typing import NamedTuple
 
 import torch
@@ -64,6 +66,18 @@ def _call_with_snapshot(fn, args, debug, dump_name, what):
         raise
 
 
+# Opt-in: when ONLY the semantic features require a gradient (the reference's default training
+# configuration, arguments/__init__.py:85-90), run the feature-gradient-only backward.  The one
+# observable difference to the full backward is that viewspace_points.grad is zero instead of the
+# screen-space gradient; dL/dsemantics is bit-identical.  Off by default; GOI_BACKWARD=semantics or
+# set_backward_mode(semantics_only=True) turns it on.
+_BACKWARD_MODE = {"semantics_only": os.environ.get("GOI_BACKWARD", "") == "semantics"}
+
+
+def set_backward_mode(semantics_only: bool) -> None:
+    _BACKWARD_MODE["semantics_only"] = bool(semantics_only)
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, semantics, opacities, scales, rotations, cov3Ds_precomp,
@@ -84,6 +98,16 @@ class _RasterizeGaussians(torch.autograd.Function):
         rs = ctx.raster_settings
         (colors_precomp, semantics, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer,
          imgBuffer, alpha) = ctx.saved_tensors
+        need = ctx.needs_input_grad  # means3D, means2D, sh, colors, semantics, opacities, scales, rotations, cov3D
+        if (_BACKWARD_MODE["semantics_only"] and need[4] and not rs.debug
+                and not (need[0] or need[2] or need[3] or need[5] or need[6] or need[7] or need[8])):
+            # only the semantic features are trainable: feature-gradient-only kernel; the screen-space
+            # placeholder (means2D) gets zeros -- nothing in a semantics-only run consumes it
+            g_sem = _C.rasterize_gaussians_backward_semantics(
+                rs.bg, means3D, radii, semantics, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_sem,
+                rs.campos, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, alpha, rs.sh_degree, rs.debug)
+            g_2d = torch.zeros((means3D.shape[0], 3), dtype=means3D.dtype, device=means3D.device) if need[1] else None
+            return (None, g_2d, None, None, g_sem, None, None, None, None, None)
         args = (rs.bg, means3D, radii, colors_precomp, semantics, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                 rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, grad_out_sem, grad_depth,
                 grad_alpha, sh, rs.sh_degree, rs.campos, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, alpha,

@@ -101,6 +101,15 @@ int goi_raster_backward(const GoiRasterScene* scene, int R,
                                          the float-atomic accumulation path (not bit-reproducible) */,
                         void* stream);
 
+/* Feature-gradient-only backward: dL/dsemantics [P,S] from dL/d(semantic map) alone, bit-identical to
+ * the dL_dsemantic of goi_raster_backward and about 3x cheaper.  For the reference's default training
+ * configuration, where only the semantic features are optimised (arguments/__init__.py:85-90,
+ * scene/gaussian_model.py:185-246).  Same workspaces, `R` and scratch as goi_raster_backward. */
+int goi_raster_backward_semantics(const GoiRasterScene* scene, int R, const void* geom_buffer,
+                                  const void* binning_buffer, const void* image_buffer, const int* radii,
+                                  const float* out_alpha, const float* dL_dout_semantic, float* dL_dsemantic,
+                                  void* scratch, void* stream);
+
 /* Trace: scene->semantics is ignored; img_sem[S,H,W] is scattered onto the Gaussians it meets
  * with alpha > 0.005.  out_color[3,H,W], gau_sem[P,S], num_gsem[P] (int32), radii[P]. */
 int goi_raster_trace(const GoiRasterScene* scene, const float* img_sem, void* geom_buffer, void* image_buffer,

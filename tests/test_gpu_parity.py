@@ -421,3 +421,42 @@ def test_larger_scene_configs_properties(dev, P, S, masked):
                               pc._features[mask], pc._semantics[mask])
             o3 = render(cam, sub, pipe, bg)
         assert torch.equal(o3["render"], o1["render"]) and torch.equal(o3["semantics"], o1["semantics"])
+
+
+@pytest.mark.parametrize("P,W,H,S", [(4000, 200, 152, 16), (2500, 97, 61, 10), (1500, 64, 48, 3), (200_000, 800, 528, 16)])
+def test_semantics_only_backward_is_bit_identical_to_the_full_one(dev, P, W, H, S):
+    """goi_raster_backward_semantics (the reference's default training configuration: only the semantic
+    features are optimised) against the dL/dsemantics of the full backward."""
+    from goi_hyperplane_amd import rasterizer
+    from goi_hyperplane_amd.render import GaussianSet, PipelineParams, TorchCamera, render
+    from goi_hyperplane_amd.scene import make_camera, make_scene
+    sc = make_scene(P, S=S, sh_degree=3, seed=5, log_scale_mean=-2.6 if P < 10000 else -3.6)
+    cam = TorchCamera(make_camera(W, H, yaw=0.1), dev)
+    pc = GaussianSet.from_scene(sc, dev)
+    bg = torch.zeros(3, device=dev)
+    g = torch.Generator(device=dev).manual_seed(1)
+    up = torch.randn((S, H, W), device=dev, generator=g)
+
+    def sem_grad(only_sem_trainable, lean):
+        rasterizer.set_backward_mode(semantics_only=lean)
+        try:
+            for p in pc.parameters():
+                p.grad = None
+                p.requires_grad_(not only_sem_trainable)
+            pc._semantics.requires_grad_(True)
+            out = render(cam, pc, PipelineParams(), bg)
+            torch.autograd.backward((out["semantics"],), (up,))
+            return pc._semantics.grad.clone(), out["viewspace_points"].grad
+        finally:
+            rasterizer.set_backward_mode(semantics_only=False)
+            for p in pc.parameters():
+                p.requires_grad_(True)
+
+    full, vs_full = sem_grad(False, False)
+    frozen_full, _ = sem_grad(True, False)      # frozen parameters, full kernel: the reference's behaviour
+    lean, vs_lean = sem_grad(True, True)
+    assert torch.equal(full, frozen_full) and torch.equal(full, lean)
+    assert float(full.abs().max()) > 0 and float(vs_lean.abs().max()) == 0.0 and float(vs_full.abs().max()) > 0
+    # the mode is inert while anything else needs a gradient
+    mixed, vs_mixed = sem_grad(False, True)
+    assert torch.equal(mixed, full) and torch.equal(vs_mixed, vs_full)

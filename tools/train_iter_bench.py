@@ -23,6 +23,8 @@ gtl = torch.randn(256, H, W, device=dev)
 
 
 def run(fused: bool, n=8):
+    from goi_hyperplane_amd import rasterizer
+    rasterizer.set_backward_mode(semantics_only=fused)  # this build: feature-gradient-only backward
     pc = GaussianSet.from_scene(sc, dev)
     for p in pc.parameters():  # the reference's default: semantic_finetune only (arguments/__init__.py:85-90)
         p.requires_grad_(False)
