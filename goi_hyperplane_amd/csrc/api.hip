@@ -139,22 +139,35 @@ int geometry_and_binning(const GoiRasterScene& sc, GeomView& g, ImageView& im, g
     if (!bin_mem && need > 0) return fail("binning allocation callback returned NULL");
     BinView bv;
     binning_layout(N, bin_mem, &bv);
+    // Tile counting fused into emit (onesweep sort, tile grid small enough for an LDS histogram): the counts give
+    // the tile ranges and the sort's digit histograms, so neither the keys nor the sorted keys are re-read for them.
+    const bool counting = N > 0 && g_options.sort_variant == 1 && emit_can_count_tiles(sc.W, sc.H);
     {
         StageTimer t(GOI_STAGE_EMIT, s);
-        if (N > 0) launch_emit(P, sc.W, sc.H, g, order, radii, bv.keys[0], bv.vals[0], s);
+        if (counting)
+            launch_emit_counting(P, sc.W, sc.H, g, order, radii, bv.keys[0], bv.vals[0], im.ranges, s);
+        else if (N > 0)
+            launch_emit(P, sc.W, sc.H, g, order, radii, bv.keys[0], bv.vals[0], s);
     }
     if (check_stage(sc, s, "emit")) return -1;
     int fin;
-    {
+    if (counting) {
+        {
+            StageTimer t(GOI_STAGE_RANGES, s);
+            launch_tile_ranges_hist(sc.W, sc.H, im.ranges, radix_sort_ghist(bv.scratch, (size_t)N), s);
+        }
         StageTimer t(GOI_STAGE_TILE_SORT, s);
-        fin = radix_sort_pairs(bv.keys, bv.vals, (size_t)N, 0, tile_key_bits((uint32_t)(gx * gy)), bv.scratch, s);
-    }
-    if (check_stage(sc, s, "tile sort")) return -1;
-    {
+        fin = radix_sort_pairs(bv.keys, bv.vals, (size_t)N, 0, tile_key_bits((uint32_t)(gx * gy)), bv.scratch, s, true);
+    } else {
+        {
+            StageTimer t(GOI_STAGE_TILE_SORT, s);
+            fin = radix_sort_pairs(bv.keys, bv.vals, (size_t)N, 0, tile_key_bits((uint32_t)(gx * gy)), bv.scratch, s);
+        }
+        if (check_stage(sc, s, "tile sort")) return -1;
         StageTimer t(GOI_STAGE_RANGES, s);
         launch_ranges(N, bv.keys[fin], im.ranges, gx * gy, s);
     }
-    if (check_stage(sc, s, "ranges")) return -1;
+    if (check_stage(sc, s, "tile sort / ranges")) return -1;
     *plist = bv.vals[fin];
     return N;
 }

@@ -77,13 +77,20 @@ void exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* ou
                         uint32_t* scratch, hipStream_t s);
 // Stable LSD radix sort of (key,val) pairs on key bits [lo, hi).  Data start in keys[0]/vals[0];
 // returns the index (0/1) of the buffers holding the sorted result.
+// ghist_ready: the caller has already written the per-pass global digit histograms ([pass][256] words at
+// radix_sort_ghist(scratch, n)); only honoured by the onesweep variant with <= 2 passes from bit 0.
 int radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], size_t n, int lo, int hi, uint32_t* scratch,
-                     hipStream_t s);
+                     hipStream_t s, bool ghist_ready = false);
+uint32_t* radix_sort_ghist(uint32_t* scratch, size_t n);
 
 // ---- stages ---------------------------------------------------------------------------------------
 void launch_preprocess_fwd(const GoiRasterScene& sc, const GeomView& g, int* radii, hipStream_t s);
 void launch_emit(int P, int W, int H, const GeomView& g, const uint32_t* order, const int* radii, uint32_t* keys,
                  uint32_t* vals, hipStream_t s);
+bool emit_can_count_tiles(int W, int H);
+void launch_emit_counting(int P, int W, int H, const GeomView& g, const uint32_t* order, const int* radii, uint32_t* keys,
+                          uint32_t* vals, uint2* ranges, hipStream_t s);
+void launch_tile_ranges_hist(int W, int H, uint2* ranges, uint32_t* ghist, hipStream_t s);
 void launch_ranges(int N, const uint32_t* sorted_keys, uint2* ranges, int T, hipStream_t s);
 void launch_render_fwd(const GoiRasterScene& sc, const GeomView& g, const ImageView& im, const uint32_t* point_list,
                        float* out_color, float* out_sem, float* out_depth, float* out_alpha, hipStream_t s);

@@ -552,41 +552,113 @@ __global__ __launch_bounds__(256) void reduce_rows_k(int P, int S, int nch, cons
 // Wave-cooperative: each lane prepares one Gaussian (rectangle, output offset), then the wave walks
 // its 64 Gaussians one at a time and all lanes write that Gaussian's instances side by side, so every
 // store instruction covers one contiguous run instead of 64 scattered words.
+// COUNT: the block also histograms its keys per tile in LDS and adds the non-empty bins to tile_count[]
+// (stride 2: the .y words of the ranges array).  The per-tile counts are the tile ranges before their
+// prefix sum AND, folded by digit, the global histograms the onesweep tile sort needs: counting here
+// removes the sort's histogram pass over the 8 M keys and the ranges pass over the sorted keys.
+constexpr int EMIT_ROUNDS = 4;
+
+template <bool COUNT>
 __global__ __launch_bounds__(256) void emit_k(int P, int gx, int gy, const GaussRec* __restrict__ rec,
                                               const int* __restrict__ radii, const uint32_t* __restrict__ order,
                                               const uint32_t* __restrict__ offsets, uint32_t* __restrict__ goff,
-                                              uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+                                              uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                              uint32_t* __restrict__ tile_count) {
+    extern __shared__ uint32_t s_cnt[];  // [gx * gy] when COUNT
+    const int T = gx * gy;
+    if (COUNT) {
+        for (int t = threadIdx.x; t < T; t += 256) s_cnt[t] = 0;
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63;
-    uint32_t g = 0, off = 0;
-    int x0 = 0, y0 = 0, w = 1, cnt = 0;
-    if (i < P) {
-        g = order[i];
-        off = offsets[i];
-        goff[g] = off;
-        const int r = radii[g];
-        if (r > 0) {
-            const float4 q0 = rec[g].q0;
-            int x1, y1;
-            tile_rect(q0.x, q0.y, r, gx, gy, x0, y0, x1, y1);
-            w = x1 - x0;
-            cnt = w * (y1 - y0);
+    // the counting variant amortises zeroing and flushing its tile histogram over EMIT_ROUNDS x 256 Gaussians
+    constexpr int ROUNDS = COUNT ? EMIT_ROUNDS : 1;
+#pragma unroll 1
+    for (int rnd = 0; rnd < ROUNDS; rnd++) {
+        const int i = (blockIdx.x * ROUNDS + rnd) * 256 + threadIdx.x;
+        uint32_t g = 0, off = 0;
+        int x0 = 0, y0 = 0, w = 1, cnt = 0;
+        if (i < P) {
+            g = order[i];
+            off = offsets[i];
+            goff[g] = off;
+            const int r = radii[g];
+            if (r > 0) {
+                const float4 q0 = rec[g].q0;
+                int x1, y1;
+                tile_rect(q0.x, q0.y, r, gx, gy, x0, y0, x1, y1);
+                w = x1 - x0;
+                cnt = w * (y1 - y0);
+            }
+        }
+        unsigned long long todo = __ballot(cnt > 0);
+        while (todo) {
+            const int j = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const int cj = __builtin_amdgcn_readlane(cnt, j);
+            const int wj = __builtin_amdgcn_readlane(w, j);
+            const int xj = __builtin_amdgcn_readlane(x0, j), yj = __builtin_amdgcn_readlane(y0, j);
+            const uint32_t oj = (uint32_t)__builtin_amdgcn_readlane((int)off, j);
+            const uint32_t gj = (uint32_t)__builtin_amdgcn_readlane((int)g, j);
+            for (int k = lane; k < cj; k += 64) {
+                const int row = k / wj, col = k - row * wj;
+                const uint32_t key = (uint32_t)((yj + row) * gx + xj + col);
+                keys[oj + k] = key;
+                vals[oj + k] = gj;
+                if (COUNT) atomicAdd(&s_cnt[key], 1u);  // lanes hold distinct tiles of one rectangle: no same-address conflicts
+            }
         }
     }
-    unsigned long long todo = __ballot(cnt > 0);
-    while (todo) {
-        const int j = __builtin_ctzll(todo);
-        todo &= todo - 1;
-        const int cj = __builtin_amdgcn_readlane(cnt, j);
-        const int wj = __builtin_amdgcn_readlane(w, j);
-        const int xj = __builtin_amdgcn_readlane(x0, j), yj = __builtin_amdgcn_readlane(y0, j);
-        const uint32_t oj = (uint32_t)__builtin_amdgcn_readlane((int)off, j);
-        const uint32_t gj = (uint32_t)__builtin_amdgcn_readlane((int)g, j);
-        for (int k = lane; k < cj; k += 64) {
-            const int row = k / wj, col = k - row * wj;
-            keys[oj + k] = (uint32_t)((yj + row) * gx + xj + col);
-            vals[oj + k] = gj;
+    if (COUNT) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < T; t += 256) {
+            const uint32_t c = s_cnt[t];
+            if (c) atomicAdd(&tile_count[2 * t], c);
         }
+    }
+}
+
+// One workgroup: per-tile counts (in ranges[t].y) -> ranges[t] = [start, end) ((0,0) for an empty tile, as
+// the reference leaves it) and the global digit histograms of the tile sort's passes.
+__global__ __launch_bounds__(1024) void tile_ranges_hist_k(int T, uint2* __restrict__ ranges, int passes, int shift0,
+                                                           int nbits0, int shift1, int nbits1,
+                                                           uint32_t* __restrict__ ghist) {
+    __shared__ uint32_t s_h[2][256];
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid < 512) (&s_h[0][0])[tid] = 0;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < T; base += 1024) {
+        const int t = base + tid;
+        const uint32_t c = t < T ? ranges[t].y : 0u;
+        // inclusive scan of the 1024 counts of this chunk
+        uint32_t v = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(v, d, 64);
+            if (lane >= d) v += o;
+        }
+        if (lane == 63) s_wave[w] = v;
+        __syncthreads();
+        uint32_t pre = s_carry;
+        for (int k = 0; k < w; k++) pre += s_wave[k];
+        const uint32_t end = pre + v;
+        if (t < T) {
+            ranges[t] = c ? make_uint2(end - c, end) : make_uint2(0u, 0u);
+            if (c) {
+                atomicAdd(&s_h[0][((uint32_t)t >> shift0) & ((1u << nbits0) - 1u)], c);
+                if (passes > 1) atomicAdd(&s_h[1][((uint32_t)t >> shift1) & ((1u << nbits1) - 1u)], c);
+            }
+        }
+        __syncthreads();
+        if (tid == 1023) s_carry = end;
+        __syncthreads();
+    }
+    if (tid < 256) {
+        ghist[tid] = s_h[0][tid];
+        ghist[256 + tid] = s_h[1][tid];
     }
 }
 
@@ -676,7 +748,32 @@ void launch_reduce_sem_rows(const GoiRasterScene& sc, const GeomView& g, const f
 void launch_emit(int P, int W, int H, const GeomView& g, const uint32_t* order, const int* radii, uint32_t* keys,
                  uint32_t* vals, hipStream_t s) {
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
-    emit_k<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, gx, gy, g.rec, radii, order, g.offsets, g.goff, keys, vals);
+    emit_k<false><<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, gx, gy, g.rec, radii, order, g.offsets, g.goff, keys, vals,
+                                                              nullptr);
+}
+
+bool emit_can_count_tiles(int W, int H) {
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+    return (size_t)gx * gy * sizeof(uint32_t) <= 48 * 1024 && tile_key_bits((uint32_t)(gx * gy)) <= 16;
+}
+
+// emit + per-tile counts; ranges must be zeroed by the caller's stream order (done here)
+void launch_emit_counting(int P, int W, int H, const GeomView& g, const uint32_t* order, const int* radii, uint32_t* keys,
+                          uint32_t* vals, uint2* ranges, hipStream_t s) {
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+    (void)hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)gx * gy, s);
+    emit_k<true><<<dim3((P + 256 * EMIT_ROUNDS - 1) / (256 * EMIT_ROUNDS)), dim3(256), (size_t)gx * gy * sizeof(uint32_t), s>>>(
+        P, gx, gy, g.rec, radii, order, g.offsets, g.goff, keys, vals, reinterpret_cast<uint32_t*>(ranges) + 1);
+}
+
+// per-tile counts -> ranges and the two digit histograms (written to ghist[0..511]) of a sort on
+// key bits [0, bits) split as radix_sort_pairs splits them
+void launch_tile_ranges_hist(int W, int H, uint2* ranges, uint32_t* ghist, hipStream_t s) {
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+    const int bits = tile_key_bits((uint32_t)(gx * gy));
+    const int passes = (bits + 7) / 8;
+    const int n0 = (bits + passes - 1) / passes, n1 = bits - n0;
+    tile_ranges_hist_k<<<dim3(1), dim3(1024), 0, s>>>(gx * gy, ranges, passes, 0, n0, n0, n1 > 0 ? n1 : 1, ghist);
 }
 
 void launch_ranges(int N, const uint32_t* sorted_keys, uint2* ranges, int T, hipStream_t s) {

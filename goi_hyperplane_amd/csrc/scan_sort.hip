@@ -408,8 +408,12 @@ void exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* ou
     scan_apply_k<<<dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s>>>(in, gather, out, n, scratch);
 }
 
+uint32_t* radix_sort_ghist(uint32_t* scratch, size_t n) {
+    return scratch + (size_t)MAX_PASSES * (uint32_t)div_up(n, SORT_TILE) * RADIX_MAX;
+}
+
 int radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], size_t n, int lo, int hi, uint32_t* scratch,
-                     hipStream_t s) {
+                     hipStream_t s, bool ghist_ready) {
     int cur = 0;
     if (n == 0) return cur;
     const uint32_t nblk = (uint32_t)div_up(n, SORT_TILE);
@@ -427,7 +431,10 @@ int radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], size_t n, int lo, int
         uint32_t* ticket = ghist + MAX_PASSES * RADIX_MAX;
         uint32_t* error = ticket + MAX_PASSES;
         (void)hipMemsetAsync(status, 0, st_words * sizeof(uint32_t), s);
-        (void)hipMemsetAsync(ghist, 0, (MAX_PASSES * RADIX_MAX + MAX_PASSES + 1) * sizeof(uint32_t), s);
+        if (ghist_ready)  // the caller has written the digit histograms (radix_sort_ghist); clear tickets + error only
+            (void)hipMemsetAsync(ticket, 0, (MAX_PASSES + 1) * sizeof(uint32_t), s);
+        else
+            (void)hipMemsetAsync(ghist, 0, (MAX_PASSES * RADIX_MAX + MAX_PASSES + 1) * sizeof(uint32_t), s);
         SweepPlan plan;
         plan.passes = passes;
         int sh = lo;
@@ -437,7 +444,7 @@ int radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], size_t n, int lo, int
             sh += plan.nbits[p];
         }
         for (int p = passes; p < MAX_PASSES; p++) plan.shift[p] = plan.nbits[p] = 0;
-        sweep_hist_k<<<dim3(nblk), dim3(SORT_THREADS), 0, s>>>(keys[0], n, plan, ghist);
+        if (!ghist_ready) sweep_hist_k<<<dim3(nblk), dim3(SORT_THREADS), 0, s>>>(keys[0], n, plan, ghist);
         for (int p = 0; p < passes; p++) {
             sweep_pass_k<<<dim3(nblk), dim3(SORT_THREADS), 0, s>>>(
                 keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, plan.shift[p], plan.nbits[p],
