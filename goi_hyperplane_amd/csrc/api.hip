@@ -123,12 +123,19 @@ int geometry_and_binning(const GoiRasterScene& sc, GeomView& g, ImageView& im, g
     }
     if (check_stage(sc, s, "depth sort")) return -1;
     const uint32_t* order = g.sort_vals[order_idx];
+    // The one host read-back of the forward (num_rendered sizes the binning workspace, as in the reference,
+    // CR/rasterizer_impl.cu:285); the copy lands in pinned memory so that it is a true asynchronous copy.
+    // (Polling the stream instead of blocking was measured: no gain, and it burns a host core per rank.)
+    static thread_local uint32_t* pinned = nullptr;
+    if (!pinned) GOI_HIP(hipHostMalloc(reinterpret_cast<void**>(&pinned), 64, hipHostMallocDefault));
     uint32_t host_counters[2] = {0, 0};
     {
         StageTimer t(GOI_STAGE_SCAN, s);
         exclusive_scan_u32(g.tiles_touched, order, g.offsets, (size_t)P, &g.counters[0], g.scratch, s);
-        GOI_HIP(hipMemcpyAsync(host_counters, g.counters, sizeof(host_counters), hipMemcpyDeviceToHost, s));
+        GOI_HIP(hipMemcpyAsync(pinned, g.counters, sizeof(host_counters), hipMemcpyDeviceToHost, s));
         GOI_HIP(hipStreamSynchronize(s));
+        host_counters[0] = pinned[0];
+        host_counters[1] = pinned[1];
     }
     if (host_counters[1] != 0)
         return fail("Point is filtered although prefiltered is set. This shouldn't happen!");
