@@ -150,8 +150,10 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, semantics, 
     lib = _lib.load()
     dev = _check_device(means3D)
     P = int(means3D.size(0))
-    H, W = int(dL_dout_color.size(1)), int(dL_dout_color.size(2))  # rasterize_points.cu:243-244
-    S = int(dL_dout_semantic.size(0))
+    # the reference reads H, W off dL_dout_color (rasterize_points.cu:243-244); here any upstream gradient may be
+    # None (an output the loss does not use), so the sizes come from tensors that always exist
+    H, W = int(alphas.size(-2)), int(alphas.size(-1))
+    S = int(semantics.size(1))
     M = 0 if (sh is None or sh.numel() == 0) else int(sh.size(1))
     f32 = dict(dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):

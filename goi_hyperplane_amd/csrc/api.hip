@@ -110,16 +110,19 @@ int geometry_and_binning(const GoiRasterScene& sc, GeomView& g, ImageView& im, g
                          int* radii, const uint32_t** plist, hipStream_t s) {
     const int P = sc.P;
     const int gx = (sc.W + TILE - 1) / TILE, gy = (sc.H + TILE - 1) / TILE;
-    GOI_HIP(hipMemsetAsync(g.counters, 0, 8 * sizeof(uint32_t), s));
+    // one memset: the counters and, right behind them, the control words of the depth sort
+    const size_t depth_ctrl = g_options.sort_variant == 1 ? radix_sort_control_words((size_t)P, 0, 32) : 0;
+    GOI_HIP(hipMemsetAsync(g.counters, 0,
+                           (size_t)(reinterpret_cast<char*>(g.scratch + depth_ctrl) - reinterpret_cast<char*>(g.counters)), s));
     {
         StageTimer t(GOI_STAGE_PREPROCESS, s);
-        launch_preprocess_fwd(sc, g, radii, s);
+        launch_preprocess_fwd(sc, g, radii, im.ranges, gx * gy, s);  // also zeroes the tile ranges
     }
     if (check_stage(sc, s, "preprocess")) return -1;
     int order_idx;
     {
         StageTimer t(GOI_STAGE_DEPTH_SORT, s);
-        order_idx = radix_sort_pairs(g.sort_keys, g.sort_vals, (size_t)P, 0, 32, g.scratch, s);
+        order_idx = radix_sort_pairs(g.sort_keys, g.sort_vals, (size_t)P, 0, 32, g.scratch, s, /*cleared=*/true);
     }
     if (check_stage(sc, s, "depth sort")) return -1;
     const uint32_t* order = g.sort_vals[order_idx];
@@ -149,10 +152,13 @@ int geometry_and_binning(const GoiRasterScene& sc, GeomView& g, ImageView& im, g
     // Tile counting fused into emit (onesweep sort, tile grid small enough for an LDS histogram): the counts give
     // the tile ranges and the sort's digit histograms, so neither the keys nor the sorted keys are re-read for them.
     const bool counting = N > 0 && g_options.sort_variant == 1 && emit_can_count_tiles(sc.W, sc.H);
+    const int tile_bits = tile_key_bits((uint32_t)(gx * gy));
     {
         StageTimer t(GOI_STAGE_EMIT, s);
-        if (counting)
+        if (counting) {
+            GOI_HIP(hipMemsetAsync(bv.scratch, 0, radix_sort_control_words((size_t)N, 0, tile_bits) * sizeof(uint32_t), s));
             launch_emit_counting(P, sc.W, sc.H, g, order, radii, bv.keys[0], bv.vals[0], im.ranges, s);
+        }
         else if (N > 0)
             launch_emit(P, sc.W, sc.H, g, order, radii, bv.keys[0], bv.vals[0], s);
     }
@@ -161,14 +167,15 @@ int geometry_and_binning(const GoiRasterScene& sc, GeomView& g, ImageView& im, g
     if (counting) {
         {
             StageTimer t(GOI_STAGE_RANGES, s);
-            launch_tile_ranges_hist(sc.W, sc.H, im.ranges, radix_sort_ghist(bv.scratch, (size_t)N), s);
+            launch_tile_ranges_hist(sc.W, sc.H, im.ranges, radix_sort_ghist(bv.scratch, (size_t)N, 0, tile_bits), s);
         }
         StageTimer t(GOI_STAGE_TILE_SORT, s);
-        fin = radix_sort_pairs(bv.keys, bv.vals, (size_t)N, 0, tile_key_bits((uint32_t)(gx * gy)), bv.scratch, s, true);
+        fin = radix_sort_pairs(bv.keys, bv.vals, (size_t)N, 0, tile_bits, bv.scratch, s, /*cleared=*/true,
+                               /*ghist_ready=*/true);
     } else {
         {
             StageTimer t(GOI_STAGE_TILE_SORT, s);
-            fin = radix_sort_pairs(bv.keys, bv.vals, (size_t)N, 0, tile_key_bits((uint32_t)(gx * gy)), bv.scratch, s);
+            fin = radix_sort_pairs(bv.keys, bv.vals, (size_t)N, 0, tile_bits, bv.scratch, s);
         }
         if (check_stage(sc, s, "tile sort")) return -1;
         StageTimer t(GOI_STAGE_RANGES, s);
@@ -207,9 +214,9 @@ size_t geom_layout(int P, char* base, GeomView* v) {
     carve(p, g.sort_vals[1], n);
     carve(p, g.offsets, n);
     carve(p, g.goff, n);
+    carve(p, g.counters, 8);  // directly in front of the sort scratch: one memset clears both
     g.scratch_words = sort_scratch_words(n) + scan_scratch_words(n);
     carve(p, g.scratch, g.scratch_words);
-    carve(p, g.counters, 8);
     return (size_t)(p - base) + 256;
 }
 

@@ -77,14 +77,19 @@ void exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* ou
                         uint32_t* scratch, hipStream_t s);
 // Stable LSD radix sort of (key,val) pairs on key bits [lo, hi).  Data start in keys[0]/vals[0];
 // returns the index (0/1) of the buffers holding the sorted result.
-// ghist_ready: the caller has already written the per-pass global digit histograms ([pass][256] words at
-// radix_sort_ghist(scratch, n)); only honoured by the onesweep variant with <= 2 passes from bit 0.
+// Onesweep control words (status, global digit histograms, tickets, error) sit at the start of `scratch`:
+//   cleared     : the caller has zeroed the first radix_sort_control_words(n, lo, hi) words (e.g. together with
+//                 neighbouring counters in one memset) -- otherwise the sort clears them itself;
+//   ghist_ready : after that clear the caller has written the per-pass global digit histograms
+//                 ([pass][256] words at radix_sort_ghist(...)), so the sort's histogram kernel is skipped.
 int radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], size_t n, int lo, int hi, uint32_t* scratch,
-                     hipStream_t s, bool ghist_ready = false);
-uint32_t* radix_sort_ghist(uint32_t* scratch, size_t n);
+                     hipStream_t s, bool cleared = false, bool ghist_ready = false);
+size_t radix_sort_control_words(size_t n, int lo, int hi);
+uint32_t* radix_sort_ghist(uint32_t* scratch, size_t n, int lo, int hi);
 
 // ---- stages ---------------------------------------------------------------------------------------
-void launch_preprocess_fwd(const GoiRasterScene& sc, const GeomView& g, int* radii, hipStream_t s);
+void launch_preprocess_fwd(const GoiRasterScene& sc, const GeomView& g, int* radii, uint2* ranges, int n_tiles,
+                           hipStream_t s);
 void launch_emit(int P, int W, int H, const GeomView& g, const uint32_t* order, const int* radii, uint32_t* keys,
                  uint32_t* vals, hipStream_t s);
 bool emit_can_count_tiles(int W, int H);

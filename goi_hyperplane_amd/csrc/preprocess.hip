@@ -86,8 +86,11 @@ __global__ __launch_bounds__(256) void preprocess_fwd_k(const PreArgs args, Gaus
                                                         uint32_t* __restrict__ tiles_touched,
                                                         uint8_t* __restrict__ clamped, uint32_t* __restrict__ sort_key,
                                                         uint32_t* __restrict__ sort_val, int* __restrict__ radii,
-                                                        uint32_t* __restrict__ counters) {
+                                                        uint32_t* __restrict__ counters, uint2* __restrict__ ranges,
+                                                        int n_tiles) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    // the tile ranges start from zero (emit accumulates per-tile counts into them): cleared here for free
+    for (int t = idx; t < n_tiles; t += gridDim.x * blockDim.x) ranges[t] = make_uint2(0u, 0u);
     if (idx >= args.P) return;
     const Camera cam = load_camera(args.view_p, args.proj_p, args.campos_p);
     struct : PreArgs {
@@ -681,7 +684,8 @@ __global__ __launch_bounds__(256) void ranges_k(int N, const uint32_t* __restric
 
 }  // namespace
 
-void launch_preprocess_fwd(const GoiRasterScene& sc, const GeomView& g, int* radii, hipStream_t s) {
+void launch_preprocess_fwd(const GoiRasterScene& sc, const GeomView& g, int* radii, uint2* ranges, int n_tiles,
+                           hipStream_t s) {
     PreArgs a;
     a.P = sc.P; a.D = sc.D; a.M = sc.M; a.W = sc.W; a.H = sc.H;
     a.gx = (sc.W + TILE - 1) / TILE;
@@ -694,7 +698,7 @@ void launch_preprocess_fwd(const GoiRasterScene& sc, const GeomView& g, int* rad
     a.focal_x = sc.W / (2.0f * sc.tan_fovx);
     a.view_p = sc.viewmatrix; a.proj_p = sc.projmatrix; a.campos_p = sc.campos;
     preprocess_fwd_k<<<dim3((sc.P + 255) / 256), dim3(256), 0, s>>>(a, g.rec, g.cov3D, g.tiles_touched, g.clamped,
-                                                                   g.sort_keys[0], g.sort_vals[0], radii, g.counters);
+                                                                   g.sort_keys[0], g.sort_vals[0], radii, g.counters, ranges, n_tiles);
 }
 
 void launch_preprocess_bwd(const GoiRasterScene& sc, const GeomView& g, const int* radii, const float* dL_dmean2D,
@@ -761,7 +765,7 @@ bool emit_can_count_tiles(int W, int H) {
 void launch_emit_counting(int P, int W, int H, const GeomView& g, const uint32_t* order, const int* radii, uint32_t* keys,
                           uint32_t* vals, uint2* ranges, hipStream_t s) {
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
-    (void)hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)gx * gy, s);
+    // `ranges` was zeroed by preprocess_fwd_k
     emit_k<true><<<dim3((P + 256 * EMIT_ROUNDS - 1) / (256 * EMIT_ROUNDS)), dim3(256), (size_t)gx * gy * sizeof(uint32_t), s>>>(
         P, gx, gy, g.rec, radii, order, g.offsets, g.goff, keys, vals, reinterpret_cast<uint32_t*>(ranges) + 1);
 }

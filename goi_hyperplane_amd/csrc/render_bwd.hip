@@ -103,12 +103,13 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
     float dLa = 0.f;
     if (t.inside) {
 #pragma unroll
-        for (int ch = 0; ch < NSEM; ch++) dLch[ch] = ch < S ? dL_dpixsem[ch * HW + pix_id] : 0.f;
-        dLch[NSEM + 0] = dL_dpix[0 * HW + pix_id];
-        dLch[NSEM + 1] = dL_dpix[1 * HW + pix_id];
-        dLch[NSEM + 2] = dL_dpix[2 * HW + pix_id];
-        dLch[NSEM + 3] = dL_dpixdepth[pix_id];
-        dLa = dL_dalphas[pix_id];
+        // an absent upstream gradient (NULL) is zero
+        for (int ch = 0; ch < NSEM; ch++) dLch[ch] = (dL_dpixsem && ch < S) ? dL_dpixsem[ch * HW + pix_id] : 0.f;
+        dLch[NSEM + 0] = dL_dpix ? dL_dpix[0 * HW + pix_id] : 0.f;
+        dLch[NSEM + 1] = dL_dpix ? dL_dpix[1 * HW + pix_id] : 0.f;
+        dLch[NSEM + 2] = dL_dpix ? dL_dpix[2 * HW + pix_id] : 0.f;
+        dLch[NSEM + 3] = dL_dpixdepth ? dL_dpixdepth[pix_id] : 0.f;
+        dLa = dL_dalphas ? dL_dalphas[pix_id] : 0.f;
     } else {
 #pragma unroll
         for (int ch = 0; ch < NCH; ch++) dLch[ch] = 0.f;

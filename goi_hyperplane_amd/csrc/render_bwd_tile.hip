@@ -86,13 +86,13 @@ __global__ __launch_bounds__(256) void render_bwd_tile_k(
     float dLch[NCH];
     float dLa = 0.f;
     if (t.inside) {
-        dLch[0] = dL_dpix[0 * HW + pix_id];
-        dLch[1] = dL_dpix[1 * HW + pix_id];
-        dLch[2] = dL_dpix[2 * HW + pix_id];
-        dLch[3] = dL_dpixdepth[pix_id];
+        dLch[0] = dL_dpix ? dL_dpix[0 * HW + pix_id] : 0.f;  // an absent upstream gradient (NULL) is zero
+        dLch[1] = dL_dpix ? dL_dpix[1 * HW + pix_id] : 0.f;
+        dLch[2] = dL_dpix ? dL_dpix[2 * HW + pix_id] : 0.f;
+        dLch[3] = dL_dpixdepth ? dL_dpixdepth[pix_id] : 0.f;
 #pragma unroll
-        for (int ch = 0; ch < 4 * S4; ch++) dLch[4 + ch] = ch < S ? dL_dpixsem[ch * HW + pix_id] : 0.f;
-        dLa = dL_dalphas[pix_id];
+        for (int ch = 0; ch < 4 * S4; ch++) dLch[4 + ch] = (dL_dpixsem && ch < S) ? dL_dpixsem[ch * HW + pix_id] : 0.f;
+        dLa = dL_dalphas ? dL_dalphas[pix_id] : 0.f;
     } else {
 #pragma unroll
         for (int ch = 0; ch < NCH; ch++) dLch[ch] = 0.f;

@@ -408,12 +408,20 @@ void exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* ou
     scan_apply_k<<<dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s>>>(in, gather, out, n, scratch);
 }
 
-uint32_t* radix_sort_ghist(uint32_t* scratch, size_t n) {
-    return scratch + (size_t)MAX_PASSES * (uint32_t)div_up(n, SORT_TILE) * RADIX_MAX;
+// Control words of the onesweep sort, contiguous at the start of the scratch so that ONE memset clears them:
+// [passes][nblk][256] status | [MAX_PASSES][256] global digit histograms | [MAX_PASSES] tickets | error
+static size_t sweep_status_words(size_t n, int lo, int hi) {
+    return (size_t)((hi - lo + 7) / 8) * div_up(n, SORT_TILE) * RADIX_MAX;
+}
+size_t radix_sort_control_words(size_t n, int lo, int hi) {
+    return n ? sweep_status_words(n, lo, hi) + MAX_PASSES * RADIX_MAX + MAX_PASSES + 1 : 0;
+}
+uint32_t* radix_sort_ghist(uint32_t* scratch, size_t n, int lo, int hi) {
+    return scratch + sweep_status_words(n, lo, hi);
 }
 
 int radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], size_t n, int lo, int hi, uint32_t* scratch,
-                     hipStream_t s, bool ghist_ready) {
+                     hipStream_t s, bool cleared, bool ghist_ready) {
     int cur = 0;
     if (n == 0) return cur;
     const uint32_t nblk = (uint32_t)div_up(n, SORT_TILE);
@@ -425,16 +433,11 @@ int radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], size_t n, int lo, int
     int shift = lo;
     if (g_options.sort_variant == 1 && passes <= MAX_PASSES) {
         // scratch: [passes][nblk][256] status words | [passes][256] global histograms | tickets | error
-        const size_t st_words = (size_t)passes * nblk * RADIX_MAX;
         uint32_t* status = scratch;
-        uint32_t* ghist = scratch + (size_t)MAX_PASSES * nblk * RADIX_MAX;
+        uint32_t* ghist = radix_sort_ghist(scratch, n, lo, hi);
         uint32_t* ticket = ghist + MAX_PASSES * RADIX_MAX;
         uint32_t* error = ticket + MAX_PASSES;
-        (void)hipMemsetAsync(status, 0, st_words * sizeof(uint32_t), s);
-        if (ghist_ready)  // the caller has written the digit histograms (radix_sort_ghist); clear tickets + error only
-            (void)hipMemsetAsync(ticket, 0, (MAX_PASSES + 1) * sizeof(uint32_t), s);
-        else
-            (void)hipMemsetAsync(ghist, 0, (MAX_PASSES * RADIX_MAX + MAX_PASSES + 1) * sizeof(uint32_t), s);
+        if (!cleared) (void)hipMemsetAsync(status, 0, radix_sort_control_words(n, lo, hi) * sizeof(uint32_t), s);
         SweepPlan plan;
         plan.passes = passes;
         int sh = lo;

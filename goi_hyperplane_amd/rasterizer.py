@@ -88,6 +88,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             _C.rasterize_gaussians, args, raster_settings.debug, "snapshot_fw.dump", "forward")
         ctx.raster_settings = raster_settings
         ctx.num_rendered = num_rendered
+        ctx.set_materialize_grads(False)  # unused outputs (depth, alpha, ...) reach backward as None, not as zero tensors
         ctx.save_for_backward(colors_precomp, semantics, means3D, scales, rotations, cov3Ds_precomp, radii, sh,
                               geomBuffer, binningBuffer, imgBuffer, alpha)
         ctx.mark_non_differentiable(radii)
@@ -103,6 +104,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                 and not (need[0] or need[2] or need[3] or need[5] or need[6] or need[7] or need[8])):
             # only the semantic features are trainable: feature-gradient-only kernel; the screen-space
             # placeholder (means2D) gets zeros -- nothing in a semantics-only run consumes it
+            if grad_out_sem is None:  # the loss does not touch the semantic map
+                return (None, None, None, None, torch.zeros_like(semantics), None, None, None, None, None)
             g_sem = _C.rasterize_gaussians_backward_semantics(
                 rs.bg, means3D, radii, semantics, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_sem,
                 rs.campos, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, alpha, rs.sh_degree, rs.debug)

@@ -87,7 +87,7 @@ int goi_raster_forward(const GoiRasterScene* scene, void* geom_buffer, void* ima
                        int* radii, void* stream);
 
 /* Backward of the forward that filled the three workspaces.  R = that forward's return value.
- * dL_dconic is [P,4] (x: a, y: b, z: unused, w: c), dL_dsh [P,M,3] (may be NULL when M == 0). */
+ * Any of the four upstream gradients dL_dout_* may be NULL (= zero).  dL_dconic is [P,4] (x: a, y: b, z: unused, w: c), dL_dsh [P,M,3] (may be NULL when M == 0). */
 int goi_raster_backward(const GoiRasterScene* scene, int R,
                         const void* geom_buffer, const void* binning_buffer, const void* image_buffer,
                         const int* radii, const float* out_alpha,
