@@ -1,0 +1,74 @@
+"""The pieces together, the way train.py:112-199 strings them: render -> code-book losses -> backward ->
+Adam on (semantics, decoder, code book).  The fused path (feature-gradient-only backward, fused losses,
+FusedAdam) must track the PyTorch pieces the reference uses around the same rasterizer, and it must learn."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def build(dev, seed=0):
+    from goi_hyperplane_amd.render import GaussianSet, TorchCamera
+    from goi_hyperplane_amd.scene import make_camera, make_scene
+    from goi_hyperplane_amd.semantic import SemanticModel
+    sc = make_scene(3000, S=16, sh_degree=3, seed=seed, log_scale_mean=-2.6)
+    pc = GaussianSet.from_scene(sc, dev)
+    for p in pc.parameters():
+        p.requires_grad_(False)
+    pc._semantics.requires_grad_(True)
+    cams = [TorchCamera(make_camera(96, 64, yaw=0.1 * i), dev) for i in range(3)]
+    torch.manual_seed(seed)
+    mlp = SemanticModel(dim_in=16, dim_out=40, num_layer=1, use_bias=True, device=dev)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    lut = torch.nn.Parameter(torch.rand(40, 64, device=dev, generator=g) * 0.03)
+    # per-view ground truth: a few flat regions, each carrying one feature vector (what a segmenter provides)
+    protos = torch.randn(6, 64, device=dev, generator=g)
+    ys, xs = torch.meshgrid(torch.arange(64, device=dev), torch.arange(96, device=dev), indexing="ij")
+    gtl = [protos[((xs // 32) + 3 * (ys // 32) + v) % 6].permute(2, 0, 1).contiguous() for v in range(3)]
+    return pc, cams, mlp, lut, gtl
+
+
+def run(dev, fused, iters):
+    from goi_hyperplane_amd import rasterizer
+    from goi_hyperplane_amd.optim import FusedAdam
+    from goi_hyperplane_amd.render import PipelineParams, render
+    from goi_hyperplane_amd.semantic import codebook_losses, fused_codebook_losses
+    pc, cams, mlp, lut, gtl = build(dev)
+    Adam = FusedAdam if fused else torch.optim.Adam
+    opts = [Adam([{"params": [pc._semantics], "lr": 5e-3, "name": "semantics"}], lr=0.0, eps=1e-15),
+            Adam(mlp.parameters(), lr=0.003), Adam([lut], lr=0.001)]
+    loss_fn = fused_codebook_losses if fused else codebook_losses
+    rasterizer.set_backward_mode(semantics_only=fused)
+    bg = torch.zeros(3, device=dev)
+    losses = []
+    try:
+        for it in range(iters):
+            out = render(cams[it % 3], pc, PipelineParams(), bg)
+            loss, _ = loss_fn(out["semantics"], mlp, lut, gtl[it % 3], it)
+            loss.backward()
+            for o in opts:
+                o.step()
+                o.zero_grad(set_to_none=True)
+            losses.append(float(loss.detach()))
+    finally:
+        rasterizer.set_backward_mode(semantics_only=False)
+    return losses, pc._semantics.detach().clone(), mlp.layers[0].weight.detach().clone(), lut.detach().clone()
+
+
+def test_fused_training_step_tracks_the_pytorch_pieces():
+    dev = torch.device("cuda")
+    la, sa, wa, ta = run(dev, True, 4)
+    lb, sb, wb, tb = run(dev, False, 4)
+    for x, y in zip(la, lb):
+        assert abs(x - y) <= 2e-4 * abs(y), (la, lb)
+    # Adam normalises the step (|update| ~ lr whatever the gradient's scale): compare against the step size
+    assert float((sa - sb).abs().max()) <= 0.05 * 5e-3 * 4
+    assert float((wa - wb).abs().max()) <= 0.05 * 3e-3 * 4
+    assert float((ta - tb).abs().max()) <= 0.05 * 1e-3 * 4
+
+
+def test_the_loop_learns():
+    dev = torch.device("cuda")
+    losses, *_ = run(dev, True, 60)
+    first, last = sum(losses[:3]) / 3, sum(losses[-3:]) / 3
+    assert last < 0.8 * first, (first, last)
