@@ -2,6 +2,7 @@
 // stage orchestration on the caller's HIP stream, per-stage event timing.
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -509,7 +510,13 @@ void goi_raster_profile_stages(unsigned stage_mask) { g_profile_mask = stage_mas
 int goi_raster_set_option(const char* name, int value) {
     if (!name) return fail("option name is NULL");
     if (!strcmp(name, "fwd_variant")) g_options.fwd_variant = value;
-    else if (!strcmp(name, "bwd_variant")) g_options.bwd_variant = value;
+    else if (!strcmp(name, "bwd_variant")) {
+        // bits 4..15 are timing experiments (skip parts of the backward / pad LDS): results are NOT valid
+        // gradients, so they are only honoured when GOI_EXPERIMENTS=1 is set in the environment
+        if ((value & ~0xF) && !(getenv("GOI_EXPERIMENTS") && !strcmp(getenv("GOI_EXPERIMENTS"), "1")))
+            return fail("bwd_variant: experiment bits need GOI_EXPERIMENTS=1 (they produce invalid gradients)");
+        g_options.bwd_variant = value;
+    }
     else if (!strcmp(name, "sort_variant")) g_options.sort_variant = value;
     else return fail(std::string("unknown option ") + name);
     return 0;

@@ -64,7 +64,8 @@ size_t binning_layout(int N, char* base, BinView* v);
 // Tuning / experiment switches (goi_raster_set_option); defaults are the shipped configuration.
 struct Options {
     int fwd_variant = 1;  // 0: one candidate per loop trip, 1: two candidates per trip (default)
-    int bwd_variant = 0;  // 0: atomic-free wave-per-quadrant backward (needs scratch), 1: workgroup-per-tile + atomics
+    int bwd_variant = 0;  // low 4 bits: 0 atomic-free wave-per-quadrant backward (needs scratch), 1 workgroup-per-tile +
+                          // atomics; bits 4..15: timing experiments (GOI_EXPERIMENTS=1 only, invalid gradients)
     int sort_variant = 1;  // 0: histogram / scan / scatter per pass, 1: onesweep (decoupled look-back, default)
 };
 extern Options g_options;
