@@ -105,6 +105,9 @@ def main():
     ap.add_argument("--views", type=int, default=16, help="distinct cameras cycled through")
     ap.add_argument("--grads", choices=["all", "semantics"], default="all",
                     help="which Gaussian gradients are all-reduced when --gpus > 1")
+    ap.add_argument("--ply", default=None,
+                    help="point_cloud.ply saved by the reference (sem_* columns) instead of the synthetic scene; "
+                         "cameras stay synthetic (the data sets are not in this image)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-P", type=int, default=100_000)
     ap.add_argument("--no-stage-timing", action="store_true")
@@ -135,9 +138,15 @@ def main():
     from goi_hyperplane_amd.scene import make_camera, make_scene
     _lib.load()
 
-    sc = make_scene(args.P, S=args.S, sh_degree=3, seed=0, extent=HEADLINE["extent"], log_scale_mean=args.mu,
-                    log_scale_std=HEADLINE["log_scale_std"])  # identical replica on every rank
-    pc = GaussianSet.from_scene(sc, dev)
+    if args.ply:
+        pc = GaussianSet.from_ply(args.ply, dev, sh_degree=3, semantic_dim=args.S)
+        args.P = int(pc.get_xyz.shape[0])
+        args.no_cpu_baseline = True  # the bounded CPU sample is defined on the synthetic scene
+        sc = None
+    else:
+        sc = make_scene(args.P, S=args.S, sh_degree=3, seed=0, extent=HEADLINE["extent"], log_scale_mean=args.mu,
+                        log_scale_std=HEADLINE["log_scale_std"])  # identical replica on every rank
+        pc = GaussianSet.from_scene(sc, dev)
     params = [pc._xyz, pc._features, pc._semantics, pc._opacity, pc._scaling, pc._rotation]
     reduce_params = params if args.grads == "all" else [pc._semantics]
     cams = [TorchCamera(make_camera(args.W, args.H, fovx=HEADLINE["fovx"], yaw=0.02 * (i - args.views / 2),
@@ -307,7 +316,7 @@ def main():
             "metric": "training views/sec (rasterizer fwd+bwd), 1M Gaussians @1600x1056 RGB+16-d feat",
             "value": args.steps * world / elapsed, "unit": "views/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not args.ply else "ply scene, synthetic cameras",
             "config": {"workload": f"{args.P} Gaussians @{args.W}x{args.H}, SH deg 3 RGB + {args.S}-d semantic, fwd+bwd"
                                    f"{' + RCCL all-reduce(' + args.grads + ' grads)' if world > 1 else ''}",
                        "P": args.P, "V": V, "N_per_view": N, "tiles": T, "HW": HW, "S": args.S,
