@@ -176,19 +176,27 @@ def main():
 
     for i in range(args.warmup):
         step(i)
-    # workload statistics of the views this rank will time (outside the timed region)
+    # workload statistics of the views this rank will time (outside the timed region).  N is SURVEY 8(d)'s instance
+    # count -- every tile of every Gaussian's 3-sigma rectangle, what the reference lists and what the algorithmic
+    # bytes are charged on (cull_variant 0); N_listed is what this build actually emits, sorts and walks.
     with torch.no_grad():
         from goi_hyperplane_amd import _C
+        stats["N_listed"] = 0
         for i in range(min(args.steps, len(cams))):
             cam = cams[((args.warmup + i) * world + rank) % len(cams)]
-            n, *_r = _C.rasterize_gaussians(bg, pc._xyz, torch.Tensor([]), pc._semantics, pc._opacity, pc._scaling,
-                                            pc._rotation, 1.0, torch.Tensor([]), cam.world_view_transform,
-                                            cam.full_proj_transform, np.tan(cam.FoVx * 0.5), np.tan(cam.FoVy * 0.5),
-                                            args.H, args.W, pc._features, 3, cam.camera_center, False, False)
-            stats["N"] += n
-            stats["V"] += int((_r[4] > 0).sum())
-            stats["views"] += 1
-            del _r
+            for variant in (0, 1):
+                _lib.set_option("cull_variant", variant)
+                n, *_r = _C.rasterize_gaussians(bg, pc._xyz, torch.Tensor([]), pc._semantics, pc._opacity, pc._scaling,
+                                                pc._rotation, 1.0, torch.Tensor([]), cam.world_view_transform,
+                                                cam.full_proj_transform, np.tan(cam.FoVx * 0.5), np.tan(cam.FoVy * 0.5),
+                                                args.H, args.W, pc._features, 3, cam.camera_center, False, False)
+                if variant == 0:
+                    stats["N"] += n
+                    stats["V"] += int((_r[4] > 0).sum())
+                    stats["views"] += 1
+                else:
+                    stats["N_listed"] += n
+                del _r
     V = stats["V"] / stats["views"]
     N = stats["N"] / stats["views"]
 
@@ -319,7 +327,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not args.ply else "ply scene, synthetic cameras",
             "config": {"workload": f"{args.P} Gaussians @{args.W}x{args.H}, SH deg 3 RGB + {args.S}-d semantic, fwd+bwd"
                                    f"{' + RCCL all-reduce(' + args.grads + ' grads)' if world > 1 else ''}",
-                       "P": args.P, "V": V, "N_per_view": N, "tiles": T, "HW": HW, "S": args.S,
+                       "P": args.P, "V": V, "N_per_view": N, "N_listed_per_view": stats["N_listed"] / stats["views"],
+                       "tiles": T, "HW": HW, "S": args.S,
                        "views_per_step": world, "parallelism": f"views sharded x{world}",
                        "allreduce_bytes": int(sum(p.numel() for p in reduce_params) * 4) if world > 1 else 0},
             "render_ms_per_frame": render_ms,

@@ -518,6 +518,7 @@ int goi_raster_set_option(const char* name, int value) {
         g_options.bwd_variant = value;
     }
     else if (!strcmp(name, "sort_variant")) g_options.sort_variant = value;
+    else if (!strcmp(name, "cull_variant")) g_options.cull_variant = value;
     else return fail(std::string("unknown option ") + name);
     return 0;
 }

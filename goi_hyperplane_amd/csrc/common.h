@@ -33,7 +33,7 @@ struct GeomView {
     uint32_t* offsets;        // [P] exclusive prefix of tiles_touched in depth order
     uint32_t* goff;           // [P] the same prefix indexed by Gaussian id = first emit-order instance of g
     uint32_t* scratch;        // scan partials + radix histograms
-    uint32_t* counters;       // [8]: 0 = num_rendered, 1 = error flag
+    uint32_t* counters;       // [8]: 0 = num_rendered, 1 = error flag, 2 = cull_variant of this forward
     size_t scratch_words;
 };
 struct ImageView {
@@ -67,6 +67,8 @@ struct Options {
     int bwd_variant = 0;  // low 4 bits: 0 atomic-free wave-per-quadrant backward (needs scratch), 1 workgroup-per-tile +
                           // atomics; bits 4..15: timing experiments (GOI_EXPERIMENTS=1 only, invalid gradients)
     int sort_variant = 1;  // 0: histogram / scan / scatter per pass, 1: onesweep (decoupled look-back, default)
+    int cull_variant = 1;  // 0: a Gaussian is listed in every tile of its 3-sigma rectangle (the reference's lists),
+                           // 1: only in the tiles its exact contribution box touches (same images and gradients)
 };
 extern Options g_options;
 
@@ -147,6 +149,34 @@ __device__ __forceinline__ void tile_rect(float px, float py, int r, int gx, int
     x1 = min(gx, max(0, (int)((px + r + TILE - 1) / TILE)));
     y1 = min(gy, max(0, (int)((py + r + TILE - 1) / TILE)));
 }
+
+// Tile rectangle actually LISTED for a Gaussian.  The reference lists it in every tile of the 3-sigma
+// rectangle above; a tile the exact contribution box (hx, hy: alpha < 1/255 is certain outside, GaussRec)
+// does not touch can never receive a contribution from it, so with `cull` those tiles are dropped --
+// the per-pixel sequence of contributing Gaussians, hence every output and gradient, is unchanged, while
+// emit, the tile sort and the list walks of the blend kernels shrink with the instance count (x0.62 on the
+// headline scene).  hx < 0: the Gaussian never reaches 1/255 (no tile); +inf: no bound known.
+__device__ __forceinline__ void listed_rect(float px, float py, int r, float hx, float hy, bool cull, int gx, int gy,
+                                            int& x0, int& y0, int& x1, int& y1) {
+    tile_rect(px, py, r, gx, gy, x0, y0, x1, y1);
+    if (!cull) return;
+    if (hx < 0.f || hy < 0.f) {
+        x1 = x0;
+        y1 = y0;
+        return;
+    }
+    if (hx < 1e30f) {  // tile t holds pixels 16t .. 16t+15; it is touched iff 16t <= px+hx and 16t+15 >= px-hx
+        x0 = max(x0, (int)ceilf((px - hx - (float)(TILE - 1)) / TILE));
+        x1 = min(x1, (int)floorf((px + hx) / TILE) + 1);
+    }
+    if (hy < 1e30f) {
+        y0 = max(y0, (int)ceilf((py - hy - (float)(TILE - 1)) / TILE));
+        y1 = min(y1, (int)floorf((py + hy) / TILE) + 1);
+    }
+    x1 = max(x1, x0);
+    y1 = max(y1, y0);
+}
+constexpr int COUNTER_CULL = 2;  // GeomView::counters[COUNTER_CULL]: the forward's cull_variant, read by emit / backward
 
 // The depth sort runs ceil(32/8) = 4 ping-pong passes from buffer 0, so its result is in buffer 0.
 inline int depth_sort_result_index() { return ((32 + 7) / 8) & 1; }

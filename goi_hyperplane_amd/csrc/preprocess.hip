@@ -50,7 +50,7 @@ __device__ __forceinline__ void ewa_cov2d(V3 mean, float fx, float fy, float tan
 }
 
 struct PreArgs {
-    int P, D, M, W, H, gx, gy, prefiltered;
+    int P, D, M, W, H, gx, gy, prefiltered, cull;
     const float* means3D;
     const float* shs;
     const float* colors_precomp;
@@ -91,6 +91,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_k(const PreArgs args, Gaus
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     // the tile ranges start from zero (emit accumulates per-tile counts into them): cleared here for free
     for (int t = idx; t < n_tiles; t += gridDim.x * blockDim.x) ranges[t] = make_uint2(0u, 0u);
+    if (idx == 0) counters[COUNTER_CULL] = (uint32_t)args.cull;  // emit and the backward list the same rectangles
     if (idx >= args.P) return;
     const Camera cam = load_camera(args.view_p, args.proj_p, args.campos_p);
     struct : PreArgs {
@@ -203,7 +204,8 @@ __global__ __launch_bounds__(256) void preprocess_fwd_k(const PreArgs args, Gaus
         r.q2 = make_float4(cg, cb, hx, hy);
         rec[idx] = r;
         my_radius_i = (int)my_radius;
-        touched = (uint32_t)((y1 - y0) * (x1 - x0));
+        listed_rect(pix, piy, my_radius_i, hx, hy, a.cull != 0, a.gx, a.gy, x0, y0, x1, y1);
+        touched = (uint32_t)((y1 - y0) * (x1 - x0));  // may be 0 for a visible Gaussian (radius stays > 0)
         key = __float_as_uint(p_view.z);
     } while (false);
 
@@ -566,7 +568,8 @@ __global__ __launch_bounds__(256) void emit_k(int P, int gx, int gy, const Gauss
                                               const int* __restrict__ radii, const uint32_t* __restrict__ order,
                                               const uint32_t* __restrict__ offsets, uint32_t* __restrict__ goff,
                                               uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                              uint32_t* __restrict__ tile_count) {
+                                              uint32_t* __restrict__ tile_count, const uint32_t* __restrict__ counters) {
+    const bool cull = counters[COUNTER_CULL] != 0;
     extern __shared__ uint32_t s_cnt[];  // [gx * gy] when COUNT
     const int T = gx * gy;
     if (COUNT) {
@@ -588,8 +591,9 @@ __global__ __launch_bounds__(256) void emit_k(int P, int gx, int gy, const Gauss
             const int r = radii[g];
             if (r > 0) {
                 const float4 q0 = rec[g].q0;
+                const float4 q2 = rec[g].q2;
                 int x1, y1;
-                tile_rect(q0.x, q0.y, r, gx, gy, x0, y0, x1, y1);
+                listed_rect(q0.x, q0.y, r, q2.z, q2.w, cull, gx, gy, x0, y0, x1, y1);
                 w = x1 - x0;
                 cnt = w * (y1 - y0);
             }
@@ -691,6 +695,7 @@ void launch_preprocess_fwd(const GoiRasterScene& sc, const GeomView& g, int* rad
     a.gx = (sc.W + TILE - 1) / TILE;
     a.gy = (sc.H + TILE - 1) / TILE;
     a.prefiltered = sc.prefiltered;
+    a.cull = g_options.cull_variant;
     a.means3D = sc.means3D; a.shs = sc.shs; a.colors_precomp = sc.colors_precomp; a.opacities = sc.opacities;
     a.scales = sc.scales; a.rotations = sc.rotations; a.cov3D_precomp = sc.cov3D_precomp;
     a.scale_modifier = sc.scale_modifier; a.tan_fovx = sc.tan_fovx; a.tan_fovy = sc.tan_fovy;
@@ -753,7 +758,7 @@ void launch_emit(int P, int W, int H, const GeomView& g, const uint32_t* order, 
                  uint32_t* vals, hipStream_t s) {
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     emit_k<false><<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, gx, gy, g.rec, radii, order, g.offsets, g.goff, keys, vals,
-                                                              nullptr);
+                                                              nullptr, g.counters);
 }
 
 bool emit_can_count_tiles(int W, int H) {
@@ -767,7 +772,7 @@ void launch_emit_counting(int P, int W, int H, const GeomView& g, const uint32_t
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     // `ranges` was zeroed by preprocess_fwd_k
     emit_k<true><<<dim3((P + 256 * EMIT_ROUNDS - 1) / (256 * EMIT_ROUNDS)), dim3(256), (size_t)gx * gy * sizeof(uint32_t), s>>>(
-        P, gx, gy, g.rec, radii, order, g.offsets, g.goff, keys, vals, reinterpret_cast<uint32_t*>(ranges) + 1);
+        P, gx, gy, g.rec, radii, order, g.offsets, g.goff, keys, vals, reinterpret_cast<uint32_t*>(ranges) + 1, g.counters);
 }
 
 // per-tile counts -> ranges and the two digit histograms (written to ghist[0..511]) of a sort on

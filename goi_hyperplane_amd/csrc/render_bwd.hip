@@ -71,8 +71,10 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
     const int* __restrict__ radii, const uint32_t* __restrict__ goff, const float* __restrict__ bg,
     const float* __restrict__ out_alpha, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
     const float* __restrict__ dL_dpixsem, const float* __restrict__ dL_dpixdepth, const float* __restrict__ dL_dalphas,
-    float* __restrict__ rows, uint8_t* __restrict__ flags, int row_floats, int exp_flags) {
+    float* __restrict__ rows, uint8_t* __restrict__ flags, int row_floats, int exp_flags,
+    const uint32_t* __restrict__ counters) {
     using Cfg = BwdCfg<S4>;
+    const bool cull = counters[COUNTER_CULL] != 0;  // the rectangles the forward listed
     constexpr int NF4 = Cfg::NF4, NSEM = Cfg::NSEM, NCH = Cfg::NCH, NB = Cfg::NB;
     __shared__ float4 s_geo[BATCH];       // x, y, conic a, b
     __shared__ float4 s_geo2[BATCH];      // conic c, opacity, slot index (bits), -
@@ -249,7 +251,7 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
             const float4* r4 = reinterpret_cast<const float4*>(rec + id);
             const float4 q1 = r4[1];
             int x0, y0, x1, y1;
-            tile_rect(q0.x, q0.y, radii[id], gx, gy, x0, y0, x1, y1);
+            listed_rect(q0.x, q0.y, radii[id], q2.z, q2.w, cull, gx, gy, x0, y0, x1, y1);
             const uint32_t inst = goff[id] + (uint32_t)((t.ty - y0) * (x1 - x0) + (t.tx - x0));
             s_geo[lane] = q0;
             s_geo2[lane] = make_float4(q1.x, q1.y, __uint_as_float(inst * 4u + (uint32_t)t.q), 0.f);
@@ -334,7 +336,7 @@ void launch_bwd_rows_s4(const GoiRasterScene& sc, const GeomView& g, const Image
     const int n_quads = gx * gy * 4;
     render_bwd_rows_k<S4><<<dim3(quad_grid(n_quads)), dim3(64), (size_t)((g_options.bwd_variant >> 8) & 0xFF) * 1024, s>>>(
         im.ranges, point_list, sc.W, sc.H, gx, gy, n_quads, sc.S, g.rec, sc.semantics, radii, g.goff, sc.bg, out_alpha,
-        im.n_contrib, dL_dpix, dL_dsem, dL_ddepth, dL_dalpha, scr.rows, scr.flags, bwd_row_floats(sc.S), (g_options.bwd_variant >> 4) & 0xF);
+        im.n_contrib, dL_dpix, dL_dsem, dL_ddepth, dL_dalpha, scr.rows, scr.flags, bwd_row_floats(sc.S), (g_options.bwd_variant >> 4) & 0xF, g.counters);
 }
 
 }  // namespace

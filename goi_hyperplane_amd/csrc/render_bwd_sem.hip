@@ -30,7 +30,9 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int gx, int gy,
     int n_quads, int S, const GaussRec* __restrict__ rec, const int* __restrict__ radii,
     const uint32_t* __restrict__ goff, const float* __restrict__ out_alpha, const uint32_t* __restrict__ n_contrib,
-    const float* __restrict__ dL_dpixsem, float* __restrict__ rows, uint8_t* __restrict__ flags, int row_floats) {
+    const float* __restrict__ dL_dpixsem, float* __restrict__ rows, uint8_t* __restrict__ flags, int row_floats,
+    const uint32_t* __restrict__ counters) {
+    const bool cull = counters[COUNTER_CULL] != 0;  // the rectangles the forward listed
     constexpr int NSEM = 4 * S4, NB = (NSEM + 15) / 16;
     __shared__ float4 s_geo[SBATCH];          // x, y, conic a, b
     __shared__ float4 s_geo2[SBATCH];         // conic c, opacity, slot index (bits), -
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
         if (hit) {
             const float4 q1 = reinterpret_cast<const float4*>(rec + id)[1];
             int x0, y0, x1, y1;
-            tile_rect(q0.x, q0.y, radii[id], gx, gy, x0, y0, x1, y1);
+            listed_rect(q0.x, q0.y, radii[id], q2.z, q2.w, cull, gx, gy, x0, y0, x1, y1);
             const uint32_t inst = goff[id] + (uint32_t)((t.ty - y0) * (x1 - x0) + (t.tx - x0));
             s_geo[lane] = q0;
             s_geo2[lane] = make_float4(q1.x, q1.y, __uint_as_float(inst * 4u + (uint32_t)t.q), 0.f);
@@ -165,7 +167,7 @@ void launch_bwd_sem_s4(const GoiRasterScene& sc, const GeomView& g, const ImageV
     const int n_quads = gx * gy * 4;
     render_bwd_sem_k<S4><<<dim3(quad_grid(n_quads)), dim3(64), 0, s>>>(im.ranges, point_list, sc.W, sc.H, gx, gy, n_quads,
                                                                         sc.S, g.rec, radii, g.goff, out_alpha, im.n_contrib,
-                                                                        dL_dsem, rows, flags, row_floats);
+                                                                        dL_dsem, rows, flags, row_floats, g.counters);
 }
 
 }  // namespace

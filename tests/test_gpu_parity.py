@@ -55,10 +55,17 @@ def run_hip(sc, cam, bg, dev, grads=None, pipe=None, debug_views=False):
                    pc._opacity.detach(), pc._scaling.detach(), pc._rotation.detach(), 1.0, torch.Tensor([]),
                    tcam.world_view_transform, tcam.full_proj_transform, cam.tanfovx, cam.tanfovy, cam.image_height,
                    cam.image_width, pc._features.detach(), sc.sh_degree, tcam.camera_center, False, False)
-        n, *_rest, geom, binning, img = _C.rasterize_gaussians(*rs_args)
-        res["N"] = n
-        res["views"] = {k: v.cpu().numpy() for k, v in _C.debug_views(sc.P, cam.image_width, cam.image_height, n, geom,
-                                                                        binning, img).items()}
+        # the integer stages are compared with the reference's lists: every tile of the 3-sigma rectangle
+        # (cull_variant 0); the images and gradients above come from the default, culled lists
+        from goi_hyperplane_amd import _lib
+        _lib.set_option("cull_variant", 0)
+        try:
+            n, *_rest, geom, binning, img = _C.rasterize_gaussians(*rs_args)
+            res["N"] = n
+            res["views"] = {k: v.cpu().numpy() for k, v in _C.debug_views(sc.P, cam.image_width, cam.image_height, n,
+                                                                            geom, binning, img).items()}
+        finally:
+            _lib.set_option("cull_variant", 1)
     return res
 
 
@@ -460,3 +467,50 @@ def test_semantics_only_backward_is_bit_identical_to_the_full_one(dev, P, W, H, 
     # the mode is inert while anything else needs a gradient
     mixed, vs_mixed = sem_grad(False, True)
     assert torch.equal(mixed, full) and torch.equal(vs_mixed, vs_full)
+
+
+@pytest.mark.parametrize("P,W,H,S,mu", [(4000, 200, 152, 16, -2.6), (1500, 123, 77, 10, -1.8), (300_000, 800, 528, 16, -3.8)])
+def test_culled_tile_lists_change_nothing_but_the_instance_count(dev, P, W, H, S, mu):
+    """cull_variant 1 (default) lists a Gaussian only in the tiles its exact contribution box touches;
+    cull_variant 0 in every tile of the 3-sigma rectangle, like the reference.  The per-pixel sequence of
+    contributing Gaussians is the same: every output is BIT-identical and every gradient equal up to the
+    order of one fp32 sum."""
+    from goi_hyperplane_amd import _C, _lib
+    from goi_hyperplane_amd.render import GaussianSet, PipelineParams, TorchCamera, render
+    from goi_hyperplane_amd.scene import make_camera, make_scene
+    sc = make_scene(P, S=S, sh_degree=3, seed=9, log_scale_mean=mu)
+    cam = TorchCamera(make_camera(W, H, yaw=-0.15, pitch=0.05), dev)
+    pc = GaussianSet.from_scene(sc, dev)
+    bg = torch.tensor([0.2, 0.1, 0.4], device=dev)
+    g = torch.Generator(device=dev).manual_seed(2)
+    ups = [torch.randn(shape, device=dev, generator=g) for shape in ((3, H, W), (S, H, W), (1, H, W), (1, H, W))]
+    got = {}
+    try:
+        for variant in (0, 1):
+            _lib.set_option("cull_variant", variant)
+            for p in pc.parameters():
+                p.grad = None
+            out = render(cam, pc, PipelineParams(), bg)
+            torch.autograd.backward((out["render"], out["semantics"], out["depth"], out["alpha"]), ups)
+            n, *_ = _C.rasterize_gaussians(bg, pc._xyz.detach(), torch.Tensor([]), pc._semantics.detach(),
+                                           pc._opacity.detach(), pc._scaling.detach(), pc._rotation.detach(), 1.0,
+                                           torch.Tensor([]), cam.world_view_transform, cam.full_proj_transform,
+                                           np.tan(cam.FoVx * 0.5), np.tan(cam.FoVy * 0.5), H, W, pc._features.detach(), 3,
+                                           cam.camera_center, False, False)
+            got[variant] = (n, {k: out[k].detach().clone() for k in ("render", "semantics", "depth", "alpha", "radii")},
+                            {k: p.grad.clone() for k, p in pc.named_parameters()}, out["viewspace_points"].grad.clone())
+    finally:
+        _lib.set_option("cull_variant", 1)
+    (n0, o0, g0, v0), (n1, o1, g1, v1) = got[0], got[1]
+    assert n1 < n0, (n0, n1)
+    for k in o0:
+        assert torch.equal(o0[k], o1[k]), k
+    # gradients: every (quadrant, Gaussian) partial row is identical; reduce_rows_k adds a Gaussian's rows in
+    # chunks of 16 listed tiles, so the fp32 summation ORDER differs between the two lists (each is deterministic)
+    # (the geometry gradients pass that rounding noise through the cancelling cov2D -> cov3D -> scale / rotation
+    # chain, which amplifies it; the parity tolerance is 1e-3)
+    for k in g0:
+        scale = float(g0[k].abs().max())
+        tol = 1e-5 if k in ("_semantics", "_opacity") else 2e-4
+        assert float((g0[k] - g1[k]).abs().max()) <= tol * scale, k
+    assert float((v0 - v1).abs().max()) <= 2e-5 * float(v0.abs().max())
