@@ -230,15 +230,43 @@ __global__ __launch_bounds__(CBL_THREADS, (CPL <= 5 ? 2 : 1)) void codebook_rows
 #pragma unroll
                 for (int s = 0; s < SP; s++) dWr[k][s] = fmaf(dz[k], fs2[s], dWr[k][s]);
             }
-            // dL/df_s = sum_c dz_c W[c][s]: lane partial over its codes, wave total, lane s keeps it
-            float dfo = 0.f;
+            // dL/df_s = sum_c dz_c W[c][s]: 16 lane partials, then a REDUCE-SCATTER over the wave (each exchange
+            // halves the values a lane carries: 8 + 4 + 2 + 1 adds instead of 16 full reductions); lane l ends up
+            // with the wave total of channel l & 15
+            float part[SP];
 #pragma unroll
             for (int s = 0; s < SP; s++) {
-                float part = 0.f;
+                float acc = 0.f;
 #pragma unroll
-                for (int k = 0; k < CPL; k++) part = fmaf(dz[k], Wr[k][s], part);
-                const float tot = wave_sum_u(part);
-                dfo = lane == s ? tot : dfo;
+                for (int k = 0; k < CPL; k++) acc = fmaf(dz[k], Wr[k][s], acc);
+                part[s] = acc;
+            }
+            float dfo;
+            {
+                static_assert(SP == 16, "the reduce-scatter below is written for 16 channels");
+                const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+                float w8[8], w4[4], w2[2];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {  // partner lane ^ 1: keep channel 2j + b0
+                    const float keep = b0 ? part[2 * j + 1] : part[2 * j], send = b0 ? part[2 * j] : part[2 * j + 1];
+                    w8[j] = keep + __int_as_float(GOI_DPP(__float_as_int(send), 0xB1, 0xF, 0));
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {  // partner lane ^ 2: keep channel 4j + 2 b1 + b0
+                    const float keep = b1 ? w8[2 * j + 1] : w8[2 * j], send = b1 ? w8[2 * j] : w8[2 * j + 1];
+                    w4[j] = keep + __int_as_float(GOI_DPP(__float_as_int(send), 0x4E, 0xF, 0));
+                }
+#pragma unroll
+                for (int j = 0; j < 2; j++) {  // partner lane ^ 4 (ds_swizzle, xor mode)
+                    const float keep = b2 ? w4[2 * j + 1] : w4[2 * j], send = b2 ? w4[2 * j] : w4[2 * j + 1];
+                    w2[j] = keep + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(send), 0x101F));
+                }
+                {  // partner lane ^ 8
+                    const float keep = b3 ? w2[1] : w2[0], send = b3 ? w2[0] : w2[1];
+                    dfo = keep + __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(send), 0x201F));
+                }
+                dfo += __shfl_xor(dfo, 16, 64);  // the four rows of 16 lanes
+                dfo += __shfl_xor(dfo, 32, 64);
             }
             if (lane < S) a.dsem[(size_t)lane * HW + p] = dfo;
         }
