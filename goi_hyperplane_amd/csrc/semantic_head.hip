@@ -22,7 +22,6 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int MAX_K4 = 8;  // S <= 32
 
 // (value, index) max with lowest-index tie break across the 16 lanes of a DPP row
 __device__ __forceinline__ void row_argmax(float& v, int& i) {
@@ -133,7 +132,7 @@ int launch_semantic_decode(const float* sem, int S, long long HW, const float* W
         break;
     switch (K4) {
         GOI_CASE(1) GOI_CASE(2) GOI_CASE(3) GOI_CASE(4) GOI_CASE(5) GOI_CASE(6) GOI_CASE(7) GOI_CASE(8)
-        default: return -1;
+        default: return -1;  // S > 32
     }
 #undef GOI_CASE
     return 0;
