@@ -120,6 +120,16 @@ int geometry_and_binning(const GoiRasterScene& sc, GeomView& g, ImageView& im, g
         launch_preprocess_fwd(sc, g, radii, im.ranges, gx * gy, s);  // also zeroes the tile ranges
     }
     if (check_stage(sc, s, "preprocess")) return -1;
+    // The one host read-back of the forward (num_rendered sizes the binning workspace, as in the reference,
+    // CR/rasterizer_impl.cu:285).  preprocess has already summed it, so the copy is queued BEFORE the depth sort and
+    // the host waits on an event recorded right behind it: it wakes up, allocates and enqueues emit / tile sort /
+    // blend while the GPU is still busy with the depth sort and the scan -- no idle gap on the device.
+    static thread_local uint32_t* pinned = nullptr;
+    static thread_local hipEvent_t n_ready = nullptr;
+    if (!pinned) GOI_HIP(hipHostMalloc(reinterpret_cast<void**>(&pinned), COUNTER_WORDS * sizeof(uint32_t), hipHostMallocDefault));
+    if (!n_ready) GOI_HIP(hipEventCreateWithFlags(&n_ready, hipEventDisableTiming));
+    GOI_HIP(hipMemcpyAsync(pinned, g.counters, COUNTER_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    GOI_HIP(hipEventRecord(n_ready, s));
     int order_idx;
     {
         StageTimer t(GOI_STAGE_DEPTH_SORT, s);
@@ -127,20 +137,14 @@ int geometry_and_binning(const GoiRasterScene& sc, GeomView& g, ImageView& im, g
     }
     if (check_stage(sc, s, "depth sort")) return -1;
     const uint32_t* order = g.sort_vals[order_idx];
-    // The one host read-back of the forward (num_rendered sizes the binning workspace, as in the reference,
-    // CR/rasterizer_impl.cu:285); the copy lands in pinned memory so that it is a true asynchronous copy.
-    // (Polling the stream instead of blocking was measured: no gain, and it burns a host core per rank.)
-    static thread_local uint32_t* pinned = nullptr;
-    if (!pinned) GOI_HIP(hipHostMalloc(reinterpret_cast<void**>(&pinned), 64, hipHostMallocDefault));
     uint32_t host_counters[2] = {0, 0};
     {
         StageTimer t(GOI_STAGE_SCAN, s);
-        exclusive_scan_u32(g.tiles_touched, order, g.offsets, (size_t)P, &g.counters[0], g.scratch, s);
-        GOI_HIP(hipMemcpyAsync(pinned, g.counters, sizeof(host_counters), hipMemcpyDeviceToHost, s));
-        GOI_HIP(hipStreamSynchronize(s));
-        host_counters[0] = pinned[0];
-        host_counters[1] = pinned[1];
+        exclusive_scan_u32(g.tiles_touched, order, g.offsets, (size_t)P, nullptr, g.scratch, s);
     }
+    GOI_HIP(hipEventSynchronize(n_ready));
+    for (int i = 0; i < NR_STRIPES; i++) host_counters[0] += pinned[NR_BASE + NR_STRIDE * i];
+    host_counters[1] = pinned[1];
     if (host_counters[1] != 0)
         return fail("Point is filtered although prefiltered is set. This shouldn't happen!");
     const int N = (int)host_counters[0];
@@ -215,7 +219,7 @@ size_t geom_layout(int P, char* base, GeomView* v) {
     carve(p, g.sort_vals[1], n);
     carve(p, g.offsets, n);
     carve(p, g.goff, n);
-    carve(p, g.counters, 8);  // directly in front of the sort scratch: one memset clears both
+    carve(p, g.counters, COUNTER_WORDS);  // directly in front of the sort scratch: one memset clears both
     g.scratch_words = sort_scratch_words(n) + scan_scratch_words(n);
     carve(p, g.scratch, g.scratch_words);
     return (size_t)(p - base) + 256;

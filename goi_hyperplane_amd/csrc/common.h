@@ -33,7 +33,7 @@ struct GeomView {
     uint32_t* offsets;        // [P] exclusive prefix of tiles_touched in depth order
     uint32_t* goff;           // [P] the same prefix indexed by Gaussian id = first emit-order instance of g
     uint32_t* scratch;        // scan partials + radix histograms
-    uint32_t* counters;       // [8]: 0 = num_rendered, 1 = error flag, 2 = cull_variant of this forward
+    uint32_t* counters;       // [COUNTER_WORDS]: 1 = error flag, 2 = cull_variant of this forward, NR_BASE.. = num_rendered stripes
     size_t scratch_words;
 };
 struct ImageView {
@@ -176,6 +176,10 @@ __device__ __forceinline__ void listed_rect(float px, float py, int r, float hx,
     x1 = max(x1, x0);
     y1 = max(y1, y0);
 }
+// num_rendered is accumulated by preprocess in NR_STRIPES partial counters, one per 128-byte line (a single hot
+// counter serialises 4 K block atomics: +130 us); word NR_BASE + NR_STRIDE * i, the host adds them up
+constexpr int NR_STRIPES = 32, NR_STRIDE = 32, NR_BASE = 32;
+constexpr int COUNTER_WORDS = NR_BASE + NR_STRIPES * NR_STRIDE;
 constexpr int COUNTER_CULL = 2;  // GeomView::counters[COUNTER_CULL]: the forward's cull_variant, read by emit / backward
 
 // The depth sort runs ceil(32/8) = 4 ping-pong passes from buffer 0, so its result is in buffer 0.

@@ -88,11 +88,13 @@ __global__ __launch_bounds__(256) void preprocess_fwd_k(const PreArgs args, Gaus
                                                         uint32_t* __restrict__ sort_val, int* __restrict__ radii,
                                                         uint32_t* __restrict__ counters, uint2* __restrict__ ranges,
                                                         int n_tiles) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
     // the tile ranges start from zero (emit accumulates per-tile counts into them): cleared here for free
-    for (int t = idx; t < n_tiles; t += gridDim.x * blockDim.x) ranges[t] = make_uint2(0u, 0u);
-    if (idx == 0) counters[COUNTER_CULL] = (uint32_t)args.cull;  // emit and the backward list the same rectangles
-    if (idx >= args.P) return;
+    for (int t = gtid; t < n_tiles; t += gridDim.x * blockDim.x) ranges[t] = make_uint2(0u, 0u);
+    if (gtid == 0) counters[COUNTER_CULL] = (uint32_t)args.cull;  // emit and the backward list the same rectangles
+    // every lane reaches the wave reduction at the end: lanes past P redo the last Gaussian and write nothing
+    const bool live = gtid < args.P;
+    const int idx = live ? gtid : args.P - 1;
     const Camera cam = load_camera(args.view_p, args.proj_p, args.campos_p);
     struct : PreArgs {
         const float *view, *proj, *campos;
@@ -209,11 +211,25 @@ __global__ __launch_bounds__(256) void preprocess_fwd_k(const PreArgs args, Gaus
         key = __float_as_uint(p_view.z);
     } while (false);
 
-    radii[idx] = my_radius_i;
-    tiles_touched[idx] = touched;
-    clamped[idx] = clamp_bits;
-    sort_key[idx] = key;
-    sort_val[idx] = (uint32_t)idx;
+    if (live) {
+        radii[idx] = my_radius_i;
+        tiles_touched[idx] = touched;
+        clamped[idx] = clamp_bits;
+        sort_key[idx] = key;
+        sort_val[idx] = (uint32_t)idx;
+    }
+    // num_rendered = sum of tiles_touched: order-independent, so it is formed HERE (one integer atomic per wave)
+    // instead of falling out of the prefix sum after the depth sort -- the host can read it while the sort runs
+    __shared__ uint32_t s_wsum[4];
+    uint32_t wsum = live ? touched : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) wsum += (uint32_t)__shfl_xor((int)wsum, d, 64);
+    if ((threadIdx.x & 63) == 0) s_wsum[threadIdx.x >> 6] = wsum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t bsum = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+        if (bsum) atomicAdd(&counters[NR_BASE + NR_STRIDE * (blockIdx.x % NR_STRIPES)], bsum);
+    }
 }
 
 struct BwdArgs {
