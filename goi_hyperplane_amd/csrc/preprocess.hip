@@ -254,8 +254,13 @@ __global__ __launch_bounds__(256) void preprocess_bwd_k(const BwdArgs args, cons
                                                         float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D,
                                                         float* __restrict__ dL_dsh, float* __restrict__ dL_dscale,
                                                         float* __restrict__ dL_drot) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= args.P) return;
+    // dL/dSH is the widest output (192 B per Gaussian at degree 3).  Written per thread it is 48 stores with a
+    // 192-byte lane stride; instead every thread fills its row of an LDS tile (odd row stride: no bank conflicts)
+    // and the block streams the tile out as full lines.
+    extern __shared__ float s_dsh[];  // [256][3 M + 1] when dL_dsh
+    const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = gtid < args.P;
+    const int idx = live ? gtid : args.P - 1;  // lanes past P redo the last Gaussian and write nothing
     const Camera cam = load_camera(args.view_p, args.proj_p, args.campos_p);
     struct : BwdArgs {
         const float *view, *proj, *campos;
@@ -269,7 +274,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_k(const BwdArgs args, cons
     V3 gscale = {0, 0, 0};
     float4 grot = make_float4(0, 0, 0, 0);
     const bool visible = radii[idx] > 0;
-    V3* dsh = dL_dsh ? reinterpret_cast<V3*>(dL_dsh) + (size_t)idx * a.M : nullptr;
+    V3* dsh = dL_dsh ? reinterpret_cast<V3*>(s_dsh + (size_t)threadIdx.x * (3 * a.M + 1)) : nullptr;
 
     if (visible) {
         const V3 mean = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
@@ -460,15 +465,27 @@ __global__ __launch_bounds__(256) void preprocess_bwd_k(const BwdArgs args, cons
     } else if (dsh) {
         for (int k = 0; k < a.M; k++) dsh[k] = V3{0, 0, 0};
     }
-    dL_dmean3D[3 * idx] = gmean.x;
-    dL_dmean3D[3 * idx + 1] = gmean.y;
-    dL_dmean3D[3 * idx + 2] = gmean.z;
+    if (live) {
+        dL_dmean3D[3 * idx] = gmean.x;
+        dL_dmean3D[3 * idx + 1] = gmean.y;
+        dL_dmean3D[3 * idx + 2] = gmean.z;
 #pragma unroll
-    for (int i = 0; i < 6; i++) dL_dcov3D[(size_t)6 * idx + i] = gcov[i];
-    dL_dscale[3 * idx] = gscale.x;
-    dL_dscale[3 * idx + 1] = gscale.y;
-    dL_dscale[3 * idx + 2] = gscale.z;
-    reinterpret_cast<float4*>(dL_drot)[idx] = grot;
+        for (int i = 0; i < 6; i++) dL_dcov3D[(size_t)6 * idx + i] = gcov[i];
+        dL_dscale[3 * idx] = gscale.x;
+        dL_dscale[3 * idx + 1] = gscale.y;
+        dL_dscale[3 * idx + 2] = gscale.z;
+        reinterpret_cast<float4*>(dL_drot)[idx] = grot;
+    }
+    if (dL_dsh) {
+        __syncthreads();
+        const int w = 3 * a.M;
+        const int rows = min(256, a.P - (int)(blockIdx.x * blockDim.x));
+        float* out = dL_dsh + (size_t)blockIdx.x * blockDim.x * w;
+        for (int i = threadIdx.x; i < rows * w; i += 256) {
+            const int row = i / w, col = i - row * w;
+            out[i] = s_dsh[row * (w + 1) + col];
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void mark_visible_k(int P, const float* __restrict__ means3D, const float* view,
@@ -733,9 +750,11 @@ void launch_preprocess_bwd(const GoiRasterScene& sc, const GeomView& g, const in
     a.focal_y = sc.H / (2.0f * sc.tan_fovy);
     a.focal_x = sc.W / (2.0f * sc.tan_fovx);
     a.view_p = sc.viewmatrix; a.proj_p = sc.projmatrix; a.campos_p = sc.campos;
-    preprocess_bwd_k<<<dim3((sc.P + 255) / 256), dim3(256), 0, s>>>(a, radii, g.clamped, dL_dmean2D, dL_dconic, dL_dcolor,
+    const bool with_sh = sc.shs && sc.M > 0;
+    const size_t lds = with_sh ? (size_t)256 * (3 * sc.M + 1) * sizeof(float) : 0;  // 50 KB at M = 16
+    preprocess_bwd_k<<<dim3((sc.P + 255) / 256), dim3(256), lds, s>>>(a, radii, g.clamped, dL_dmean2D, dL_dconic, dL_dcolor,
                                                                    dL_ddepth, dL_dmean3D, dL_dcov3D,
-                                                                   (sc.shs && sc.M > 0) ? dL_dsh : nullptr, dL_dscale,
+                                                                   with_sh ? dL_dsh : nullptr, dL_dscale,
                                                                    dL_drot);
 }
 
