@@ -366,7 +366,7 @@ int goi_raster_backward(const GoiRasterScene* scene, int R, const void* geom_buf
         }
         if (check_stage(sc, s, "backward blend")) return -1;
         StageTimer t(GOI_STAGE_PREPROCESS_BWD, s);
-        launch_reduce_rows(sc, g, scr, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dsemantic, dL_ddepth, s);
+        launch_reduce_rows(sc, g, R, scr, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dsemantic, dL_ddepth, s);
         launch_preprocess_bwd(sc, g, radii, dL_dmean2D, dL_dconic, dL_dcolor, dL_ddepth, dL_dmean3D, dL_dcov3D, dL_dsh,
                               dL_dscale, dL_drot, s);
     } else {
@@ -423,7 +423,7 @@ int goi_raster_backward_semantics(const GoiRasterScene* scene, int R, const void
     }
     if (check_stage(sc, s, "backward blend (semantics)")) return -1;
     StageTimer t(GOI_STAGE_PREPROCESS_BWD, s);
-    launch_reduce_sem_rows(sc, g, scr.rows, scr.flags, row_floats, dL_dsemantic, s);
+    launch_reduce_sem_rows(sc, g, R, scr.rows, scr.flags, row_floats, dL_dsemantic, s);
     GOI_HIP(hipGetLastError());
     return 0;
 }

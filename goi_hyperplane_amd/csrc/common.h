@@ -113,10 +113,10 @@ void launch_render_bwd_rows(const GoiRasterScene& sc, const GeomView& g, const I
 void launch_render_bwd_sem(const GoiRasterScene& sc, const GeomView& g, const ImageView& im, const uint32_t* point_list,
                            const int* radii, const float* out_alpha, const float* dL_dsem, float* rows, uint8_t* flags,
                            int row_floats, hipStream_t s);
-void launch_reduce_sem_rows(const GoiRasterScene& sc, const GeomView& g, const float* rows, const uint8_t* flags,
+void launch_reduce_sem_rows(const GoiRasterScene& sc, const GeomView& g, int N, const float* rows, const uint8_t* flags,
                             int row_floats, float* dL_dsemantic, hipStream_t s);
 // sums every Gaussian's partial rows (fixed order) into the six blend-gradient arrays; writes all P rows
-void launch_reduce_rows(const GoiRasterScene& sc, const GeomView& g, const BwdScratchView& scr, float* dL_dmean2D,
+void launch_reduce_rows(const GoiRasterScene& sc, const GeomView& g, int N, const BwdScratchView& scr, float* dL_dmean2D,
                         float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dsemantic, float* dL_ddepth,
                         hipStream_t s);
 void launch_render_bwd_tile(const GoiRasterScene& sc, const GeomView& g, const ImageView& im,

@@ -507,9 +507,8 @@ __global__ __launch_bounds__(256) void mark_visible_k(int P, const float* __rest
 // slots of the chunk are packed into a 64-bit mask (quadrant-major), and up to 16 rows are requested
 // back to back before the first is consumed (lane e reads row elements e, e+16, ...: coalesced).
 template <int K>  // K = row_floats / 16
-__global__ __launch_bounds__(256) void reduce_rows_k(int P, int S, int nch, const uint32_t* __restrict__ order,
+__global__ __launch_bounds__(256) void reduce_rows_k(int P, int S, int nch, uint32_t N, const uint32_t* __restrict__ order,
                                                      const uint32_t* __restrict__ offsets,
-                                                     const uint32_t* __restrict__ tiles_touched,
                                                      const float* __restrict__ rows, const uint8_t* __restrict__ flags,
                                                      float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic,
                                                      float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor,
@@ -522,9 +521,13 @@ __global__ __launch_bounds__(256) void reduce_rows_k(int P, int S, int nch, cons
     // per-Gaussian outputs are scattered
     const int i = blockIdx.x * 16 + (threadIdx.x >> 4);
     const bool live = i < P;
+    // slots of the i-th Gaussian in depth order: [offsets[i], offsets[i+1]) -- straight from the prefix sum, so the
+    // chain of dependent loads is offsets -> flags -> rows; the Gaussian's id is only needed for the final store
     const uint32_t g = live ? order[i] : 0u;
-    const uint32_t cnt = live ? tiles_touched[g] : 0u;
-    const size_t inst0 = cnt ? (size_t)offsets[i] : 0;
+    const uint32_t off0 = live ? offsets[i] : 0u;
+    const uint32_t off1 = live ? (i + 1 < P ? offsets[i + 1] : N) : 0u;
+    const uint32_t cnt = off1 - off0;
+    const size_t inst0 = off0;
     const uint32_t* flags32 = reinterpret_cast<const uint32_t*>(flags);
     float sum[K];
 #pragma unroll
@@ -758,34 +761,34 @@ void launch_preprocess_bwd(const GoiRasterScene& sc, const GeomView& g, const in
                                                                    dL_drot);
 }
 
-void launch_reduce_rows(const GoiRasterScene& sc, const GeomView& g, const BwdScratchView& scr, float* dL_dmean2D,
+void launch_reduce_rows(const GoiRasterScene& sc, const GeomView& g, int N, const BwdScratchView& scr, float* dL_dmean2D,
                         float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dsemantic, float* dL_ddepth,
                         hipStream_t s) {
     const int rf = bwd_row_floats(sc.S), nch = 4 * ((sc.S + 3) / 4) + 4;
     const dim3 grid((sc.P + 15) / 16);
     const uint32_t* order = g.sort_vals[depth_sort_result_index()];
     if (rf == 32)
-        reduce_rows_k<2><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, order, g.offsets, g.tiles_touched, scr.rows, scr.flags,
+        reduce_rows_k<2><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, order, g.offsets, scr.rows, scr.flags,
                                                     dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dsemantic, dL_ddepth);
     else if (rf == 16)
-        reduce_rows_k<1><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, order, g.offsets, g.tiles_touched, scr.rows, scr.flags,
+        reduce_rows_k<1><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, order, g.offsets, scr.rows, scr.flags,
                                                     dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dsemantic, dL_ddepth);
     else
-        reduce_rows_k<3><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, order, g.offsets, g.tiles_touched, scr.rows, scr.flags,
+        reduce_rows_k<3><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, order, g.offsets, scr.rows, scr.flags,
                                                     dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dsemantic, dL_ddepth);
 }
 
-void launch_reduce_sem_rows(const GoiRasterScene& sc, const GeomView& g, const float* rows, const uint8_t* flags,
+void launch_reduce_sem_rows(const GoiRasterScene& sc, const GeomView& g, int N, const float* rows, const uint8_t* flags,
                             int row_floats, float* dL_dsemantic, hipStream_t s) {
     // rows hold semantic channels only: with nch = row_floats + 4 every element index is a semantic one
     const int nch = row_floats + 4;
     const dim3 grid((sc.P + 15) / 16);
     const uint32_t* order = g.sort_vals[depth_sort_result_index()];
     if (row_floats == 16)
-        reduce_rows_k<1><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, order, g.offsets, g.tiles_touched, rows, flags, nullptr,
+        reduce_rows_k<1><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, order, g.offsets, rows, flags, nullptr,
                                                     nullptr, nullptr, nullptr, dL_dsemantic, nullptr);
     else
-        reduce_rows_k<2><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, order, g.offsets, g.tiles_touched, rows, flags, nullptr,
+        reduce_rows_k<2><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, order, g.offsets, rows, flags, nullptr,
                                                     nullptr, nullptr, nullptr, dL_dsemantic, nullptr);
 }
 
