@@ -553,8 +553,14 @@ __global__ __launch_bounds__(256) void reduce_rows_k(int P, int S, int nch, uint
                 const int bit = have ? __builtin_ctzll(m) : 0;
                 if (have) m &= m - 1;
                 const float* r = chunk + (size_t)((bit & 15) * 4 + (bit >> 4)) * RF;
+                if (K == 2) {  // one 8-byte load per lane: the quarter wave reads the 128-byte row in one request
+                    const float2 t = have ? reinterpret_cast<const float2*>(r)[e] : make_float2(0.f, 0.f);
+                    v[i][0] = t.x;
+                    v[i][K - 1] = t.y;
+                } else {
 #pragma unroll
-                for (int k = 0; k < K; k++) v[i][k] = have ? r[e + 16 * k] : 0.f;
+                    for (int k = 0; k < K; k++) v[i][k] = have ? r[e + 16 * k] : 0.f;
+                }
             }
 #pragma unroll
             for (int i = 0; i < INFLIGHT; i++)
@@ -567,7 +573,7 @@ __global__ __launch_bounds__(256) void reduce_rows_k(int P, int S, int nch, uint
 #pragma unroll
     for (int k = 0; k < K; k++) {
         const float v = sum[k];
-        const int el = e + 16 * k;
+        const int el = K == 2 ? 2 * e + k : e + 16 * k;  // element of the row this lane summed
         if (el < nsem) {
             if (el < S) dL_dsemantic[(size_t)g * S + el] = v;
         } else if (el < nsem + 3) {
