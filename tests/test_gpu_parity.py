@@ -514,3 +514,31 @@ def test_culled_tile_lists_change_nothing_but_the_instance_count(dev, P, W, H, S
         tol = 1e-5 if k in ("_semantics", "_opacity") else 2e-4
         assert float((g0[k] - g1[k]).abs().max()) <= tol * scale, k
     assert float((v0 - v1).abs().max()) <= 2e-5 * float(v0.abs().max())
+
+
+def test_runs_on_a_side_stream_with_identical_results(dev):
+    """Everything is enqueued on torch's CURRENT stream (the stream argument of the C ABI): a render +
+    backward issued under torch.cuda.stream(side) must give the default stream's bits."""
+    from goi_hyperplane_amd.render import GaussianSet, PipelineParams, TorchCamera, render
+    from goi_hyperplane_amd.scene import make_camera, make_scene
+    sc = make_scene(20000, S=16, sh_degree=3, seed=11, log_scale_mean=-3.2)
+    cam = TorchCamera(make_camera(320, 208, yaw=0.1), dev)
+    pc = GaussianSet.from_scene(sc, dev)
+    bg = torch.zeros(3, device=dev)
+
+    def go():
+        for p in pc.parameters():
+            p.grad = None
+        out = render(cam, pc, PipelineParams(), bg)
+        (out["render"].sum() + out["semantics"].sum() + out["depth"].sum()).backward()
+        return out["render"].detach().clone(), out["semantics"].detach().clone(), pc._xyz.grad.clone(), pc._semantics.grad.clone()
+
+    a = go()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        b = go()
+    side.synchronize()
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
