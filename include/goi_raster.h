@@ -72,6 +72,9 @@ typedef struct GoiRasterScene {
  * stays valid until the matching backward has run (NULL = failure). */
 typedef void* (*goi_alloc_fn)(void* user, size_t bytes);
 
+/* Thread safety: entry points may be called from several host threads (one per stream); the last-error
+ * string and the pinned read-back buffer are per thread.  The profiling hooks and goi_raster_set_option touch
+ * process-wide state and are meant for single-threaded measurement runs. */
 int goi_raster_abi_version(void);
 const char* goi_raster_last_error(void);
 
