@@ -20,7 +20,10 @@ constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS = 8;
 constexpr int SCAN_CHUNK = SCAN_THREADS * SCAN_ITEMS;  // 2048
 
-constexpr int SORT_THREADS = 256;
+#ifndef GOI_SORT_THREADS
+#define GOI_SORT_THREADS 512  // 8192-key onesweep tiles: 256 -> 512 threads took the tile sort from 107 to 89 us (look-back chain)
+#endif
+constexpr int SORT_THREADS = GOI_SORT_THREADS;
 constexpr int SORT_ITEMS = 16;
 constexpr int SORT_TILE = SORT_THREADS * SORT_ITEMS;  // 4096
 constexpr int SORT_WAVES = SORT_THREADS / WAVE;        // 4
@@ -133,8 +136,12 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_hist_k(const uint32_t* __r
         if (i < n) atomicAdd(&h[w][(keys[i] >> shift) & mask], 1u);
     }
     __syncthreads();
-    for (uint32_t d = threadIdx.x; d <= mask; d += SORT_THREADS)
-        hist[(size_t)d * nblk + blockIdx.x] = h[0][d] + h[1][d] + h[2][d] + h[3][d];
+    for (uint32_t d = threadIdx.x; d <= mask; d += SORT_THREADS) {
+        uint32_t t = 0;
+#pragma unroll
+        for (int ww = 0; ww < SORT_WAVES; ww++) t += h[ww][d];
+        hist[(size_t)d * nblk + blockIdx.x] = t;
+    }
 }
 
 __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_k(const uint32_t* __restrict__ keys_in,
@@ -205,7 +212,7 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_k(const uint32_t* 
 }
 
 // ---- single-pass-per-digit radix sort ("onesweep") -----------------------------------------------
-// One kernel per digit: every block ranks its 4096 elements, publishes its per-digit counts, obtains
+// One kernel per digit: every block ranks its 8192 elements, publishes its per-digit counts, obtains
 // the counts of all earlier blocks by decoupled look-back over per-(block, digit) status words, and
 // scatters through LDS so that each digit's elements leave as one contiguous run.  A prologue kernel
 // computes the global digit histograms of every pass in one read of the keys.
@@ -256,8 +263,9 @@ __global__ __launch_bounds__(SORT_THREADS) void sweep_pass_k(const uint32_t* __r
     __shared__ uint32_t cnt[SORT_WAVES][RADIX_MAX];  // per-wave digit counts -> per-wave local offsets
     __shared__ uint32_t gbase[RADIX_MAX];            // global position of this block's first element of digit d
     __shared__ uint32_t lbase[RADIX_MAX];            // local (in-block) exclusive offset of digit d
-    __shared__ uint32_t s_keys[SORT_TILE];
-    __shared__ uint32_t s_vals[SORT_TILE];
+    extern __shared__ uint32_t s_dyn[];  // [2][SORT_TILE]: the tile's keys and values in digit order
+    uint32_t* s_keys = s_dyn;
+    uint32_t* s_vals = s_dyn + SORT_TILE;
     __shared__ uint32_t s_bid;
     const uint32_t radix = 1u << nbits, mask = radix - 1u;
     if (threadIdx.x == 0) s_bid = atomicAdd(ticket, 1u);
@@ -447,9 +455,16 @@ int radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], size_t n, int lo, int
             sh += plan.nbits[p];
         }
         for (int p = passes; p < MAX_PASSES; p++) plan.shift[p] = plan.nbits[p] = 0;
+        constexpr size_t SWEEP_LDS = (size_t)2 * SORT_TILE * sizeof(uint32_t);
+        static bool attr_set = false;
+        if (!attr_set && SWEEP_LDS > 48 * 1024) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_pass_k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)SWEEP_LDS);
+            attr_set = true;
+        }
         if (!ghist_ready) sweep_hist_k<<<dim3(nblk), dim3(SORT_THREADS), 0, s>>>(keys[0], n, plan, ghist);
         for (int p = 0; p < passes; p++) {
-            sweep_pass_k<<<dim3(nblk), dim3(SORT_THREADS), 0, s>>>(
+            sweep_pass_k<<<dim3(nblk), dim3(SORT_THREADS), SWEEP_LDS, s>>>(
                 keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, plan.shift[p], plan.nbits[p],
                 ghist + (size_t)p * RADIX_MAX, status + (size_t)p * nblk * RADIX_MAX, ticket + p, error);
             cur ^= 1;
