@@ -246,6 +246,22 @@ def main():
             render(cams[(i * world + rank) % len(cams)], pc, pipe, bg)
         barrier()
         render_ms = (time.perf_counter() - r0) / nfr * 1e3
+        # GUI frame: render + fused semantic decode (code-book argmax + hyperplane score + mask, gui/main.py:364-386)
+        from goi_hyperplane_amd.semantic import LinearSVM, SemanticModel, compute_similarity, svm_score_fn
+        torch.manual_seed(0)
+        mlp = SemanticModel(dim_in=args.S, dim_out=300, num_layer=1, use_bias=True, device=dev)
+        lut = torch.rand(300, 256, device=dev) * 0.03
+        score = svm_score_fn(LinearSVM().to(dev))
+        gui_ms = None
+        if args.S <= 32:
+            for i in range(2):
+                compute_similarity(render(cams[i % len(cams)], pc, pipe, bg)["semantics"], mlp, lut, score, 0.5)
+            barrier()
+            r0 = time.perf_counter()
+            for i in range(nfr):
+                compute_similarity(render(cams[(i * world + rank) % len(cams)], pc, pipe, bg)["semantics"], mlp, lut, score, 0.5)
+            barrier()
+            gui_ms = (time.perf_counter() - r0) / nfr * 1e3
 
     # Secondary figure: the reference's DEFAULT training configuration optimises only the semantic features
     # (arguments/__init__.py:85-90).  With every other parameter frozen the feature-gradient-only backward
@@ -332,6 +348,7 @@ def main():
                        "views_per_step": world, "parallelism": f"views sharded x{world}",
                        "allreduce_bytes": int(sum(p.numel() for p in reduce_params) * 4) if world > 1 else 0},
             "render_ms_per_frame": render_ms,
+            "gui_frame_ms": gui_ms,  # render + fused semantic decode (300 codes)
             "semantic_finetune": sem_only,
             "roofline": roofline,
             "whole_view": {"alg_bytes_fwd": b_fwd, "alg_bytes_bwd": b_bwd,
