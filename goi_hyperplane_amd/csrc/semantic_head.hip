@@ -29,7 +29,7 @@ __device__ __forceinline__ void row_argmax(float& v, int& i) {
     {                                                                                                   \
         const float ov = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), ctrl, 0xF, 0xF, false)); \
         const int oi = __builtin_amdgcn_update_dpp(i, i, ctrl, 0xF, 0xF, false);                        \
-        const bool take = (ov > v) || (ov == v && oi < i);                                              \
+        const bool take = (ov > v) | ((ov == v) & (oi < i)); /* bitwise: no exec-mask branches */        \
         v = take ? ov : v;                                                                              \
         i = take ? oi : i;                                                                              \
     }
@@ -40,14 +40,16 @@ __device__ __forceinline__ void row_argmax(float& v, int& i) {
 #undef GOI_STEP
 }
 
-template <int K4>
+// NBLK_T > 0: the number of 16-code blocks is a compile-time constant (19 for the reference's 300 codes): every LDS
+// operand then sits at a constant offset from one base address and the block loop unrolls completely.
+template <int K4, int NBLK_T>
 __global__ __launch_bounds__(256) void semantic_decode_k(const float* __restrict__ sem, int S, long long HW,
                                                          const float* __restrict__ Wm, const float* __restrict__ bias,
                                                          int n_codes, const float* __restrict__ code_score, float thresh,
                                                          float* __restrict__ sim_out, int* __restrict__ idx_out,
                                                          uint8_t* __restrict__ bg_mask_out) {
     extern __shared__ __attribute__((aligned(16))) float s_w[];  // W^T padded: [4*K4][ncp], then bias[ncp]
-    const int nblk = (n_codes + 15) / 16, ncp = nblk * 16;
+    const int nblk = NBLK_T > 0 ? NBLK_T : (n_codes + 15) / 16, ncp = nblk * 16;
     float* s_b = s_w + (size_t)4 * K4 * ncp;
     for (int i = threadIdx.x; i < 4 * K4 * ncp; i += 256) {
         const int ch = i / ncp, code = i - ch * ncp;
@@ -59,27 +61,45 @@ __global__ __launch_bounds__(256) void semantic_decode_k(const float* __restrict
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int kq = lane >> 4, mm = lane & 15;
     const long long n_groups = (HW + 63) / 64;
-    for (long long grp = (long long)blockIdx.x * 4 + wave; grp < n_groups; grp += (long long)gridDim.x * 4) {
-        const long long pix0 = grp * 64;
-#pragma unroll 1
-        for (int mb = 0; mb < 4; mb++) {
-            // A fragments: pixel pix0 + 16 mb + mm, channels 4 s + kq
-            const long long pa = pix0 + 16 * mb + mm;
-            float a[K4];
+    // A fragments of pixel block `it` (16 pixels): pixel 16 it + mm, channels 4 s + kq.  The blocks a wave handles
+    // are 16 it for it = 4 grp + mb; the next block's loads are issued before the current block's MFMAs.
+    auto load_a = [&](long long it, float (&dst)[K4]) {
+        const long long pa = it * 16 + mm;
 #pragma unroll
-            for (int s = 0; s < K4; s++) {
-                const int ch = 4 * s + kq;
-                a[s] = (ch < S && pa < HW) ? sem[(size_t)ch * HW + pa] : 0.f;
-            }
+        for (int s = 0; s < K4; s++) {
+            const int ch = 4 * s + kq;
+            dst[s] = (ch < S && pa < HW && it >= 0) ? sem[(size_t)ch * HW + pa] : 0.f;
+        }
+    };
+    const long long n_it = n_groups * 4, it_stride = (long long)gridDim.x * 16;
+    auto next_it = [&](long long it) { return ((it & 3) != 3) ? it + 1 : it - 3 + it_stride; };
+    long long it = ((long long)blockIdx.x * 4 + wave) * 4;
+    float a[K4], a_next[K4];
+    if (it < n_it) load_a(it, a);
+    for (; it < n_it; it = next_it(it)) {
+        const long long pix0 = (it >> 2) * 64;
+        const int mb = (int)(it & 3);
+        {
+            const long long nx = next_it(it);
+            load_a(nx < n_it ? nx : -1, a_next);
             float bv[4] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
             int bi[4] = {0, 0, 0, 0};
+            // B fragments (decoder weights) and the bias of code block nb + 1 are fetched from LDS while block nb is
+            // on the matrix cores: left to itself the compiler issues read -> wait -> MFMA five times per block
+            const float* wp = s_w + (size_t)kq * ncp + mm;
+            float wv[K4], wn[K4], b0 = s_b[mm], bn = 0.f;
+#pragma unroll
+            for (int s = 0; s < K4; s++) wv[s] = wp[(size_t)4 * s * ncp];
+#pragma unroll
             for (int nb = 0; nb < nblk; nb++) {
-                const float b0 = s_b[nb * 16 + mm];
+                if (nb + 1 < nblk) {
+                    bn = s_b[(nb + 1) * 16 + mm];
+#pragma unroll
+                    for (int s = 0; s < K4; s++) wn[s] = wp[(size_t)4 * s * ncp + (nb + 1) * 16];
+                }
                 f32x4 acc = {b0, b0, b0, b0};
 #pragma unroll
-                for (int s = 0; s < K4; s++)
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], s_w[(size_t)(4 * s + kq) * ncp + nb * 16 + mm], acc, 0,
-                                                               0, 0);
+                for (int s = 0; s < K4; s++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], wv[s], acc, 0, 0, 0);
                 const int code = nb * 16 + mm;
 #pragma unroll
                 for (int r = 0; r < 4; r++)
@@ -87,6 +107,9 @@ __global__ __launch_bounds__(256) void semantic_decode_k(const float* __restrict
                         bv[r] = acc[r];
                         bi[r] = code;
                     }
+                b0 = bn;
+#pragma unroll
+                for (int s = 0; s < K4; s++) wv[s] = wn[s];
             }
 #pragma unroll
             for (int r = 0; r < 4; r++) row_argmax(bv[r], bi[r]);
@@ -105,6 +128,8 @@ __global__ __launch_bounds__(256) void semantic_decode_k(const float* __restrict
                     }
                 }
             }
+#pragma unroll
+            for (int s = 0; s < K4; s++) a[s] = a_next[s];
         }
     }
 }
@@ -122,19 +147,28 @@ int launch_semantic_decode(const float* sem, int S, long long HW, const float* W
     long long blocks = (n_groups + 3) / 4;
     if (blocks > 256 * 8) blocks = 256 * 8;  // grid-stride: W^T is staged into LDS once per workgroup
     if (blocks < 1) blocks = 1;
-#define GOI_CASE(N)                                                                                            \
-    case N:                                                                                                    \
+#define GOI_LAUNCH(KERNEL)                                                                                     \
+    do {                                                                                                       \
         if (lds > 64 * 1024)                                                                                   \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(semantic_decode_k<N>),                     \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL),                                   \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
-        semantic_decode_k<N><<<dim3((unsigned)blocks), dim3(256), lds, s>>>(sem, S, HW, W, bias, n_codes, code_score, \
-                                                                             thresh, sim_out, idx_out, bg_mask_out); \
+        KERNEL<<<dim3((unsigned)blocks), dim3(256), lds, s>>>(sem, S, HW, W, bias, n_codes, code_score, thresh, \
+                                                              sim_out, idx_out, bg_mask_out);                  \
+    } while (0)
+#define GOI_CASE(N)                          \
+    case N:                                  \
+        GOI_LAUNCH((semantic_decode_k<N, 0>)); \
         break;
+    if (K4 == 4 && ncp == 19 * 16) {  // the reference's configuration: S = 16 (or 13..16), 300 codes
+        GOI_LAUNCH((semantic_decode_k<4, 19>));
+        return 0;
+    }
     switch (K4) {
         GOI_CASE(1) GOI_CASE(2) GOI_CASE(3) GOI_CASE(4) GOI_CASE(5) GOI_CASE(6) GOI_CASE(7) GOI_CASE(8)
         default: return -1;  // S > 32
     }
 #undef GOI_CASE
+#undef GOI_LAUNCH
     return 0;
 }
 
