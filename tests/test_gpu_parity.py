@@ -103,6 +103,7 @@ CASES = [
     (1500, 3, 96, 80, -2.5, 0),       # S not a multiple of 4
     (500, 32, 80, 64, -2.5, 3),       # widest supported S
     (20000, 16, 400, 300, -3.5, 3),   # BASELINE config 1 shape at S = 16
+    (1500, 4, 3840, 2160, -2.0, 1),   # 32 400 tiles: per-tile counters no longer fit LDS -> separate histogram / ranges passes
 ]
 
 
