@@ -543,3 +543,25 @@ def test_runs_on_a_side_stream_with_identical_results(dev):
     side.synchronize()
     for x, y in zip(a, b):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("option,value", [("bwd_variant", 1), ("fwd_variant", 0), ("sort_variant", 0), ("cull_variant", 0)])
+def test_alternative_kernels_stay_correct(oracle_mod, dev, option, value):
+    """The non-default variants kept behind goi_raster_set_option (tile + atomics backward, one-candidate forward
+    loop, histogram/scan/scatter sort, the reference's un-culled lists) against the oracle on one case."""
+    from goi_hyperplane_amd import _lib
+    P, S, W, H, mu, deg = 3000, 16, 123, 77, -2.6, 2
+    sc = make_scene(P, S=S, sh_degree=deg, seed=3, log_scale_mean=mu)
+    cam = make_camera(W, H, yaw=0.2, pitch=-0.1)
+    bg = np.array([0.1, 0.3, 0.6], np.float32)
+    grads = upstream_grads(S, H, W, seed=5)
+    o = oracle_mod.from_scene(sc, cam, bg=bg)
+    f = o.forward()
+    default = {"bwd_variant": 0, "fwd_variant": 1, "sort_variant": 1, "cull_variant": 1}[option]
+    _lib.set_option(option, value)
+    try:
+        res = run_hip(sc, cam, bg, dev, grads=grads)
+    finally:
+        _lib.set_option(option, default)
+    check_forward(res, f, f"{option}={value}")
+    check_backward(res["grads"], o.backward(*grads), f"{option}={value}")
