@@ -59,7 +59,10 @@ class _BinningAllocator:
 
     def _alloc(self, _user, nbytes):
         try:
-            self.tensor = torch.empty(int(nbytes), dtype=torch.uint8, device=self.dev)
+            # num_rendered changes with every view; rounding the request up to 16 MiB steps lets the caching allocator
+            # hand back the same block instead of growing a new one (a fresh hipMalloc inside a training step)
+            step = 16 << 20
+            self.tensor = torch.empty((int(nbytes) + step - 1) // step * step, dtype=torch.uint8, device=self.dev)
             return self.tensor.data_ptr()
         except Exception as ex:  # never let an exception cross the C boundary
             self.error = ex
