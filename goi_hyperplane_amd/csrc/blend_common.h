@@ -7,22 +7,52 @@ namespace goi {
 constexpr float kAlphaMin = 1.0f / 255.0f;
 constexpr float kTMin = 0.0001f;
 constexpr float kAlphaMax = 0.99f;
+constexpr float kPowerTol = 1e-4f;
 
 // alpha evaluation shared by forward, backward and trace so that all three agree on which
 // (pixel, Gaussian) pairs contribute (guards of CR/forward.cu:341-351, CR/backward.cu:535-542).
 struct PairEval {
-    float dx, dy, power, G, alpha;
+    float power, G, alpha;
     bool hit;
 };
-__device__ __forceinline__ PairEval eval_pair(float gx_, float gy_, float ca, float cb, float cc, float o, float pxf,
-                                              float pyf) {
+
+// The exponent of a Gaussian over one 8x8 quadrant as a quadratic in QUADRANT-CENTRED pixel coordinates
+// (u, v) in [-3.5, 3.5]:  power(u, v) = A0 + u (A1 + A3 u + A4 v) + v (A2 + A5 v).
+// With dx = Dx - u, dy = Dy - v (Dx, Dy: Gaussian centre relative to the quadrant centre) this is exactly
+// -0.5 (a dx^2 + c dy^2) - b dx dy (CR/forward.cu:341-345).  The six coefficients are formed once per
+// (quadrant, Gaussian) by the lane that stages the Gaussian; every pixel then needs 5 FMAs instead of the 11
+// instructions of the direct form.  Centring keeps all terms small (|u|, |v| <= 3.5), so the rounding error of
+// the expanded form stays at the 1e-6 level.  Forward, trace and every backward kernel evaluate a pair ONLY through
+// these two functions, spelled with explicit fmaf so that all of them take identical contribution decisions.
+//
+// The reference skips a pair whose exponent is > 0 (CR/forward.cu:346).  For a positive-definite conic that can
+// only be a rounding artefact next to the Gaussian's centre, where the exact exponent is ~0; the expanded form
+// rounds differently there (|error| <= ~5e-5 for the sharpest admissible conic, a = c = 1/0.3), so the guard is
+// applied with a tolerance: power <= kPowerTol contributes (with G = exp(power) <= 1.0001).  A conic that is NOT
+// positive definite still fails the guard wherever its exponent is meaningfully positive.
+struct PolyCoef {
+    float A0, A1, A2, A3, A4, A5;
+};
+__device__ __forceinline__ PolyCoef poly_coefs(float gx_, float gy_, float ca, float cb, float cc, float qcx, float qcy) {
+    const float Dx = gx_ - qcx, Dy = gy_ - qcy;
+    PolyCoef p;
+    p.A1 = fmaf(ca, Dx, cb * Dy);
+    p.A2 = fmaf(cc, Dy, cb * Dx);
+    p.A0 = -0.5f * fmaf(Dx, p.A1, Dy * p.A2);  // -0.5 (a Dx^2 + 2 b Dx Dy + c Dy^2)
+    p.A3 = -0.5f * ca;
+    p.A4 = -cb;
+    p.A5 = -0.5f * cc;
+    return p;
+}
+__device__ __forceinline__ PairEval eval_poly(float A0, float A1, float A2, float A3, float A4, float A5, float o, float u,
+                                              float v) {
     PairEval e;
-    e.dx = gx_ - pxf;
-    e.dy = gy_ - pyf;
-    e.power = -0.5f * (ca * e.dx * e.dx + cc * e.dy * e.dy) - cb * e.dx * e.dy;
+    const float t1 = fmaf(A4, v, fmaf(A3, u, A1));
+    const float t2 = fmaf(A5, v, A2);
+    e.power = fmaf(v, t2, fmaf(u, t1, A0));
     e.G = __expf(e.power);
     e.alpha = fminf(kAlphaMax, o * e.G);
-    e.hit = (e.power <= 0.0f) && (e.alpha >= kAlphaMin);
+    e.hit = (e.power <= kPowerTol) && (e.alpha >= kAlphaMin);
     return e;
 }
 

@@ -76,11 +76,11 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
     using Cfg = BwdCfg<S4>;
     const bool cull = counters[COUNTER_CULL] != 0;  // the rectangles the forward listed
     constexpr int NF4 = Cfg::NF4, NSEM = Cfg::NSEM, NCH = Cfg::NCH, NB = Cfg::NB;
-    __shared__ float4 s_geo[BATCH];       // x, y, conic a, b
-    __shared__ float4 s_geo2[BATCH];      // conic c, opacity, slot index (bits), -
+    __shared__ float4 s_geo[BATCH];       // A0..A3 of the quadrant-centred exponent polynomial (blend_common.h)
+    __shared__ float4 s_geo2[BATCH];      // A4, A5, opacity, slot index (bits)
     __shared__ float4 s_feat[BATCH * NF4];  // (r,g,b,depth), semantics...
     __shared__ float s_t[2 * GROUP * TSTRIDE];  // [row][pixel]: rows 0..7 = w of slot, rows 8..15 = h of slot
-    __shared__ float4 s_gmeta[GROUP * 2];    // per group member: (x, y, a, b), (c, opacity, slot bits, -)
+    __shared__ float4 s_gmeta[GROUP * 2];    // per group member: (Dx, Dy, A3, A4), (A5, opacity, slot bits, -)
 
     const QuadGeom t = quad_geom(W, H, gx, n_quads);
     if (t.tile < 0) return;
@@ -160,6 +160,7 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
         __builtin_amdgcn_wave_barrier();
     }
     const float QCX = t.QX0 + 3.5f, QCY = t.QY0 + 3.5f;  // quadrant centre (pixel coordinates)
+    const float pu = t.pxf - QCX, pv = t.pyf - QCY;      // this lane's pixel, quadrant-centred
     const float half_W = 0.5f * W, half_H = 0.5f * H;
 
     // software prefetch of the next batch's id / position / box (one list entry per lane)
@@ -219,7 +220,8 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
             const float4 g = s_gmeta[lane * 2];
             const float4 g2 = s_gmeta[lane * 2 + 1];
             const uint32_t slot = __float_as_uint(g2.z);  // (emit-order instance) * 4 + quadrant
-            const float Dx = g.x - QCX, Dy = g.y - QCY;   // dx = Dx - u, dy = Dy - v
+            const float Dx = g.x, Dy = g.y;               // centre - quadrant centre: dx = Dx - u, dy = Dy - v
+            const float ca = -2.f * g.z, cb = -g.w, cc = -2.f * g2.x;  // conic back from A3, A4, A5 (exact)
             const float m0 = m03.x, mu = m03.y, mv = m03.z, muu = m03.w, muv = m45.x, mvv = m45.y;
             const float sx = Dx * m0 - mu;                             // sum h dx
             const float sy = Dy * m0 - mv;                             // sum h dy
@@ -228,8 +230,8 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
             const float syy = Dy * Dy * m0 - 2.f * Dy * mv + mvv;      // sum h dy^2
             const float o = g2.y;
             float* dst = rows + (size_t)slot * row_floats + NCH;
-            dst[0] = -o * half_W * (g.z * sx + g.w * sy);   // dL/dmean2D.x (NDC units)
-            dst[1] = -o * half_H * (g2.x * sy + g.w * sx);  // dL/dmean2D.y
+            dst[0] = -o * half_W * (ca * sx + cb * sy);   // dL/dmean2D.x (NDC units)
+            dst[1] = -o * half_H * (cc * sy + cb * sx);  // dL/dmean2D.y
             dst[2] = -0.5f * o * sxx;                       // dL/dconic a
             dst[3] = -0.5f * o * sxy;                       // dL/dconic b
             dst[4] = -0.5f * o * syy;                       // dL/dconic c
@@ -246,6 +248,7 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
         if (b + 1 < rounds) prefetch(b + 1);
         unsigned long long m = __ballot(hit);
         if (m == 0) continue;
+        const float Dx_st = q0.x - QCX, Dy_st = q0.y - QCY;  // kept in registers: the flush metadata reads them by lane
         // ---- stage the hits (slot = lane)
         if (hit) {
             const float4* r4 = reinterpret_cast<const float4*>(rec + id);
@@ -253,8 +256,9 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
             int x0, y0, x1, y1;
             listed_rect(q0.x, q0.y, radii[id], q2.z, q2.w, cull, gx, gy, x0, y0, x1, y1);
             const uint32_t inst = goff[id] + (uint32_t)((t.ty - y0) * (x1 - x0) + (t.tx - x0));
-            s_geo[lane] = q0;
-            s_geo2[lane] = make_float4(q1.x, q1.y, __uint_as_float(inst * 4u + (uint32_t)t.q), 0.f);
+            const PolyCoef pc = poly_coefs(q0.x, q0.y, q0.z, q0.w, q1.x, QCX, QCY);
+            s_geo[lane] = make_float4(pc.A0, pc.A1, pc.A2, pc.A3);
+            s_geo2[lane] = make_float4(pc.A4, pc.A5, q1.y, __uint_as_float(inst * 4u + (uint32_t)t.q));
             s_feat[lane * NF4] = make_float4(q1.w, q2.x, q2.y, q1.z);
             const float* srow = semantics + (size_t)id * S;
             if ((S & 3) == 0) {
@@ -280,7 +284,7 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
             const int pos0 = n_proc - 1 - (b * BATCH + j);  // 0-based list position
             const float4 g = s_geo[j];
             const float4 g2 = s_geo2[j];
-            const PairEval e = eval_pair(g.x, g.y, g.z, g.w, g2.x, g2.y, t.pxf, t.pyf);
+            const PairEval e = eval_poly(g.x, g.y, g.z, g.w, g2.x, g2.y, g2.z, pu, pv);
             const bool c = (pos0 < last_contributor) && e.hit;
             if (!__any(c)) continue;
 
@@ -313,9 +317,12 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
             }
             s_t[nslot * TSTRIDE + lane] = wgt;
             s_t[(GROUP + nslot) * TSTRIDE + lane] = hval;
+            // wave-uniform reads of the staging lane's registers (outside the lane-0 branch: every lane is active here)
+            const float Dxj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Dx_st), j));
+            const float Dyj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Dy_st), j));
             if (lane == 0) {  // group members may outlive this batch's staging slots: keep their metadata
-                s_gmeta[nslot * 2] = g;
-                s_gmeta[nslot * 2 + 1] = g2;
+                s_gmeta[nslot * 2] = make_float4(Dxj, Dyj, g.w, g2.x);
+                s_gmeta[nslot * 2 + 1] = make_float4(g2.y, g2.z, g2.w, 0.f);
             }
             nslot++;
             if (nslot == GROUP) {

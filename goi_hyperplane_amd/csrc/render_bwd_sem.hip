@@ -34,8 +34,8 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
     const uint32_t* __restrict__ counters) {
     const bool cull = counters[COUNTER_CULL] != 0;  // the rectangles the forward listed
     constexpr int NSEM = 4 * S4, NB = (NSEM + 15) / 16;
-    __shared__ float4 s_geo[SBATCH];          // x, y, conic a, b
-    __shared__ float4 s_geo2[SBATCH];         // conic c, opacity, slot index (bits), -
+    __shared__ float4 s_geo[SBATCH];          // A0..A3 of the quadrant-centred exponent polynomial
+    __shared__ float4 s_geo2[SBATCH];         // A4, A5, opacity, slot index (bits)
     __shared__ float s_t[SGROUP * STSTRIDE];  // w columns, [member][pixel]
     __shared__ uint32_t s_slot[SGROUP];
 
@@ -43,6 +43,8 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
     if (t.tile < 0) return;
     const int lane = t.lane;
     const uint2 range = ranges[t.tile];
+    const float QCX = t.QX0 + 3.5f, QCY = t.QY0 + 3.5f;  // quadrant centre
+    const float pu = t.pxf - QCX, pv = t.pyf - QCY;      // this lane's pixel, quadrant-centred
     const size_t HW = (size_t)W * H;
     const size_t pix_id = (size_t)W * t.py + t.px;
     const int last_contributor = t.inside ? (int)n_contrib[pix_id] : 0;
@@ -125,8 +127,9 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
             int x0, y0, x1, y1;
             listed_rect(q0.x, q0.y, radii[id], q2.z, q2.w, cull, gx, gy, x0, y0, x1, y1);
             const uint32_t inst = goff[id] + (uint32_t)((t.ty - y0) * (x1 - x0) + (t.tx - x0));
-            s_geo[lane] = q0;
-            s_geo2[lane] = make_float4(q1.x, q1.y, __uint_as_float(inst * 4u + (uint32_t)t.q), 0.f);
+            const PolyCoef pc = poly_coefs(q0.x, q0.y, q0.z, q0.w, q1.x, QCX, QCY);
+            s_geo[lane] = make_float4(pc.A0, pc.A1, pc.A2, pc.A3);
+            s_geo2[lane] = make_float4(pc.A4, pc.A5, q1.y, __uint_as_float(inst * 4u + (uint32_t)t.q));
         }
         __builtin_amdgcn_wave_barrier();
         while (m) {
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
             const int pos0 = n_proc - 1 - (b * SBATCH + j);
             const float4 g = s_geo[j];
             const float4 g2 = s_geo2[j];
-            const PairEval e = eval_pair(g.x, g.y, g.z, g.w, g2.x, g2.y, t.pxf, t.pyf);
+            const PairEval e = eval_poly(g.x, g.y, g.z, g.w, g2.x, g2.y, g2.z, pu, pv);
             const bool c = (pos0 < last_contributor) && e.hit;
             if (!__any(c)) continue;
             const float one_m_a = 1.f - e.alpha;
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
                 wgt = e.alpha * Tn;
             }
             s_t[nslot * STSTRIDE + lane] = wgt;
-            if (lane == 0) s_slot[nslot] = __float_as_uint(g2.z);
+            if (lane == 0) s_slot[nslot] = __float_as_uint(g2.w);
             nslot++;
             if (nslot == SGROUP) {
                 flush_group(SGROUP);

@@ -243,7 +243,10 @@ __global__ __launch_bounds__(256) void render_bwd_tile_k(
             const int pos0 = n_proc - 1 - (b * BATCH + j);  // 0-based list position
             const float4 g = s_geo[j];
             const float4 g2 = s_geo2[j];
-            const PairEval e = eval_pair(g.x, g.y, g.z, g.w, g2.x, g2.y, t.pxf, t.pyf);
+            // same coefficients, bit for bit, as the ones the forward staged for this (quadrant, Gaussian)
+            const PolyCoef pc = poly_coefs(g.x, g.y, g.z, g.w, g2.x, QX0 + 3.5f, QY0 + 3.5f);
+            const PairEval e = eval_poly(pc.A0, pc.A1, pc.A2, pc.A3, pc.A4, pc.A5, g2.y, t.pxf - (QX0 + 3.5f),
+                                         t.pyf - (QY0 + 3.5f));
             const bool c = (pos0 < last_contributor) && e.hit;
             if (!__any(c)) continue;
 

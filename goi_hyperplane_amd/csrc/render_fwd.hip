@@ -34,14 +34,16 @@ __global__ __launch_bounds__(64) void render_fwd_k(const uint2* __restrict__ ran
                                                    float* __restrict__ gau_sem, int* __restrict__ num_gsem) {
     constexpr int NF4 = TRACE ? 1 : 1 + S4;  // float4 words staged per Gaussian: (r,g,b,depth) + semantics
     constexpr int NSEM = TRACE ? 0 : 4 * S4;
-    __shared__ float4 s_geo[64];
-    __shared__ float2 s_geo2[64];
+    __shared__ float4 s_geo[64];   // A0..A3 of the quadrant-centred exponent polynomial (blend_common.h)
+    __shared__ float4 s_geo2[64];  // A4, A5, opacity, -
     __shared__ float4 s_feat[64 * NF4];
     __shared__ uint32_t s_id[TRACE ? 64 : 1];
 
     const QuadGeom t = quad_geom(W, H, gx, n_quads);
     if (t.tile < 0) return;
     const uint2 range = ranges[t.tile];
+    const float QCX = t.QX0 + 3.5f, QCY = t.QY0 + 3.5f;  // quadrant centre
+    const float pu = t.pxf - QCX, pv = t.pyf - QCY;      // this lane's pixel, quadrant-centred
     const int len = (int)(range.y - range.x);
     const int rounds = (len + 63) / 64;
     const size_t HW = (size_t)W * H;
@@ -83,8 +85,9 @@ __global__ __launch_bounds__(64) void render_fwd_k(const uint2* __restrict__ ran
         if (hit) {
             const float4* r4 = reinterpret_cast<const float4*>(rec + id);
             const float4 q1 = r4[1];
-            s_geo[lane] = q0;
-            s_geo2[lane] = make_float2(q1.x, q1.y);
+            const PolyCoef pc = poly_coefs(q0.x, q0.y, q0.z, q0.w, q1.x, QCX, QCY);
+            s_geo[lane] = make_float4(pc.A0, pc.A1, pc.A2, pc.A3);
+            s_geo2[lane] = make_float4(pc.A4, pc.A5, q1.y, 0.f);
             s_feat[lane * NF4] = make_float4(q1.w, q2.x, q2.y, q1.z);
             if constexpr (TRACE) {
                 s_id[lane] = id;
@@ -157,9 +160,9 @@ __global__ __launch_bounds__(64) void render_fwd_k(const uint2* __restrict__ ran
                 const int j1 = has1 ? __builtin_ctzll(m) : j0;
                 if (has1) m &= m - 1;
                 const float4 ga = s_geo[j0], gb = s_geo[j1];
-                const float2 ha = s_geo2[j0], hb = s_geo2[j1];
-                const PairEval e0 = eval_pair(ga.x, ga.y, ga.z, ga.w, ha.x, ha.y, t.pxf, t.pyf);
-                const PairEval e1 = eval_pair(gb.x, gb.y, gb.z, gb.w, hb.x, hb.y, t.pxf, t.pyf);
+                const float4 ha = s_geo2[j0], hb = s_geo2[j1];
+                const PairEval e0 = eval_poly(ga.x, ga.y, ga.z, ga.w, ha.x, ha.y, ha.z, pu, pv);
+                const PairEval e1 = eval_poly(gb.x, gb.y, gb.z, gb.w, hb.x, hb.y, hb.z, pu, pv);
                 apply(j0, e0, true);
                 apply(j1, e1, has1);
                 if (__all(done)) m = 0;
@@ -169,8 +172,8 @@ __global__ __launch_bounds__(64) void render_fwd_k(const uint2* __restrict__ ran
                 const int j = __builtin_ctzll(m);
                 m &= m - 1;
                 const float4 g = s_geo[j];
-                const float2 g2 = s_geo2[j];
-                const PairEval e = eval_pair(g.x, g.y, g.z, g.w, g2.x, g2.y, t.pxf, t.pyf);
+                const float4 g2 = s_geo2[j];
+                const PairEval e = eval_poly(g.x, g.y, g.z, g.w, g2.x, g2.y, g2.z, pu, pv);
                 apply(j, e, true);
                 if (__all(done)) m = 0;
             }
