@@ -28,7 +28,7 @@ UNITS = {
     "api.hip": [],
     "scan_sort.hip": [],
     "preprocess.hip": ["-ffp-contract=off"],
-    "render_fwd.hip": [],
+    "render_fwd.hip": ["-fno-slp-vectorize"],
     "render_bwd.hip": [],
     "render_bwd_tile.hip": [],
     "render_bwd_sem.hip": [],

@@ -9,50 +9,61 @@ constexpr float kTMin = 0.0001f;
 constexpr float kAlphaMax = 0.99f;
 constexpr float kPowerTol = 1e-4f;
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 // alpha evaluation shared by forward, backward and trace so that all three agree on which
 // (pixel, Gaussian) pairs contribute (guards of CR/forward.cu:341-351, CR/backward.cu:535-542).
 struct PairEval {
-    float power, G, alpha;
+    float E;      // opacity * exp(power), before the 0.99 clamp (CR/forward.cu:350: alpha = min(0.99, E))
+    float alpha;  // min(0.99, E)
     bool hit;
 };
 
-// The exponent of a Gaussian over one 8x8 quadrant as a quadratic in QUADRANT-CENTRED pixel coordinates
-// (u, v) in [-3.5, 3.5]:  power(u, v) = A0 + u (A1 + A3 u + A4 v) + v (A2 + A5 v).
-// With dx = Dx - u, dy = Dy - v (Dx, Dy: Gaussian centre relative to the quadrant centre) this is exactly
-// -0.5 (a dx^2 + c dy^2) - b dx dy (CR/forward.cu:341-345).  The six coefficients are formed once per
-// (quadrant, Gaussian) by the lane that stages the Gaussian; every pixel then needs 5 FMAs instead of the 11
-// instructions of the direct form.  Centring keeps all terms small (|u|, |v| <= 3.5), so the rounding error of
-// the expanded form stays at the 1e-6 level.  Forward, trace and every backward kernel evaluate a pair ONLY through
-// these two functions, spelled with explicit fmaf so that all of them take identical contribution decisions.
+// alpha of a Gaussian over one 8x8 quadrant.  With (u, v) in [-3.5, 3.5] the QUADRANT-CENTRED pixel coordinates
+// and dx = Dx - u, dy = Dy - v (Dx, Dy: Gaussian centre relative to the quadrant centre)
+//     log2(opacity * exp(-0.5 (a dx^2 + c dy^2) - b dx dy))  =  A0 + u (A1 + A3 u + A4 v) + v (A2 + A5 v)
+// (CR/forward.cu:341-350 with log2(e) and log2(opacity) folded into the coefficients).  The coefficients are
+// formed once per (quadrant, Gaussian) by the lane that stages the Gaussian; a pixel then spends one packed FMA,
+// three FMAs and one v_exp_f32 instead of the 11 instructions + multiply + exp + multiply of the direct form.
+// Centring keeps every term small (|u|, |v| <= 3.5): the rounding error of the expanded exponent is <= ~5e-5
+// for the sharpest admissible conic (a = c = 1/0.3) and ~1e-6 typically.  Forward, trace and every backward kernel
+// evaluate a pair ONLY through these two functions, spelled with explicit FMAs, so that all of them take
+// bit-identical contribution decisions.
 //
 // The reference skips a pair whose exponent is > 0 (CR/forward.cu:346).  For a positive-definite conic that can
 // only be a rounding artefact next to the Gaussian's centre, where the exact exponent is ~0; the expanded form
-// rounds differently there (|error| <= ~5e-5 for the sharpest admissible conic, a = c = 1/0.3), so the guard is
-// applied with a tolerance: power <= kPowerTol contributes (with G = exp(power) <= 1.0001).  A conic that is NOT
-// positive definite still fails the guard wherever its exponent is meaningfully positive.
+// rounds differently there, so the guard is applied with a tolerance: power <= kPowerTol contributes (with
+// exp(power) <= 1.0001).  In the folded form the guard reads  A0 + ... <= lim = log2(opacity) + kPowerTol log2(e).
 struct PolyCoef {
-    float A0, A1, A2, A3, A4, A5;
+    f32x2 A35, A12;  // (A3, A5), (A1, A2): operands of the packed FMA
+    float A0, A4, lim;
 };
-__device__ __forceinline__ PolyCoef poly_coefs(float gx_, float gy_, float ca, float cb, float cc, float qcx, float qcy) {
+constexpr float kLog2e = 1.4426950408889634f;
+__device__ __forceinline__ PolyCoef poly_coefs(float gx_, float gy_, float ca, float cb, float cc, float o, float qcx,
+                                               float qcy) {
     const float Dx = gx_ - qcx, Dy = gy_ - qcy;
+    const float a1 = fmaf(ca, Dx, cb * Dy);
+    const float a2 = fmaf(cc, Dy, cb * Dx);
+    const float a0 = -0.5f * fmaf(Dx, a1, Dy * a2);  // -0.5 (a Dx^2 + 2 b Dx Dy + c Dy^2)
+    const float lo = __builtin_amdgcn_logf(o);       // v_log_f32 = log2; opacity 0 gives -inf: never contributes
     PolyCoef p;
-    p.A1 = fmaf(ca, Dx, cb * Dy);
-    p.A2 = fmaf(cc, Dy, cb * Dx);
-    p.A0 = -0.5f * fmaf(Dx, p.A1, Dy * p.A2);  // -0.5 (a Dx^2 + 2 b Dx Dy + c Dy^2)
-    p.A3 = -0.5f * ca;
-    p.A4 = -cb;
-    p.A5 = -0.5f * cc;
+    p.A0 = fmaf(kLog2e, a0, lo);
+    p.A12 = f32x2{kLog2e * a1, kLog2e * a2};
+    p.A35 = f32x2{(-0.5f * kLog2e) * ca, (-0.5f * kLog2e) * cc};
+    p.A4 = -kLog2e * cb;
+    p.lim = lo + kPowerTol * kLog2e;
     return p;
 }
-__device__ __forceinline__ PairEval eval_poly(float A0, float A1, float A2, float A3, float A4, float A5, float o, float u,
-                                              float v) {
+// uv = this lane's (u, v)
+__device__ __forceinline__ PairEval eval_poly(f32x2 A35, f32x2 A12, float A0, float A4, float lim, f32x2 uv) {
     PairEval e;
-    const float t1 = fmaf(A4, v, fmaf(A3, u, A1));
-    const float t2 = fmaf(A5, v, A2);
-    e.power = fmaf(v, t2, fmaf(u, t1, A0));
-    e.G = __expf(e.power);
-    e.alpha = fminf(kAlphaMax, o * e.G);
-    e.hit = (e.power <= kPowerTol) && (e.alpha >= kAlphaMin);
+    const f32x2 t = __builtin_elementwise_fma(A35, uv, A12);  // (A3 u + A1, A5 v + A2)
+    const float t1 = fmaf(A4, uv.y, t.x);
+    const float P = fmaf(uv.y, t.y, fmaf(uv.x, t1, A0));
+    e.E = __builtin_amdgcn_exp2f(P);
+    e.alpha = fminf(kAlphaMax, e.E);
+    e.hit = (P <= lim) && (e.alpha >= kAlphaMin);
     return e;
 }
 

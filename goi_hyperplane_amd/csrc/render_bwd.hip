@@ -39,8 +39,6 @@ namespace goi {
 
 namespace {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // Up to 16 semantic channels the kernel fits 128 VGPRs without spilling and 8 KB of LDS per wave:
 // 4 waves per SIMD.  Wider features (17..32 channels) need ~200 VGPRs: 2 waves per SIMD.
@@ -76,11 +74,11 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
     using Cfg = BwdCfg<S4>;
     const bool cull = counters[COUNTER_CULL] != 0;  // the rectangles the forward listed
     constexpr int NF4 = Cfg::NF4, NSEM = Cfg::NSEM, NCH = Cfg::NCH, NB = Cfg::NB;
-    __shared__ float4 s_geo[BATCH];       // A0..A3 of the quadrant-centred exponent polynomial (blend_common.h)
-    __shared__ float4 s_geo2[BATCH];      // A4, A5, opacity, slot index (bits)
+    __shared__ f32x4 s_geo[BATCH];        // (A3, A5, A1, A2) of the quadrant-centred log2-alpha polynomial (blend_common.h)
+    __shared__ f32x4 s_geo2[BATCH];       // (A0, A4, lim, slot index (bits))
     __shared__ float4 s_feat[BATCH * NF4];  // (r,g,b,depth), semantics...
     __shared__ float s_t[2 * GROUP * TSTRIDE];  // [row][pixel]: rows 0..7 = w of slot, rows 8..15 = h of slot
-    __shared__ float4 s_gmeta[GROUP * 2];    // per group member: (Dx, Dy, A3, A4), (A5, opacity, slot bits, -)
+    __shared__ f32x4 s_gmeta[GROUP * 2];     // per group member: (Dx, Dy, A3, A5), (A0, A4, lim, slot bits)
 
     const QuadGeom t = quad_geom(W, H, gx, n_quads);
     if (t.tile < 0) return;
@@ -160,7 +158,7 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
         __builtin_amdgcn_wave_barrier();
     }
     const float QCX = t.QX0 + 3.5f, QCY = t.QY0 + 3.5f;  // quadrant centre (pixel coordinates)
-    const float pu = t.pxf - QCX, pv = t.pyf - QCY;      // this lane's pixel, quadrant-centred
+    const f32x2 uv = {t.pxf - QCX, t.pyf - QCY};         // this lane's pixel, quadrant-centred
     const float half_W = 0.5f * W, half_H = 0.5f * H;
 
     // software prefetch of the next batch's id / position / box (one list entry per lane)
@@ -203,7 +201,7 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
             const int row = 4 * kq + r;
             if (row >= GROUP && mm >= 4 && mm < 12) s_t[(row - GROUP) * 8 + (mm - 4)] = accx[r];  // moments -> exchange area
             if (row < cnt && !(exp_flags & 2)) {
-                float* dst = rows + (size_t)__float_as_uint(s_gmeta[row * 2 + 1].z) * row_floats;
+                float* dst = rows + (size_t)__float_as_uint(s_gmeta[row * 2 + 1].w) * row_floats;
 #pragma unroll
                 for (int nb = 0; nb < NB; nb++) {
                     const int ch = nb * 16 + mm;
@@ -217,25 +215,28 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
         if (lane < cnt && !(exp_flags & 2)) {
             const float4 m03 = *reinterpret_cast<const float4*>(&s_t[lane * 8]);
             const float2 m45 = *reinterpret_cast<const float2*>(&s_t[lane * 8 + 4]);
-            const float4 g = s_gmeta[lane * 2];
-            const float4 g2 = s_gmeta[lane * 2 + 1];
-            const uint32_t slot = __float_as_uint(g2.z);  // (emit-order instance) * 4 + quadrant
+            const f32x4 g = s_gmeta[lane * 2];
+            const f32x4 g2 = s_gmeta[lane * 2 + 1];
+            const uint32_t slot = __float_as_uint(g2.w);  // (emit-order instance) * 4 + quadrant
             const float Dx = g.x, Dy = g.y;               // centre - quadrant centre: dx = Dx - u, dy = Dy - v
-            const float ca = -2.f * g.z, cb = -g.w, cc = -2.f * g2.x;  // conic back from A3, A4, A5 (exact)
+            // conic back from A3, A4, A5 (= -log2e/2 a, -log2e b, -log2e/2 c) and 1/opacity from lim
+            constexpr float kLn2 = 0.6931471805599453f;
+            const float ca = (-2.f * kLn2) * g.z, cb = -kLn2 * g2.y, cc = (-2.f * kLn2) * g.w;
+            const float inv_o = __builtin_amdgcn_exp2f(kPowerTol * kLog2e - g2.z);
             const float m0 = m03.x, mu = m03.y, mv = m03.z, muu = m03.w, muv = m45.x, mvv = m45.y;
             const float sx = Dx * m0 - mu;                             // sum h dx
             const float sy = Dy * m0 - mv;                             // sum h dy
             const float sxx = Dx * Dx * m0 - 2.f * Dx * mu + muu;      // sum h dx^2
             const float sxy = Dx * Dy * m0 - Dx * mv - Dy * mu + muv;  // sum h dx dy
             const float syy = Dy * Dy * m0 - 2.f * Dy * mv + mvv;      // sum h dy^2
-            const float o = g2.y;
             float* dst = rows + (size_t)slot * row_floats + NCH;
-            dst[0] = -o * half_W * (ca * sx + cb * sy);   // dL/dmean2D.x (NDC units)
-            dst[1] = -o * half_H * (cc * sy + cb * sx);  // dL/dmean2D.y
-            dst[2] = -0.5f * o * sxx;                       // dL/dconic a
-            dst[3] = -0.5f * o * sxy;                       // dL/dconic b
-            dst[4] = -0.5f * o * syy;                       // dL/dconic c
-            dst[5] = m0;                                    // dL/dopacity = sum G dL/dalpha
+            // (the moments already carry the factor `opacity` of dL/dG = opacity dL/dalpha)
+            dst[0] = -half_W * (ca * sx + cb * sy);  // dL/dmean2D.x (NDC units)
+            dst[1] = -half_H * (cc * sy + cb * sx);  // dL/dmean2D.y
+            dst[2] = -0.5f * sxx;                    // dL/dconic a
+            dst[3] = -0.5f * sxy;                    // dL/dconic b
+            dst[4] = -0.5f * syy;                    // dL/dconic c
+            dst[5] = m0 * inv_o;                     // dL/dopacity = sum G dL/dalpha
             flags[slot] = 1;
         }
         __builtin_amdgcn_wave_barrier();
@@ -256,14 +257,19 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
             int x0, y0, x1, y1;
             listed_rect(q0.x, q0.y, radii[id], q2.z, q2.w, cull, gx, gy, x0, y0, x1, y1);
             const uint32_t inst = goff[id] + (uint32_t)((t.ty - y0) * (x1 - x0) + (t.tx - x0));
-            const PolyCoef pc = poly_coefs(q0.x, q0.y, q0.z, q0.w, q1.x, QCX, QCY);
-            s_geo[lane] = make_float4(pc.A0, pc.A1, pc.A2, pc.A3);
-            s_geo2[lane] = make_float4(pc.A4, pc.A5, q1.y, __uint_as_float(inst * 4u + (uint32_t)t.q));
-            s_feat[lane * NF4] = make_float4(q1.w, q2.x, q2.y, q1.z);
+            const PolyCoef pc = poly_coefs(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, QCX, QCY);
+            // the staging addresses are formed HERE from an opaque copy of the lane id: hoisted out of the batch
+            // loop they cost one live VGPR per destination (the compiler spilled four of them to scratch)
+            int sl = lane;
+            asm volatile("" : "+v"(sl));
+            s_geo[sl] = f32x4{pc.A35.x, pc.A35.y, pc.A12.x, pc.A12.y};
+            s_geo2[sl] = f32x4{pc.A0, pc.A4, pc.lim, __uint_as_float(inst * 4u + (uint32_t)t.q)};
+            float4* fdst = &s_feat[sl * NF4];
+            fdst[0] = make_float4(q1.w, q2.x, q2.y, q1.z);
             const float* srow = semantics + (size_t)id * S;
             if ((S & 3) == 0) {
 #pragma unroll
-                for (int i = 0; i < S4; i++) s_feat[lane * NF4 + 1 + i] = reinterpret_cast<const float4*>(srow)[i];
+                for (int i = 0; i < S4; i++) fdst[1 + i] = reinterpret_cast<const float4*>(srow)[i];
             } else {
 #pragma unroll
                 for (int i = 0; i < S4; i++) {
@@ -272,7 +278,7 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
                     v.y = (4 * i + 1 < S) ? srow[4 * i + 1] : 0.f;
                     v.z = (4 * i + 2 < S) ? srow[4 * i + 2] : 0.f;
                     v.w = (4 * i + 3 < S) ? srow[4 * i + 3] : 0.f;
-                    s_feat[lane * NF4 + 1 + i] = v;
+                    fdst[1 + i] = v;
                 }
             }
         }
@@ -282,11 +288,11 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
             const int j = __builtin_ctzll(m);
             m &= m - 1;
             const int pos0 = n_proc - 1 - (b * BATCH + j);  // 0-based list position
-            const float4 g = s_geo[j];
-            const float4 g2 = s_geo2[j];
-            const PairEval e = eval_poly(g.x, g.y, g.z, g.w, g2.x, g2.y, g2.z, pu, pv);
+            const f32x4 g = s_geo[j];
+            const f32x4 g2 = s_geo2[j];
+            const PairEval e = eval_poly(g.xy, g.zw, g2.x, g2.y, g2.z, uv);
             const bool c = (pos0 < last_contributor) && e.hit;
-            if (!__any(c)) continue;
+            if (__builtin_amdgcn_ballot_w64(c) == 0) continue;  // (the builtin takes the bool: no int round trip)
 
             // <feature, dL/dpixel> as packed fp32 FMAs (v_pk_fma_f32: two channels per instruction)
             f32x2 dot2 = {0.f, 0.f};
@@ -313,7 +319,7 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
                 R = e.alpha * dotv + one_m_a * R;
                 T = Tn;
                 wgt = e.alpha * Tn;
-                hval = e.G * dL_dopa;
+                hval = e.E * dL_dopa;  // opacity * G * dL/dalpha: the moments carry the factor `opacity`
             }
             s_t[nslot * TSTRIDE + lane] = wgt;
             s_t[(GROUP + nslot) * TSTRIDE + lane] = hval;
@@ -321,8 +327,8 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
             const float Dxj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Dx_st), j));
             const float Dyj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Dy_st), j));
             if (lane == 0) {  // group members may outlive this batch's staging slots: keep their metadata
-                s_gmeta[nslot * 2] = make_float4(Dxj, Dyj, g.w, g2.x);
-                s_gmeta[nslot * 2 + 1] = make_float4(g2.y, g2.z, g2.w, 0.f);
+                s_gmeta[nslot * 2] = f32x4{Dxj, Dyj, g.x, g.y};
+                s_gmeta[nslot * 2 + 1] = g2;
             }
             nslot++;
             if (nslot == GROUP) {

@@ -19,7 +19,6 @@ namespace goi {
 
 namespace {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int SGROUP = 16;
 constexpr int SBATCH = 32;
@@ -34,8 +33,8 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
     const uint32_t* __restrict__ counters) {
     const bool cull = counters[COUNTER_CULL] != 0;  // the rectangles the forward listed
     constexpr int NSEM = 4 * S4, NB = (NSEM + 15) / 16;
-    __shared__ float4 s_geo[SBATCH];          // A0..A3 of the quadrant-centred exponent polynomial
-    __shared__ float4 s_geo2[SBATCH];         // A4, A5, opacity, slot index (bits)
+    __shared__ f32x4 s_geo[SBATCH];           // (A3, A5, A1, A2) of the quadrant-centred log2-alpha polynomial
+    __shared__ f32x4 s_geo2[SBATCH];          // (A0, A4, lim, slot index (bits))
     __shared__ float s_t[SGROUP * STSTRIDE];  // w columns, [member][pixel]
     __shared__ uint32_t s_slot[SGROUP];
 
@@ -44,7 +43,7 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
     const int lane = t.lane;
     const uint2 range = ranges[t.tile];
     const float QCX = t.QX0 + 3.5f, QCY = t.QY0 + 3.5f;  // quadrant centre
-    const float pu = t.pxf - QCX, pv = t.pyf - QCY;      // this lane's pixel, quadrant-centred
+    const f32x2 uv = {t.pxf - QCX, t.pyf - QCY};         // this lane's pixel, quadrant-centred
     const size_t HW = (size_t)W * H;
     const size_t pix_id = (size_t)W * t.py + t.px;
     const int last_contributor = t.inside ? (int)n_contrib[pix_id] : 0;
@@ -127,20 +126,20 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
             int x0, y0, x1, y1;
             listed_rect(q0.x, q0.y, radii[id], q2.z, q2.w, cull, gx, gy, x0, y0, x1, y1);
             const uint32_t inst = goff[id] + (uint32_t)((t.ty - y0) * (x1 - x0) + (t.tx - x0));
-            const PolyCoef pc = poly_coefs(q0.x, q0.y, q0.z, q0.w, q1.x, QCX, QCY);
-            s_geo[lane] = make_float4(pc.A0, pc.A1, pc.A2, pc.A3);
-            s_geo2[lane] = make_float4(pc.A4, pc.A5, q1.y, __uint_as_float(inst * 4u + (uint32_t)t.q));
+            const PolyCoef pc = poly_coefs(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, QCX, QCY);
+            s_geo[lane] = f32x4{pc.A35.x, pc.A35.y, pc.A12.x, pc.A12.y};
+            s_geo2[lane] = f32x4{pc.A0, pc.A4, pc.lim, __uint_as_float(inst * 4u + (uint32_t)t.q)};
         }
         __builtin_amdgcn_wave_barrier();
         while (m) {
             const int j = __builtin_ctzll(m);
             m &= m - 1;
             const int pos0 = n_proc - 1 - (b * SBATCH + j);
-            const float4 g = s_geo[j];
-            const float4 g2 = s_geo2[j];
-            const PairEval e = eval_poly(g.x, g.y, g.z, g.w, g2.x, g2.y, g2.z, pu, pv);
+            const f32x4 g = s_geo[j];
+            const f32x4 g2 = s_geo2[j];
+            const PairEval e = eval_poly(g.xy, g.zw, g2.x, g2.y, g2.z, uv);
             const bool c = (pos0 < last_contributor) && e.hit;
-            if (!__any(c)) continue;
+            if (__builtin_amdgcn_ballot_w64(c) == 0) continue;  // (the builtin takes the bool: no int round trip)
             const float one_m_a = 1.f - e.alpha;
             const float inv = __builtin_amdgcn_rcpf(one_m_a);
             const float Tn = T * inv;

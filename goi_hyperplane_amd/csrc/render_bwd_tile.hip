@@ -29,7 +29,6 @@ namespace goi {
 
 namespace {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BATCH = 64;    // Gaussians staged per round
 constexpr int GROUP = 16;    // contributing Gaussians per MFMA group (the M of 16x16x4)
@@ -244,11 +243,11 @@ __global__ __launch_bounds__(256) void render_bwd_tile_k(
             const float4 g = s_geo[j];
             const float4 g2 = s_geo2[j];
             // same coefficients, bit for bit, as the ones the forward staged for this (quadrant, Gaussian)
-            const PolyCoef pc = poly_coefs(g.x, g.y, g.z, g.w, g2.x, QX0 + 3.5f, QY0 + 3.5f);
-            const PairEval e = eval_poly(pc.A0, pc.A1, pc.A2, pc.A3, pc.A4, pc.A5, g2.y, t.pxf - (QX0 + 3.5f),
-                                         t.pyf - (QY0 + 3.5f));
+            const PolyCoef pc = poly_coefs(g.x, g.y, g.z, g.w, g2.x, g2.y, QX0 + 3.5f, QY0 + 3.5f);
+            const PairEval e = eval_poly(pc.A35, pc.A12, pc.A0, pc.A4, pc.lim,
+                                         f32x2{t.pxf - (QX0 + 3.5f), t.pyf - (QY0 + 3.5f)});
             const bool c = (pos0 < last_contributor) && e.hit;
-            if (!__any(c)) continue;
+            if (__builtin_amdgcn_ballot_w64(c) == 0) continue;  // (the builtin takes the bool: no int round trip)
 
             const float4 f0 = s_feat[j * NF4];
             float dotv = f0.x * dLch[0] + f0.y * dLch[1] + f0.z * dLch[2] + f0.w * dLch[3] + dLa;
@@ -267,7 +266,7 @@ __global__ __launch_bounds__(256) void render_bwd_tile_k(
                 R = e.alpha * dotv + one_m_a * R;
                 T = Tn;
                 wgt = e.alpha * Tn;
-                hval = e.G * dL_dopa;
+                hval = e.E * dL_dopa;  // opacity * G * dL/dalpha: the moments carry the factor `opacity`
             }
             wt[nslot * TSTRIDE + t.lane] = wgt;
             ht[nslot * TSTRIDE + t.lane] = hval;
@@ -312,13 +311,12 @@ __global__ __launch_bounds__(256) void render_bwd_tile_k(
                 const float sxx = Dx * Dx * m0 - 2.f * Dx * mu + muu;      // sum h dx^2
                 const float sxy = Dx * Dy * m0 - Dx * mv - Dy * mu + muv;  // sum h dx dy
                 const float syy = Dy * Dy * m0 - 2.f * Dy * mv + mvv;      // sum h dy^2
-                const float o = g2.y;
-                atomicAdd(dL_dmean2D + (size_t)id * 3 + 0, -o * (0.5f * W) * (g.z * sx + g.w * sy));
-                atomicAdd(dL_dmean2D + (size_t)id * 3 + 1, -o * (0.5f * H) * (g2.x * sy + g.w * sx));
-                atomicAdd(dL_dconic + (size_t)id * 4 + 0, -0.5f * o * sxx);
-                atomicAdd(dL_dconic + (size_t)id * 4 + 1, -0.5f * o * sxy);
-                atomicAdd(dL_dconic + (size_t)id * 4 + 3, -0.5f * o * syy);
-                atomicAdd(dL_dopacity + id, m0);
+                atomicAdd(dL_dmean2D + (size_t)id * 3 + 0, -(0.5f * W) * (g.z * sx + g.w * sy));
+                atomicAdd(dL_dmean2D + (size_t)id * 3 + 1, -(0.5f * H) * (g2.x * sy + g.w * sx));
+                atomicAdd(dL_dconic + (size_t)id * 4 + 0, -0.5f * sxx);
+                atomicAdd(dL_dconic + (size_t)id * 4 + 1, -0.5f * sxy);
+                atomicAdd(dL_dconic + (size_t)id * 4 + 3, -0.5f * syy);
+                atomicAdd(dL_dopacity + id, m0 / g2.y);  // a contributing Gaussian has opacity >= 1/255
             }
         }
     }

@@ -34,29 +34,35 @@ __global__ __launch_bounds__(64) void render_fwd_k(const uint2* __restrict__ ran
                                                    float* __restrict__ gau_sem, int* __restrict__ num_gsem) {
     constexpr int NF4 = TRACE ? 1 : 1 + S4;  // float4 words staged per Gaussian: (r,g,b,depth) + semantics
     constexpr int NSEM = TRACE ? 0 : 4 * S4;
-    __shared__ float4 s_geo[64];   // A0..A3 of the quadrant-centred exponent polynomial (blend_common.h)
-    __shared__ float4 s_geo2[64];  // A4, A5, opacity, -
+    __shared__ f32x4 s_geo[64];   // (A3, A5, A1, A2) of the quadrant-centred log2-alpha polynomial (blend_common.h)
+    __shared__ f32x4 s_geo2[64];  // (A0, A4, lim, -)
     __shared__ float4 s_feat[64 * NF4];
+    const f32x4* s_feat4 = reinterpret_cast<const f32x4*>(s_feat);
     __shared__ uint32_t s_id[TRACE ? 64 : 1];
 
     const QuadGeom t = quad_geom(W, H, gx, n_quads);
     if (t.tile < 0) return;
     const uint2 range = ranges[t.tile];
     const float QCX = t.QX0 + 3.5f, QCY = t.QY0 + 3.5f;  // quadrant centre
-    const float pu = t.pxf - QCX, pv = t.pyf - QCY;      // this lane's pixel, quadrant-centred
+    const f32x2 uv = {t.pxf - QCX, t.pyf - QCY};         // this lane's pixel, quadrant-centred
     const int len = (int)(range.y - range.x);
     const int rounds = (len + 63) / 64;
     const size_t HW = (size_t)W * H;
     const size_t pix_id = (size_t)W * t.py + t.px;
     const int lane = t.lane;
 
-    bool done = !t.inside;
-    float T = 1.0f;
+    float T = 1.0f;                         // transmittance that is written out (frozen once the pixel is done)
+    float T_live = t.inside ? 1.0f : 0.0f;  // == T while the pixel is live, 0 once it is done: a finished pixel fails
+                                            // the T(1-alpha) >= 1e-4 test by itself, no separate flag to test
+    auto all_done = [&]() { return __builtin_amdgcn_ballot_w64(T_live != 0.0f) == 0; };
     uint32_t last_contributor = 0;
-    float C[4] = {0.f, 0.f, 0.f, 0.f};  // r, g, b, depth
-    float Cs[NSEM > 0 ? NSEM : 1];
+    // accumulators as register pairs: one v_pk_fma_f32 adds two channels (this TU is compiled with the SLP
+    // vectoriser off -- it packs the alpha evaluations of two candidates at the price of six moves -- so the
+    // packing is spelled out)
+    f32x2 C2[2] = {{0.f, 0.f}, {0.f, 0.f}};  // (r, g), (b, depth)
+    f32x2 Cs2[NSEM > 0 ? NSEM / 2 : 1];
 #pragma unroll
-    for (int i = 0; i < NSEM; i++) Cs[i] = 0.f;
+    for (int i = 0; i < NSEM / 2; i++) Cs2[i] = f32x2{0.f, 0.f};
 
     // software prefetch of the next batch's id / position / box (one Gaussian per lane)
     uint32_t id_n = 0;
@@ -74,7 +80,7 @@ __global__ __launch_bounds__(64) void render_fwd_k(const uint2* __restrict__ ran
     if (rounds > 0) prefetch(0);
 
     for (int b = 0; b < rounds; b++) {
-        if (__all(done)) break;
+        if (all_done()) break;
         const uint32_t id = id_n;
         const float4 q0 = q0_n, q2 = q2_n;
         const bool hit = box_hits_quadrant(q0.x, q0.y, q2.z, q2.w, t.QX0, t.QY0);  // hx < 0 for absent lanes
@@ -85,9 +91,9 @@ __global__ __launch_bounds__(64) void render_fwd_k(const uint2* __restrict__ ran
         if (hit) {
             const float4* r4 = reinterpret_cast<const float4*>(rec + id);
             const float4 q1 = r4[1];
-            const PolyCoef pc = poly_coefs(q0.x, q0.y, q0.z, q0.w, q1.x, QCX, QCY);
-            s_geo[lane] = make_float4(pc.A0, pc.A1, pc.A2, pc.A3);
-            s_geo2[lane] = make_float4(pc.A4, pc.A5, q1.y, 0.f);
+            const PolyCoef pc = poly_coefs(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, QCX, QCY);
+            s_geo[lane] = f32x4{pc.A35.x, pc.A35.y, pc.A12.x, pc.A12.y};
+            s_geo2[lane] = f32x4{pc.A0, pc.A4, pc.lim, 0.f};
             s_feat[lane * NF4] = make_float4(q1.w, q2.x, q2.y, q1.z);
             if constexpr (TRACE) {
                 s_id[lane] = id;
@@ -114,27 +120,22 @@ __global__ __launch_bounds__(64) void render_fwd_k(const uint2* __restrict__ ran
         // ---- pair loop over the hits, front to back
         // applies one candidate to the per-pixel state (sequential part) and accumulates its features
         auto apply = [&](int j, const PairEval& e, bool valid) {
-            bool c = valid && !done && e.hit;
-            const float test_T = T * (1.f - e.alpha);
-            if (c && test_T < kTMin) {
-                done = true;
-                c = false;
-            }
-            if (__any(c)) {
-                const float wgt = c ? e.alpha * T : 0.f;
-                const float4 f0 = s_feat[j * NF4];
-                C[0] += f0.x * wgt;
-                C[1] += f0.y * wgt;
-                C[2] += f0.z * wgt;
-                C[3] += f0.w * wgt;
+            const float test_T = T_live * (1.f - e.alpha);
+            const bool c0 = valid && e.hit;
+            const bool ok = test_T >= kTMin;  // CR/forward.cu:352-356: a failing contributor ends the pixel
+            const bool c = c0 && ok;
+            if (__builtin_amdgcn_ballot_w64(c) != 0) {
+                const float wgt = c ? e.alpha * T_live : 0.f;
+                const f32x2 w2 = {wgt, wgt};
+                const f32x4 f0 = s_feat4[j * NF4];
+                C2[0] = __builtin_elementwise_fma(f0.xy, w2, C2[0]);
+                C2[1] = __builtin_elementwise_fma(f0.zw, w2, C2[1]);
                 if constexpr (!TRACE) {
 #pragma unroll
                     for (int i = 0; i < S4; i++) {
-                        const float4 f = s_feat[j * NF4 + 1 + i];
-                        Cs[4 * i + 0] += f.x * wgt;
-                        Cs[4 * i + 1] += f.y * wgt;
-                        Cs[4 * i + 2] += f.z * wgt;
-                        Cs[4 * i + 3] += f.w * wgt;
+                        const f32x4 f = s_feat4[j * NF4 + 1 + i];
+                        Cs2[2 * i] = __builtin_elementwise_fma(f.xy, w2, Cs2[2 * i]);
+                        Cs2[2 * i + 1] = __builtin_elementwise_fma(f.zw, w2, Cs2[2 * i + 1]);
                     }
                 } else {
                     if (c && (double)e.alpha > 0.005) {
@@ -149,6 +150,7 @@ __global__ __launch_bounds__(64) void render_fwd_k(const uint2* __restrict__ ran
                     last_contributor = (uint32_t)(b * 64 + j + 1);
                 }
             }
+            T_live = c0 ? (ok ? test_T : 0.0f) : T_live;
         };
         if constexpr (UNROLL2) {
             // two candidates per trip: their alpha evaluations are independent (ILP, half the
@@ -159,23 +161,23 @@ __global__ __launch_bounds__(64) void render_fwd_k(const uint2* __restrict__ ran
                 const bool has1 = m != 0;
                 const int j1 = has1 ? __builtin_ctzll(m) : j0;
                 if (has1) m &= m - 1;
-                const float4 ga = s_geo[j0], gb = s_geo[j1];
-                const float4 ha = s_geo2[j0], hb = s_geo2[j1];
-                const PairEval e0 = eval_poly(ga.x, ga.y, ga.z, ga.w, ha.x, ha.y, ha.z, pu, pv);
-                const PairEval e1 = eval_poly(gb.x, gb.y, gb.z, gb.w, hb.x, hb.y, hb.z, pu, pv);
+                const f32x4 ga = s_geo[j0], gb = s_geo[j1];
+                const f32x4 ha = s_geo2[j0], hb = s_geo2[j1];
+                const PairEval e0 = eval_poly(ga.xy, ga.zw, ha.x, ha.y, ha.z, uv);
+                const PairEval e1 = eval_poly(gb.xy, gb.zw, hb.x, hb.y, hb.z, uv);
                 apply(j0, e0, true);
                 apply(j1, e1, has1);
-                if (__all(done)) m = 0;
+                if (all_done()) m = 0;
             }
         } else {
             while (m) {
                 const int j = __builtin_ctzll(m);
                 m &= m - 1;
-                const float4 g = s_geo[j];
-                const float4 g2 = s_geo2[j];
-                const PairEval e = eval_poly(g.x, g.y, g.z, g.w, g2.x, g2.y, g2.z, pu, pv);
+                const f32x4 g = s_geo[j];
+                const f32x4 g2 = s_geo2[j];
+                const PairEval e = eval_poly(g.xy, g.zw, g2.x, g2.y, g2.z, uv);
                 apply(j, e, true);
-                if (__all(done)) m = 0;
+                if (all_done()) m = 0;
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -183,15 +185,15 @@ __global__ __launch_bounds__(64) void render_fwd_k(const uint2* __restrict__ ran
 
     if (t.inside) {
         n_contrib[pix_id] = last_contributor;
-        out_color[0 * HW + pix_id] = C[0] + T * bg[0];
-        out_color[1 * HW + pix_id] = C[1] + T * bg[1];
-        out_color[2 * HW + pix_id] = C[2] + T * bg[2];
+        out_color[0 * HW + pix_id] = C2[0].x + T * bg[0];
+        out_color[1 * HW + pix_id] = C2[0].y + T * bg[1];
+        out_color[2 * HW + pix_id] = C2[1].x + T * bg[2];
         if constexpr (!TRACE) {
 #pragma unroll
             for (int ch = 0; ch < NSEM; ch++)
-                if (ch < S) out_sem[ch * HW + pix_id] = Cs[ch];
+                if (ch < S) out_sem[ch * HW + pix_id] = Cs2[ch >> 1][ch & 1];
             out_alpha[pix_id] = 1.f - T;
-            out_depth[pix_id] = C[3];
+            out_depth[pix_id] = C2[1].y;
         }
     }
 }
