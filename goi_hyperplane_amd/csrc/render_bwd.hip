@@ -62,14 +62,16 @@ struct BwdCfg {
     static constexpr int NB = (NSEM + 15) / 16;  // 16-column MFMA blocks of semantic channels (+ 1 mixed block)
 };
 
-template <int S4>
+// EXP: timing-experiment build (bits of bwd_variant skip parts of the work; invalid gradients).  The production
+// instantiation has the flags as a compile-time 0: no per-member branches on them.
+template <int S4, bool EXP>
 __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int gx, int gy,
     int n_quads, int S, const GaussRec* __restrict__ rec, const float* __restrict__ semantics,
     const int* __restrict__ radii, const uint32_t* __restrict__ goff, const float* __restrict__ bg,
     const float* __restrict__ out_alpha, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
     const float* __restrict__ dL_dpixsem, const float* __restrict__ dL_dpixdepth, const float* __restrict__ dL_dalphas,
-    float* __restrict__ rows, uint8_t* __restrict__ flags, int row_floats, int exp_flags,
+    float* __restrict__ rows, uint8_t* __restrict__ flags, int row_floats, int exp_flags_rt,
     const uint32_t* __restrict__ counters) {
     using Cfg = BwdCfg<S4>;
     const bool cull = counters[COUNTER_CULL] != 0;  // the rectangles the forward listed
@@ -80,6 +82,7 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
     __shared__ float s_t[2 * GROUP * TSTRIDE];  // [row][pixel]: rows 0..7 = w of slot, rows 8..15 = h of slot
     __shared__ f32x4 s_gmeta[GROUP * 2];     // per group member: (Dx, Dy, A3, A5), (A0, A4, lim, slot bits)
 
+    const int exp_flags = EXP ? exp_flags_rt : 0;
     const QuadGeom t = quad_geom(W, H, gx, n_quads);
     if (t.tile < 0) return;
     const int lane = t.lane;
@@ -347,9 +350,17 @@ void launch_bwd_rows_s4(const GoiRasterScene& sc, const GeomView& g, const Image
                         const float* dL_ddepth, const float* dL_dalpha, const BwdScratchView& scr, hipStream_t s) {
     const int gx = (sc.W + TILE - 1) / TILE, gy = (sc.H + TILE - 1) / TILE;
     const int n_quads = gx * gy * 4;
-    render_bwd_rows_k<S4><<<dim3(quad_grid(n_quads)), dim3(64), (size_t)((g_options.bwd_variant >> 8) & 0xFF) * 1024, s>>>(
-        im.ranges, point_list, sc.W, sc.H, gx, gy, n_quads, sc.S, g.rec, sc.semantics, radii, g.goff, sc.bg, out_alpha,
-        im.n_contrib, dL_dpix, dL_dsem, dL_ddepth, dL_dalpha, scr.rows, scr.flags, bwd_row_floats(sc.S), (g_options.bwd_variant >> 4) & 0xF, g.counters);
+    const int exp_flags = (g_options.bwd_variant >> 4) & 0xF;
+    const size_t extra_lds = (size_t)((g_options.bwd_variant >> 8) & 0xFF) * 1024;
+    if (exp_flags)
+        render_bwd_rows_k<S4, true><<<dim3(quad_grid(n_quads)), dim3(64), extra_lds, s>>>(
+            im.ranges, point_list, sc.W, sc.H, gx, gy, n_quads, sc.S, g.rec, sc.semantics, radii, g.goff, sc.bg, out_alpha,
+            im.n_contrib, dL_dpix, dL_dsem, dL_ddepth, dL_dalpha, scr.rows, scr.flags, bwd_row_floats(sc.S), exp_flags,
+            g.counters);
+    else
+        render_bwd_rows_k<S4, false><<<dim3(quad_grid(n_quads)), dim3(64), extra_lds, s>>>(
+            im.ranges, point_list, sc.W, sc.H, gx, gy, n_quads, sc.S, g.rec, sc.semantics, radii, g.goff, sc.bg, out_alpha,
+            im.n_contrib, dL_dpix, dL_dsem, dL_ddepth, dL_dalpha, scr.rows, scr.flags, bwd_row_floats(sc.S), 0, g.counters);
 }
 
 }  // namespace
