@@ -67,6 +67,27 @@ __device__ __forceinline__ PairEval eval_poly(f32x2 A35, f32x2 A12, float A0, fl
     return e;
 }
 
+// ---- split-bf16 operands of the backward kernels' MFMA reductions (render_bwd.hip, "Two flushes")
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int RS16 = 72;  // row stride (bf16 elements) of the split planes: 64 pixels + 8 (b128 reads conflict-free)
+
+// (a, b) -> packed bf16 pairs: hi = rne(a), rne(b) (a in the low half), lo = rne(a - hi_a), rne(b - hi_b)
+__device__ __forceinline__ void split_pair(float a, float b, uint32_t& hi, uint32_t& lo) {
+    hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, bf16x2));  // v_cvt_pk_bf16_f32
+    const float ah = __uint_as_float(hi << 16), bh = __uint_as_float(hi & 0xFFFF0000u);
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a - ah, b - bh}, bf16x2));
+}
+// eight consecutive K values of an MFMA operand -> hi and lo planes
+__device__ __forceinline__ void split_pack8(const float (&y)[8], bf16x8& h, bf16x8& l) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    uint32_t hw[4], lw[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) split_pair(y[2 * i], y[2 * i + 1], hw[i], lw[i]);
+    h = __builtin_bit_cast(bf16x8, u32x4{hw[0], hw[1], hw[2], hw[3]});
+    l = __builtin_bit_cast(bf16x8, u32x4{lw[0], lw[1], lw[2], lw[3]});
+}
+
 // Does the Gaussian's exact contribution box (GaussRec hx/hy) touch the 8x8 quadrant whose first
 // pixel is (X0, Y0)?  hx < 0: the Gaussian can never reach alpha >= 1/255.
 __device__ __forceinline__ bool box_hits_quadrant(float x, float y, float hx, float hy, float X0, float Y0) {

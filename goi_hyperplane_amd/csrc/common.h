@@ -64,8 +64,9 @@ size_t binning_layout(int N, char* base, BinView* v);
 // Tuning / experiment switches (goi_raster_set_option); defaults are the shipped configuration.
 struct Options {
     int fwd_variant = 1;  // 0: one candidate per loop trip, 1: two candidates per trip (default)
-    int bwd_variant = 0;  // low 4 bits: 0 atomic-free wave-per-quadrant backward (needs scratch), 1 workgroup-per-tile +
-                          // atomics; bits 4..15: timing experiments (GOI_EXPERIMENTS=1 only, invalid gradients)
+    int bwd_variant = 0;  // low 4 bits: 0 atomic-free wave-per-quadrant backward (needs scratch) with the split-bf16
+                          // MFMA flush, 2 the same with the exact-fp32 flush, 1 workgroup-per-tile + atomics;
+                          // bits 4..15: timing experiments (GOI_EXPERIMENTS=1 only, invalid gradients)
     int sort_variant = 1;  // 0: histogram / scan / scatter per pass, 1: onesweep (decoupled look-back, default)
     int cull_variant = 1;  // 0: a Gaussian is listed in every tile of its 3-sigma rectangle (the reference's lists),
                            // 1: only in the tiles its exact contribution box touches (same images and gradients)

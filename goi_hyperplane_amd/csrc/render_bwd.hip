@@ -15,7 +15,7 @@
 //         dL/dalpha_i = (d_i - R_i) * T_i - T_final/(1-alpha_i) * <bg, dL/dcolour>,
 //         R_{i-1} = alpha_i * d_i + (1-alpha_i) * R_i          (R = <accum_rec, dL/dpixel>).
 //  4. The per-Gaussian sums over the 64 pixels of the wave are MATRIX PRODUCTS and run on the matrix
-//     cores in exact fp32 (v_mfma_f32_16x16x4_f32 == an fmaf chain):
+//     cores (see "Two flushes" below for the arithmetic):
 //         dL/dfeature[j][ch] = sum_pix w[pix][j] * dL/dpixel[pix][ch],      w = alpha * T
 //         moments[j][m]      = sum_pix h[pix][j] * basis[pix][m],           h = G * dL/dalpha
 //     with basis = (1, u, v, u^2, uv, v^2) in quadrant-centred pixel coordinates; the 2D-mean, conic
@@ -33,6 +33,17 @@
 //     plus the quadrant.  Rows are written once with plain stores plus a validity byte;
 //     reduce_rows_k then sums each Gaussian's rows, which are contiguous in slot space, in a fixed
 //     order.  Gradients are bit-reproducible run to run.
+//
+// Two flushes.  fp32 MFMA (v_mfma_f32_16x16x4_f32) runs at the vector rate (32 clocks per instruction per SIMD)
+// and its time ADDS to the VALU time of the co-resident waves (tools/mfma_mix_probe.hip): the 32 instructions of
+// one group flush were ~20 % of this kernel.  The default flush (MODE 0) therefore uses the bf16 matrix rate with
+// SPLIT operands: every fp32 value x is carried as two bf16 numbers, hi = rne(x) and lo = rne(x - hi)
+// (|x - hi - lo| <= 2^-17 |x|), kept in two LDS planes (A: w / h) and two register planes (B: dL / basis; the basis
+// values are exact in bf16), and a product is formed as  hi*hi + lo*hi + hi*lo  by three
+// v_mfma_f32_16x16x32_bf16 per 32 pixels, accumulated in fp32: 12 instructions of ~20 clocks per flush instead
+// of 32 of ~35.  The dropped lo*lo term is <= 2^-16 of the product; the sums differ from exact fp32 by ~1e-5
+// relative in the worst case (the reference's own float atomicAdd order noise is ~1e-6), still bit-reproducible.
+// MODE 1 (bwd_variant = 2) keeps the exact-fp32 flush (an fmaf chain per output) for users who want it.
 #include "blend_common.h"
 
 namespace goi {
@@ -62,9 +73,9 @@ struct BwdCfg {
     static constexpr int NB = (NSEM + 15) / 16;  // 16-column MFMA blocks of semantic channels (+ 1 mixed block)
 };
 
-// EXP: timing-experiment build (bits of bwd_variant skip parts of the work; invalid gradients).  The production
-// instantiation has the flags as a compile-time 0: no per-member branches on them.
-template <int S4, bool EXP>
+// MODE 0: split-bf16 flush (default).  MODE 1: exact-fp32 flush.  MODE 2: exact-fp32 flush + timing-experiment
+// flags (bits of bwd_variant skip parts of the work; invalid gradients).  Only MODE 2 reads the flags at run time.
+template <int S4, int MODE>
 __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int gx, int gy,
     int n_quads, int S, const GaussRec* __restrict__ rec, const float* __restrict__ semantics,
@@ -79,7 +90,14 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
     __shared__ f32x4 s_geo[BATCH];        // (A3, A5, A1, A2) of the quadrant-centred log2-alpha polynomial (blend_common.h)
     __shared__ f32x4 s_geo2[BATCH];       // (A0, A4, lim, slot index (bits))
     __shared__ float4 s_feat[BATCH * NF4];  // (r,g,b,depth), semantics...
-    __shared__ float s_t[2 * GROUP * TSTRIDE];  // [row][pixel]: rows 0..7 = w of slot, rows 8..15 = h of slot
+    constexpr bool SPLIT = MODE == 0, EXP = MODE == 2;
+    // [row][pixel]: rows 0..7 = w of slot, rows 8..15 = h of slot.  fp32 flush: floats, row stride TSTRIDE.
+    // Split flush: two bf16 planes (hi, lo) of 16 rows x RS16.
+    constexpr int T_BYTES = SPLIT ? 2 * 16 * RS16 * 2 : 2 * GROUP * TSTRIDE * 4;
+    __shared__ __attribute__((aligned(16))) char s_traw[T_BYTES];
+    float* const s_t = reinterpret_cast<float*>(s_traw);
+    uint16_t* const s_hi = reinterpret_cast<uint16_t*>(s_traw);
+    uint16_t* const s_lo = s_hi + 16 * RS16;
     __shared__ f32x4 s_gmeta[GROUP * 2];     // per group member: (Dx, Dy, A3, A5), (A0, A4, lim, slot bits)
 
     const int exp_flags = EXP ? exp_flags_rt : 0;
@@ -127,10 +145,21 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
     // ---- MFMA B operands (fixed for the whole kernel), built once through LDS:
     //      bfrag[nb][s] = dL[pixel 4s + (lane>>4)][channel 16 nb + (lane&15)]
     const int kq = lane >> 4, mm = lane & 15;
-    float bfrag[NB][16];  // semantic blocks
-    float bmix[16];       // mixed block: columns 0..3 = dL/d(r, g, b, depth), 4..9 = moment basis
-    {
-        static_assert(64 * 16 <= 2 * GROUP * TSTRIDE, "staging region too small");
+    float bfrag[SPLIT ? 1 : NB][SPLIT ? 1 : 16];  // semantic blocks (fp32 flush)
+    float bmix[SPLIT ? 1 : 16];  // mixed block: columns 0..3 = dL/d(r, g, b, depth), 4..9 = moment basis
+    // split flush: Bh/Bl[block][chunk] = bf16 hi / lo of B[pixel 32 chunk + 8 kq + i][column mm], i = 0..7
+    // (block NB = the mixed block)
+    bf16x8 Bh[SPLIT ? NB + 1 : 1][2], Bl[SPLIT ? NB + 1 : 1][2];
+    static_assert(64 * 16 * 4 <= T_BYTES, "staging region too small");
+    // basis_m(pixel p) in quadrant-centred coordinates u, v in [-3.5, 3.5] (pixel p = column p & 7, row p >> 3);
+    // m = mm - 4: 1, u, v, u^2, uv, v^2
+    const float k1 = mm == 4 ? 1.f : 0.f, ku = mm == 5 ? 1.f : 0.f, kv = mm == 6 ? 1.f : 0.f;
+    const float kuu = mm == 7 ? 1.f : 0.f, kuv = mm == 8 ? 1.f : 0.f, kvv = mm == 9 ? 1.f : 0.f;
+    auto basis = [&](int p) {
+        const float u = (float)(p & 7) - 3.5f, v = (float)(p >> 3) - 3.5f;
+        return k1 + ku * u + kv * v + kuu * (u * u) + kuv * (u * v) + kvv * (v * v);
+    };
+    if constexpr (!SPLIT) {
 #pragma unroll
         for (int nb = 0; nb < NB; nb++) {
 #pragma unroll
@@ -146,17 +175,39 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
 #pragma unroll
         for (int c = 0; c < 4; c++) s_t[lane * 4 + c] = dLch[NSEM + c];
         __builtin_amdgcn_wave_barrier();
-        // basis_m(pixel 4s + kq) in quadrant-centred coordinates u, v in [-3.5, 3.5]
-        // (pixel 4s+kq = column 4(s&1)+kq, row s>>1); m = mm - 4: 1, u, v, u^2, uv, v^2
-        const float u_even = (float)kq - 3.5f;
-        const float k1 = mm == 4 ? 1.f : 0.f, ku = mm == 5 ? 1.f : 0.f, kv = mm == 6 ? 1.f : 0.f;
-        const float kuu = mm == 7 ? 1.f : 0.f, kuv = mm == 8 ? 1.f : 0.f, kvv = mm == 9 ? 1.f : 0.f;
 #pragma unroll
-        for (int s = 0; s < 16; s++) {
-            const float u = u_even + (float)(4 * (s & 1));
-            const float v = (float)(s >> 1) - 3.5f;
-            const float bm = k1 + ku * u + kv * v + kuu * (u * u) + kuv * (u * v) + kvv * (v * v);
-            bmix[s] = mm < 4 ? s_t[(4 * s + kq) * 4 + mm] : bm;
+        for (int s = 0; s < 16; s++) bmix[s] = mm < 4 ? s_t[(4 * s + kq) * 4 + mm] : basis(4 * s + kq);
+        __builtin_amdgcn_wave_barrier();
+    } else {
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++) {
+#pragma unroll
+            for (int c = 0; c < 16; c++) {
+                const int ch = nb * 16 + c;
+                s_t[lane * 16 + c] = ch < NSEM ? dLch[ch] : 0.f;
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int c2 = 0; c2 < 2; c2++) {
+                float y[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) y[i] = s_t[(32 * c2 + 8 * kq + i) * 16 + mm];
+                split_pack8(y, Bh[nb][c2], Bl[nb][c2]);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++) s_t[lane * 4 + c] = dLch[NSEM + c];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c2 = 0; c2 < 2; c2++) {
+            float y[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int p = 32 * c2 + 8 * kq + i;
+                y[i] = mm < 4 ? s_t[p * 4 + mm] : basis(p);
+            }
+            split_pack8(y, Bh[NB][c2], Bl[NB][c2]);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -189,13 +240,35 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
 #pragma unroll
         for (int nb = 0; nb < NB; nb++) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
         __builtin_amdgcn_wave_barrier();
+        if constexpr (!SPLIT) {
 #pragma unroll
-        for (int s = 0; s < 16; s++) {
-            const float a = s_t[mm * TSTRIDE + 4 * s + kq];
+            for (int s = 0; s < 16; s++) {
+                const float a = s_t[mm * TSTRIDE + 4 * s + kq];
 #pragma unroll
-            for (int nb = 0; nb < NB; nb++)
-                acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bfrag[nb][s], acc[nb], 0, 0, 0);
-            accx = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bmix[s], accx, 0, 0, 0);
+                for (int nb = 0; nb < NB; nb++)
+                    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bfrag[nb][s], acc[nb], 0, 0, 0);
+                accx = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bmix[s], accx, 0, 0, 0);
+            }
+        } else {
+            // A[row = mm][pixel 32 c + 8 kq + i]: one ds_read_b128 per plane and 32-pixel chunk
+            bf16x8 Ah[2], Al[2];
+#pragma unroll
+            for (int c2 = 0; c2 < 2; c2++) {
+                Ah[c2] = *reinterpret_cast<const bf16x8*>(s_hi + mm * RS16 + 32 * c2 + 8 * kq);
+                Al[c2] = *reinterpret_cast<const bf16x8*>(s_lo + mm * RS16 + 32 * c2 + 8 * kq);
+            }
+#pragma unroll
+            for (int c2 = 0; c2 < 2; c2++) {
+#pragma unroll
+                for (int nb = 0; nb < NB; nb++) {
+                    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al[c2], Bh[nb][c2], acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[c2], Bl[nb][c2], acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[c2], Bh[nb][c2], acc[nb], 0, 0, 0);
+                }
+                accx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al[c2], Bh[NB][c2], accx, 0, 0, 0);
+                accx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[c2], Bl[NB][c2], accx, 0, 0, 0);
+                accx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[c2], Bh[NB][c2], accx, 0, 0, 0);
+            }
         }
         // D[row = 4*kq + r][col = mm]: rows 0..7 = w of slot `row` (x dL), rows 8..15 = h of slot row-8 (x basis)
         __builtin_amdgcn_wave_barrier();
@@ -324,8 +397,17 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
                 wgt = e.alpha * Tn;
                 hval = e.E * dL_dopa;  // opacity * G * dL/dalpha: the moments carry the factor `opacity`
             }
-            s_t[nslot * TSTRIDE + lane] = wgt;
-            s_t[(GROUP + nslot) * TSTRIDE + lane] = hval;
+            if constexpr (!SPLIT) {
+                s_t[nslot * TSTRIDE + lane] = wgt;
+                s_t[(GROUP + nslot) * TSTRIDE + lane] = hval;
+            } else {
+                uint32_t hi, lo;  // (w, h) as bf16 pairs: low half = w, high half = h
+                split_pair(wgt, hval, hi, lo);
+                s_hi[nslot * RS16 + lane] = (uint16_t)hi;
+                s_hi[(GROUP + nslot) * RS16 + lane] = (uint16_t)(hi >> 16);
+                s_lo[nslot * RS16 + lane] = (uint16_t)lo;
+                s_lo[(GROUP + nslot) * RS16 + lane] = (uint16_t)(lo >> 16);
+            }
             // wave-uniform reads of the staging lane's registers (outside the lane-0 branch: every lane is active here)
             const float Dxj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Dx_st), j));
             const float Dyj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Dy_st), j));
@@ -352,15 +434,18 @@ void launch_bwd_rows_s4(const GoiRasterScene& sc, const GeomView& g, const Image
     const int n_quads = gx * gy * 4;
     const int exp_flags = (g_options.bwd_variant >> 4) & 0xF;
     const size_t extra_lds = (size_t)((g_options.bwd_variant >> 8) & 0xFF) * 1024;
+#define GOI_LAUNCH_ROWS(MODE)                                                                                          \
+    render_bwd_rows_k<S4, MODE><<<dim3(quad_grid(n_quads)), dim3(64), extra_lds, s>>>(                                   \
+        im.ranges, point_list, sc.W, sc.H, gx, gy, n_quads, sc.S, g.rec, sc.semantics, radii, g.goff, sc.bg, out_alpha, \
+        im.n_contrib, dL_dpix, dL_dsem, dL_ddepth, dL_dalpha, scr.rows, scr.flags, bwd_row_floats(sc.S), exp_flags,      \
+        g.counters)
     if (exp_flags)
-        render_bwd_rows_k<S4, true><<<dim3(quad_grid(n_quads)), dim3(64), extra_lds, s>>>(
-            im.ranges, point_list, sc.W, sc.H, gx, gy, n_quads, sc.S, g.rec, sc.semantics, radii, g.goff, sc.bg, out_alpha,
-            im.n_contrib, dL_dpix, dL_dsem, dL_ddepth, dL_dalpha, scr.rows, scr.flags, bwd_row_floats(sc.S), exp_flags,
-            g.counters);
+        GOI_LAUNCH_ROWS(2);
+    else if ((g_options.bwd_variant & 15) == 2)
+        GOI_LAUNCH_ROWS(1);
     else
-        render_bwd_rows_k<S4, false><<<dim3(quad_grid(n_quads)), dim3(64), extra_lds, s>>>(
-            im.ranges, point_list, sc.W, sc.H, gx, gy, n_quads, sc.S, g.rec, sc.semantics, radii, g.goff, sc.bg, out_alpha,
-            im.n_contrib, dL_dpix, dL_dsem, dL_ddepth, dL_dalpha, scr.rows, scr.flags, bwd_row_floats(sc.S), 0, g.counters);
+        GOI_LAUNCH_ROWS(0);
+#undef GOI_LAUNCH_ROWS
 }
 
 }  // namespace

@@ -11,8 +11,9 @@
 // T_final / prod(1 - alpha), MFMA reduction over the 64 pixels, one scratch row per (quadrant,
 // Gaussian), no atomics) and drops the rest: no feature rows are staged, there is no <feature, dL>
 // product, no dL/dalpha recurrence, no moments; 16 members form a group and all 16 MFMA rows carry w.
-// The w values, the k-order of the MFMA and the reduce order are those of the full kernel, so the
-// result is bit-identical to the dL/dsemantics of the full backward.
+// The w values, the arithmetic of the MFMA reduction (SPLIT: the split-bf16 flush of render_bwd.hip, same
+// instruction order per output; otherwise the exact-fp32 flush) and the reduce order are those of the full
+// kernel, so the result is bit-identical to the dL/dsemantics of the full backward in the same mode.
 #include "blend_common.h"
 
 namespace goi {
@@ -24,7 +25,7 @@ constexpr int SGROUP = 16;
 constexpr int SBATCH = 32;
 constexpr int STSTRIDE = 66;
 
-template <int S4>
+template <int S4, bool SPLIT>
 __global__ __launch_bounds__(64) void render_bwd_sem_k(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int gx, int gy,
     int n_quads, int S, const GaussRec* __restrict__ rec, const int* __restrict__ radii,
@@ -35,7 +36,13 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
     constexpr int NSEM = 4 * S4, NB = (NSEM + 15) / 16;
     __shared__ f32x4 s_geo[SBATCH];           // (A3, A5, A1, A2) of the quadrant-centred log2-alpha polynomial
     __shared__ f32x4 s_geo2[SBATCH];          // (A0, A4, lim, slot index (bits))
-    __shared__ float s_t[SGROUP * STSTRIDE];  // w columns, [member][pixel]
+    // w columns, [member][pixel]: floats (row stride STSTRIDE), or two bf16 planes (hi, lo) of 16 rows x RS16
+    constexpr int T_BYTES = SPLIT ? 2 * 16 * RS16 * 2 : SGROUP * STSTRIDE * 4;
+    static_assert(64 * 16 * 4 <= T_BYTES, "staging region too small");
+    __shared__ __attribute__((aligned(16))) char s_traw[T_BYTES];
+    float* const s_t = reinterpret_cast<float*>(s_traw);
+    uint16_t* const s_hi = reinterpret_cast<uint16_t*>(s_traw);
+    uint16_t* const s_lo = s_hi + 16 * RS16;
     __shared__ uint32_t s_slot[SGROUP];
 
     const QuadGeom t = quad_geom(W, H, gx, n_quads);
@@ -57,7 +64,8 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
 
     // MFMA B operands: bfrag[nb][s] = dL[pixel 4s + (lane>>4)][channel 16 nb + (lane&15)]
     const int kq = lane >> 4, mm = lane & 15;
-    float bfrag[NB][16];
+    float bfrag[SPLIT ? 1 : NB][SPLIT ? 1 : 16];
+    bf16x8 Bh[SPLIT ? NB : 1][2], Bl[SPLIT ? NB : 1][2];  // split: B[pixel 32 chunk + 8 kq + i][column mm]
 #pragma unroll
     for (int nb = 0; nb < NB; nb++) {
 #pragma unroll
@@ -66,8 +74,18 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
             s_t[lane * 16 + c] = (t.inside && ch < S) ? dL_dpixsem[ch * HW + pix_id] : 0.f;
         }
         __builtin_amdgcn_wave_barrier();
+        if constexpr (!SPLIT) {
 #pragma unroll
-        for (int s = 0; s < 16; s++) bfrag[nb][s] = s_t[(4 * s + kq) * 16 + mm];
+            for (int s = 0; s < 16; s++) bfrag[nb][s] = s_t[(4 * s + kq) * 16 + mm];
+        } else {
+#pragma unroll
+            for (int c2 = 0; c2 < 2; c2++) {
+                float y[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) y[i] = s_t[(32 * c2 + 8 * kq + i) * 16 + mm];
+                split_pack8(y, Bh[nb][c2], Bl[nb][c2]);
+            }
+        }
         __builtin_amdgcn_wave_barrier();
     }
 
@@ -91,12 +109,26 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
 #pragma unroll
         for (int nb = 0; nb < NB; nb++) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
         __builtin_amdgcn_wave_barrier();
+        if constexpr (!SPLIT) {
 #pragma unroll
-        for (int s = 0; s < 16; s++) {
-            const float a = s_t[mm * STSTRIDE + 4 * s + kq];
+            for (int s = 0; s < 16; s++) {
+                const float a = s_t[mm * STSTRIDE + 4 * s + kq];
 #pragma unroll
-            for (int nb = 0; nb < NB; nb++)
-                acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bfrag[nb][s], acc[nb], 0, 0, 0);
+                for (int nb = 0; nb < NB; nb++)
+                    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bfrag[nb][s], acc[nb], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int c2 = 0; c2 < 2; c2++) {
+                const bf16x8 Ah = *reinterpret_cast<const bf16x8*>(s_hi + mm * RS16 + 32 * c2 + 8 * kq);
+                const bf16x8 Al = *reinterpret_cast<const bf16x8*>(s_lo + mm * RS16 + 32 * c2 + 8 * kq);
+#pragma unroll
+                for (int nb = 0; nb < NB; nb++) {  // same order of terms as render_bwd_rows_k
+                    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bh[nb][c2], acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bl[nb][c2], acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh[nb][c2], acc[nb], 0, 0, 0);
+                }
+            }
         }
 #pragma unroll
         for (int r = 0; r < 4; r++) {
@@ -148,7 +180,14 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
                 T = Tn;
                 wgt = e.alpha * Tn;
             }
-            s_t[nslot * STSTRIDE + lane] = wgt;
+            if constexpr (!SPLIT) {
+                s_t[nslot * STSTRIDE + lane] = wgt;
+            } else {
+                uint32_t hi, lo;
+                split_pair(wgt, 0.f, hi, lo);
+                s_hi[nslot * RS16 + lane] = (uint16_t)hi;
+                s_lo[nslot * RS16 + lane] = (uint16_t)lo;
+            }
             if (lane == 0) s_slot[nslot] = __float_as_uint(g2.w);
             nslot++;
             if (nslot == SGROUP) {
@@ -167,9 +206,14 @@ void launch_bwd_sem_s4(const GoiRasterScene& sc, const GeomView& g, const ImageV
                        int row_floats, hipStream_t s) {
     const int gx = (sc.W + TILE - 1) / TILE, gy = (sc.H + TILE - 1) / TILE;
     const int n_quads = gx * gy * 4;
-    render_bwd_sem_k<S4><<<dim3(quad_grid(n_quads)), dim3(64), 0, s>>>(im.ranges, point_list, sc.W, sc.H, gx, gy, n_quads,
-                                                                        sc.S, g.rec, radii, g.goff, out_alpha, im.n_contrib,
-                                                                        dL_dsem, rows, flags, row_floats, g.counters);
+    if ((g_options.bwd_variant & 15) == 2)  // exact-fp32 flush, as in the full backward
+        render_bwd_sem_k<S4, false><<<dim3(quad_grid(n_quads)), dim3(64), 0, s>>>(
+            im.ranges, point_list, sc.W, sc.H, gx, gy, n_quads, sc.S, g.rec, radii, g.goff, out_alpha, im.n_contrib, dL_dsem,
+            rows, flags, row_floats, g.counters);
+    else
+        render_bwd_sem_k<S4, true><<<dim3(quad_grid(n_quads)), dim3(64), 0, s>>>(
+            im.ranges, point_list, sc.W, sc.H, gx, gy, n_quads, sc.S, g.rec, radii, g.goff, out_alpha, im.n_contrib, dL_dsem,
+            rows, flags, row_floats, g.counters);
 }
 
 }  // namespace

@@ -460,14 +460,25 @@ def test_semantics_only_backward_is_bit_identical_to_the_full_one(dev, P, W, H, 
             for p in pc.parameters():
                 p.requires_grad_(True)
 
-    full, vs_full = sem_grad(False, False)
-    frozen_full, _ = sem_grad(True, False)      # frozen parameters, full kernel: the reference's behaviour
-    lean, vs_lean = sem_grad(True, True)
-    assert torch.equal(full, frozen_full) and torch.equal(full, lean)
-    assert float(full.abs().max()) > 0 and float(vs_lean.abs().max()) == 0.0 and float(vs_full.abs().max()) > 0
-    # the mode is inert while anything else needs a gradient
-    mixed, vs_mixed = sem_grad(False, True)
-    assert torch.equal(mixed, full) and torch.equal(vs_mixed, vs_full)
+    from goi_hyperplane_amd import _lib
+    by_variant = {}
+    for variant in (0, 2):  # split-bf16 MFMA flush (default) and exact-fp32 flush: bit-identical within a mode
+        _lib.set_option("bwd_variant", variant)
+        try:
+            full, vs_full = sem_grad(False, False)
+            frozen_full, _ = sem_grad(True, False)      # frozen parameters, full kernel: the reference's behaviour
+            lean, vs_lean = sem_grad(True, True)
+            assert torch.equal(full, frozen_full) and torch.equal(full, lean)
+            assert float(full.abs().max()) > 0 and float(vs_lean.abs().max()) == 0.0 and float(vs_full.abs().max()) > 0
+            # the mode is inert while anything else needs a gradient
+            mixed, vs_mixed = sem_grad(False, True)
+            assert torch.equal(mixed, full) and torch.equal(vs_mixed, vs_full)
+            by_variant[variant] = full
+        finally:
+            _lib.set_option("bwd_variant", 0)
+    # the two flushes agree to the precision of the split operands (16 significant bits per factor)
+    scale = float(by_variant[2].abs().max())
+    assert float((by_variant[0] - by_variant[2]).abs().max()) <= 3e-5 * scale
 
 
 @pytest.mark.parametrize("P,W,H,S,mu", [(4000, 200, 152, 16, -2.6), (1500, 123, 77, 10, -1.8), (300_000, 800, 528, 16, -3.8)])
@@ -545,10 +556,10 @@ def test_runs_on_a_side_stream_with_identical_results(dev):
         assert torch.equal(x, y)
 
 
-@pytest.mark.parametrize("option,value", [("bwd_variant", 1), ("fwd_variant", 0), ("sort_variant", 0), ("cull_variant", 0)])
+@pytest.mark.parametrize("option,value", [("bwd_variant", 1), ("bwd_variant", 2), ("fwd_variant", 0), ("sort_variant", 0), ("cull_variant", 0)])
 def test_alternative_kernels_stay_correct(oracle_mod, dev, option, value):
     """The non-default variants kept behind goi_raster_set_option (tile + atomics backward, one-candidate forward
-    loop, histogram/scan/scatter sort, the reference's un-culled lists) against the oracle on one case."""
+    loop, the exact-fp32 MFMA flush of the backward, histogram/scan/scatter sort, the reference's un-culled lists) against the oracle on one case."""
     from goi_hyperplane_amd import _lib
     P, S, W, H, mu, deg = 3000, 16, 123, 77, -2.6, 2
     sc = make_scene(P, S=S, sh_degree=deg, seed=3, log_scale_mean=mu)
