@@ -87,8 +87,11 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
     using Cfg = BwdCfg<S4>;
     const bool cull = counters[COUNTER_CULL] != 0;  // the rectangles the forward listed
     constexpr int NF4 = Cfg::NF4, NSEM = Cfg::NSEM, NCH = Cfg::NCH, NB = Cfg::NB;
-    __shared__ f32x4 s_geo[BATCH];        // (A3, A5, A1, A2) of the quadrant-centred log2-alpha polynomial (blend_common.h)
-    __shared__ f32x4 s_geo2[BATCH];       // (A0, A4, lim, slot index (bits))
+    // Staging slots 0..BATCH-1 belong to the current batch; slots BATCH..BATCH+GROUP-1 carry the members of an
+    // unfinished MFMA group across a batch boundary (see `jpack`).
+    __shared__ f32x4 s_geo[BATCH + GROUP];   // (A3, A5, A1, A2) of the quadrant-centred log2-alpha polynomial (blend_common.h)
+    __shared__ f32x4 s_geo2[BATCH + GROUP];  // (A0, A4, lim, slot index (bits))
+    __shared__ float2 s_cen[BATCH + GROUP];  // Gaussian centre - quadrant centre (the flush expands the moments around it)
     __shared__ float4 s_feat[BATCH * NF4];  // (r,g,b,depth), semantics...
     constexpr bool SPLIT = MODE == 0, EXP = MODE == 2;
     // [row][pixel]: rows 0..7 = w of slot, rows 8..15 = h of slot.  fp32 flush: floats, row stride TSTRIDE.
@@ -98,7 +101,6 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
     float* const s_t = reinterpret_cast<float*>(s_traw);
     uint16_t* const s_hi = reinterpret_cast<uint16_t*>(s_traw);
     uint16_t* const s_lo = s_hi + 16 * RS16;
-    __shared__ f32x4 s_gmeta[GROUP * 2];     // per group member: (Dx, Dy, A3, A5), (A0, A4, lim, slot bits)
 
     const int exp_flags = EXP ? exp_flags_rt : 0;
     const QuadGeom t = quad_geom(W, H, gx, n_quads);
@@ -231,6 +233,10 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
     prefetch(0);
 
     int nslot = 0;  // filled slots of the current MFMA group (wave-uniform)
+    // staging slot of every group member, one byte per member, in SGPRs: the flush finds a member's coefficients,
+    // centre and row index where the staging lane left them -- no per-member copy (a lane-0 ds_write_b128 costs
+    // the LDS 13 cycles whatever the number of active lanes)
+    unsigned long long jpack = 0;
 
     // flushes `cnt` filled slots: D = [w]^T dL (NB blocks) and [h]^T basis, then one row per member
     auto flush_group = [&](int cnt) {
@@ -277,7 +283,8 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
             const int row = 4 * kq + r;
             if (row >= GROUP && mm >= 4 && mm < 12) s_t[(row - GROUP) * 8 + (mm - 4)] = accx[r];  // moments -> exchange area
             if (row < cnt && !(exp_flags & 2)) {
-                float* dst = rows + (size_t)__float_as_uint(s_gmeta[row * 2 + 1].w) * row_floats;
+                const int idx = (int)((jpack >> (8 * row)) & 0xFF);
+                float* dst = rows + (size_t)__float_as_uint(s_geo2[idx].w) * row_floats;
 #pragma unroll
                 for (int nb = 0; nb < NB; nb++) {
                     const int ch = nb * 16 + mm;
@@ -291,13 +298,15 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
         if (lane < cnt && !(exp_flags & 2)) {
             const float4 m03 = *reinterpret_cast<const float4*>(&s_t[lane * 8]);
             const float2 m45 = *reinterpret_cast<const float2*>(&s_t[lane * 8 + 4]);
-            const f32x4 g = s_gmeta[lane * 2];
-            const f32x4 g2 = s_gmeta[lane * 2 + 1];
+            const int idx = (int)((jpack >> (8 * lane)) & 0xFF);
+            const f32x4 g = s_geo[idx];
+            const f32x4 g2 = s_geo2[idx];
+            const float2 cen = s_cen[idx];
             const uint32_t slot = __float_as_uint(g2.w);  // (emit-order instance) * 4 + quadrant
-            const float Dx = g.x, Dy = g.y;               // centre - quadrant centre: dx = Dx - u, dy = Dy - v
+            const float Dx = cen.x, Dy = cen.y;           // centre - quadrant centre: dx = Dx - u, dy = Dy - v
             // conic back from A3, A4, A5 (= -log2e/2 a, -log2e b, -log2e/2 c) and 1/opacity from lim
             constexpr float kLn2 = 0.6931471805599453f;
-            const float ca = (-2.f * kLn2) * g.z, cb = -kLn2 * g2.y, cc = (-2.f * kLn2) * g.w;
+            const float ca = (-2.f * kLn2) * g.x, cb = -kLn2 * g2.y, cc = (-2.f * kLn2) * g.y;
             const float inv_o = __builtin_amdgcn_exp2f(kPowerTol * kLog2e - g2.z);
             const float m0 = m03.x, mu = m03.y, mv = m03.z, muu = m03.w, muv = m45.x, mvv = m45.y;
             const float sx = Dx * m0 - mu;                             // sum h dx
@@ -325,7 +334,6 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
         if (b + 1 < rounds) prefetch(b + 1);
         unsigned long long m = __ballot(hit);
         if (m == 0) continue;
-        const float Dx_st = q0.x - QCX, Dy_st = q0.y - QCY;  // kept in registers: the flush metadata reads them by lane
         // ---- stage the hits (slot = lane)
         if (hit) {
             const float4* r4 = reinterpret_cast<const float4*>(rec + id);
@@ -340,6 +348,7 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
             asm volatile("" : "+v"(sl));
             s_geo[sl] = f32x4{pc.A35.x, pc.A35.y, pc.A12.x, pc.A12.y};
             s_geo2[sl] = f32x4{pc.A0, pc.A4, pc.lim, __uint_as_float(inst * 4u + (uint32_t)t.q)};
+            s_cen[sl] = make_float2(q0.x - QCX, q0.y - QCY);
             float4* fdst = &s_feat[sl * NF4];
             fdst[0] = make_float4(q1.w, q2.x, q2.y, q1.z);
             const float* srow = semantics + (size_t)id * S;
@@ -408,20 +417,30 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
                 s_lo[nslot * RS16 + lane] = (uint16_t)lo;
                 s_lo[(GROUP + nslot) * RS16 + lane] = (uint16_t)(lo >> 16);
             }
-            // wave-uniform reads of the staging lane's registers (outside the lane-0 branch: every lane is active here)
-            const float Dxj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Dx_st), j));
-            const float Dyj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(Dy_st), j));
-            if (lane == 0) {  // group members may outlive this batch's staging slots: keep their metadata
-                s_gmeta[nslot * 2] = f32x4{Dxj, Dyj, g.x, g.y};
-                s_gmeta[nslot * 2 + 1] = g2;
-            }
+            jpack |= (unsigned long long)j << (8 * nslot);
             nslot++;
             if (nslot == GROUP) {
                 flush_group(GROUP);
                 nslot = 0;
+                jpack = 0;
             }
         }
         __builtin_amdgcn_wave_barrier();
+        if (nslot > 0 && b + 1 < rounds) {
+            // the next batch overwrites the staging slots: move the unfinished group's members to the carry slots
+            // (member l -> slot BATCH + l; a member carried before is already there)
+            // (lane l reads slot idx_l -- below BATCH, or BATCH + l itself -- and writes BATCH + l: no lane writes
+            // what another lane reads)
+            const int idx = (int)((jpack >> (8 * (lane & 7))) & 0xFF);
+            if (lane < nslot) {
+                s_geo[BATCH + lane] = s_geo[idx];
+                s_geo2[BATCH + lane] = s_geo2[idx];
+                s_cen[BATCH + lane] = s_cen[idx];
+            }
+            constexpr unsigned long long CARRY = 0x0706050403020100ull + 0x0101010101010101ull * BATCH;
+            jpack = CARRY & ((1ull << (8 * nslot)) - 1ull);  // nslot < GROUP = 8 here
+            __builtin_amdgcn_wave_barrier();
+        }
     }
     if (nslot > 0) flush_group(nslot);
 }
