@@ -70,7 +70,7 @@ __device__ __forceinline__ PairEval eval_poly(f32x2 A35, f32x2 A12, float A0, fl
 // ---- split-bf16 operands of the backward kernels' MFMA reductions (render_bwd.hip, "Two flushes")
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int RS16 = 72;  // row stride (bf16 elements) of the split planes: 64 pixels + 8 (b128 reads conflict-free)
+constexpr int TS_SPLIT = 68;  // row stride (floats) of the [member][pixel] transposition buffer: 64 + 4, rows 16-byte aligned
 
 // (a, b) -> packed bf16 pairs: hi = rne(a), rne(b) (a in the low half), lo = rne(a - hi_a), rne(b - hi_b)
 __device__ __forceinline__ void split_pair(float a, float b, uint32_t& hi, uint32_t& lo) {

@@ -38,8 +38,8 @@
 // and its time ADDS to the VALU time of the co-resident waves (tools/mfma_mix_probe.hip): the 32 instructions of
 // one group flush were ~20 % of this kernel.  The default flush (MODE 0) therefore uses the bf16 matrix rate with
 // SPLIT operands: every fp32 value x is carried as two bf16 numbers, hi = rne(x) and lo = rne(x - hi)
-// (|x - hi - lo| <= 2^-17 |x|), kept in two LDS planes (A: w / h) and two register planes (B: dL / basis; the basis
-// values are exact in bf16), and a product is formed as  hi*hi + lo*hi + hi*lo  by three
+// (|x - hi - lo| <= 2^-17 |x|) -- the A operand (w / h) right after it is read from LDS, the B operand (dL / basis;
+// the basis values are exact in bf16) once per kernel in registers -- and a product is formed as  hi*hi + lo*hi + hi*lo  by three
 // v_mfma_f32_16x16x32_bf16 per 32 pixels, accumulated in fp32: 12 instructions of ~20 clocks per flush instead
 // of 32 of ~35.  The dropped lo*lo term is <= 2^-16 of the product; the sums differ from exact fp32 by ~1e-5
 // relative in the worst case (the reference's own float atomicAdd order noise is ~1e-6), still bit-reproducible.
@@ -95,12 +95,12 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
     __shared__ float4 s_feat[BATCH * NF4];  // (r,g,b,depth), semantics...
     constexpr bool SPLIT = MODE == 0, EXP = MODE == 2;
     // [row][pixel]: rows 0..7 = w of slot, rows 8..15 = h of slot.  fp32 flush: floats, row stride TSTRIDE.
-    // Split flush: two bf16 planes (hi, lo) of 16 rows x RS16.
-    constexpr int T_BYTES = SPLIT ? 2 * 16 * RS16 * 2 : 2 * GROUP * TSTRIDE * 4;
+    // Split flush: floats as well (row stride TS_SPLIT, 16-byte aligned rows); the flush splits them into bf16
+    // hi / lo after reading its A operand (two dword stores per member cost the LDS half of four 16-bit ones).
+    constexpr int TS = SPLIT ? TS_SPLIT : TSTRIDE;
+    constexpr int T_BYTES = 2 * GROUP * TS * 4;
     __shared__ __attribute__((aligned(16))) char s_traw[T_BYTES];
     float* const s_t = reinterpret_cast<float*>(s_traw);
-    uint16_t* const s_hi = reinterpret_cast<uint16_t*>(s_traw);
-    uint16_t* const s_lo = s_hi + 16 * RS16;
 
     const int exp_flags = EXP ? exp_flags_rt : 0;
     const QuadGeom t = quad_geom(W, H, gx, n_quads);
@@ -249,19 +249,21 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
         if constexpr (!SPLIT) {
 #pragma unroll
             for (int s = 0; s < 16; s++) {
-                const float a = s_t[mm * TSTRIDE + 4 * s + kq];
+                const float a = s_t[mm * TS + 4 * s + kq];
 #pragma unroll
                 for (int nb = 0; nb < NB; nb++)
                     acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bfrag[nb][s], acc[nb], 0, 0, 0);
                 accx = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bmix[s], accx, 0, 0, 0);
             }
         } else {
-            // A[row = mm][pixel 32 c + 8 kq + i]: one ds_read_b128 per plane and 32-pixel chunk
+            // A[row = mm][pixel 32 c + 8 kq + i]: two ds_read_b128 per 32-pixel chunk, split in registers
             bf16x8 Ah[2], Al[2];
 #pragma unroll
             for (int c2 = 0; c2 < 2; c2++) {
-                Ah[c2] = *reinterpret_cast<const bf16x8*>(s_hi + mm * RS16 + 32 * c2 + 8 * kq);
-                Al[c2] = *reinterpret_cast<const bf16x8*>(s_lo + mm * RS16 + 32 * c2 + 8 * kq);
+                const f32x4* src = reinterpret_cast<const f32x4*>(s_t + mm * TS + 32 * c2 + 8 * kq);
+                const f32x4 a0 = src[0], a1 = src[1];
+                const float y[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                split_pack8(y, Ah[c2], Al[c2]);
             }
 #pragma unroll
             for (int c2 = 0; c2 < 2; c2++) {
@@ -406,17 +408,8 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
                 wgt = e.alpha * Tn;
                 hval = e.E * dL_dopa;  // opacity * G * dL/dalpha: the moments carry the factor `opacity`
             }
-            if constexpr (!SPLIT) {
-                s_t[nslot * TSTRIDE + lane] = wgt;
-                s_t[(GROUP + nslot) * TSTRIDE + lane] = hval;
-            } else {
-                uint32_t hi, lo;  // (w, h) as bf16 pairs: low half = w, high half = h
-                split_pair(wgt, hval, hi, lo);
-                s_hi[nslot * RS16 + lane] = (uint16_t)hi;
-                s_hi[(GROUP + nslot) * RS16 + lane] = (uint16_t)(hi >> 16);
-                s_lo[nslot * RS16 + lane] = (uint16_t)lo;
-                s_lo[(GROUP + nslot) * RS16 + lane] = (uint16_t)(lo >> 16);
-            }
+            s_t[nslot * TS + lane] = wgt;
+            s_t[(GROUP + nslot) * TS + lane] = hval;
             jpack |= (unsigned long long)j << (8 * nslot);
             nslot++;
             if (nslot == GROUP) {

@@ -36,13 +36,12 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
     constexpr int NSEM = 4 * S4, NB = (NSEM + 15) / 16;
     __shared__ f32x4 s_geo[SBATCH];           // (A3, A5, A1, A2) of the quadrant-centred log2-alpha polynomial
     __shared__ f32x4 s_geo2[SBATCH];          // (A0, A4, lim, slot index (bits))
-    // w columns, [member][pixel]: floats (row stride STSTRIDE), or two bf16 planes (hi, lo) of 16 rows x RS16
-    constexpr int T_BYTES = SPLIT ? 2 * 16 * RS16 * 2 : SGROUP * STSTRIDE * 4;
+    // w columns, [member][pixel] floats; the split flush wants 16-byte aligned rows
+    constexpr int TS = SPLIT ? TS_SPLIT : STSTRIDE;
+    constexpr int T_BYTES = SGROUP * TS * 4;
     static_assert(64 * 16 * 4 <= T_BYTES, "staging region too small");
     __shared__ __attribute__((aligned(16))) char s_traw[T_BYTES];
     float* const s_t = reinterpret_cast<float*>(s_traw);
-    uint16_t* const s_hi = reinterpret_cast<uint16_t*>(s_traw);
-    uint16_t* const s_lo = s_hi + 16 * RS16;
     __shared__ uint32_t s_slot[SGROUP];
 
     const QuadGeom t = quad_geom(W, H, gx, n_quads);
@@ -112,7 +111,7 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
         if constexpr (!SPLIT) {
 #pragma unroll
             for (int s = 0; s < 16; s++) {
-                const float a = s_t[mm * STSTRIDE + 4 * s + kq];
+                const float a = s_t[mm * TS + 4 * s + kq];
 #pragma unroll
                 for (int nb = 0; nb < NB; nb++)
                     acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bfrag[nb][s], acc[nb], 0, 0, 0);
@@ -120,8 +119,11 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
         } else {
 #pragma unroll
             for (int c2 = 0; c2 < 2; c2++) {
-                const bf16x8 Ah = *reinterpret_cast<const bf16x8*>(s_hi + mm * RS16 + 32 * c2 + 8 * kq);
-                const bf16x8 Al = *reinterpret_cast<const bf16x8*>(s_lo + mm * RS16 + 32 * c2 + 8 * kq);
+                const f32x4* src = reinterpret_cast<const f32x4*>(s_t + mm * TS + 32 * c2 + 8 * kq);
+                const f32x4 a0 = src[0], a1 = src[1];
+                const float y[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                bf16x8 Ah, Al;
+                split_pack8(y, Ah, Al);
 #pragma unroll
                 for (int nb = 0; nb < NB; nb++) {  // same order of terms as render_bwd_rows_k
                     acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bh[nb][c2], acc[nb], 0, 0, 0);
@@ -180,14 +182,7 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
                 T = Tn;
                 wgt = e.alpha * Tn;
             }
-            if constexpr (!SPLIT) {
-                s_t[nslot * STSTRIDE + lane] = wgt;
-            } else {
-                uint32_t hi, lo;
-                split_pair(wgt, 0.f, hi, lo);
-                s_hi[nslot * RS16 + lane] = (uint16_t)hi;
-                s_lo[nslot * RS16 + lane] = (uint16_t)lo;
-            }
+            s_t[nslot * TS + lane] = wgt;
             if (lane == 0) s_slot[nslot] = __float_as_uint(g2.w);
             nslot++;
             if (nslot == SGROUP) {
