@@ -70,7 +70,13 @@ __device__ __forceinline__ PairEval eval_poly(f32x2 A35, f32x2 A12, float A0, fl
 // ---- split-bf16 operands of the backward kernels' MFMA reductions (render_bwd.hip, "Two flushes")
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int TS_SPLIT = 68;  // row stride (floats) of the [member][pixel] transposition buffer: 64 + 4, rows 16-byte aligned
+// [member row][pixel] transposition buffer of the split flush: row r starts at float split_row(r).  The flush reads
+// it with ds_read_b128 (lane (kq, mm): row mm, pixels 32 c + 8 kq ..), which the LDS serves in the lane groups
+// {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ...: a stride of 80 floats plus 4 floats for rows 8..15 puts the 16
+// lanes of every group on 16 different bank quads (no conflicts; a plain stride of 68 gives 2-way conflicts).
+constexpr int TS_SPLIT = 80;
+__device__ __forceinline__ constexpr int split_row(int r) { return r * TS_SPLIT + 4 * ((r >> 3) & 1); }
+constexpr int SPLIT_FLOATS = 16 * TS_SPLIT + 4;
 
 // (a, b) -> packed bf16 pairs: hi = rne(a), rne(b) (a in the low half), lo = rne(a - hi_a), rne(b - hi_b)
 __device__ __forceinline__ void split_pair(float a, float b, uint32_t& hi, uint32_t& lo) {

@@ -97,8 +97,8 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
     // [row][pixel]: rows 0..7 = w of slot, rows 8..15 = h of slot.  fp32 flush: floats, row stride TSTRIDE.
     // Split flush: floats as well (row stride TS_SPLIT, 16-byte aligned rows); the flush splits them into bf16
     // hi / lo after reading its A operand (two dword stores per member cost the LDS half of four 16-bit ones).
-    constexpr int TS = SPLIT ? TS_SPLIT : TSTRIDE;
-    constexpr int T_BYTES = 2 * GROUP * TS * 4;
+    constexpr int TS = TSTRIDE;  // (fp32 flush)
+    constexpr int T_BYTES = SPLIT ? SPLIT_FLOATS * 4 : 2 * GROUP * TSTRIDE * 4;
     __shared__ __attribute__((aligned(16))) char s_traw[T_BYTES];
     float* const s_t = reinterpret_cast<float*>(s_traw);
 
@@ -260,7 +260,7 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
             bf16x8 Ah[2], Al[2];
 #pragma unroll
             for (int c2 = 0; c2 < 2; c2++) {
-                const f32x4* src = reinterpret_cast<const f32x4*>(s_t + mm * TS + 32 * c2 + 8 * kq);
+                const f32x4* src = reinterpret_cast<const f32x4*>(s_t + split_row(mm) + 32 * c2 + 8 * kq);
                 const f32x4 a0 = src[0], a1 = src[1];
                 const float y[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
                 split_pack8(y, Ah[c2], Al[c2]);
@@ -408,8 +408,8 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
                 wgt = e.alpha * Tn;
                 hval = e.E * dL_dopa;  // opacity * G * dL/dalpha: the moments carry the factor `opacity`
             }
-            s_t[nslot * TS + lane] = wgt;
-            s_t[(GROUP + nslot) * TS + lane] = hval;
+            s_t[(SPLIT ? split_row(nslot) : nslot * TS) + lane] = wgt;
+            s_t[(SPLIT ? split_row(GROUP + nslot) : (GROUP + nslot) * TS) + lane] = hval;
             jpack |= (unsigned long long)j << (8 * nslot);
             nslot++;
             if (nslot == GROUP) {

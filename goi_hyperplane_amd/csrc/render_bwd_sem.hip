@@ -37,8 +37,8 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
     __shared__ f32x4 s_geo[SBATCH];           // (A3, A5, A1, A2) of the quadrant-centred log2-alpha polynomial
     __shared__ f32x4 s_geo2[SBATCH];          // (A0, A4, lim, slot index (bits))
     // w columns, [member][pixel] floats; the split flush wants 16-byte aligned rows
-    constexpr int TS = SPLIT ? TS_SPLIT : STSTRIDE;
-    constexpr int T_BYTES = SGROUP * TS * 4;
+    constexpr int TS = STSTRIDE;  // (fp32 flush)
+    constexpr int T_BYTES = SPLIT ? SPLIT_FLOATS * 4 : SGROUP * STSTRIDE * 4;
     static_assert(64 * 16 * 4 <= T_BYTES, "staging region too small");
     __shared__ __attribute__((aligned(16))) char s_traw[T_BYTES];
     float* const s_t = reinterpret_cast<float*>(s_traw);
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
         } else {
 #pragma unroll
             for (int c2 = 0; c2 < 2; c2++) {
-                const f32x4* src = reinterpret_cast<const f32x4*>(s_t + mm * TS + 32 * c2 + 8 * kq);
+                const f32x4* src = reinterpret_cast<const f32x4*>(s_t + split_row(mm) + 32 * c2 + 8 * kq);
                 const f32x4 a0 = src[0], a1 = src[1];
                 const float y[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
                 bf16x8 Ah, Al;
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
                 T = Tn;
                 wgt = e.alpha * Tn;
             }
-            s_t[nslot * TS + lane] = wgt;
+            s_t[(SPLIT ? split_row(nslot) : nslot * TS) + lane] = wgt;
             if (lane == 0) s_slot[nslot] = __float_as_uint(g2.w);
             nslot++;
             if (nslot == SGROUP) {
