@@ -324,15 +324,18 @@ def main():
                         "bytes_per_launch": sb[dominant], "avg_ms": d["ms"]}
             # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process);
             # only quoted for the workload they were collected on
-            pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_g_pmc_traffic.json")
+            import glob
+            pmcs = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
+                                                 "r*_pmc_traffic.json")))
+            pmc = pmcs[-1] if pmcs else ""  # the newest committed set (names sort by round and build letter)
             headline = (args.P, args.W, args.H, args.S, args.mu) == (HEADLINE["P"], HEADLINE["W"], HEADLINE["H"],
                                                                      HEADLINE["S"], HEADLINE["log_scale_mean"])
-            if headline and os.path.exists(pmc):
+            if headline and pmc:
                 tj = json.load(open(pmc))
                 k = tj["kernels"].get(tj["stage_kernel"].get(dominant, ""))
                 if k:
                     roofline["traffic"] = k["hbm_bytes_corrected"]
-                    roofline["traffic_source"] = ("profiles/r01_g_pmc_traffic.json: 2*FETCH_SIZE + WRITE_SIZE of "
+                    roofline["traffic_source"] = ("profiles/" + os.path.basename(pmc) + ": 2*FETCH_SIZE + WRITE_SIZE of "
                                                   + tj["stage_kernel"][dominant] + ", separate rocprofv3 --pmc passes")
         gpu_ms = sum(v["ms"] for v in stage_out.values())
         ms_per_step = elapsed / args.steps * 1e3
