@@ -613,12 +613,15 @@ __global__ __launch_bounds__(256) void emit_k(int P, int gx, int gy, const Gauss
                                               uint32_t* __restrict__ tile_count, const uint32_t* __restrict__ counters) {
     const bool cull = counters[COUNTER_CULL] != 0;
     extern __shared__ uint32_t s_cnt[];  // [gx * gy] when COUNT
+    __shared__ int s_incl[4][64];    // per wave: inclusive scan of the rectangles' tile counts
+    __shared__ uint4 s_info[4][64];  // (x0 | y0 << 16, exclusive count, offsets[] - exclusive count, Gaussian id)
+    __shared__ int s_w[4][64];       // rectangle width in tiles
     const int T = gx * gy;
     if (COUNT) {
         for (int t = threadIdx.x; t < T; t += 256) s_cnt[t] = 0;
         __syncthreads();
     }
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // the counting variant amortises zeroing and flushing its tile histogram over EMIT_ROUNDS x 256 Gaussians
     constexpr int ROUNDS = COUNT ? EMIT_ROUNDS : 1;
 #pragma unroll 1
@@ -640,23 +643,41 @@ __global__ __launch_bounds__(256) void emit_k(int P, int gx, int gy, const Gauss
                 cnt = w * (y1 - y0);
             }
         }
-        unsigned long long todo = __ballot(cnt > 0);
-        while (todo) {
-            const int j = __builtin_ctzll(todo);
-            todo &= todo - 1;
-            const int cj = __builtin_amdgcn_readlane(cnt, j);
-            const int wj = __builtin_amdgcn_readlane(w, j);
-            const int xj = __builtin_amdgcn_readlane(x0, j), yj = __builtin_amdgcn_readlane(y0, j);
-            const uint32_t oj = (uint32_t)__builtin_amdgcn_readlane((int)off, j);
-            const uint32_t gj = (uint32_t)__builtin_amdgcn_readlane((int)g, j);
-            for (int k = lane; k < cj; k += 64) {
-                const int row = k / wj, col = k - row * wj;
-                const uint32_t key = (uint32_t)((yj + row) * gx + xj + col);
-                keys[oj + k] = key;
-                vals[oj + k] = gj;
-                if (COUNT) atomicAdd(&s_cnt[key], 1u);  // lanes hold distinct tiles of one rectangle: no same-address conflicts
-            }
+        // Load-balanced expansion: the wave's 64 rectangles hold `total` (tile, Gaussian) instances; lane l of trip
+        // t0 produces instance t0 + l, whichever rectangle it falls into (binary search in the inclusive scan of the
+        // counts).  A rectangle has ~10 tiles on average: one rectangle per trip would leave 5/6 of the lanes idle.
+        // Consecutive instances are consecutive addresses (offsets[] is the exclusive scan of the same counts in the
+        // same order): full-line stores.
+        int incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += o;
         }
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        const int excl = incl - cnt;
+        s_incl[wv][lane] = incl;
+        s_info[wv][lane] = make_uint4((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)excl, off - (uint32_t)excl, g);
+        s_w[wv][lane] = w;
+        __builtin_amdgcn_wave_barrier();
+        for (int t = lane; t < total; t += 64) {
+            int lo = 0;  // smallest l with incl[l] > t
+#pragma unroll
+            for (int step = 32; step >= 1; step >>= 1)
+                if (s_incl[wv][lo + step - 1] <= t) lo += step;
+            const uint4 info = s_info[wv][lo];
+            const int wl = s_w[wv][lo];
+            const int k = t - (int)info.y;
+            int row = (int)((float)k * __builtin_amdgcn_rcpf((float)wl));  // k / wl, off by at most one
+            row -= (row * wl > k);
+            row += ((row + 1) * wl <= k);
+            const int col = k - row * wl;
+            const uint32_t key = (uint32_t)(((int)(info.x >> 16) + row) * gx + (int)(info.x & 0xFFFFu) + col);
+            keys[info.z + (uint32_t)t] = key;
+            vals[info.z + (uint32_t)t] = info.w;
+            if (COUNT) atomicAdd(&s_cnt[key], 1u);
+        }
+        __builtin_amdgcn_wave_barrier();
     }
     if (COUNT) {
         __syncthreads();
