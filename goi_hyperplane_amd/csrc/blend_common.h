@@ -100,6 +100,36 @@ __device__ __forceinline__ bool box_hits_quadrant(float x, float y, float hx, fl
     return (hx >= 0.f) && (x - hx <= X0 + 7.f) && (x + hx >= X0) && (y - hy <= Y0 + 7.f) && (y + hy >= Y0);
 }
 
+// Can the Gaussian reach alpha >= 1/255 at some point of the 8x8 quadrant whose first pixel is (X0, Y0)?  Exact test
+// against the ELLIPSE  1/2 (a dx^2 + c dy^2) + b dx dy <= tau  (tau = the inflated ln(255 opacity) the contribution
+// box was built from, preprocess_fwd_k): the minimum of the convex quadratic over the rectangle is 0 when the
+// centre lies inside and otherwise sits on one of the four edges, where it is a clamped 1-D minimisation.  The
+// bounding box of the ellipse (box_hits_quadrant) keeps a quadrant whenever the BOX touches it: for round
+// Gaussians 1 - pi/4 of the box is empty, for elongated diagonal ones most of it.  Every candidate the test
+// removes saves the staging of the Gaussian and a 64-lane evaluation that could not contribute.  Conservative:
+// the continuous minimum over the rectangle bounds the minimum over its pixel centres, tau carries the 1 % + 0.01
+// margin of the box, and an unknown bound (hx = +inf) keeps the candidate.  hx < 0: can never contribute (also
+// marks absent lanes).
+__device__ __forceinline__ bool ellipse_hits_quadrant(float x, float y, float ca, float cb, float cc, float o, float hx,
+                                                      float hy, float X0, float Y0) {
+    if (!box_hits_quadrant(x, y, hx, hy, X0, Y0)) return false;
+    if (!(hx < 3.0e38f)) return true;  // no bound known
+    const float ux0 = X0 - x, ux1 = ux0 + 7.f, uy0 = Y0 - y, uy1 = uy0 + 7.f;  // rectangle relative to the centre
+    if (ux0 <= 0.f && ux1 >= 0.f && uy0 <= 0.f && uy1 >= 0.f) return true;     // centre inside
+    const float tau = 1.01f * 0.6931471805599453f * __builtin_amdgcn_logf(255.f * o) + 0.0101f;
+    const float rb_c = -cb * __builtin_amdgcn_rcpf(cc), rb_a = -cb * __builtin_amdgcn_rcpf(ca);
+    auto edge_x = [&](float ex) {  // min over dy in [uy0, uy1] at dx = ex
+        const float dy = fminf(fmaxf(rb_c * ex, uy0), uy1);
+        return 0.5f * (ca * ex * ex + cc * dy * dy) + cb * ex * dy;
+    };
+    auto edge_y = [&](float ey) {
+        const float dx = fminf(fmaxf(rb_a * ey, ux0), ux1);
+        return 0.5f * (ca * dx * dx + cc * ey * ey) + cb * dx * ey;
+    };
+    const float qmin = fminf(fminf(edge_x(ux0), edge_x(ux1)), fminf(edge_y(uy0), edge_y(uy1)));
+    return !(qmin > tau * 1.0001f + 1e-4f);  // (NaN keeps the candidate)
+}
+
 // One workgroup = one 16x16 tile; wave w owns quadrant (w&1, w>>1); lane l owns pixel
 // (l&7, l>>3) of the quadrant.
 struct TileGeom {

@@ -220,6 +220,7 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
     // software prefetch of the next batch's id / position / box (one list entry per lane)
     uint32_t id_n = 0;
     float4 q0_n = make_float4(0, 0, 0, 0), q2_n = make_float4(0, 0, -1.f, -1.f);
+    float2 co_n = make_float2(1.f, 0.f);  // conic c, opacity (first half of q1: the ellipse test needs them)
     auto prefetch = [&](int b) {
         const int k = b * BATCH + lane;  // list position n_proc-1-k, walking back to front
         q2_n.z = -1.f;
@@ -227,6 +228,7 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
             id_n = point_list[range.x + (n_proc - 1 - k)];
             const float4* r4 = reinterpret_cast<const float4*>(rec + id_n);
             q0_n = r4[0];
+            co_n = *reinterpret_cast<const float2*>(r4 + 1);
             q2_n = r4[2];
         }
     };
@@ -332,7 +334,8 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
     for (int b = 0; b < rounds; b++) {
         const uint32_t id = id_n;
         const float4 q0 = q0_n, q2 = q2_n;
-        const bool hit = box_hits_quadrant(q0.x, q0.y, q2.z, q2.w, t.QX0, t.QY0);  // hx < 0 for absent lanes
+        const float2 co = co_n;
+        const bool hit = ellipse_hits_quadrant(q0.x, q0.y, q0.z, q0.w, co.x, co.y, q2.z, q2.w, t.QX0, t.QY0);  // hx < 0 for absent lanes
         if (b + 1 < rounds) prefetch(b + 1);
         unsigned long long m = __ballot(hit);
         if (m == 0) continue;

@@ -90,6 +90,7 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
 
     uint32_t id_n = 0;
     float4 q0_n = make_float4(0, 0, 0, 0), q2_n = make_float4(0, 0, -1.f, -1.f);
+    float2 co_n = make_float2(1.f, 0.f);  // conic c, opacity (first half of q1: the ellipse test needs them)
     auto prefetch = [&](int b) {
         const int k = b * SBATCH + lane;
         q2_n.z = -1.f;
@@ -97,6 +98,7 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
             id_n = point_list[range.x + (n_proc - 1 - k)];
             const float4* r4 = reinterpret_cast<const float4*>(rec + id_n);
             q0_n = r4[0];
+            co_n = *reinterpret_cast<const float2*>(r4 + 1);
             q2_n = r4[2];
         }
     };
@@ -151,7 +153,8 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
     for (int b = 0; b < rounds; b++) {
         const uint32_t id = id_n;
         const float4 q0 = q0_n, q2 = q2_n;
-        const bool hit = box_hits_quadrant(q0.x, q0.y, q2.z, q2.w, t.QX0, t.QY0);
+        const float2 co = co_n;
+        const bool hit = ellipse_hits_quadrant(q0.x, q0.y, q0.z, q0.w, co.x, co.y, q2.z, q2.w, t.QX0, t.QY0);
         if (b + 1 < rounds) prefetch(b + 1);
         unsigned long long m = __ballot(hit);
         if (m == 0) continue;

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void render_bwd_tile_k(
             if (k < n_proc && (n_proc - 1 - k) < wmax) {
                 const float4 g = s_geo[t.lane];
                 const float4 g2 = s_geo2[t.lane];
-                hit = box_hits_quadrant(g.x, g.y, g2.z, g2.w, QX0, QY0);
+                hit = ellipse_hits_quadrant(g.x, g.y, g.z, g.w, g2.x, g2.y, g2.z, g2.w, QX0, QY0);
             }
             cand = __ballot(hit);
         }
