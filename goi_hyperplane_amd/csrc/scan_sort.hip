@@ -254,38 +254,44 @@ __global__ __launch_bounds__(SORT_THREADS) void sweep_hist_k(const uint32_t* __r
     }
 }
 
-__global__ __launch_bounds__(SORT_THREADS) void sweep_pass_k(const uint32_t* __restrict__ keys_in,
+// Tile shape: THREADS x ITEMS keys per workgroup.  A pass lasts about as long as ONE tile takes (every tile of a
+// 1 M-key sort is resident at once), and that is set by the ITEMS ranking rounds each thread runs back to back:
+// 1024 x 4 sorts 1 M keys in 89 us (4 passes) where 512 x 16 needs 102; with 5 M keys the larger tile wins
+// (88 vs 96 us for 2 passes: fewer tiles to look back over, fewer partial runs per digit).
+template <int THREADS, int ITEMS>
+__global__ __launch_bounds__(THREADS) void sweep_pass_k(const uint32_t* __restrict__ keys_in,
                                                              const uint32_t* __restrict__ vals_in,
                                                              uint32_t* __restrict__ keys_out,
                                                              uint32_t* __restrict__ vals_out, size_t n, int shift,
                                                              int nbits, const uint32_t* __restrict__ ghist,
                                                              uint32_t* status, uint32_t* ticket, uint32_t* error) {
-    __shared__ uint32_t cnt[SORT_WAVES][RADIX_MAX];  // per-wave digit counts -> per-wave local offsets
+    constexpr int TILE_KEYS = THREADS * ITEMS, WAVES = THREADS / WAVE, WAVE_ITEMS = TILE_KEYS / WAVES;
+    __shared__ uint32_t cnt[WAVES][RADIX_MAX];  // per-wave digit counts -> per-wave local offsets
     __shared__ uint32_t gbase[RADIX_MAX];            // global position of this block's first element of digit d
     __shared__ uint32_t lbase[RADIX_MAX];            // local (in-block) exclusive offset of digit d
-    extern __shared__ uint32_t s_dyn[];  // [2][SORT_TILE]: the tile's keys and values in digit order
+    extern __shared__ uint32_t s_dyn[];  // [2][TILE_KEYS]: the tile's keys and values in digit order
     uint32_t* s_keys = s_dyn;
-    uint32_t* s_vals = s_dyn + SORT_TILE;
+    uint32_t* s_vals = s_dyn + TILE_KEYS;
     __shared__ uint32_t s_bid;
     const uint32_t radix = 1u << nbits, mask = radix - 1u;
     if (threadIdx.x == 0) s_bid = atomicAdd(ticket, 1u);
-    for (int i = threadIdx.x; i < SORT_WAVES * RADIX_MAX; i += SORT_THREADS) (&cnt[0][0])[i] = 0;
+    for (int i = threadIdx.x; i < WAVES * RADIX_MAX; i += THREADS) (&cnt[0][0])[i] = 0;
     __syncthreads();
     const uint32_t bid = s_bid;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint64_t lt = (1ull << lane) - 1ull;
-    const size_t tile_base = (size_t)bid * SORT_TILE;
-    const size_t wbase = tile_base + (size_t)w * SORT_WAVE_ITEMS;
-    uint32_t key[SORT_ITEMS], val[SORT_ITEMS], rank[SORT_ITEMS];
+    const size_t tile_base = (size_t)bid * TILE_KEYS;
+    const size_t wbase = tile_base + (size_t)w * WAVE_ITEMS;
+    uint32_t key[ITEMS], val[ITEMS], rank[ITEMS];
 #pragma unroll
-    for (int r = 0; r < SORT_ITEMS; r++) {
+    for (int r = 0; r < ITEMS; r++) {
         size_t i = wbase + (size_t)r * WAVE + lane;
         const bool ok = i < n;
         key[r] = ok ? keys_in[i] : 0xFFFFFFFFu;
         val[r] = ok ? vals_in[i] : 0u;
     }
 #pragma unroll
-    for (int r = 0; r < SORT_ITEMS; r++) {
+    for (int r = 0; r < ITEMS; r++) {
         size_t i = wbase + (size_t)r * WAVE + lane;
         const bool ok = i < n;
         const uint32_t d = (key[r] >> shift) & mask;
@@ -312,7 +318,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sweep_pass_k(const uint32_t* __r
         const uint32_t d = threadIdx.x;
         uint32_t run = 0;
 #pragma unroll
-        for (int ww = 0; ww < SORT_WAVES; ww++) {
+        for (int ww = 0; ww < WAVES; ww++) {
             const uint32_t t = cnt[ww][d];
             cnt[ww][d] = run;  // exclusive offset of wave ww inside the block's run of digit d
             run += t;
@@ -370,7 +376,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sweep_pass_k(const uint32_t* __r
     __syncthreads();
     // ---- reorder through LDS: element -> local position lbase[d] + wave offset + rank
 #pragma unroll
-    for (int r = 0; r < SORT_ITEMS; r++) {
+    for (int r = 0; r < ITEMS; r++) {
         size_t i = wbase + (size_t)r * WAVE + lane;
         if (i < n) {
             const uint32_t d = (key[r] >> shift) & mask;
@@ -380,8 +386,8 @@ __global__ __launch_bounds__(SORT_THREADS) void sweep_pass_k(const uint32_t* __r
         }
     }
     __syncthreads();
-    const uint32_t count = (uint32_t)(tile_base + SORT_TILE <= n ? SORT_TILE : (n > tile_base ? n - tile_base : 0));
-    for (uint32_t i = threadIdx.x; i < count; i += SORT_THREADS) {
+    const uint32_t count = (uint32_t)(tile_base + TILE_KEYS <= n ? TILE_KEYS : (n > tile_base ? n - tile_base : 0));
+    for (uint32_t i = threadIdx.x; i < count; i += THREADS) {
         const uint32_t k = s_keys[i];
         const uint32_t d = (k >> shift) & mask;
         const uint32_t pos = gbase[d] + (i - lbase[d]);
@@ -397,7 +403,7 @@ inline size_t div_up(size_t a, size_t b) { return (a + b - 1) / b; }
 size_t scan_scratch_words(size_t n) { return div_up(n, SCAN_CHUNK) + 16; }
 
 size_t sort_scratch_words(size_t n) {
-    size_t nblk = div_up(n, SORT_TILE);
+    size_t nblk = div_up(n, 4096);  // the smallest tile any variant uses
     size_t table = (size_t)RADIX_MAX * nblk;
     size_t three_kernel = table + scan_scratch_words(table) + 16;
     size_t onesweep = (size_t)MAX_PASSES * table + (size_t)MAX_PASSES * RADIX_MAX + 64;
@@ -418,8 +424,9 @@ void exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* ou
 
 // Control words of the onesweep sort, contiguous at the start of the scratch so that ONE memset clears them:
 // [passes][nblk][256] status | [MAX_PASSES][256] global digit histograms | [MAX_PASSES] tickets | error
+static size_t sweep_tile_keys(size_t n) { return n <= ((size_t)2 << 20) ? 4096 : 8192; }  // 1024 x 4 or 512 x 16
 static size_t sweep_status_words(size_t n, int lo, int hi) {
-    return (size_t)((hi - lo + 7) / 8) * div_up(n, SORT_TILE) * RADIX_MAX;
+    return (size_t)((hi - lo + 7) / 8) * div_up(n, sweep_tile_keys(n)) * RADIX_MAX;
 }
 size_t radix_sort_control_words(size_t n, int lo, int hi) {
     return n ? sweep_status_words(n, lo, hi) + MAX_PASSES * RADIX_MAX + MAX_PASSES + 1 : 0;
@@ -455,18 +462,25 @@ int radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], size_t n, int lo, int
             sh += plan.nbits[p];
         }
         for (int p = passes; p < MAX_PASSES; p++) plan.shift[p] = plan.nbits[p] = 0;
-        constexpr size_t SWEEP_LDS = (size_t)2 * SORT_TILE * sizeof(uint32_t);
+        if (!ghist_ready) sweep_hist_k<<<dim3(nblk), dim3(SORT_THREADS), 0, s>>>(keys[0], n, plan, ghist);
+        const size_t tile = sweep_tile_keys(n);
+        const uint32_t nt = (uint32_t)div_up(n, tile);
+        const size_t lds = 2 * tile * sizeof(uint32_t);  // the tile's keys and values in digit order
         static bool attr_set = false;
-        if (!attr_set && SWEEP_LDS > 48 * 1024) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_pass_k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)SWEEP_LDS);
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_pass_k<512, 16>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8192 * (int)sizeof(uint32_t));
             attr_set = true;
         }
-        if (!ghist_ready) sweep_hist_k<<<dim3(nblk), dim3(SORT_THREADS), 0, s>>>(keys[0], n, plan, ghist);
         for (int p = 0; p < passes; p++) {
-            sweep_pass_k<<<dim3(nblk), dim3(SORT_THREADS), SWEEP_LDS, s>>>(
-                keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, plan.shift[p], plan.nbits[p],
-                ghist + (size_t)p * RADIX_MAX, status + (size_t)p * nblk * RADIX_MAX, ticket + p, error);
+            if (tile == 4096)
+                sweep_pass_k<1024, 4><<<dim3(nt), dim3(1024), lds, s>>>(
+                    keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, plan.shift[p], plan.nbits[p],
+                    ghist + (size_t)p * RADIX_MAX, status + (size_t)p * nt * RADIX_MAX, ticket + p, error);
+            else
+                sweep_pass_k<512, 16><<<dim3(nt), dim3(512), lds, s>>>(
+                    keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, plan.shift[p], plan.nbits[p],
+                    ghist + (size_t)p * RADIX_MAX, status + (size_t)p * nt * RADIX_MAX, ticket + p, error);
             cur ^= 1;
         }
         return cur;
