@@ -105,6 +105,9 @@ def main():
     ap.add_argument("--views", type=int, default=16, help="distinct cameras cycled through")
     ap.add_argument("--grads", choices=["all", "semantics"], default="all",
                     help="which Gaussian gradients are all-reduced when --gpus > 1")
+    ap.add_argument("--exchange", choices=["factored", "allreduce"], default="factored",
+                    help="--gpus > 1, --grads all: 'factored' all-gathers the factors of dL/dSH (12 B per Gaussian "
+                         "and view) and all-reduces the other 27 gradient floats; 'allreduce' all-reduces all 75")
     ap.add_argument("--ply", default=None,
                     help="point_cloud.ply saved by the reference (sem_* columns) instead of the synthetic scene; "
                          "cameras stay synthetic (the data sets are not in this image)")
@@ -133,7 +136,8 @@ def main():
         dist.init_process_group(backend="nccl", device_id=dev)
 
     from goi_hyperplane_amd import _lib
-    from goi_hyperplane_amd.dist import allreduce_gradients
+    from goi_hyperplane_amd import rasterizer
+    from goi_hyperplane_amd.dist import allreduce_gradients, allreduce_gradients_sh_factored
     from goi_hyperplane_amd.render import GaussianSet, PipelineParams, TorchCamera, render
     from goi_hyperplane_amd.scene import make_camera, make_scene
     _lib.load()
@@ -162,6 +166,9 @@ def main():
     g_color = torch.randn((3, args.H, args.W), device=dev, generator=gen) * inv_hw
     g_sem = torch.randn((args.S, args.H, args.W), device=dev, generator=gen) * inv_hw
 
+    exchange = {"mode": "allreduce", "note": None}
+    non_sh_params = [pc._xyz, pc._semantics, pc._opacity, pc._scaling, pc._rotation]
+
     def step(i, record=False):
         cam = cams[(i * world + rank) % len(cams)]  # rank r takes views r, r+G, ... of the cycle
         for p in params:
@@ -169,10 +176,40 @@ def main():
         out = render(cam, pc, pipe, bg)
         torch.autograd.backward((out["render"], out["semantics"]), (g_color, g_sem))
         if dist is not None:
-            allreduce_gradients(reduce_params, dist)
+            if exchange["mode"] == "factored":
+                allreduce_gradients_sh_factored(non_sh_params, (pc._features,), pc._xyz, rasterizer.take_sh_factor(), dist)
+            else:
+                allreduce_gradients(reduce_params, dist)
         if record:
             stats["radii"] = out["radii"]
         return out
+
+    if dist is not None and args.grads == "all" and args.exchange == "factored":
+        # Exchange dL/dSH as its factors -- after checking, on this machine and this scene, that it reproduces the
+        # plain all-reduce (the ring adds the ranks in another order: agreement to rounding, not bit for bit).  Any
+        # failure falls back to the plain all-reduce and is reported in config.exchange.
+        local_ok, why = True, ""
+        try:
+            step(0)
+            want = pc._features.grad.clone()
+            exchange["mode"] = "factored"
+            rasterizer.set_backward_mode(sh_factored=True)
+            step(0)
+            err = float((pc._features.grad - want).abs().max())
+            scale = float(want.abs().max())
+            if not err <= 1e-5 * scale + 1e-12:
+                local_ok, why = False, f"factored dL/dSH differs from the all-reduced one by {err:.3e} (scale {scale:.3e})"
+            else:
+                why = f"verified against the plain all-reduce: max |diff| = {err:.2e} of {scale:.2e}"
+        except Exception as e:  # noqa: BLE001 -- never lose the scaling run to the optimisation
+            local_ok, why = False, f"{type(e).__name__}: {e}"
+        ok = torch.tensor([1.0 if local_ok else 0.0], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # the ranks switch together
+        if float(ok.item()) == 1.0:
+            exchange["note"] = why
+        else:
+            exchange["mode"], exchange["note"] = "allreduce", "factored exchange disabled: " + (why or "another rank failed")
+            rasterizer.set_backward_mode(sh_factored=False)
 
     for i in range(args.warmup):
         step(i)
@@ -349,7 +386,11 @@ def main():
                        "P": args.P, "V": V, "N_per_view": N, "N_listed_per_view": stats["N_listed"] / stats["views"],
                        "tiles": T, "HW": HW, "S": args.S,
                        "views_per_step": world, "parallelism": f"views sharded x{world}",
-                       "allreduce_bytes": int(sum(p.numel() for p in reduce_params) * 4) if world > 1 else 0},
+                       "allreduce_bytes": (0 if world <= 1 else
+                                           int(sum(p.numel() for p in non_sh_params) * 4) if exchange["mode"] == "factored"
+                                           else int(sum(p.numel() for p in reduce_params) * 4)),
+                       "allgather_bytes": int(args.P * 3 * 4 * world) if (world > 1 and exchange["mode"] == "factored") else 0,
+                       "exchange": exchange["mode"] if world > 1 else None, "exchange_note": exchange["note"]},
             "render_ms_per_frame": render_ms,
             "gui_frame_ms": gui_ms,  # render + fused semantic decode (300 codes)
             "semantic_finetune": sem_only,

@@ -144,12 +144,16 @@ def rasterize_gaussians(background, means3D, colors, semantics, opacity, scales,
     return n, out_color, out_sem, out_depth, out_alpha, radii, geom, alloc.tensor, img
 
 
-def rasterize_gaussians_backward(background, means3D, radii, colors, semantics, scales, rotations, scale_modifier,
+def _backward_impl(background, means3D, radii, colors, semantics, scales, rotations, scale_modifier,
                                  cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
                                  dL_dout_semantic, dL_dout_depth, dL_dout_alpha, sh, degree, campos, geomBuffer, R,
-                                 binningBuffer, imageBuffer, alphas, debug):
+                                 binningBuffer, imageBuffer, alphas, debug, sh_factored=False):
     """-> (dL_dmeans2D[P,3], dL_dcolors[P,3], dL_dsemantics[P,S], dL_dopacity[P,1], dL_dmeans3D[P,3],
-    dL_dcov3D[P,6], dL_dsh[P,M,3], dL_dscales[P,3], dL_drotations[P,4])"""
+    dL_dcov3D[P,6], dL_dsh[P,M,3], dL_dscales[P,3], dL_drotations[P,4])
+
+    sh_factored (not in the reference's pybind module; FACTORED mode of goi_raster_backward): dL_dsh is not formed
+    (returned as None) and dL_dcolors is the clamp-masked colour gradient g, the factor of
+    dL/dSH[k] = basis_k(view direction) * g -- see sh_grad_from_views and dist.allreduce_gradients_sh_factored."""
     lib = _lib.load()
     dev = _check_device(means3D)
     P = int(means3D.size(0))
@@ -158,14 +162,15 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, semantics, 
     H, W = int(alphas.size(-2)), int(alphas.size(-1))
     S = int(semantics.size(1))
     M = 0 if (sh is None or sh.numel() == 0) else int(sh.size(1))
+    sh_factored = bool(sh_factored) and M > 0
     f32 = dict(dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         # every element is written by the library (atomically accumulated ones are zeroed there).
         # The gradients of the six Gaussian parameter tensors are views of ONE flat buffer (256-byte
         # aligned sections): autograd hands these views to the leaves as .grad, so the data-parallel
         # exchange can be a single all-reduce over the buffer instead of one per tensor (dist.py).
-        sections = (("means3D", (P, 3)), ("sh", (P, M, 3)), ("semantics", (P, S)), ("opacity", (P, 1)),
-                    ("scales", (P, 3)), ("rotations", (P, 4)))
+        sections = (("means3D", (P, 3)), ("sh", (P, 0 if sh_factored else M, 3)), ("semantics", (P, S)),
+                    ("opacity", (P, 1)), ("scales", (P, 3)), ("rotations", (P, 4)))
         offs, total = {}, 0
         for name, shape in sections:
             offs[name] = total
@@ -181,7 +186,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, semantics, 
                 n *= d
             return flat[offs[name]:offs[name] + n].view(shape)
         dL_dmeans3D = view("means3D", (P, 3))
-        dL_dsh = view("sh", (P, M, 3))
+        dL_dsh = None if sh_factored else view("sh", (P, M, 3))
         dL_dsemantics = view("semantics", (P, S))
         dL_dopacity = view("opacity", (P, 1))
         dL_dscales = view("scales", (P, 3))
@@ -216,6 +221,45 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, semantics, 
                 raise RuntimeError(_lib.last_error())
     return (dL_dmeans2D, dL_dcolors, dL_dsemantics, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales,
             dL_drotations)
+
+
+def rasterize_gaussians_backward(background, means3D, radii, colors, semantics, scales, rotations, scale_modifier,
+                                 cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
+                                 dL_dout_semantic, dL_dout_depth, dL_dout_alpha, sh, degree, campos, geomBuffer, R,
+                                 binningBuffer, imageBuffer, alphas, debug):
+    """-> (dL_dmeans2D[P,3], dL_dcolors[P,3], dL_dsemantics[P,S], dL_dopacity[P,1], dL_dmeans3D[P,3],
+    dL_dcov3D[P,6], dL_dsh[P,M,3], dL_dscales[P,3], dL_drotations[P,4]) -- the reference's RasterizeGaussiansBackwardCUDA
+    (rasterize_points.cu:213-306), same argument list."""
+    return _backward_impl(background, means3D, radii, colors, semantics, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_semantic, dL_dout_depth, dL_dout_alpha, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, alphas, debug)
+
+
+def rasterize_gaussians_backward_sh_factored(background, means3D, radii, colors, semantics, scales, rotations, scale_modifier,
+                                 cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
+                                 dL_dout_semantic, dL_dout_depth, dL_dout_alpha, sh, degree, campos, geomBuffer, R,
+                                 binningBuffer, imageBuffer, alphas, debug):
+    """Same arguments and result tuple as rasterize_gaussians_backward (not in the reference's pybind module), in the
+    FACTORED mode of goi_raster_backward: dL_dsh is None and dL_dcolors is the clamp-masked colour gradient."""
+    return _backward_impl(background, means3D, radii, colors, semantics, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_semantic, dL_dout_depth, dL_dout_alpha, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, alphas, debug, sh_factored=True)
+
+
+def sh_grad_from_views(means3D, campos, gcol, degree, M):
+    """dL/dSH [P,M,3] of V views from means3D [P,3], the camera centres campos [V,3] and the clamp-masked colour
+    gradients gcol [V,P,3] that rasterize_gaussians_backward(sh_factored=True) returns as dL_dcolors
+    (goi_raster_sh_grad_from_views): sum over the views, in index order, of basis(view direction) x gcol."""
+    lib = _lib.load()
+    dev = _check_device(means3D)
+    P, V = int(means3D.size(0)), int(campos.size(0))
+    if tuple(gcol.shape) != (V, P, 3):
+        raise ValueError(f"gcol must be [V={V}, P={P}, 3], got {tuple(gcol.shape)}")
+    with torch.cuda.device(dev):
+        out = torch.empty((P, int(M), 3), dtype=torch.float32, device=dev)
+        if P and V:
+            m, c, g = _prep(means3D, "means3D", dev), _prep(campos, "campos", dev), _prep(gcol, "gcol", dev)
+            if lib.goi_raster_sh_grad_from_views(P, int(degree), int(M), V, _ptr(m), _ptr(c), _ptr(g), _ptr(out), _stream(dev)) < 0:
+                raise RuntimeError(_lib.last_error())
+        elif P:
+            out.zero_()
+    return out
 
 
 def rasterize_gaussians_backward_semantics(background, means3D, radii, semantics, viewmatrix, projmatrix, tan_fovx,

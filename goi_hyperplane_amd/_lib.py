@@ -55,6 +55,8 @@ SYMBOLS = {
     "goi_adam_step": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
     "goi_knn_workspace_bytes": (C.c_size_t, [C.c_int]),
     "goi_knn_dist2": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "goi_raster_sh_grad_from_views": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p]),
     "goi_raster_profile_enable": (None, [C.c_int]),
     "goi_raster_profile_stages": (None, [C.c_uint]),
     "goi_raster_profile_collect": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int)]),

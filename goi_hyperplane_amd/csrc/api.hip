@@ -477,6 +477,16 @@ int goi_codebook_dlut(const float* dsim, const float* g, long long HW, int C, in
     return 0;
 }
 
+int goi_raster_sh_grad_from_views(int P, int D, int M, int V, const float* means3D, const float* campos, const float* gcol,
+                           float* dL_dsh, void* stream) {
+    if (P <= 0 || V <= 0) return 0;
+    if (D < 0 || D > 3 || M < (D + 1) * (D + 1) || M > 16) return fail("goi_raster_sh_grad_from_views: need 0 <= D <= 3 and (D+1)^2 <= M <= 16");
+    if (!means3D || !campos || !gcol || !dL_dsh) return fail("goi_raster_sh_grad_from_views: NULL pointer");
+    launch_sh_grad_from_views(P, D, M, V, means3D, campos, gcol, dL_dsh, static_cast<hipStream_t>(stream));
+    if (hipGetLastError() != hipSuccess) return fail("goi_raster_sh_grad_from_views: launch failed");
+    return 0;
+}
+
 int goi_adam_step(const GoiAdamGroup* groups, int n_groups, double beta1, double beta2, double eps,
                   const unsigned char* nograd_mask, void* stream) {
     if (n_groups < 0 || n_groups > GOI_ADAM_MAX_GROUPS) return fail("goi_adam_step: n_groups must be 0..8");

@@ -125,6 +125,8 @@ void launch_render_bwd_tile(const GoiRasterScene& sc, const GeomView& g, const I
                             const float* dL_dsem, const float* dL_ddepth, const float* dL_dalpha, float* dL_dmean2D,
                             float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dsemantic,
                             float* dL_ddepths, hipStream_t s);
+void launch_sh_grad_from_views(int P, int D, int M, int V, const float* means3D, const float* campos, const float* gcol,
+                               float* dL_dsh, hipStream_t s);
 void launch_preprocess_bwd(const GoiRasterScene& sc, const GeomView& g, const int* radii, const float* dL_dmean2D,
                            const float* dL_dconic, float* dL_dcolor, const float* dL_ddepth, float* dL_dmean3D,
                            float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, hipStream_t s);

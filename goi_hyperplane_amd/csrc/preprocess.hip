@@ -245,11 +245,15 @@ struct BwdArgs {
     const float* campos_p;
 };
 
+// WITH_DSH: dL/dSH is formed ([P,M,3], staged through LDS).  Otherwise (the caller passed dL_dsh = NULL with SH
+// colours: "factored" mode of goi_raster_backward) the kernel writes the clamp-masked colour gradient g back to
+// dL_dcolor instead: dL/dSH[k] = basis_k(view direction) * g is then formed elsewhere (goi_raster_sh_grad_from_views).
+template <bool WITH_DSH>
 __global__ __launch_bounds__(256) void preprocess_bwd_k(const BwdArgs args, const int* __restrict__ radii,
                                                         const uint8_t* __restrict__ clamped,
                                                         const float* __restrict__ dL_dmean2D,
                                                         const float* __restrict__ dL_dconic,
-                                                        const float* __restrict__ dL_dcolor,
+                                                        float* dL_dcolor,
                                                         const float* __restrict__ dL_ddepth,
                                                         float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D,
                                                         float* __restrict__ dL_dsh, float* __restrict__ dL_dscale,
@@ -274,7 +278,10 @@ __global__ __launch_bounds__(256) void preprocess_bwd_k(const BwdArgs args, cons
     V3 gscale = {0, 0, 0};
     float4 grot = make_float4(0, 0, 0, 0);
     const bool visible = radii[idx] > 0;
-    V3* dsh = dL_dsh ? reinterpret_cast<V3*>(s_dsh + (size_t)threadIdx.x * (3 * a.M + 1)) : nullptr;
+    V3* dsh = WITH_DSH ? reinterpret_cast<V3*>(s_dsh + (size_t)threadIdx.x * (3 * a.M + 1)) : nullptr;
+    auto put = [&](int k, const V3& v) {
+        if constexpr (WITH_DSH) dsh[k] = v;
+    };
 
     if (visible) {
         const V3 mean = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
@@ -367,38 +374,45 @@ __global__ __launch_bounds__(256) void preprocess_bwd_k(const BwdArgs args, cons
             g.x *= (cl & 1) ? 0.f : 1.f;
             g.y *= (cl & 2) ? 0.f : 1.f;
             g.z *= (cl & 4) ? 0.f : 1.f;
+            if constexpr (!WITH_DSH) {
+                if (live) {
+                    dL_dcolor[3 * idx] = g.x;
+                    dL_dcolor[3 * idx + 1] = g.y;
+                    dL_dcolor[3 * idx + 2] = g.z;
+                }
+            }
             V3 dRGBdx = {0, 0, 0}, dRGBdy = {0, 0, 0}, dRGBdz = {0, 0, 0};
             const float x = dir.x, y = dir.y, z = dir.z;
             const int ncoef = (a.D + 1) * (a.D + 1);
-            for (int k = ncoef; k < a.M; k++) dsh[k] = V3{0, 0, 0};
-            dsh[0] = kSH0 * g;
+            for (int k = ncoef; k < a.M; k++) put(k, V3{0, 0, 0});
+            put(0, kSH0 * g);
             if (a.D > 0) {
-                dsh[1] = (-kSH1 * y) * g;
-                dsh[2] = (kSH1 * z) * g;
-                dsh[3] = (-kSH1 * x) * g;
+                put(1, (-kSH1 * y) * g);
+                put(2, (kSH1 * z) * g);
+                put(3, (-kSH1 * x) * g);
                 dRGBdx = -kSH1 * sh[3];
                 dRGBdy = -kSH1 * sh[1];
                 dRGBdz = kSH1 * sh[2];
                 if (a.D > 1) {
                     const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-                    dsh[4] = (kSH2[0] * xy) * g;
-                    dsh[5] = (kSH2[1] * yz) * g;
-                    dsh[6] = (kSH2[2] * (2.f * zz - xx - yy)) * g;
-                    dsh[7] = (kSH2[3] * xz) * g;
-                    dsh[8] = (kSH2[4] * (xx - yy)) * g;
+                    put(4, (kSH2[0] * xy) * g);
+                    put(5, (kSH2[1] * yz) * g);
+                    put(6, (kSH2[2] * (2.f * zz - xx - yy)) * g);
+                    put(7, (kSH2[3] * xz) * g);
+                    put(8, (kSH2[4] * (xx - yy)) * g);
                     dRGBdx = dRGBdx + (kSH2[0] * y * sh[4] + kSH2[2] * 2.f * -x * sh[6] + kSH2[3] * z * sh[7] +
                                        kSH2[4] * 2.f * x * sh[8]);
                     dRGBdy = dRGBdy + (kSH2[0] * x * sh[4] + kSH2[1] * z * sh[5] + kSH2[2] * 2.f * -y * sh[6] +
                                        kSH2[4] * 2.f * -y * sh[8]);
                     dRGBdz = dRGBdz + (kSH2[1] * y * sh[5] + kSH2[2] * 2.f * 2.f * z * sh[6] + kSH2[3] * x * sh[7]);
                     if (a.D > 2) {
-                        dsh[9] = (kSH3[0] * y * (3.f * xx - yy)) * g;
-                        dsh[10] = (kSH3[1] * xy * z) * g;
-                        dsh[11] = (kSH3[2] * y * (4.f * zz - xx - yy)) * g;
-                        dsh[12] = (kSH3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy)) * g;
-                        dsh[13] = (kSH3[4] * x * (4.f * zz - xx - yy)) * g;
-                        dsh[14] = (kSH3[5] * z * (xx - yy)) * g;
-                        dsh[15] = (kSH3[6] * x * (xx - 3.f * yy)) * g;
+                        put(9, (kSH3[0] * y * (3.f * xx - yy)) * g);
+                        put(10, (kSH3[1] * xy * z) * g);
+                        put(11, (kSH3[2] * y * (4.f * zz - xx - yy)) * g);
+                        put(12, (kSH3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy)) * g);
+                        put(13, (kSH3[4] * x * (4.f * zz - xx - yy)) * g);
+                        put(14, (kSH3[5] * z * (xx - yy)) * g);
+                        put(15, (kSH3[6] * x * (xx - 3.f * yy)) * g);
                         dRGBdx = dRGBdx + (kSH3[0] * sh[9] * 3.f * 2.f * xy + kSH3[1] * sh[10] * yz +
                                            kSH3[2] * sh[11] * -2.f * xy + kSH3[3] * sh[12] * -3.f * 2.f * xz +
                                            kSH3[4] * sh[13] * (-3.f * xx + 4.f * zz - yy) +
@@ -462,8 +476,8 @@ __global__ __launch_bounds__(256) void preprocess_bwd_k(const BwdArgs args, cons
             grot.w = 2 * r * (A[0][1] - A[1][0]) + 2 * x * (A[2][0] + A[0][2]) + 2 * y * (A[1][2] + A[2][1]) -
                      4 * z * (A[1][1] + A[0][0]);
         }
-    } else if (dsh) {
-        for (int k = 0; k < a.M; k++) dsh[k] = V3{0, 0, 0};
+    } else if (WITH_DSH) {
+        for (int k = 0; k < a.M; k++) put(k, V3{0, 0, 0});
     }
     if (live) {
         dL_dmean3D[3 * idx] = gmean.x;
@@ -476,7 +490,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_k(const BwdArgs args, cons
         dL_dscale[3 * idx + 2] = gscale.z;
         reinterpret_cast<float4*>(dL_drot)[idx] = grot;
     }
-    if (dL_dsh) {
+    if constexpr (WITH_DSH) {
         __syncthreads();
         const int w = 3 * a.M;
         const int rows = min(256, a.P - (int)(blockIdx.x * blockDim.x));
@@ -485,6 +499,77 @@ __global__ __launch_bounds__(256) void preprocess_bwd_k(const BwdArgs args, cons
             const int row = i / w, col = i - row * w;
             out[i] = s_dsh[row * (w + 1) + col];
         }
+    }
+}
+
+// dL/dSH of a batch of views from its factors: dL/dSH[g][k] = sum_v basis_k(dir(g, v)) * gcol[v][g], with gcol the
+// clamp-masked colour gradients that preprocess_bwd_k<false> leaves in dL_dcolor and dir the normalised direction
+// camera v -> Gaussian g.  The basis expressions are those of the SH backward above, term by term, and the views are
+// added in index order starting from view 0: the result is bit-identical to summing the per-view dL/dSH arrays in
+// that order.  Used by the data-parallel gradient exchange (dist.py): 12 bytes per Gaussian and view travel instead
+// of 192.  One thread per Gaussian, rows staged through LDS like preprocess_bwd_k.
+__global__ __launch_bounds__(256) void sh_grad_from_views_k(int P, int D, int M, int V, const float* __restrict__ means3D,
+                                                            const float* __restrict__ campos,  // [V,3]
+                                                            const float* __restrict__ gcol,    // [V,P,3]
+                                                            float* __restrict__ dL_dsh) {      // [P,M,3]
+    extern __shared__ float s_dsh[];  // [256][3 M + 1]
+    const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int idx = gtid < P ? gtid : P - 1;
+    const V3 mean = {means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]};
+    V3 acc[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) acc[k] = V3{0, 0, 0};
+    for (int v = 0; v < V; v++) {
+        const V3 cp = {campos[3 * v], campos[3 * v + 1], campos[3 * v + 2]};
+        const V3 dir_orig = mean - cp;
+        const V3 dir = dir_orig / sqrtf(dot3(dir_orig, dir_orig));
+        const float* gp = gcol + ((size_t)v * P + idx) * 3;
+        const V3 g = {gp[0], gp[1], gp[2]};
+        const float x = dir.x, y = dir.y, z = dir.z;
+        V3 t[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) t[k] = V3{0, 0, 0};
+        t[0] = kSH0 * g;
+        if (D > 0) {
+            t[1] = (-kSH1 * y) * g;
+            t[2] = (kSH1 * z) * g;
+            t[3] = (-kSH1 * x) * g;
+            if (D > 1) {
+                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                t[4] = (kSH2[0] * xy) * g;
+                t[5] = (kSH2[1] * yz) * g;
+                t[6] = (kSH2[2] * (2.f * zz - xx - yy)) * g;
+                t[7] = (kSH2[3] * xz) * g;
+                t[8] = (kSH2[4] * (xx - yy)) * g;
+                if (D > 2) {
+                    t[9] = (kSH3[0] * y * (3.f * xx - yy)) * g;
+                    t[10] = (kSH3[1] * xy * z) * g;
+                    t[11] = (kSH3[2] * y * (4.f * zz - xx - yy)) * g;
+                    t[12] = (kSH3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy)) * g;
+                    t[13] = (kSH3[4] * x * (4.f * zz - xx - yy)) * g;
+                    t[14] = (kSH3[5] * z * (xx - yy)) * g;
+                    t[15] = (kSH3[6] * x * (xx - 3.f * yy)) * g;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k++) acc[k] = v == 0 ? t[k] : acc[k] + t[k];
+    }
+    float* row = s_dsh + (size_t)threadIdx.x * (3 * M + 1);
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        if (k < M) {
+            row[3 * k] = acc[k].x;
+            row[3 * k + 1] = acc[k].y;
+            row[3 * k + 2] = acc[k].z;
+        }
+    __syncthreads();
+    const int w = 3 * M;
+    const int rows = min(256, P - (int)(blockIdx.x * blockDim.x));
+    float* out = dL_dsh + (size_t)blockIdx.x * blockDim.x * w;
+    for (int i = threadIdx.x; i < rows * w; i += 256) {
+        const int r = i / w, col = i - r * w;
+        out[i] = s_dsh[r * (w + 1) + col];
     }
 }
 
@@ -780,12 +865,20 @@ void launch_preprocess_bwd(const GoiRasterScene& sc, const GeomView& g, const in
     a.focal_y = sc.H / (2.0f * sc.tan_fovy);
     a.focal_x = sc.W / (2.0f * sc.tan_fovx);
     a.view_p = sc.viewmatrix; a.proj_p = sc.projmatrix; a.campos_p = sc.campos;
-    const bool with_sh = sc.shs && sc.M > 0;
+    const bool with_sh = sc.shs && sc.M > 0 && dL_dsh;  // dL_dsh == NULL with SH colours: factored mode
     const size_t lds = with_sh ? (size_t)256 * (3 * sc.M + 1) * sizeof(float) : 0;  // 50 KB at M = 16
-    preprocess_bwd_k<<<dim3((sc.P + 255) / 256), dim3(256), lds, s>>>(a, radii, g.clamped, dL_dmean2D, dL_dconic, dL_dcolor,
-                                                                   dL_ddepth, dL_dmean3D, dL_dcov3D,
-                                                                   with_sh ? dL_dsh : nullptr, dL_dscale,
-                                                                   dL_drot);
+    if (with_sh)
+        preprocess_bwd_k<true><<<dim3((sc.P + 255) / 256), dim3(256), lds, s>>>(
+            a, radii, g.clamped, dL_dmean2D, dL_dconic, dL_dcolor, dL_ddepth, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+    else
+        preprocess_bwd_k<false><<<dim3((sc.P + 255) / 256), dim3(256), 0, s>>>(
+            a, radii, g.clamped, dL_dmean2D, dL_dconic, dL_dcolor, dL_ddepth, dL_dmean3D, dL_dcov3D, nullptr, dL_dscale, dL_drot);
+}
+
+void launch_sh_grad_from_views(int P, int D, int M, int V, const float* means3D, const float* campos, const float* gcol,
+                               float* dL_dsh, hipStream_t s) {
+    const size_t lds = (size_t)256 * (3 * M + 1) * sizeof(float);
+    sh_grad_from_views_k<<<dim3((P + 255) / 256), dim3(256), lds, s>>>(P, D, M, V, means3D, campos, gcol, dL_dsh);
 }
 
 void launch_reduce_rows(const GoiRasterScene& sc, const GeomView& g, int N, const BwdScratchView& scr, float* dL_dmean2D,

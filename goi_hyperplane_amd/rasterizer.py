@@ -71,11 +71,29 @@ def _call_with_snapshot(fn, args, debug, dump_name, what):
 # observable difference to the full backward is that viewspace_points.grad is zero instead of the
 # screen-space gradient; dL/dsemantics is bit-identical.  Off by default; GOI_BACKWARD=semantics or
 # set_backward_mode(semantics_only=True) turns it on.
-_BACKWARD_MODE = {"semantics_only": os.environ.get("GOI_BACKWARD", "") == "semantics"}
+#
+# sh_factored (data-parallel training, dist.allreduce_gradients_sh_factored): the backward does not form dL/dSH
+# (192 of the 300 gradient bytes per Gaussian); the SH tensor gets NO gradient from autograd, and the factor of
+#     dL/dSH[g][k] = basis_k(direction camera -> g) * gcol[g]
+# -- the clamp-masked colour gradient gcol [P,3] -- is left for take_sh_factor().  The ranks then all-gather 12 bytes
+# per Gaussian and view instead of all-reducing 192, and every rank rebuilds the summed dL/dSH locally.
+_BACKWARD_MODE = {"semantics_only": os.environ.get("GOI_BACKWARD", "") == "semantics", "sh_factored": False}
+_SH_FACTOR = {"last": None}
 
 
-def set_backward_mode(semantics_only: bool) -> None:
-    _BACKWARD_MODE["semantics_only"] = bool(semantics_only)
+def set_backward_mode(semantics_only: bool = None, sh_factored: bool = None) -> None:
+    if semantics_only is not None:
+        _BACKWARD_MODE["semantics_only"] = bool(semantics_only)
+    if sh_factored is not None:
+        _BACKWARD_MODE["sh_factored"] = bool(sh_factored)
+        _SH_FACTOR["last"] = None
+
+
+def take_sh_factor():
+    """-> dict(gcol [P,3], campos [3], degree, M) of the most recent backward run in sh_factored mode (None if
+    there was none since the last call)."""
+    f, _SH_FACTOR["last"] = _SH_FACTOR["last"], None
+    return f
 
 
 class _RasterizeGaussians(torch.autograd.Function):
@@ -115,9 +133,16 @@ class _RasterizeGaussians(torch.autograd.Function):
                 rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, grad_out_sem, grad_depth,
                 grad_alpha, sh, rs.sh_degree, rs.campos, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, alpha,
                 rs.debug)
-        (grad_means2D, grad_colors_precomp, grad_semantics, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
-         grad_scales, grad_rotations) = _call_with_snapshot(_C.rasterize_gaussians_backward, args, rs.debug,
-                                                            "snapshot_bw.dump", "backward")
+        factored = bool(_BACKWARD_MODE["sh_factored"] and sh is not None and sh.numel() > 0 and need[2] and not rs.debug)
+        if factored:
+            (grad_means2D, gcol, grad_semantics, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
+             grad_scales, grad_rotations) = _C.rasterize_gaussians_backward_sh_factored(*args)
+            grad_colors_precomp = None
+            _SH_FACTOR["last"] = dict(gcol=gcol, campos=rs.campos, degree=int(rs.sh_degree), M=int(sh.size(1)))
+        else:
+            (grad_means2D, grad_colors_precomp, grad_semantics, grad_opacities, grad_means3D, grad_cov3Ds_precomp,
+             grad_sh, grad_scales, grad_rotations) = _call_with_snapshot(_C.rasterize_gaussians_backward, args,
+                                                                         rs.debug, "snapshot_bw.dump", "backward")
         # input order: means3D, means2D, sh, colors_precomp, semantics, opacities, scales, rotations, cov3Ds_precomp
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_semantics, grad_opacities, grad_scales,
                 grad_rotations, grad_cov3Ds_precomp, None)

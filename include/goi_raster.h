@@ -90,7 +90,10 @@ int goi_raster_forward(const GoiRasterScene* scene, void* geom_buffer, void* ima
                        int* radii, void* stream);
 
 /* Backward of the forward that filled the three workspaces.  R = that forward's return value.
- * Any of the four upstream gradients dL_dout_* may be NULL (= zero).  dL_dconic is [P,4] (x: a, y: b, z: unused, w: c), dL_dsh [P,M,3] (may be NULL when M == 0). */
+ * Any of the four upstream gradients dL_dout_* may be NULL (= zero).  dL_dconic is [P,4] (x: a, y: b, z: unused, w: c), dL_dsh [P,M,3] (may be NULL when M == 0).
+ * FACTORED mode: dL_dsh == NULL while the scene has SH colours.  dL/dSH is not formed (192 of the 300 bytes of
+ * gradient per Gaussian at degree 3); dL_dcolor returns the colour gradient with the forward's clamp mask applied
+ * (CR/backward.cu:44-47), the factor g of dL/dSH[k] = basis_k(view direction) * g -- see goi_raster_sh_grad_from_views. */
 int goi_raster_backward(const GoiRasterScene* scene, int R,
                         const void* geom_buffer, const void* binning_buffer, const void* image_buffer,
                         const int* radii, const float* out_alpha,
@@ -158,6 +161,15 @@ int goi_raster_profile_collect(double* ms, int* calls);
 
 /* Tuning / experiment switches ("fwd_variant", "bwd_variant"); defaults are the shipped kernels. */
 int goi_raster_set_option(const char* name, int value);
+
+/* dL/dSH [P,M,3] of V views from the factors goi_raster_backward leaves in FACTORED mode: means3D [P,3], the V camera
+ * centres campos [V,3] and the clamp-masked colour gradients gcol [V,P,3]:
+ *     dL_dsh[g][k] = sum_v basis_k(normalize(means3D[g] - campos[v])) * gcol[v][g]
+ * with the basis of CR/backward.cu:49-109 (degree D, (D+1)^2 <= M <= 16; coefficients above (D+1)^2 get 0), views added
+ * in index order: bit-identical to adding the per-view dL_dsh arrays of goi_raster_backward in that order.  Lets a
+ * data-parallel job exchange 12 bytes per Gaussian and view (all-gather) instead of all-reducing 192. */
+int goi_raster_sh_grad_from_views(int P, int D, int M, int V, const float* means3D, const float* campos, const float* gcol,
+                           float* dL_dsh, void* stream);
 
 /* ---- simple_knn._C.distCUDA2 (submodules/simple-knn/ext.cpp:15-17, spatial.cu:15-26,
  * simple_knn.cu:170-221): mean squared distance of every point to its 3 nearest OTHER points,

@@ -100,3 +100,62 @@ def test_allreduce_equals_sum_of_single_view_gradients_per_tensor():
 
 def test_allreduce_equals_sum_of_single_view_gradients_bucketed():
     _run(1 << 12)
+
+
+def _worker_factored(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from goi_hyperplane_amd.dist import allreduce_gradients_sh_factored
+    from goi_hyperplane_amd.scene import make_camera, make_scene
+    from oracle import oracle
+    from tests.sh_basis_ref import C0, sh_grad_from_views
+    sc = make_scene(300, S=10, sh_degree=3, seed=2, log_scale_mean=-2.4)
+    cam = make_camera(64, 48, yaw=0.35 * rank, pitch=0.1 * rank)
+    o = oracle.from_scene(sc, cam, threads=1)
+    o.forward()
+    HW = 64 * 48
+    g = o.backward(np.full((3, 48, 64), 1 / HW, np.float32), np.full((10, 48, 64), 1 / HW, np.float32))
+    names = ["means3D", "semantics", "opacity", "scales", "rotations"]  # every leaf but the SH tensors
+    params = []
+    for n in names:
+        p = torch.nn.Parameter(torch.zeros(g[n].shape))
+        p.grad = torch.tensor(g[n]).clone()
+        params.append(p)
+    dsh = torch.tensor(g["sh"])  # [P,16,3] of THIS view (what the factored mode does not form)
+    # the factor the HIP backward leaves in sh_factored mode: the clamp-masked colour gradient = dL/dSH[0] / C0
+    factor = dict(gcol=dsh[:, 0, :] / C0, campos=torch.tensor(np.asarray(cam.camera_center, np.float32)), degree=3, M=16)
+    dc = torch.nn.Parameter(torch.zeros(dsh.shape[0], 1, 3))
+    rest = torch.nn.Parameter(torch.zeros(dsh.shape[0], 15, 3))
+    local = [p.grad.clone().numpy() for p in params]
+    allreduce_gradients_sh_factored(params, (dc, rest), torch.tensor(np.asarray(sc.means3D, np.float32)), factor, dist,
+                                    reconstruct=sh_grad_from_views)
+    q.put((rank, local, dsh.numpy(), [p.grad.numpy() for p in params],
+           torch.cat([dc.grad, rest.grad], dim=1).numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sh_factored_exchange_equals_sum_of_single_view_gradients():
+    """SURVEY.md 8(e) with the SH gradient exchanged as factors (all-gather of the masked colour gradients + local
+    reconstruction): same sums as the plain all-reduce, on every rank."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_factored, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    got.sort(key=lambda t: t[0])
+    summed = [a + b for a, b in zip(got[0][1], got[1][1])]
+    dsh_sum = got[0][2] + got[1][2]
+    assert float(np.abs(dsh_sum).max()) > 0
+    for r in range(world):
+        for s, red in zip(summed, got[r][3]):
+            np.testing.assert_allclose(red, s, rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(got[r][4], dsh_sum, rtol=2e-5, atol=1e-6 * float(np.abs(dsh_sum).max()))
+    np.testing.assert_array_equal(got[0][4], got[1][4])  # every rank holds the same bits
