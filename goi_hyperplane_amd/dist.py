@@ -94,8 +94,8 @@ def allreduce_gradients_sh_factored(params, sh_leaves, means3D, factor, dist, re
     clamp-masked colour gradient gcol (3 floats).  So instead of all-reducing 192 bytes per Gaussian, the ranks
     all-gather gcol (12 bytes per Gaussian and view) and their camera centres, and each rebuilds the SUM over all
     views with one kernel (goi_raster_sh_grad_from_views; views added in rank order: every rank gets the same bits).
-    The other gradients (`params`: every leaf except the two SH tensors) are all-reduced as usual, and that
-    collective is in flight while the SH part is gathered and rebuilt.  xGMI rings are per-link bound: at 1 M
+    The other gradients (`params`: every leaf except the SH tensors) are all-reduced as usual; that collective is
+    on the wire while the SH part is rebuilt.  xGMI rings are per-link bound: at 1 M
     Gaussians, degree 3, 8 ranks this moves 108 MB (all-reduce) + 96 MB (all-gather) instead of 300 MB.
 
     factor: rasterizer.take_sh_factor() of this rank's backward (run with set_backward_mode(sh_factored=True)).
@@ -109,8 +109,6 @@ def allreduce_gradients_sh_factored(params, sh_leaves, means3D, factor, dist, re
         from . import _C
         reconstruct = _C.sh_grad_from_views
     world = dist.get_world_size()
-    grads = [p.grad for p in params if p.grad is not None]
-    works = [dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True) for g in coalesce_shared_storage(grads)]
     gcol = factor["gcol"].detach().contiguous()
     campos = factor["campos"].detach().reshape(1, 3).to(gcol.dtype).contiguous()
     all_g = torch.empty((world,) + tuple(gcol.shape), dtype=gcol.dtype, device=gcol.device)
@@ -121,6 +119,10 @@ def allreduce_gradients_sh_factored(params, sh_leaves, means3D, factor, dist, re
     except (RuntimeError, AttributeError, NotImplementedError):  # a backend without the flat form
         dist.all_gather(list(all_g.unbind(0)), gcol)
         dist.all_gather(list(all_c.unbind(0)), campos.reshape(3))
+    # one communicator runs its collectives in order: the (small) gathers go first, then the all-reduce of the other
+    # gradients is queued and the reconstruction kernel runs on the compute stream while it is on the wire
+    grads = [p.grad for p in params if p.grad is not None]
+    works = [dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True) for g in coalesce_shared_storage(grads)]
     dsh = reconstruct(means3D.detach(), all_c, all_g, int(factor["degree"]), int(factor["M"]))
     k = 0
     for leaf in sh_leaves:
