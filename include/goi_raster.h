@@ -159,7 +159,13 @@ void goi_raster_profile_stages(unsigned stage_mask);
  * since the last reset into ms[GOI_STAGE_COUNT] / calls[GOI_STAGE_COUNT]; then resets. */
 int goi_raster_profile_collect(double* ms, int* calls);
 
-/* Tuning / experiment switches ("fwd_variant", "bwd_variant"); defaults are the shipped kernels. */
+/* Tuning / experiment switches; the defaults are the shipped configuration.
+ *   "fwd_variant"  1 (default) two candidates per loop trip in the forward blend, 0 one
+ *   "bwd_variant"  0 (default) atomic-free backward, MFMA reductions at the bf16 rate with split (hi + lo) operands
+ *                  (within ~1e-5 relative of exact fp32, bit-reproducible); 2 the same with exact-fp32 MFMA (an fmaf chain
+ *                  per output); 1 workgroup-per-tile backward with float atomics (what scratch = NULL selects)
+ *   "sort_variant" 1 (default) onesweep radix sort, 0 histogram / scan / scatter per pass
+ *   "cull_variant" 1 (default) tile lists culled by the exact contribution box, 0 the reference's 3-sigma squares */
 int goi_raster_set_option(const char* name, int value);
 
 /* dL/dSH [P,M,3] of V views from the factors goi_raster_backward leaves in FACTORED mode: means3D [P,3], the V camera
