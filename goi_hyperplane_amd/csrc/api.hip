@@ -533,6 +533,7 @@ int goi_raster_set_option(const char* name, int value) {
     }
     else if (!strcmp(name, "sort_variant")) g_options.sort_variant = value;
     else if (!strcmp(name, "cull_variant")) g_options.cull_variant = value;
+    else if (!strcmp(name, "decode_variant")) g_options.decode_variant = value;
     else return fail(std::string("unknown option ") + name);
     return 0;
 }

@@ -9,8 +9,9 @@
 //     sim[sim < thresh] = 0
 // Everything after the argmax depends on the code index only, so the host folds it into a table
 // code_score[n_codes]; the per-pixel work is the dense contraction F[HW,S] x W^T[S,n_codes] + b and an
-// argmax.  That contraction runs on the matrix cores in exact fp32 (v_mfma_f32_16x16x4_f32: M = 16
-// pixels, N = 16 codes, K = 4 channels per instruction) and never materialises the [HW, n_codes]
+// argmax.  That contraction runs on the matrix cores -- for S <= 16 as three bf16 MFMAs on exact 3-way
+// splits of the fp32 operands (semantic_decode3_k, below), otherwise in fp32 (v_mfma_f32_16x16x4_f32:
+// M = 16 pixels, N = 16 codes, K = 4 channels per instruction) -- and never materialises the [HW, n_codes]
 // logits, the [HW, 256] gathered features or the permuted [HW, S] copy of the rasterizer output:
 // the kernel reads the rasterizer's channel-major [S, H, W] tensor directly (A operand: 16
 // consecutive pixels of one channel = one 64-byte segment) and writes 4-8 bytes per pixel.
@@ -134,6 +135,143 @@ __global__ __launch_bounds__(256) void semantic_decode_k(const float* __restrict
     }
 }
 
+// ---- S <= 16: the same contraction at the bf16 matrix rate, to fp32 accuracy ---------------------------------
+// fp32 MFMA runs at the vector rate (32 clocks per 16x16x4 instruction per SIMD) and its time adds to the VALU time
+// of the co-resident waves (tools/mfma_mix_probe.hip); the four instructions per (16 pixels, 16 codes) were ~40 % of
+// this kernel.  Here every fp32 operand is carried EXACTLY as three bf16 numbers, x = h + m + l (8 + 8 + 8 mantissa
+// bits), and the products of weight >= 2^-24 are formed by three v_mfma_f32_16x16x32_bf16 (K = 32 = two 16-channel
+// halves) accumulating in fp32:
+//     [f_h | f_m] x [W_h | W_h]  =  (f_h + f_m) W_h
+//     [f_h | f_m] x [W_m | W_m]  =  (f_h + f_m) W_m
+//     [f_l | f_h] x [W_h | W_l]  =  f_l W_h + f_h W_l
+// (dropped: f_m W_l, f_l W_m, f_l W_l <= 2^-24 of the product -- the rounding level of the fp32 chain itself).
+// 3 x ~20 clocks instead of 4 x 32.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
+// (a, b) -> three packed bf16 pairs (a in the low half): h = rne(x), m = rne(x - h), l = rne(x - h - m)
+__device__ __forceinline__ void split3_pair(float a, float b, uint32_t& h, uint32_t& m, uint32_t& l) {
+    h = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
+    const float a1 = a - __uint_as_float(h << 16), b1 = b - __uint_as_float(h & 0xFFFF0000u);
+    m = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{a1, b1}, bf16x2_t));
+    const float a2 = a1 - __uint_as_float(m << 16), b2 = b1 - __uint_as_float(m & 0xFFFF0000u);
+    l = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{a2, b2}, bf16x2_t));
+}
+
+template <int NBLK_T>
+__global__ __launch_bounds__(256) void semantic_decode3_k(const float* __restrict__ sem, int S, long long HW,
+                                                          const float* __restrict__ Wm, const float* __restrict__ bias,
+                                                          int n_codes, const float* __restrict__ code_score, float thresh,
+                                                          float* __restrict__ sim_out, int* __restrict__ idx_out,
+                                                          uint8_t* __restrict__ bg_mask_out) {
+    // three bf16 planes of W, [code][16 channels] (32 bytes per code: one ds_read_b128 per operand), then bias[ncp]
+    extern __shared__ __attribute__((aligned(16))) char s_raw3[];
+    const int nblk = NBLK_T > 0 ? NBLK_T : (n_codes + 15) / 16, ncp = nblk * 16;
+    uint16_t* s_h = reinterpret_cast<uint16_t*>(s_raw3);
+    uint16_t* s_m = s_h + (size_t)ncp * 16;
+    uint16_t* s_l = s_m + (size_t)ncp * 16;
+    float* s_b = reinterpret_cast<float*>(s_l + (size_t)ncp * 16);
+    for (int i = threadIdx.x; i < ncp * 8; i += 256) {  // two channels per thread
+        const int code = i >> 3, ch = (i & 7) * 2;
+        const float w0 = (ch < S && code < n_codes) ? Wm[(size_t)code * S + ch] : 0.f;
+        const float w1 = (ch + 1 < S && code < n_codes) ? Wm[(size_t)code * S + ch + 1] : 0.f;
+        uint32_t h, m, l;
+        split3_pair(w0, w1, h, m, l);
+        reinterpret_cast<uint32_t*>(s_h)[i] = h;
+        reinterpret_cast<uint32_t*>(s_m)[i] = m;
+        reinterpret_cast<uint32_t*>(s_l)[i] = l;
+    }
+    for (int i = threadIdx.x; i < ncp; i += 256) s_b[i] = i < n_codes ? bias[i] : -__builtin_inff();
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kq = lane >> 4, mm = lane & 15;
+    const int ch0 = 8 * (kq & 1);  // this lane's 8 channels of either K half
+    const long long n_groups = (HW + 63) / 64;
+    auto load_a = [&](long long it, float (&dst)[8]) {
+        const long long pa = it * 16 + mm;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int ch = ch0 + i;
+            dst[i] = (ch < S && pa < HW && it >= 0) ? sem[(size_t)ch * HW + pa] : 0.f;
+        }
+    };
+    const long long n_it = n_groups * 4, it_stride = (long long)gridDim.x * 16;
+    auto next_it = [&](long long it) { return ((it & 3) != 3) ? it + 1 : it - 3 + it_stride; };
+    long long it = ((long long)blockIdx.x * 4 + wave) * 4;
+    float a[8], a_next[8];
+    if (it < n_it) load_a(it, a);
+    // B operands: lane (kq, mm) holds code 16 nb + mm, channels ch0 .. ch0 + 7 of the plane its K half takes
+    const uint16_t* p1 = s_h + (size_t)mm * 16 + ch0;
+    const uint16_t* p2 = s_m + (size_t)mm * 16 + ch0;
+    const uint16_t* p3 = (kq < 2 ? s_h : s_l) + (size_t)mm * 16 + ch0;
+    for (; it < n_it; it = next_it(it)) {
+        const long long pix0 = (it >> 2) * 64;
+        const int mb = (int)(it & 3);
+        const long long nx = next_it(it);
+        load_a(nx < n_it ? nx : -1, a_next);
+        // A operands of this pixel block: [f_h | f_m] and [f_l | f_h]
+        uint32_t hw[4], mw[4], lw[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) split3_pair(a[2 * i], a[2 * i + 1], hw[i], mw[i], lw[i]);
+        const bool lowk = kq < 2;
+        const bf16x8_t A1 = __builtin_bit_cast(bf16x8_t, lowk ? u32x4_t{hw[0], hw[1], hw[2], hw[3]} : u32x4_t{mw[0], mw[1], mw[2], mw[3]});
+        const bf16x8_t A3 = __builtin_bit_cast(bf16x8_t, lowk ? u32x4_t{lw[0], lw[1], lw[2], lw[3]} : u32x4_t{hw[0], hw[1], hw[2], hw[3]});
+        float bv[4] = {-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+        int bi[4] = {0, 0, 0, 0};
+        bf16x8_t B1 = *reinterpret_cast<const bf16x8_t*>(p1), B2 = *reinterpret_cast<const bf16x8_t*>(p2),
+                 B3 = *reinterpret_cast<const bf16x8_t*>(p3);
+        float b0 = s_b[mm];
+#pragma unroll
+        for (int nb = 0; nb < nblk; nb++) {
+            bf16x8_t N1 = B1, N2 = B2, N3 = B3;
+            float bn = 0.f;
+            if (nb + 1 < nblk) {  // the next block's operands are fetched while this one is on the matrix cores
+                bn = s_b[(nb + 1) * 16 + mm];
+                N1 = *reinterpret_cast<const bf16x8_t*>(p1 + (size_t)(nb + 1) * 256);
+                N2 = *reinterpret_cast<const bf16x8_t*>(p2 + (size_t)(nb + 1) * 256);
+                N3 = *reinterpret_cast<const bf16x8_t*>(p3 + (size_t)(nb + 1) * 256);
+            }
+            f32x4 acc = {b0, b0, b0, b0};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A3, B3, acc, 0, 0, 0);  // smallest terms first
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1, B2, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1, B1, acc, 0, 0, 0);
+            const int code = nb * 16 + mm;
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                if (acc[r] > bv[r]) {  // strict: earlier (lower) codes win ties
+                    bv[r] = acc[r];
+                    bi[r] = code;
+                }
+            b0 = bn;
+            B1 = N1;
+            B2 = N2;
+            B3 = N3;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) row_argmax(bv[r], bi[r]);
+        if (mm == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const long long p = pix0 + 16 * mb + 4 * kq + r;  // D row = 4*kq + r
+                if (p < HW) {
+                    const int code = bi[r];
+                    float sc = code_score ? code_score[code] : 0.f;
+                    const bool bg = sc < thresh;
+                    if (bg) sc = 0.f;
+                    if (sim_out) sim_out[p] = sc;
+                    if (idx_out) idx_out[p] = code;
+                    if (bg_mask_out) bg_mask_out[p] = bg ? 1 : 0;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) a[i] = a_next[i];
+    }
+}
+
 }  // namespace
 
 int launch_semantic_decode(const float* sem, int S, long long HW, const float* W, const float* bias, int n_codes,
@@ -159,6 +297,15 @@ int launch_semantic_decode(const float* sem, int S, long long HW, const float* W
     case N:                                  \
         GOI_LAUNCH((semantic_decode_k<N, 0>)); \
         break;
+    if (S <= 16 && g_options.decode_variant == 1) {  // split-bf16 contraction (fp32 accuracy at the bf16 matrix rate)
+        const size_t lds3 = (size_t)ncp * 16 * 2 * 3 + (size_t)ncp * sizeof(float);
+        if (lds3 > 64 * 1024) return -1;
+        // (the code-block loop is NOT unrolled here: fully unrolled, the compiler hoists all 57 operand loads and
+        // needs 256 VGPRs)
+        semantic_decode3_k<0><<<dim3((unsigned)blocks), dim3(256), lds3, s>>>(sem, S, HW, W, bias, n_codes, code_score, thresh,
+                                                                           sim_out, idx_out, bg_mask_out);
+        return 0;
+    }
     if (K4 == 4 && ncp == 19 * 16) {  // the reference's configuration: S = 16 (or 13..16), 300 codes
         GOI_LAUNCH((semantic_decode_k<4, 19>));
         return 0;

@@ -165,7 +165,9 @@ int goi_raster_profile_collect(double* ms, int* calls);
  *                  (within ~1e-5 relative of exact fp32, bit-reproducible); 2 the same with exact-fp32 MFMA (an fmaf chain
  *                  per output); 1 workgroup-per-tile backward with float atomics (what scratch = NULL selects)
  *   "sort_variant" 1 (default) onesweep radix sort, 0 histogram / scan / scatter per pass
- *   "cull_variant" 1 (default) tile lists culled by the exact contribution box, 0 the reference's 3-sigma squares */
+ *   "cull_variant" 1 (default) tile lists culled by the exact contribution box, 0 the reference's 3-sigma squares
+ *   "decode_variant" (goi_semantic_decode, S <= 16) 1 (default) contraction as three bf16 MFMAs on exact 3-way splits of
+ *                  the fp32 operands (fp32 accuracy), 0 fp32 MFMA */
 int goi_raster_set_option(const char* name, int value);
 
 /* dL/dSH [P,M,3] of V views from the factors goi_raster_backward leaves in FACTORED mode: means3D [P,3], the V camera

@@ -357,6 +357,16 @@ def test_fused_semantic_decode_matches_unfused_reference(dev):
     agree = (idx_f.long() == idx_r)
     assert agree.float().mean().item() > 0.9999
     assert (sim_f[agree] - sim_r[agree]).abs().max().item() < 1e-6
+    # the fp32-MFMA contraction kept behind decode_variant = 0 (default: three bf16 MFMAs on exact 3-way splits)
+    from goi_hyperplane_amd import _lib
+    _lib.set_option("decode_variant", 0)
+    try:
+        sim_0, idx_0 = compute_similarity(sem, mlp16, lut16, svm_score_fn(svm), 0.5, return_index=True)
+    finally:
+        _lib.set_option("decode_variant", 1)
+    same = idx_0 == idx_f
+    assert same.float().mean().item() > 0.99999 and torch.equal(sim_0[same], sim_f[same])
+    assert ((idx_0.long() == idx_r).float().mean().item()) > 0.9999
     # odd sizes: HW not a multiple of 64, S not a multiple of 4, n_codes not a multiple of 16
     mlp7 = SemanticModel(dim_in=7, dim_out=37, num_layer=1, use_bias=True, device=dev)
     lut7 = torch.rand(37, 256, device=dev)
