@@ -78,6 +78,10 @@ def load():
                 f"{LIB_PATH} is missing: the HIP extension has not been built. Run "
                 "`python -m goi_hyperplane_amd.build` (needs hipcc; cross-compiles for gfx950 without a GPU). "
                 "There is deliberately no CPU fallback.")
+        # The tensors this library is handed live in the HIP runtime PyTorch loaded: that copy of libamdhip64 must
+        # be the one in the process before ours resolves its dependency (loaded first, libgoi_raster.so would pull in
+        # the system copy and the two runtimes would not see each other's devices and allocations).
+        import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
