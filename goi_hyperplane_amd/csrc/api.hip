@@ -161,8 +161,9 @@ int geometry_and_binning(const GoiRasterScene& sc, GeomView& g, ImageView& im, g
     {
         StageTimer t(GOI_STAGE_EMIT, s);
         if (counting) {
-            GOI_HIP(hipMemsetAsync(bv.scratch, 0, radix_sort_control_words((size_t)N, 0, tile_bits) * sizeof(uint32_t), s));
-            launch_emit_counting(P, sc.W, sc.H, g, order, radii, bv.keys[0], bv.vals[0], im.ranges, s);
+            // emit also clears the control words of the tile sort (status words, histograms, tickets): one launch less
+            launch_emit_counting(P, sc.W, sc.H, g, order, radii, bv.keys[0], bv.vals[0], im.ranges, bv.scratch,
+                                 radix_sort_control_words((size_t)N, 0, tile_bits), s);
         }
         else if (N > 0)
             launch_emit(P, sc.W, sc.H, g, order, radii, bv.keys[0], bv.vals[0], s);

@@ -99,7 +99,7 @@ void launch_emit(int P, int W, int H, const GeomView& g, const uint32_t* order, 
                  uint32_t* vals, hipStream_t s);
 bool emit_can_count_tiles(int W, int H);
 void launch_emit_counting(int P, int W, int H, const GeomView& g, const uint32_t* order, const int* radii, uint32_t* keys,
-                          uint32_t* vals, uint2* ranges, hipStream_t s);
+                          uint32_t* vals, uint2* ranges, uint32_t* clear, size_t clear_words, hipStream_t s);
 void launch_tile_ranges_hist(int W, int H, uint2* ranges, uint32_t* ghist, hipStream_t s);
 void launch_ranges(int N, const uint32_t* sorted_keys, uint2* ranges, int T, hipStream_t s);
 void launch_render_fwd(const GoiRasterScene& sc, const GeomView& g, const ImageView& im, const uint32_t* point_list,

@@ -695,8 +695,12 @@ __global__ __launch_bounds__(256) void emit_k(int P, int gx, int gy, const Gauss
                                               const int* __restrict__ radii, const uint32_t* __restrict__ order,
                                               const uint32_t* __restrict__ offsets, uint32_t* __restrict__ goff,
                                               uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                              uint32_t* __restrict__ tile_count, const uint32_t* __restrict__ counters) {
+                                              uint32_t* __restrict__ tile_count, const uint32_t* __restrict__ counters,
+                                              uint32_t* __restrict__ clear, uint32_t clear_words) {
     const bool cull = counters[COUNTER_CULL] != 0;
+    // COUNT: the blocks also zero the control words of the tile sort that follows (its own memset launch otherwise)
+    if (COUNT)
+        for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < clear_words; i += gridDim.x * 256u) clear[i] = 0u;
     extern __shared__ uint32_t s_cnt[];  // [gx * gy] when COUNT
     __shared__ int s_incl[4][64];    // per wave: inclusive scan of the rectangles' tile counts
     __shared__ uint4 s_info[4][64];  // (x0 | y0 << 16, exclusive count, offsets[] - exclusive count, Gaussian id)
@@ -916,7 +920,7 @@ void launch_emit(int P, int W, int H, const GeomView& g, const uint32_t* order, 
                  uint32_t* vals, hipStream_t s) {
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     emit_k<false><<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, gx, gy, g.rec, radii, order, g.offsets, g.goff, keys, vals,
-                                                              nullptr, g.counters);
+                                                              nullptr, g.counters, nullptr, 0u);
 }
 
 bool emit_can_count_tiles(int W, int H) {
@@ -926,11 +930,12 @@ bool emit_can_count_tiles(int W, int H) {
 
 // emit + per-tile counts; ranges must be zeroed by the caller's stream order (done here)
 void launch_emit_counting(int P, int W, int H, const GeomView& g, const uint32_t* order, const int* radii, uint32_t* keys,
-                          uint32_t* vals, uint2* ranges, hipStream_t s) {
+                          uint32_t* vals, uint2* ranges, uint32_t* clear, size_t clear_words, hipStream_t s) {
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     // `ranges` was zeroed by preprocess_fwd_k
     emit_k<true><<<dim3((P + 256 * EMIT_ROUNDS - 1) / (256 * EMIT_ROUNDS)), dim3(256), (size_t)gx * gy * sizeof(uint32_t), s>>>(
-        P, gx, gy, g.rec, radii, order, g.offsets, g.goff, keys, vals, reinterpret_cast<uint32_t*>(ranges) + 1, g.counters);
+        P, gx, gy, g.rec, radii, order, g.offsets, g.goff, keys, vals, reinterpret_cast<uint32_t*>(ranges) + 1, g.counters,
+        clear, (uint32_t)clear_words);
 }
 
 // per-tile counts -> ranges and the two digit histograms (written to ghist[0..511]) of a sort on
