@@ -105,6 +105,8 @@ int validate(const GoiRasterScene* sc, bool need_sem, bool need_opacity = true) 
     return 0;
 }
 
+static inline size_t round_up_256(size_t n) { return (n + 255) & ~(size_t)255; }
+
 // Shared front end of forward and trace: preprocess -> depth sort -> scan -> emit -> tile sort ->
 // ranges.  Returns num_rendered (>= 0) and the final point list through *plist.
 int geometry_and_binning(const GoiRasterScene& sc, GeomView& g, ImageView& im, goi_alloc_fn alloc, void* user,
@@ -113,8 +115,11 @@ int geometry_and_binning(const GoiRasterScene& sc, GeomView& g, ImageView& im, g
     const int gx = (sc.W + TILE - 1) / TILE, gy = (sc.H + TILE - 1) / TILE;
     // one memset: the counters and, right behind them, the control words of the depth sort
     const size_t depth_ctrl = g_options.sort_variant == 1 ? radix_sort_control_words((size_t)P, 0, 32) : 0;
+    // (sizes rounded up to 256 bytes: the runtime splits a memset of any other size into two fill kernels; the few
+    // extra words are scratch that is written before it is read)
     GOI_HIP(hipMemsetAsync(g.counters, 0,
-                           (size_t)(reinterpret_cast<char*>(g.scratch + depth_ctrl) - reinterpret_cast<char*>(g.counters)), s));
+                           round_up_256((size_t)(reinterpret_cast<char*>(g.scratch + depth_ctrl) -
+                                                 reinterpret_cast<char*>(g.counters))), s));
     {
         StageTimer t(GOI_STAGE_PREPROCESS, s);
         launch_preprocess_fwd(sc, g, radii, im.ranges, gx * gy, s);  // also zeroes the tile ranges
@@ -360,7 +365,7 @@ int goi_raster_backward(const GoiRasterScene* scene, int R, const void* geom_buf
         {
             StageTimer t(GOI_STAGE_BLEND_BWD, s);
             if (R > 0) {
-                GOI_HIP(hipMemsetAsync(scr.flags, 0, (size_t)R * 4, s));
+                GOI_HIP(hipMemsetAsync(scr.flags, 0, round_up_256((size_t)R * 4), s));  // (the layout ends with 256 spare bytes)
                 launch_render_bwd_rows(sc, g, im, bv.vals[fin], radii, out_alpha, dL_dout_color, dL_dout_semantic,
                                        dL_dout_depth, dL_dout_alpha, scr, s);
             }
@@ -417,7 +422,7 @@ int goi_raster_backward_semantics(const GoiRasterScene* scene, int R, const void
     {
         StageTimer t(GOI_STAGE_BLEND_BWD, s);
         if (R > 0) {
-            GOI_HIP(hipMemsetAsync(scr.flags, 0, (size_t)R * 4, s));
+            GOI_HIP(hipMemsetAsync(scr.flags, 0, round_up_256((size_t)R * 4), s));  // (the layout ends with 256 spare bytes)
             launch_render_bwd_sem(sc, g, im, bv.vals[fin], radii, out_alpha, dL_dout_semantic, scr.rows, scr.flags,
                                   row_floats, s);
         }
