@@ -17,7 +17,7 @@
 //  4. The per-Gaussian sums over the 64 pixels of the wave are MATRIX PRODUCTS and run on the matrix
 //     cores (see "Two flushes" below for the arithmetic):
 //         dL/dfeature[j][ch] = sum_pix w[pix][j] * dL/dpixel[pix][ch],      w = alpha * T
-//         moments[j][m]      = sum_pix h[pix][j] * basis[pix][m],           h = G * dL/dalpha
+//         moments[j][m]      = sum_pix h[pix][j] * basis[pix][m],           h = opacity * G * dL/dalpha
 //     with basis = (1, u, v, u^2, uv, v^2) in quadrant-centred pixel coordinates; the 2D-mean, conic
 //     and opacity gradients are exact linear combinations of the six moments, expanded around the
 //     Gaussian's centre right after the MFMA.  8 contributing Gaussians form a group; their w columns
