@@ -42,14 +42,21 @@ struct PolyCoef {
 constexpr float kLog2e = 1.4426950408889634f;
 __device__ __forceinline__ PolyCoef poly_coefs(float gx_, float gy_, float ca, float cb, float cc, float o, float qcx,
                                                float qcy) {
-    const float Dx = gx_ - qcx, Dy = gy_ - qcy;
-    const float a1 = fmaf(ca, Dx, cb * Dy);
-    const float a2 = fmaf(cc, Dy, cb * Dx);
-    const float a0 = -0.5f * fmaf(Dx, a1, Dy * a2);  // -0.5 (a Dx^2 + 2 b Dx Dy + c Dy^2)
-    const float lo = __builtin_amdgcn_logf(o);       // v_log_f32 = log2; opacity 0 gives -inf: never contributes
+    // Formed in DOUBLE precision, then rounded: A0 and A1, A2 are differences of terms of size a Dx^2 and a Dx, which
+    // for a long thin Gaussian (thin across, hundreds of pixels along) are 1e3..1e6 times the result -- in fp32 the
+    // exponent would be off by up to ~0.3 there (the reference's own per-pixel evaluation has that same error; with
+    // exact coefficients this one is bounded by the 5e-5 of the quadrant-centred polynomial whatever the Gaussian's
+    // size).  One lane does this once per (quadrant, Gaussian): a dozen fp64 operations.
+    const double Dx = (double)gx_ - (double)qcx, Dy = (double)gy_ - (double)qcy;
+    const double a = ca, b = cb, c = cc;
+    const double a1 = a * Dx + b * Dy;
+    const double a2 = c * Dy + b * Dx;
+    const double a0 = -0.5 * (Dx * a1 + Dy * a2);  // -0.5 (a Dx^2 + 2 b Dx Dy + c Dy^2)
+    const float lo = __builtin_amdgcn_logf(o);     // v_log_f32 = log2; opacity 0 gives -inf: never contributes
+    constexpr double L = 1.4426950408889634;
     PolyCoef p;
-    p.A0 = fmaf(kLog2e, a0, lo);
-    p.A12 = f32x2{kLog2e * a1, kLog2e * a2};
+    p.A0 = (float)(L * a0 + (double)lo);
+    p.A12 = f32x2{(float)(L * a1), (float)(L * a2)};
     p.A35 = f32x2{(-0.5f * kLog2e) * ca, (-0.5f * kLog2e) * cc};
     p.A4 = -kLog2e * cb;
     p.lim = lo + kPowerTol * kLog2e;
@@ -118,15 +125,19 @@ __device__ __forceinline__ bool ellipse_hits_quadrant(float x, float y, float ca
     if (ux0 <= 0.f && ux1 >= 0.f && uy0 <= 0.f && uy1 >= 0.f) return true;     // centre inside
     const float tau = 1.01f * 0.6931471805599453f * __builtin_amdgcn_logf(255.f * o) + 0.0101f;
     const float rb_c = -cb * __builtin_amdgcn_rcpf(cc), rb_a = -cb * __builtin_amdgcn_rcpf(ca);
+    // The minimiser along an edge may be slightly off (fp32): being at a minimum that costs nothing.  The VALUE is
+    // formed in double: for a long thin Gaussian its terms are 1e3..1e6 times the result, and an fp32 value could be
+    // wrong by more than the margin -- the test must never remove a candidate that contributes.
+    const double A = ca, B = cb, Cc = cc;
     auto edge_x = [&](float ex) {  // min over dy in [uy0, uy1] at dx = ex
-        const float dy = fminf(fmaxf(rb_c * ex, uy0), uy1);
-        return 0.5f * (ca * ex * ex + cc * dy * dy) + cb * ex * dy;
+        const double dy = fminf(fmaxf(rb_c * ex, uy0), uy1), dx = ex;
+        return 0.5 * (A * dx * dx + Cc * dy * dy) + B * dx * dy;
     };
     auto edge_y = [&](float ey) {
-        const float dx = fminf(fmaxf(rb_a * ey, ux0), ux1);
-        return 0.5f * (ca * dx * dx + cc * ey * ey) + cb * dx * ey;
+        const double dx = fminf(fmaxf(rb_a * ey, ux0), ux1), dy = ey;
+        return 0.5 * (A * dx * dx + Cc * dy * dy) + B * dx * dy;
     };
-    const float qmin = fminf(fminf(edge_x(ux0), edge_x(ux1)), fminf(edge_y(uy0), edge_y(uy1)));
+    const float qmin = (float)fmin(fmin(edge_x(ux0), edge_x(ux1)), fmin(edge_y(uy0), edge_y(uy1)));
     return !(qmin > tau * 1.0001f + 1e-4f);  // (NaN keeps the candidate)
 }
 

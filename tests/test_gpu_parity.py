@@ -82,7 +82,8 @@ def check_forward(res, f, tag=""):
     return worst
 
 
-def check_backward(g_hip, g_orc, tag=""):
+def check_backward(g_hip, g_orc, tag="", tol=None):
+    tol = BWD_TOL if tol is None else tol
     for name in ("means3D", "opacity", "semantics", "sh", "scales", "rotations", "means2D"):
         a, b = g_hip[name], g_orc[name]
         if a is None:
@@ -91,7 +92,7 @@ def check_backward(g_hip, g_orc, tag=""):
         scale = np.abs(b).max() + 1e-20
         err = np.abs(a - b).max() / scale
         assert np.isfinite(a).all(), f"{tag}: {name} has non-finite values"
-        assert err < BWD_TOL, f"{tag}: grad {name} rel err {err:.3e} (scale {scale:.3e})"
+        assert err < tol, f"{tag}: grad {name} rel err {err:.3e} (scale {scale:.3e})"
 
 
 CASES = [

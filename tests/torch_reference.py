@@ -174,3 +174,25 @@ def covariance_from_scaling_rotation(scales, scale_modifier, rotations):
     L = quat_to_rot(q) @ torch.diag_embed(scale_modifier * scales)
     Sg = L @ L.transpose(1, 2)
     return torch.stack([Sg[:, 0, 0], Sg[:, 0, 1], Sg[:, 0, 2], Sg[:, 1, 1], Sg[:, 1, 2], Sg[:, 2, 2]], -1)
+
+
+def float64_gradients(sc, cam, bg, upstream, sh_degree):
+    """dict of float64 gradients (means3D, opacity, semantics, means2D, sh, scales, rotations) of
+    sum(out * upstream) for a goi_hyperplane_amd.scene scene / camera: the exact-arithmetic yardstick the fp32
+    implementations (oracle, HIP) are measured against when they disagree with each other."""
+    import numpy as np
+    dt = torch.float64
+    T = lambda a: torch.tensor(np.asarray(a), dtype=dt)  # noqa: E731
+    inp = dict(means3D=T(sc.means3D).requires_grad_(), opacities=T(sc.opacities).requires_grad_(),
+               semantics=T(sc.semantics).requires_grad_(), shs=T(sc.shs).requires_grad_(),
+               scales=T(sc.scales).requires_grad_(), rotations=T(sc.rotations).requires_grad_())
+    sink = torch.zeros(sc.P, 3, dtype=dt, requires_grad=True)
+    r = render(viewmatrix=T(cam.world_view_transform), projmatrix=T(cam.full_proj_transform),
+               campos=T(cam.camera_center), tan_fovx=cam.tanfovx, tan_fovy=cam.tanfovy, W=cam.image_width,
+               H=cam.image_height, bg=T(bg), sh_degree=sh_degree, means2D_sink=sink, **inp)
+    gc, gs, gd, ga = upstream
+    loss = (r["color"] * T(gc)).sum() + (r["semantic"] * T(gs)).sum() + (r["depth"] * T(gd)).sum() + (r["alpha"] * T(ga)).sum()
+    loss.backward()
+    return dict(means3D=inp["means3D"].grad.numpy(), opacity=inp["opacities"].grad.numpy(),
+                semantics=inp["semantics"].grad.numpy(), means2D=sink.grad.numpy(), sh=inp["shs"].grad.numpy(),
+                scales=inp["scales"].grad.numpy(), rotations=inp["rotations"].grad.numpy())
