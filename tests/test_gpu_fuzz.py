@@ -64,15 +64,30 @@ def test_random_configuration(oracle_mod, dev, k, P, S, W, H, mu, deg, yaw, pitc
             try:
                 check_backward(res["grads"], o2.backward(*grads), tag + "_vs_fma_twin")
             except AssertionError:
-                # Neither build: then a pair must have taken the other side of a guard in THIS implementation (its
+                # Neither build: then a pair may have taken the other side of a guard in THIS implementation (its
                 # alpha differs from the oracle's by up to ~1e-5 relative: polynomial evaluation, v_exp_f32).  That
-                # shows in the forward as an alpha / colour jump of ~1/255 at a pixel the oracle itself marks as
-                # fragile (a pair within 1e-4 of a guard).  Only then, and only if every such pixel is fragile, the
+                # shows in the forward as an output jump of ~1/255 of the pair's weight at a pixel the oracle itself
+                # marks as fragile (a pair within 1e-4 of a guard).  Only then, and only if every such pixel is fragile, the
                 # gradients are compared at 1e-2: a flipped far-tail pair of a needle-shaped Gaussian carries a large
                 # gradient although its alpha is 1/255.
-                d_alpha = np.abs(np.asarray(res["alpha"]).reshape(-1) - f.alpha.reshape(-1))
-                flipped = d_alpha > 1e-3
-                assert flipped.any() and not (flipped & ok).any(), tag + ": gradients differ without a guard flip"
-                check_backward(res["grads"], o.backward(*grads), tag + "_guard_flip", tol=1e-2)
+                # (the jump is looked for in every output: on a saturated pixel a flipped pair moves alpha = 1 - T by
+                # 1/255 of T_final ~ 1e-4 only, but colour and features by 1/255 of the pair's own weight)
+                jump = np.zeros(W * H, bool)
+                for key, ref in (("render", f.color), ("semantics", f.semantic), ("depth", f.depth), ("alpha", f.alpha)):
+                    dd = np.abs(np.asarray(res[key]).reshape(ref.shape[0], -1) - ref.reshape(ref.shape[0], -1))
+                    jump |= (dd > 2e-4).any(axis=0)
+                flipped = jump
+                if flipped.any():
+                    assert not (flipped & ok).any(), tag + ": an output jump at a pixel that is not fragile"
+                    check_backward(res["grads"], o.backward(*grads), tag + "_guard_flip", tol=1e-2)
+                else:
+                    # no flip: plain rounding noise, amplified by an ill-conditioned Gaussian (a needle several scene
+                    # units long: its cov2D -> cov3D -> rotation chain cancels).  The two oracle builds measure that
+                    # amplification: the tolerance is widened to three times their own disagreement, never beyond 1e-2.
+                    ga, gb = o.backward(*grads), o2.backward(*grads)
+                    floor = max(float(np.abs(np.asarray(ga[n]) - np.asarray(gb[n])).max() / (np.abs(ga[n]).max() + 1e-20))
+                                for n in ("means3D", "opacity", "semantics", "sh", "scales", "rotations"))
+                    assert floor > 1e-4, tag + ": gradients differ although the oracle builds agree"
+                    check_backward(res["grads"], ga, tag + f"_noise_floor_{floor:.1e}", tol=min(1e-2, 3 * floor))
     else:  # pathological draw (e.g. one huge Gaussian grazing every guard): only the exact stages are meaningful
         assert (res["radii"] == f.radii).all(), tag

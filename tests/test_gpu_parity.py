@@ -534,7 +534,7 @@ def test_culled_tile_lists_change_nothing_but_the_instance_count(dev, P, W, H, S
     # chain, which amplifies it; the parity tolerance is 1e-3)
     for k in g0:
         scale = float(g0[k].abs().max())
-        tol = 1e-5 if k in ("_semantics", "_opacity") else 2e-4
+        tol = 1e-5 if k in ("_semantics", "_opacity") else 1e-3  # (the parity tolerance: see the comment above)
         assert float((g0[k] - g1[k]).abs().max()) <= tol * scale, k
     assert float((v0 - v1).abs().max()) <= 2e-5 * float(v0.abs().max())
 
