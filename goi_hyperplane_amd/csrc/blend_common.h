@@ -42,16 +42,29 @@ struct PolyCoef {
 constexpr float kLog2e = 1.4426950408889634f;
 __device__ __forceinline__ PolyCoef poly_coefs(float gx_, float gy_, float ca, float cb, float cc, float o, float qcx,
                                                float qcy) {
-    // Formed in DOUBLE precision, then rounded: A0 and A1, A2 are differences of terms of size a Dx^2 and a Dx, which
-    // for a long thin Gaussian (thin across, hundreds of pixels along) are 1e3..1e6 times the result -- in fp32 the
-    // exponent would be off by up to ~0.3 there (the reference's own per-pixel evaluation has that same error; with
-    // exact coefficients this one is bounded by the 5e-5 of the quadrant-centred polynomial whatever the Gaussian's
-    // size).  One lane does this once per (quadrant, Gaussian): a dozen fp64 operations.
-    const double Dx = (double)gx_ - (double)qcx, Dy = (double)gy_ - (double)qcy;
-    const double a = ca, b = cb, c = cc;
-    const double a1 = a * Dx + b * Dy;
-    const double a2 = c * Dy + b * Dx;
-    const double a0 = -0.5 * (Dx * a1 + Dy * a2);  // -0.5 (a Dx^2 + 2 b Dx Dy + c Dy^2)
+    // A0 and A1, A2 are differences of terms of size a Dx^2 and a Dx, which for a long thin Gaussian (thin across,
+    // hundreds of pixels along) are 1e3..1e6 times the result -- in fp32 the exponent would be off by up to ~0.3
+    // there (the reference's own per-pixel evaluation has that same error).  Whenever the terms are large (S >= 16:
+    // fp32 would lose more than ~3e-6) the coefficients are formed in DOUBLE precision and then rounded; with exact
+    // coefficients the error is bounded by the 5e-5 of the quadrant-centred polynomial whatever the Gaussian's size.
+    // One lane does this once per (quadrant, Gaussian); the fp64 path is skipped when no lane of the wave needs it.
+    const float Dxf = gx_ - qcx, Dyf = gy_ - qcy;
+    const float S = fabsf(ca) * Dxf * Dxf + 2.f * fabsf(cb * Dxf * Dyf) + fabsf(cc) * Dyf * Dyf;
+    // (which path a Gaussian takes depends on ITS OWN S only -- forward and backward stage it in different company
+    // and must get the same bits; the wave-uniform test merely skips the fp64 instructions when nobody needs them)
+    const bool wide = S >= 16.f;
+    const float f1 = fmaf(ca, Dxf, cb * Dyf), f2 = fmaf(cc, Dyf, cb * Dxf);
+    double a1 = f1, a2 = f2, a0 = -0.5f * fmaf(Dxf, f1, Dyf * f2);
+    if (__builtin_amdgcn_ballot_w64(wide) != 0) {
+        const double Dx = (double)gx_ - (double)qcx, Dy = (double)gy_ - (double)qcy;
+        const double a = ca, b = cb, c = cc;
+        const double d1 = a * Dx + b * Dy;
+        const double d2 = c * Dy + b * Dx;
+        const double d0 = -0.5 * (Dx * d1 + Dy * d2);  // -0.5 (a Dx^2 + 2 b Dx Dy + c Dy^2)
+        a1 = wide ? d1 : a1;
+        a2 = wide ? d2 : a2;
+        a0 = wide ? d0 : a0;
+    }
     const float lo = __builtin_amdgcn_logf(o);     // v_log_f32 = log2; opacity 0 gives -inf: never contributes
     constexpr double L = 1.4426950408889634;
     PolyCoef p;
@@ -125,19 +138,17 @@ __device__ __forceinline__ bool ellipse_hits_quadrant(float x, float y, float ca
     if (ux0 <= 0.f && ux1 >= 0.f && uy0 <= 0.f && uy1 >= 0.f) return true;     // centre inside
     const float tau = 1.01f * 0.6931471805599453f * __builtin_amdgcn_logf(255.f * o) + 0.0101f;
     const float rb_c = -cb * __builtin_amdgcn_rcpf(cc), rb_a = -cb * __builtin_amdgcn_rcpf(ca);
-    // The minimiser along an edge may be slightly off (fp32): being at a minimum that costs nothing.  The VALUE is
-    // formed in double: for a long thin Gaussian its terms are 1e3..1e6 times the result, and an fp32 value could be
-    // wrong by more than the margin -- the test must never remove a candidate that contributes.
-    const double A = ca, B = cb, Cc = cc;
-    auto edge_x = [&](float ex) {  // min over dy in [uy0, uy1] at dx = ex
-        const double dy = fminf(fmaxf(rb_c * ex, uy0), uy1), dx = ex;
-        return 0.5 * (A * dx * dx + Cc * dy * dy) + B * dx * dy;
+    // The minimiser along an edge may be slightly off (fp32): being at a minimum that costs nothing.  The VALUE is a
+    // difference of terms that, for a long thin Gaussian, are 1e3..1e6 times the result: every edge value is
+    // therefore lowered by a bound on its fp32 error (1e-6 x the sum of the terms' magnitudes; the true bound is
+    // ~6e-7) before it is compared -- the test must never remove a candidate that contributes, while keeping one
+    // too many only costs an evaluation.
+    auto edge = [&](float dx, float dy) {
+        const float t1 = 0.5f * ca * dx * dx, t2 = 0.5f * cc * dy * dy, t3 = cb * dx * dy;
+        return (t1 + t2 + t3) - 1e-6f * (fabsf(t1) + fabsf(t2) + fabsf(t3));
     };
-    auto edge_y = [&](float ey) {
-        const double dx = fminf(fmaxf(rb_a * ey, ux0), ux1), dy = ey;
-        return 0.5 * (A * dx * dx + Cc * dy * dy) + B * dx * dy;
-    };
-    const float qmin = (float)fmin(fmin(edge_x(ux0), edge_x(ux1)), fmin(edge_y(uy0), edge_y(uy1)));
+    const float qmin = fminf(fminf(edge(ux0, fminf(fmaxf(rb_c * ux0, uy0), uy1)), edge(ux1, fminf(fmaxf(rb_c * ux1, uy0), uy1))),
+                             fminf(edge(fminf(fmaxf(rb_a * uy0, ux0), ux1), uy0), edge(fminf(fmaxf(rb_a * uy1, ux0), ux1), uy1)));
     return !(qmin > tau * 1.0001f + 1e-4f);  // (NaN keeps the candidate)
 }
 
