@@ -53,23 +53,24 @@ __device__ __forceinline__ PolyCoef poly_coefs(float gx_, float gy_, float ca, f
     // (which path a Gaussian takes depends on ITS OWN S only -- forward and backward stage it in different company
     // and must get the same bits; the wave-uniform test merely skips the fp64 instructions when nobody needs them)
     const bool wide = S >= 16.f;
+    const float lo = __builtin_amdgcn_logf(o);  // v_log_f32 = log2; opacity 0 gives -inf: never contributes
     const float f1 = fmaf(ca, Dxf, cb * Dyf), f2 = fmaf(cc, Dyf, cb * Dxf);
-    double a1 = f1, a2 = f2, a0 = -0.5f * fmaf(Dxf, f1, Dyf * f2);
+    float A0 = fmaf(kLog2e, -0.5f * fmaf(Dxf, f1, Dyf * f2), lo), A1 = kLog2e * f1, A2 = kLog2e * f2;
     if (__builtin_amdgcn_ballot_w64(wide) != 0) {
+        constexpr double L = 1.4426950408889634;
         const double Dx = (double)gx_ - (double)qcx, Dy = (double)gy_ - (double)qcy;
         const double a = ca, b = cb, c = cc;
         const double d1 = a * Dx + b * Dy;
         const double d2 = c * Dy + b * Dx;
         const double d0 = -0.5 * (Dx * d1 + Dy * d2);  // -0.5 (a Dx^2 + 2 b Dx Dy + c Dy^2)
-        a1 = wide ? d1 : a1;
-        a2 = wide ? d2 : a2;
-        a0 = wide ? d0 : a0;
+        const float w0 = (float)(L * d0 + (double)lo), w1 = (float)(L * d1), w2 = (float)(L * d2);
+        A0 = wide ? w0 : A0;
+        A1 = wide ? w1 : A1;
+        A2 = wide ? w2 : A2;
     }
-    const float lo = __builtin_amdgcn_logf(o);     // v_log_f32 = log2; opacity 0 gives -inf: never contributes
-    constexpr double L = 1.4426950408889634;
     PolyCoef p;
-    p.A0 = (float)(L * a0 + (double)lo);
-    p.A12 = f32x2{(float)(L * a1), (float)(L * a2)};
+    p.A0 = A0;
+    p.A12 = f32x2{A1, A2};
     p.A35 = f32x2{(-0.5f * kLog2e) * ca, (-0.5f * kLog2e) * cc};
     p.A4 = -kLog2e * cb;
     p.lim = lo + kPowerTol * kLog2e;
