@@ -121,6 +121,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hook: GOI_BENCH_BACKEND=gloo GOI_BENCH_SHARE_GPU=1 runs several ranks on ONE GPU over gloo (exercises the
+    # multi-rank code path, the factored exchange included, where only one GPU is available; not a measurement)
+    test_backend = os.environ.get("GOI_BENCH_BACKEND", "")
+    if os.environ.get("GOI_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
@@ -133,7 +138,10 @@ def main():
     if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if test_backend:
+            dist.init_process_group(backend=test_backend)
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     from goi_hyperplane_amd import _lib
     from goi_hyperplane_amd import rasterizer
