@@ -17,8 +17,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct PairEval {
     float E;      // opacity * exp(power), before the 0.99 clamp (CR/forward.cu:350: alpha = min(0.99, E))
     float alpha;  // min(0.99, E)
-    bool hit;
+    bool below, seen;  // the two guards: power <= tolerance, alpha >= 1/255
+    bool hit;          // both
 };
+// "does any lane satisfy all of these?" from the comparisons themselves: each ballot of a comparison IS the mask the
+// v_cmp wrote, the AND is scalar -- a ballot of the combined bool makes the compiler materialise it per lane first
+__device__ __forceinline__ bool any_all(bool a, bool b, bool c) {
+    return (__builtin_amdgcn_ballot_w64(a) & __builtin_amdgcn_ballot_w64(b) & __builtin_amdgcn_ballot_w64(c)) != 0;
+}
 
 // alpha of a Gaussian over one 8x8 quadrant.  With (u, v) in [-3.5, 3.5] the QUADRANT-CENTRED pixel coordinates
 // and dx = Dx - u, dy = Dy - v (Dx, Dy: Gaussian centre relative to the quadrant centre)
@@ -84,7 +90,9 @@ __device__ __forceinline__ PairEval eval_poly(f32x2 A35, f32x2 A12, float A0, fl
     const float P = fmaf(uv.y, t.y, fmaf(uv.x, t1, A0));
     e.E = __builtin_amdgcn_exp2f(P);
     e.alpha = fminf(kAlphaMax, e.E);
-    e.hit = (P <= lim) && (e.alpha >= kAlphaMin);
+    e.below = P <= lim;
+    e.seen = e.alpha >= kAlphaMin;
+    e.hit = e.below && e.seen;
     return e;
 }
 

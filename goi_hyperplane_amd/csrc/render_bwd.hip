@@ -381,8 +381,9 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
             const f32x4 g = s_geo[j];
             const f32x4 g2 = s_geo2[j];
             const PairEval e = eval_poly(g.xy, g.zw, g2.x, g2.y, g2.z, uv);
-            const bool c = (pos0 < last_contributor) && e.hit;
-            if (__builtin_amdgcn_ballot_w64(c) == 0) continue;  // (the builtin takes the bool: no int round trip)
+            const bool live = pos0 < last_contributor;
+            if (!any_all(live, e.below, e.seen)) continue;
+            const bool c = live && e.hit;
 
             // <feature, dL/dpixel> as packed fp32 FMAs (v_pk_fma_f32: two channels per instruction)
             f32x2 dot2 = {0.f, 0.f};

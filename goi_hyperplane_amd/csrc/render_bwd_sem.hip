@@ -175,8 +175,9 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
             const f32x4 g = s_geo[j];
             const f32x4 g2 = s_geo2[j];
             const PairEval e = eval_poly(g.xy, g.zw, g2.x, g2.y, g2.z, uv);
-            const bool c = (pos0 < last_contributor) && e.hit;
-            if (__builtin_amdgcn_ballot_w64(c) == 0) continue;  // (the builtin takes the bool: no int round trip)
+            const bool live = pos0 < last_contributor;
+            if (!any_all(live, e.below, e.seen)) continue;
+            const bool c = live && e.hit;
             const float one_m_a = 1.f - e.alpha;
             const float inv = __builtin_amdgcn_rcpf(one_m_a);
             const float Tn = T * inv;
