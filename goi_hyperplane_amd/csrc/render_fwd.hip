@@ -127,7 +127,8 @@ __global__ __launch_bounds__(64) void render_fwd_k(const uint2* __restrict__ ran
             const bool c0 = valid && e.hit;
             const bool ok = test_T >= kTMin;  // CR/forward.cu:352-356: a failing contributor ends the pixel
             const bool c = c0 && ok;
-            if (__builtin_amdgcn_ballot_w64(c) != 0) {
+            const bool some = any_all(e.below, e.seen, ok);  // (taken where the comparisons are: their masks are used as they are)
+            if (valid && some) {                             // (valid is wave-uniform)
                 const float wgt = c ? e.alpha * T_live : 0.f;
                 const f32x2 w2 = {wgt, wgt};
                 const f32x4 f0 = s_feat4[j * NF4];
