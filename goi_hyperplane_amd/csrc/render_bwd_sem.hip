@@ -168,12 +168,20 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
             s_geo2[lane] = f32x4{pc.A0, pc.A4, pc.lim, __uint_as_float(inst * 4u + (uint32_t)t.q)};
         }
         __builtin_amdgcn_wave_barrier();
+        // the next candidate's coefficients are requested one trip ahead: a member costs ~20 VALU instructions here, the
+        // LDS round trip at the head of every trip was most of it (in the full backward the same prefetch lost: it is
+        // register-bound)
+        int j_n = __builtin_ctzll(m);
+        f32x4 g_n = s_geo[j_n], g2_n = s_geo2[j_n];
         while (m) {
-            const int j = __builtin_ctzll(m);
+            const int j = j_n;
             m &= m - 1;
             const int pos0 = n_proc - 1 - (b * SBATCH + j);
-            const f32x4 g = s_geo[j];
-            const f32x4 g2 = s_geo2[j];
+            const f32x4 g = g_n;
+            const f32x4 g2 = g2_n;
+            j_n = m ? __builtin_ctzll(m) : j;
+            g_n = s_geo[j_n];
+            g2_n = s_geo2[j_n];
             const PairEval e = eval_poly(g.xy, g.zw, g2.x, g2.y, g2.z, uv);
             const bool live = pos0 < last_contributor;
             if (!any_all(live, e.below, e.seen)) continue;
