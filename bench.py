@@ -267,11 +267,19 @@ def main():
         # ... and, live over the timed region, events around the dominant kernel only.
         _lib.profile_stages([dominant])
     barrier()
-    t0 = time.perf_counter()
+    # host time of every step's enqueue (a clock read per step, no synchronisation: the timed region is unchanged).
+    # Informational only -- `value` is K steps over the barrier-bracketed time -- it separates a host stall
+    # (max >> median; see profiles/r01_n0_bench_anomalous.json) from a run that is uniformly slow.
+    marks = [0.0] * (args.steps + 1)
+    t0 = marks[0] = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
+        marks[i + 1] = time.perf_counter()
     barrier()
     elapsed = time.perf_counter() - t0
+    enq = sorted((marks[i + 1] - marks[i]) * 1e3 for i in range(args.steps))
+    step_enqueue_ms = {"median": round(enq[len(enq) // 2], 4), "max": round(enq[-1], 4),
+                       "drain": round((elapsed - (marks[-1] - t0)) * 1e3, 4)} if enq else None
     if timing:
         _lib.profile_enable(False)
         stages[dominant] = _lib.profile_collect()[dominant]
@@ -401,6 +409,7 @@ def main():
                        "exchange": exchange["mode"] if world > 1 else None, "exchange_note": exchange["note"]},
             "render_ms_per_frame": render_ms,
             "gui_frame_ms": gui_ms,  # render + fused semantic decode (300 codes)
+            "step_enqueue_ms": step_enqueue_ms,  # host-side, informational (stall detector; not used for value)
             "semantic_finetune": sem_only,
             "roofline": roofline,
             "whole_view": {"alg_bytes_fwd": b_fwd, "alg_bytes_bwd": b_bwd,
