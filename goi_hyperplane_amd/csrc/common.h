@@ -68,7 +68,7 @@ struct Options {
                           // MFMA flush, 2 the same with the exact-fp32 flush, 1 workgroup-per-tile + atomics;
                           // bits 4..15: timing experiments (GOI_EXPERIMENTS=1 only, invalid gradients)
     int sort_variant = 1;  // 0: histogram / scan / scatter per pass, 1: onesweep (decoupled look-back, default)
-    int decode_variant = 1;  // semantic decode, S <= 16: 1 split-bf16 MFMA contraction (fp32 accuracy), 0 fp32 MFMA
+    int decode_variant = 1;  // semantic decode, S <= 16: 1 split-bf16 MFMA contraction, 2 pixel blocks per operand fetch (2: 4 blocks, 3: 1 block; bit-identical), 0 fp32 MFMA
     int cull_variant = 1;  // 0: a Gaussian is listed in every tile of its 3-sigma rectangle (the reference's lists),
                            // 1: only in the tiles its exact contribution box touches (same images and gradients)
 };

@@ -167,7 +167,8 @@ int goi_raster_profile_collect(double* ms, int* calls);
  *   "sort_variant" 1 (default) onesweep radix sort, 0 histogram / scan / scatter per pass
  *   "cull_variant" 1 (default) tile lists culled by the exact contribution box, 0 the reference's 3-sigma squares
  *   "decode_variant" (goi_semantic_decode, S <= 16) 1 (default) contraction as three bf16 MFMAs on exact 3-way splits of
- *                  the fp32 operands (fp32 accuracy), 0 fp32 MFMA */
+ *                  the fp32 operands (fp32 accuracy), two 16-pixel blocks per code-book operand fetch; 2 / 3 the same
+ *                  with four / one block per fetch (bit-identical results, slower); 0 fp32 MFMA */
 int goi_raster_set_option(const char* name, int value);
 
 /* dL/dSH [P,M,3] of V views from the factors goi_raster_backward leaves in FACTORED mode: means3D [P,3], the V camera

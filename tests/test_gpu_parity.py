@@ -360,14 +360,36 @@ def test_fused_semantic_decode_matches_unfused_reference(dev):
     assert (sim_f[agree] - sim_r[agree]).abs().max().item() < 1e-6
     # the fp32-MFMA contraction kept behind decode_variant = 0 (default: three bf16 MFMAs on exact 3-way splits)
     from goi_hyperplane_amd import _lib
-    _lib.set_option("decode_variant", 0)
-    try:
-        sim_0, idx_0 = compute_similarity(sem, mlp16, lut16, svm_score_fn(svm), 0.5, return_index=True)
-    finally:
-        _lib.set_option("decode_variant", 1)
+
+    def with_variant(v, *a, **k):
+        _lib.set_option("decode_variant", v)
+        try:
+            return compute_similarity(*a, **k)
+        finally:
+            _lib.set_option("decode_variant", 1)
+
+    sim_0, idx_0 = with_variant(0, sem, mlp16, lut16, svm_score_fn(svm), 0.5, return_index=True)
     same = idx_0 == idx_f
     assert same.float().mean().item() > 0.99999 and torch.equal(sim_0[same], sim_f[same])
     assert ((idx_0.long() == idx_r).float().mean().item()) > 0.9999
+    # the split-bf16 kernel blocked over 4 and 1 pixel blocks per operand fetch (default 2): the arithmetic per
+    # (pixel, code) does not depend on the blocking, so everything must agree bit for bit -- also on shapes that
+    # leave partial units, partial code blocks and single elements
+    for v in (2, 3):
+        sim_v, idx_v = with_variant(v, sem, mlp16, lut16, svm_score_fn(svm), 0.5, return_index=True)
+        assert torch.equal(idx_v, idx_f) and torch.equal(sim_v, sim_f)
+    for (Sx, Hx, Wx, Cx) in ((7, 13, 11, 37), (16, 33, 65, 301), (1, 1, 1, 1), (16, 40, 40, 17), (13, 257, 129, 300)):
+        torch.manual_seed(Sx * 1000 + Cx)
+        mlpx = SemanticModel(dim_in=Sx, dim_out=Cx, num_layer=1, use_bias=True, device=dev)
+        lutx = torch.rand(Cx, 256, device=dev)
+        semx = torch.randn(Sx, Hx, Wx, device=dev)
+        want = with_variant(1, semx, mlpx, lutx, svm_score_fn(svm), 0.5, return_index=True)
+        for v in (2, 3):
+            got = with_variant(v, semx, mlpx, lutx, svm_score_fn(svm), 0.5, return_index=True)
+            assert torch.equal(got[1], want[1]) and torch.equal(got[0], want[0]), (v, Sx, Hx, Wx, Cx)
+        ref_sim, ref_idx = compute_similarity_reference(semx.permute(1, 2, 0).reshape(-1, Sx), mlpx, lutx, svm_score_fn(svm), 0.5)
+        ok = want[1].long().reshape(-1) == ref_idx.reshape(-1)
+        assert ok.float().mean().item() > 0.999, (Sx, Hx, Wx, Cx)
     # odd sizes: HW not a multiple of 64, S not a multiple of 4, n_codes not a multiple of 16
     mlp7 = SemanticModel(dim_in=7, dim_out=37, num_layer=1, use_bias=True, device=dev)
     lut7 = torch.rand(37, 256, device=dev)
