@@ -44,7 +44,7 @@ __device__ __forceinline__ void row_argmax(float& v, int& i) {
 // NBLK_T > 0: the number of 16-code blocks is a compile-time constant (19 for the reference's 300 codes): every LDS
 // operand then sits at a constant offset from one base address and the block loop unrolls completely.
 template <int K4, int NBLK_T>
-__global__ __launch_bounds__(256) void semantic_decode_k(const float* __restrict__ sem, int S, long long HW,
+__global__ __launch_bounds__(256, 2) void semantic_decode_k(const float* __restrict__ sem, int S, long long HW,
                                                          const float* __restrict__ Wm, const float* __restrict__ bias,
                                                          int n_codes, const float* __restrict__ code_score, float thresh,
                                                          float* __restrict__ sim_out, int* __restrict__ idx_out,
