@@ -358,16 +358,22 @@ int launch_semantic_decode(const float* sem, int S, long long HW, const float* W
         const int npb = g_options.decode_variant == 1 ? 2 : g_options.decode_variant == 2 ? 4 : 1;
         // persistent grid: as many workgroups as are resident at once (W is split and staged once per workgroup)
         long long nb3 = ((HW + 16 * npb - 1) / (16 * npb) + 3) / 4;
-        auto resident = [&](const void* k) {
-            int dev = 0, cus = 256, per_cu = 0;
-            (void)hipGetDevice(&dev);
-            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, 256, lds3) != hipSuccess || per_cu < 1) per_cu = 2;
-            return (long long)cus * per_cu;
+        // (queried once per instantiation and LDS size: the GPUs of a node are identical)
+        auto resident = [&](const void* k, long long (&cache)[2]) {
+            if (cache[0] != (long long)lds3) {
+                int dev = 0, cus = 256, per_cu = 0;
+                (void)hipGetDevice(&dev);
+                (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, 256, lds3) != hipSuccess || per_cu < 1) per_cu = 2;
+                cache[1] = (long long)cus * per_cu;
+                cache[0] = (long long)lds3;
+            }
+            return cache[1];
         };
 #define GOI_L3(N)                                                                                                  \
     do {                                                                                                           \
-        const long long cap = resident(reinterpret_cast<const void*>(semantic_decode3n_k<N>));                     \
+        static long long cache[2] = {-1, 0};                                                                       \
+        const long long cap = resident(reinterpret_cast<const void*>(semantic_decode3n_k<N>), cache);              \
         if (nb3 > cap) nb3 = cap;                                                                                  \
         if (nb3 < 1) nb3 = 1;                                                                                      \
         semantic_decode3n_k<N><<<dim3((unsigned)nb3), dim3(256), lds3, s>>>(sem, S, HW, W, bias, n_codes, code_score, \
