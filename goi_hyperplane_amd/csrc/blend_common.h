@@ -113,6 +113,24 @@ __device__ __forceinline__ void split_pair(float a, float b, uint32_t& hi, uint3
     const float ah = __uint_as_float(hi << 16), bh = __uint_as_float(hi & 0xFFFF0000u);
     lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a - ah, b - bh}, bf16x2));
 }
+// eight consecutive K values of an MFMA operand -> hi, lo and a THIRD plane t = rne(x - hi - lo): hi + lo + t carries x
+// to ~2^-25 (against a B operand that is exact in bf16 -- the moment basis -- the product is then fp32-grade)
+__device__ __forceinline__ void split3_pack8(const float (&y)[8], bf16x8& h, bf16x8& l, bf16x8& t) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    uint32_t hw[4], lw[4], tw[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float a = y[2 * i], b = y[2 * i + 1];
+        hw[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, bf16x2));
+        const float a1 = a - __uint_as_float(hw[i] << 16), b1 = b - __uint_as_float(hw[i] & 0xFFFF0000u);
+        lw[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a1, b1}, bf16x2));
+        const float a2 = a1 - __uint_as_float(lw[i] << 16), b2 = b1 - __uint_as_float(lw[i] & 0xFFFF0000u);
+        tw[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a2, b2}, bf16x2));
+    }
+    h = __builtin_bit_cast(bf16x8, u32x4{hw[0], hw[1], hw[2], hw[3]});
+    l = __builtin_bit_cast(bf16x8, u32x4{lw[0], lw[1], lw[2], lw[3]});
+    t = __builtin_bit_cast(bf16x8, u32x4{tw[0], tw[1], tw[2], tw[3]});
+}
 // eight consecutive K values of an MFMA operand -> hi and lo planes
 __device__ __forceinline__ void split_pack8(const float (&y)[8], bf16x8& h, bf16x8& l) {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));

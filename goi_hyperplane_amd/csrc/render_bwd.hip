@@ -41,8 +41,11 @@
 // (|x - hi - lo| <= 2^-17 |x|) -- the A operand (w / h) right after it is read from LDS, the B operand (dL / basis;
 // the basis values are exact in bf16) once per kernel in registers -- and a product is formed as  hi*hi + lo*hi + hi*lo  by three
 // v_mfma_f32_16x16x32_bf16 per 32 pixels, accumulated in fp32: 12 instructions of ~20 clocks per flush instead
-// of 32 of ~35.  The dropped lo*lo term is <= 2^-16 of the product; the sums differ from exact fp32 by ~1e-5
-// relative in the worst case (the reference's own float atomicAdd order noise is ~1e-6), still bit-reproducible.
+// of 32 of ~35.  The dropped lo*lo term is <= 2^-16 of the product; the feature / colour / depth sums differ from
+// exact fp32 by ~1e-5 relative in the worst case (the reference's own float atomicAdd order noise is ~1e-6), still
+// bit-reproducible.  The six MOMENTS get a third plane of h (+2 instructions per flush): the basis is exact in bf16,
+// so they come out fp32-grade -- they are what the ill-conditioned geometry chain of a needle-shaped Gaussian
+// amplifies (found by the fuzz soak: 2.4e-3 of the rotation gradient's scale with two planes).
 // MODE 1 (bwd_variant = 2) keeps the exact-fp32 flush (an fmaf chain per output) for users who want it.
 #include "blend_common.h"
 
@@ -259,13 +262,16 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
             }
         } else {
             // A[row = mm][pixel 32 c + 8 kq + i]: two ds_read_b128 per 32-pixel chunk, split in registers
-            bf16x8 Ah[2], Al[2];
+            // (hi, lo for every product; a third plane for the MOMENTS only: their B operand, the basis, is exact in
+            // bf16, so h = hi + lo + t makes them fp32-grade -- they feed the cancelling conic -> cov3D -> scale /
+            // rotation chain, which amplifies a 1e-5 error of a needle-shaped Gaussian beyond the 1e-3 tolerance)
+            bf16x8 Ah[2], Al[2], At[2];
 #pragma unroll
             for (int c2 = 0; c2 < 2; c2++) {
                 const f32x4* src = reinterpret_cast<const f32x4*>(s_t + split_row(mm) + 32 * c2 + 8 * kq);
                 const f32x4 a0 = src[0], a1 = src[1];
                 const float y[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-                split_pack8(y, Ah[c2], Al[c2]);
+                split3_pack8(y, Ah[c2], Al[c2], At[c2]);
             }
 #pragma unroll
             for (int c2 = 0; c2 < 2; c2++) {
@@ -275,6 +281,7 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
                     acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[c2], Bl[nb][c2], acc[nb], 0, 0, 0);
                     acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[c2], Bh[nb][c2], acc[nb], 0, 0, 0);
                 }
+                accx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(At[c2], Bh[NB][c2], accx, 0, 0, 0);
                 accx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al[c2], Bh[NB][c2], accx, 0, 0, 0);
                 accx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[c2], Bl[NB][c2], accx, 0, 0, 0);
                 accx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[c2], Bh[NB][c2], accx, 0, 0, 0);

@@ -91,3 +91,28 @@ def test_random_configuration(oracle_mod, dev, k, P, S, W, H, mu, deg, yaw, pitc
                     check_backward(res["grads"], ga, tag + f"_noise_floor_{floor:.1e}", tol=min(1e-2, 3 * floor))
     else:  # pathological draw (e.g. one huge Gaussian grazing every guard): only the exact stages are meaningful
         assert (res["radii"] == f.radii).all(), tag
+
+
+# Configurations a soak run found where this build ALONE was outside the gradient tolerance (the oracle agreed with
+# float64 to 1e-5): kept as strict cases -- plain 1e-3 against the oracle, no fallback criteria.
+#   (k, n, seed) = (201, 1500, 8102): ONE Gaussian; its opacity gradient is a sum over pixels that cancels to 1/600 of
+#   its terms, and the two-plane split-bf16 flush (products to ~1e-5) left 2.1e-3 there; the moments now get a third
+#   plane.
+SOAK_REGRESSIONS = [(201, 1500, 8102)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,n,seed", SOAK_REGRESSIONS)
+def test_soak_regression_is_within_the_plain_tolerance(oracle_mod, dev, k, n, seed):  # noqa: F811
+    cfg = [c for c in configs(n, seed) if c[0] == k][0]
+    _k, P, S, W, H, mu, deg, yaw, pitch = cfg
+    sc = make_scene(P, S=S, sh_degree=deg, seed=100 + k, log_scale_mean=mu)
+    cam = make_camera(W, H, yaw=yaw, pitch=pitch)
+    bg = np.random.default_rng(k).random(3).astype(np.float32)
+    grads = upstream_grads(S, H, W, seed=k)
+    o = oracle_mod.from_scene(sc, cam, bg=bg)
+    f = o.forward()
+    res = run_hip(sc, cam, bg, dev, grads=grads)
+    tag = f"soak{seed}_{k}_P{P}_S{S}_{W}x{H}"
+    check_forward(res, f, tag)
+    check_backward(res["grads"], o.backward(*grads), tag)
