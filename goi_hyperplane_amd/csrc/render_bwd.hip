@@ -44,8 +44,10 @@
 // of 32 of ~35.  The dropped lo*lo term is <= 2^-16 of the product; the feature / colour / depth sums differ from
 // exact fp32 by ~1e-5 relative in the worst case (the reference's own float atomicAdd order noise is ~1e-6), still
 // bit-reproducible.  The six MOMENTS get a third plane of h (+2 instructions per flush): the basis is exact in bf16,
-// so they come out fp32-grade -- they are what the ill-conditioned geometry chain of a needle-shaped Gaussian
-// amplifies (found by the fuzz soak: 2.4e-3 of the rotation gradient's scale with two planes).
+// so they come out fp32-grade.  They are sums over pixels that can cancel to a small fraction of their terms: the
+// opacity gradient of an isolated Gaussian under a +- upstream gradient (|sum| ~ sum|.|/600) was 2.1e-3 off with two
+// planes and is 5.9e-5 off with three (soak case 8102/201, tests/test_gpu_fuzz.py).  (Needle-shaped Gaussians, the
+// original motivation, are NOT helped: their residue is guard flips and the fp32 conditioning of either side.)
 // MODE 1 (bwd_variant = 2) keeps the exact-fp32 flush (an fmaf chain per output) for users who want it.
 #include "blend_common.h"
 
@@ -263,8 +265,8 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
         } else {
             // A[row = mm][pixel 32 c + 8 kq + i]: two ds_read_b128 per 32-pixel chunk, split in registers
             // (hi, lo for every product; a third plane for the MOMENTS only: their B operand, the basis, is exact in
-            // bf16, so h = hi + lo + t makes them fp32-grade -- they feed the cancelling conic -> cov3D -> scale /
-            // rotation chain, which amplifies a 1e-5 error of a needle-shaped Gaussian beyond the 1e-3 tolerance)
+            // bf16, so h = hi + lo + t makes them fp32-grade -- a moment is a sum over pixels that may cancel to 1/600
+            // of its terms, which turns 1e-5 per product into > 1e-3 of the result)
             bf16x8 Ah[2], Al[2], At[2];
 #pragma unroll
             for (int c2 = 0; c2 < 2; c2++) {
