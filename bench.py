@@ -151,8 +151,9 @@ def main():
     _lib.load()
 
     if args.ply:
-        pc = GaussianSet.from_ply(args.ply, dev, sh_degree=3, semantic_dim=args.S)
-        args.P = int(pc.get_xyz.shape[0])
+        pc = GaussianSet.from_ply(args.ply, dev, sh_degree=3)  # the semantic width is the file's (10 for a default
+        args.P = int(pc.get_xyz.shape[0])                      # reference run), not --S
+        args.S = int(pc.get_semantics.shape[1])
         args.no_cpu_baseline = True  # the bounded CPU sample is defined on the synthetic scene
         sc = None
     else:
@@ -351,7 +352,7 @@ def main():
         sem_only = {"views_per_s": nss * world / sem_elapsed, "ms_per_step": sem_elapsed / nss * 1e3, "steps": nss,
                     "what": "only the semantic features trainable (the reference's default): forward + "
                             "feature-gradient-only backward" + (" + RCCL all-reduce of dL/dsemantics" if world > 1 else "")}
-        rasterizer.set_backward_mode(semantics_only=False)
+        rasterizer.set_backward_mode(semantics_only="auto")
         for p in params:
             p.requires_grad_(True)
 

@@ -87,6 +87,16 @@ def _backward_scratch(nbytes: int, dev) -> torch.Tensor:
     return buf
 
 
+def release_scratch(device=None) -> int:
+    """Frees the grow-only backward scratch buffers (all devices, or one): they are dead between calls, hold
+    ~1.25 x the largest view's 4*R*129 bytes per (device, stream) and are invisible to torch.cuda.empty_cache()
+    while referenced here.  Returns the number of bytes released to the caching allocator."""
+    freed = 0
+    for key in [k for k in _SCRATCH if device is None or k[0] == torch.device(device).index]:
+        freed += _SCRATCH.pop(key).numel()
+    return freed
+
+
 def _scene(P, S, H, W, bg, means3D, sh, colors, semantics, opacity, scales, rotations, scale_modifier, cov3D,
            viewmatrix, projmatrix, tan_fovx, tan_fovy, degree, campos, prefiltered, debug):
     M = 0 if (sh is None or sh.numel() == 0) else int(sh.size(1))

@@ -100,8 +100,10 @@ int validate(const GoiRasterScene* sc, bool need_sem, bool need_opacity = true) 
     if (((sc->scales == nullptr || sc->rotations == nullptr) && sc->cov3D_precomp == nullptr) ||
         ((sc->scales != nullptr || sc->rotations != nullptr) && sc->cov3D_precomp != nullptr))
         return fail("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
-    if (sc->shs && (sc->D < 0 || sc->D > 3 || sc->M < (sc->D + 1) * (sc->D + 1)))
-        return fail("SH degree must be 0..3 and M >= (D+1)^2");
+    // M <= 16: the kernels hold at most the 16 coefficients of degree 3, and preprocess_bwd stages 256 x (3M+1) floats
+    // of dL/dSH in LDS (50 KB at M = 16) -- a larger M would only fail at backward time
+    if (sc->shs && (sc->D < 0 || sc->D > 3 || sc->M < (sc->D + 1) * (sc->D + 1) || sc->M > 16))
+        return fail("SH degree must be 0..3 and (D+1)^2 <= M <= 16");
     return 0;
 }
 

@@ -12,12 +12,28 @@ from __future__ import annotations
 import torch
 
 
-def shard_views(num_views: int, rank: int, world: int, epoch: int = 0, seed: int = 0) -> list:
+def shard_views(num_views: int, rank: int, world: int, epoch: int = 0, seed: int = 0, even: str = "pad") -> list:
     """Indices of the views rank `rank` renders in `epoch`: a seeded permutation dealt round-robin.
-    Every rank computes the same permutation, so the shards are disjoint and cover all views."""
+    Every rank computes the same permutation, so the shards cover all views.
+
+    A training loop issues one gradient exchange per local view, so every rank must hold the SAME number of views or
+    the ranks with fewer never enter the last collective.  even="pad" (default): when num_views is not a multiple of
+    `world` the permutation is extended by wrapping around to its start, every rank gets ceil(num_views / world) views
+    and a few views are rendered twice in that epoch; even="drop": the tail is dropped, floor(num_views / world) views
+    per rank; even="none": the plain deal (a partition; shard lengths may differ by one -- only for loops that do not
+    exchange per view)."""
+    if even not in ("pad", "drop", "none"):
+        raise ValueError("even must be 'pad', 'drop' or 'none'")
     g = torch.Generator()
     g.manual_seed(seed * 1_000_003 + epoch)
     perm = torch.randperm(num_views, generator=g).tolist()
+    rem = num_views % world
+    if rem and num_views:
+        if even == "pad":
+            need = -(-num_views // world) * world  # wrap around as often as it takes (num_views may be < world)
+            perm = (perm * (need // num_views + 1))[:need]
+        elif even == "drop":
+            perm = perm[:num_views - rem]
     return perm[rank::world]
 
 
@@ -47,6 +63,10 @@ def coalesce_shared_storage(grads, max_waste: float = 0.25):
 
 def allreduce_gradients(params, dist, bucket_bytes: int = 0):
     """Sum-all-reduce `.grad` of every parameter in place.
+
+    SUM, not mean: the result is the gradient of the sum of the ranks' per-view losses, i.e. what the reference's
+    single process would accumulate over the same views (all-reduced == sum of the single-view
+    gradients).  A caller that wants the data-parallel mean divides by dist.get_world_size() (or scales the lr).
 
     bucket_bytes == 0: one asynchronous collective per gradient tensor, all in flight together
     (RCCL pipelines them; no flattening copy).  bucket_bytes > 0: gradients are packed into flat
@@ -127,7 +147,11 @@ def allreduce_gradients_sh_factored(params, sh_leaves, means3D, factor, dist, re
     k = 0
     for leaf in sh_leaves:
         n = int(leaf.shape[1])
-        leaf.grad = dsh[:, k:k + n, :].contiguous() if (k or n != dsh.shape[1]) else dsh
+        part = dsh[:, k:k + n, :].contiguous() if (k or n != dsh.shape[1]) else dsh
+        if leaf.grad is None:  # autograd semantics: a gradient that is already there is accumulated into
+            leaf.grad = part
+        else:
+            leaf.grad.add_(part)
         k += n
     if k != dsh.shape[1]:
         raise ValueError(f"sh_leaves hold {k} coefficients, the rasterizer was given {dsh.shape[1]}")

@@ -104,10 +104,17 @@ def read_ply_vertex(path) -> np.ndarray:
         return data
 
 
-def load_ply(path, max_sh_degree: int = 3, semantic_dim: int = 16) -> dict:
+REFERENCE_SEM_DIM = 10  # arguments/__init__.py:39 (sem_dim), cuda_rasterizer/config.h:18 (SEM_CHANNELS)
+
+
+def load_ply(path, max_sh_degree: int = 3, semantic_dim: int | None = None) -> dict:
     """load_ply (scene/gaussian_model.py:308-358): raw parameter arrays in the reference's layout
-    (features_dc [P,1,3], features_rest [P,(D+1)^2-1,3]) as float32 numpy arrays.  A file whose number
-    of sem_* columns differs from `semantic_dim` yields zeros, exactly like the reference."""
+    (features_dc [P,1,3], features_rest [P,(D+1)^2-1,3]) as float32 numpy arrays.
+
+    semantic_dim=None (default): the semantic features have the width the FILE has (its sem_* columns; a file without
+    any gets REFERENCE_SEM_DIM zero columns).  An explicit semantic_dim follows the reference's rule -- a file whose
+    number of sem_* columns differs yields ZEROS of the file's width (gaussian_model.py:332-336) -- and warns, because
+    decoding or training on those zeros is silent garbage (e.g. a default reference run saves 10 columns)."""
     v = read_ply_vertex(path)
     names = v.dtype.names
     P = v.shape[0]
@@ -125,10 +132,16 @@ def load_ply(path, max_sh_degree: int = 3, semantic_dim: int = 16) -> dict:
     features_extra = np.stack([v[n] for n in extra], axis=1).reshape(P, 3, (max_sh_degree + 1) ** 2 - 1) if extra \
         else np.zeros((P, 3, 0))
     sem_names = numbered("sem_")
-    sems = np.zeros((P, len(sem_names) or semantic_dim))
-    if len(sem_names) == semantic_dim:
+    want = len(sem_names) if semantic_dim is None else int(semantic_dim)
+    sems = np.zeros((P, len(sem_names) or want or REFERENCE_SEM_DIM))
+    if len(sem_names) == want:
         for i, n in enumerate(sem_names):
             sems[:, i] = v[n]
+    elif sem_names:
+        import warnings
+        warnings.warn(f"{path}: the file has {len(sem_names)} sem_* columns but semantic_dim={want} was requested; "
+                      f"following the reference, the semantic features are ZERO [P,{len(sem_names)}]. Pass "
+                      f"semantic_dim=None (or {len(sem_names)}) to load them.", stacklevel=2)
     scales = np.stack([v[n] for n in numbered("scale_")], axis=1)
     rots = np.stack([v[n] for n in numbered("rot")], axis=1)
     f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)  # noqa: E731

@@ -38,6 +38,8 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        if nograd_mask is not None and nograd_mask.dim() != 1:
+            raise ValueError("nograd_mask must be a 1-D [P] tensor")
         lib = _lib.load()
         launches = {}  # (beta1, beta2, eps, device) -> list of GoiAdamGroup
         keep = []
@@ -64,15 +66,18 @@ class FusedAdam(torch.optim.Optimizer):
                 step_size = group["lr"] / (1.0 - beta1 ** t)
                 bc2_sqrt = math.sqrt(1.0 - beta2 ** t)
                 row_len = p.numel() // p.shape[0] if p.dim() > 0 and p.shape[0] > 0 else 1
-                if nograd_mask is not None and p.shape[0] != nograd_mask.shape[0]:
-                    raise ValueError("nograd_mask must have one entry per Gaussian (parameter rows)")
+                if nograd_mask is not None:
+                    if p.dim() == 0:
+                        raise ValueError("nograd_mask: a 0-dim parameter has no per-Gaussian rows to mask")
+                    if p.shape[0] != nograd_mask.shape[0]:
+                        raise ValueError("nograd_mask must have one entry per Gaussian (parameter rows)")
                 launches.setdefault((beta1, beta2, group["eps"], p.device), []).append(_lib.GoiAdamGroup(
                     p.data_ptr(), grad.data_ptr(), state["exp_avg"].data_ptr(), state["exp_avg_sq"].data_ptr(),
                     p.numel(), max(row_len, 1), step_size, bc2_sqrt))
-        mask = None
-        if nograd_mask is not None:
-            mask = nograd_mask.to(torch.uint8).contiguous()
         for (beta1, beta2, eps, dev), groups in launches.items():
+            # the kernel dereferences the mask on the launch device: a CPU (or other-GPU) mask is copied there, never
+            # handed over as a foreign pointer
+            mask = None if nograd_mask is None else nograd_mask.to(device=dev, dtype=torch.uint8).contiguous()
             with torch.cuda.device(dev):
                 stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
                 for i in range(0, len(groups), _lib.ADAM_MAX_GROUPS):

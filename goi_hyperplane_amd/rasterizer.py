@@ -10,8 +10,9 @@ gaussian_renderer/__init__.py:14,36-95 and gui/gs_renderer.py:10-13,263-334 run 
 
 Differences, all behind the same surface:
   * compute goes through goi_hyperplane_amd._C (C ABI of libgoi_raster.so, hand-written HIP);
-  * the backward is gated on ctx.needs_input_grad only for what Python returns (the kernels always
-    produce the full gradient set in this version);
+  * the backward is gated on ctx.needs_input_grad: with only the semantic features trainable (the reference's
+    default training configuration) the feature-gradient-only kernel runs, with the SH coefficients frozen dL/dSH
+    is not formed (see set_backward_mode);
   * the number of semantic channels S is read from `semantics.shape[1]` at run time (the reference
     compiles SEM_CHANNELS = 10 in, cuda_rasterizer/config.h:18).
 """
@@ -66,27 +67,50 @@ def _call_with_snapshot(fn, args, debug, dump_name, what):
         raise
 
 
-# Opt-in: when ONLY the semantic features require a gradient (the reference's default training
-# configuration, arguments/__init__.py:85-90), run the feature-gradient-only backward.  The one
-# observable difference to the full backward is that viewspace_points.grad is zero instead of the
-# screen-space gradient; dL/dsemantics is bit-identical.  Off by default; GOI_BACKWARD=semantics or
-# set_backward_mode(semantics_only=True) turns it on.
+# Gradient gating ("skip unneeded gradients").  The reference's kernels always compute every
+# gradient; its DEFAULT training configuration optimises only the semantic features (arguments/__init__.py:85-90,
+# scene/gaussian_model.py:185-246 freeze the rest).  ctx.needs_input_grad says which inputs want a gradient:
+#
+#   * only `semantics` (and the screen-space placeholder means2D): the feature-gradient-only backward
+#     (goi_raster_backward_semantics) runs -- dL/dsemantics is BIT-IDENTICAL to the full backward's, 2.3x faster.  The
+#     one observable difference: viewspace_points.grad is zero instead of the screen-space gradient (nothing in a
+#     semantics-only run consumes it; train.py has no densification).  This is the default ("auto");
+#     GOI_BACKWARD=full or set_backward_mode(semantics_only=False) always runs the full kernel,
+#     GOI_BACKWARD=semantics / semantics_only=True is the same as "auto" (kept for round-1 callers).
+#   * `sh` frozen while other geometry trains: the 192-byte-per-Gaussian dL/dSH row is not formed.
 #
 # sh_factored (data-parallel training, dist.allreduce_gradients_sh_factored): the backward does not form dL/dSH
 # (192 of the 300 gradient bytes per Gaussian); the SH tensor gets NO gradient from autograd, and the factor of
 #     dL/dSH[g][k] = basis_k(direction camera -> g) * gcol[g]
 # -- the clamp-masked colour gradient gcol [P,3] -- is left for take_sh_factor().  The ranks then all-gather 12 bytes
 # per Gaussian and view instead of all-reducing 192, and every rank rebuilds the summed dL/dSH locally.
-_BACKWARD_MODE = {"semantics_only": os.environ.get("GOI_BACKWARD", "") == "semantics", "sh_factored": False}
+def _env_backward_mode():
+    v = os.environ.get("GOI_BACKWARD", "auto").strip().lower()
+    if v in ("full", "0", "off"):
+        return False
+    if v in ("auto", "", "semantics", "1", "on"):
+        return "auto"
+    raise ValueError(f"GOI_BACKWARD={v!r}: expected auto, semantics or full")
+
+
+_BACKWARD_MODE = {"semantics_only": _env_backward_mode(), "sh_factored": False}
 _SH_FACTOR = {"last": None}
+_LAST_BACKWARD = {"kernel": None}  # "semantics" | "full" | "full_no_dsh" | "factored": which path the last backward took
 
 
-def set_backward_mode(semantics_only: bool = None, sh_factored: bool = None) -> None:
+def set_backward_mode(semantics_only=None, sh_factored: bool = None) -> None:
+    """semantics_only: "auto" / True -- take the feature-gradient-only backward whenever nothing but the semantic
+    features needs a gradient (default); False -- always the full kernel; None -- leave unchanged."""
     if semantics_only is not None:
-        _BACKWARD_MODE["semantics_only"] = bool(semantics_only)
+        _BACKWARD_MODE["semantics_only"] = "auto" if semantics_only in ("auto", True) else False
     if sh_factored is not None:
         _BACKWARD_MODE["sh_factored"] = bool(sh_factored)
         _SH_FACTOR["last"] = None
+
+
+def last_backward_kernel():
+    """Which backward path the most recent _RasterizeGaussians.backward took (tests, bench reporting)."""
+    return _LAST_BACKWARD["kernel"]
 
 
 def take_sh_factor():
@@ -120,6 +144,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         need = ctx.needs_input_grad  # means3D, means2D, sh, colors, semantics, opacities, scales, rotations, cov3D
         if (_BACKWARD_MODE["semantics_only"] and need[4] and not rs.debug
                 and not (need[0] or need[2] or need[3] or need[5] or need[6] or need[7] or need[8])):
+            _LAST_BACKWARD["kernel"] = "semantics"
             # only the semantic features are trainable: feature-gradient-only kernel; the screen-space
             # placeholder (means2D) gets zeros -- nothing in a semantics-only run consumes it
             if grad_out_sem is None:  # the loss does not touch the semantic map
@@ -133,13 +158,23 @@ class _RasterizeGaussians(torch.autograd.Function):
                 rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, grad_out_sem, grad_depth,
                 grad_alpha, sh, rs.sh_degree, rs.campos, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, alpha,
                 rs.debug)
-        factored = bool(_BACKWARD_MODE["sh_factored"] and sh is not None and sh.numel() > 0 and need[2] and not rs.debug)
+        has_sh = sh is not None and sh.numel() > 0
+        factored = bool(_BACKWARD_MODE["sh_factored"] and has_sh and need[2] and not rs.debug)
         if factored:
             (grad_means2D, gcol, grad_semantics, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
              grad_scales, grad_rotations) = _C.rasterize_gaussians_backward_sh_factored(*args)
             grad_colors_precomp = None
             _SH_FACTOR["last"] = dict(gcol=gcol, campos=rs.campos, degree=int(rs.sh_degree), M=int(sh.size(1)))
+            _LAST_BACKWARD["kernel"] = "factored"
+        elif has_sh and not need[2] and not rs.debug and _BACKWARD_MODE["semantics_only"]:
+            # the SH coefficients are frozen: same kernels without the dL/dSH row (the colour gradient that mode leaves
+            # behind belongs to no input here -- colours come from the SH -- and is dropped)
+            (grad_means2D, _gcol, grad_semantics, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
+             grad_scales, grad_rotations) = _C.rasterize_gaussians_backward_sh_factored(*args)
+            grad_colors_precomp = None
+            _LAST_BACKWARD["kernel"] = "full_no_dsh"
         else:
+            _LAST_BACKWARD["kernel"] = "full"
             (grad_means2D, grad_colors_precomp, grad_semantics, grad_opacities, grad_means3D, grad_cov3Ds_precomp,
              grad_sh, grad_scales, grad_rotations) = _call_with_snapshot(_C.rasterize_gaussians_backward, args,
                                                                          rs.debug, "snapshot_bw.dump", "backward")

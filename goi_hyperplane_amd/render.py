@@ -54,9 +54,9 @@ class GaussianSet(torch.nn.Module):
                    t(scene.semantics), scene.sh_degree)
 
     @classmethod
-    def from_ply(cls, path, device, sh_degree=3, semantic_dim=16):
+    def from_ply(cls, path, device, sh_degree=3, semantic_dim=None):
         """A scene saved by the reference (point_cloud.ply with sem_* columns, scene/gaussian_model.py:308-358),
-        activated the way its get_* properties do."""
+        activated the way its get_* properties do.  semantic_dim=None: the width the file has (io.load_ply)."""
         from . import io as gio
         a = gio.activate(gio.load_ply(path, max_sh_degree=sh_degree, semantic_dim=semantic_dim))
         return cls(*(a[k].to(device) for k in ("means3D", "scales", "rotations", "opacities", "shs", "semantics")),

@@ -51,7 +51,7 @@ def run(dev, fused, iters):
                 o.zero_grad(set_to_none=True)
             losses.append(float(loss.detach()))
     finally:
-        rasterizer.set_backward_mode(semantics_only=False)
+        rasterizer.set_backward_mode(semantics_only="auto")
     return losses, pc._semantics.detach().clone(), mlp.layers[0].weight.detach().clone(), lut.detach().clone()
 
 

@@ -5,6 +5,7 @@ make_golden.py: kmeans_pins); the PLY layout to the header grammar plyfile emits
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from goi_hyperplane_amd import io as gio
@@ -47,8 +48,11 @@ def test_ply_round_trip_and_semantic_dim_rule(tmp_path):
     back = gio.load_ply(path, max_sh_degree=3, semantic_dim=16)
     for k, v in m.items():
         assert np.array_equal(back[k], v.numpy()), k
-    other = gio.load_ply(path, max_sh_degree=3, semantic_dim=10)  # mismatch -> zeros with the FILE's width
+    with pytest.warns(UserWarning, match="16 sem_\\* columns but semantic_dim=10"):
+        other = gio.load_ply(path, max_sh_degree=3, semantic_dim=10)  # mismatch -> zeros with the FILE's width, loudly
     assert other["semantics"].shape == (37, 16) and not other["semantics"].any()
+    auto = gio.load_ply(path, max_sh_degree=3)  # default: whatever the file holds (a default reference run
+    assert np.array_equal(auto["semantics"], m["semantics"].numpy())  # saves 10 columns; they must not turn into zeros)
     act = gio.activate(back)
     assert act["shs"].shape == (37, 16, 3) and torch.all(act["scales"] > 0)
     assert torch.allclose(act["rotations"].norm(dim=1), torch.ones(37))
