@@ -63,31 +63,49 @@ def survey_bytes(P, V, N, T, HW, S):
 
 
 def cpu_baseline(args, n_full_per_view):
-    """Times the CPU oracle (forward + backward, all host threads) on a bounded sample: the first
-    P_sample Gaussians of the same scene at the full resolution; linear extrapolation in N."""
+    """Times the CPU oracle (forward + backward, all host threads) on ONE view of the bench workload.  By default the
+    sample is the whole workload (all P Gaussians at the full resolution: ~20 s on the GPU box's cores, nothing is
+    extrapolated); --cpu-sample-P bounds it to the first P_sample Gaussians, linearly extrapolated in N.  A second,
+    quarter-size sample measures how linear the oracle's time is in N (reported, never used for `value`)."""
     from goi_hyperplane_amd.scene import HEADLINE, make_camera, make_scene
     from oracle import oracle
     oracle.build()
     cores = os.cpu_count() or 1
-    Ps = min(args.P, args.cpu_sample_P)
-    sc = make_scene(Ps, S=args.S, sh_degree=3, seed=0, extent=HEADLINE["extent"], log_scale_mean=args.mu,
-                    log_scale_std=HEADLINE["log_scale_std"])
     cam = make_camera(args.W, args.H, fovx=HEADLINE["fovx"])
-    o = oracle.from_scene(sc, cam, threads=cores)
     HW = args.W * args.H
-    t0 = time.perf_counter()
-    f = o.forward()
-    t1 = time.perf_counter()
-    o.backward(np.full((3, args.H, args.W), 1.0 / HW, np.float32), np.full((args.S, args.H, args.W), 1.0 / HW, np.float32))
-    t2 = time.perf_counter()
-    sample_s = t2 - t0
-    scale = max(n_full_per_view, 1) / max(f.num_rendered, 1)
+    full = make_scene(args.P, S=args.S, sh_degree=3, seed=0, extent=HEADLINE["extent"], log_scale_mean=args.mu,
+                      log_scale_std=HEADLINE["log_scale_std"])  # every array has its own RNG stream: a prefix of the
+                                                                # full scene IS the smaller scene
+
+    def timed(Ps):
+        import copy
+        sc = copy.copy(full)
+        for k in ("means3D", "scales", "rotations", "opacities", "shs", "semantics"):
+            setattr(sc, k, np.ascontiguousarray(getattr(full, k)[:Ps]))
+        o = oracle.from_scene(sc, cam, threads=cores)
+        t0 = time.perf_counter()
+        f = o.forward()
+        t1 = time.perf_counter()
+        o.backward(np.full((3, args.H, args.W), 1.0 / HW, np.float32), np.full((args.S, args.H, args.W), 1.0 / HW, np.float32))
+        t2 = time.perf_counter()
+        return int(f.num_rendered), t1 - t0, t2 - t1
+
+    Ps = min(args.P, args.cpu_sample_P) if args.cpu_sample_P > 0 else args.P
+    n_s, fwd_s, bwd_s = timed(Ps)
+    sample_s = fwd_s + bwd_s
+    scale = 1.0 if Ps == args.P else max(n_full_per_view, 1) / max(n_s, 1)
+    n_q, fq, bq = timed(max(1, Ps // 4))
+    # seconds per instance at the two sizes: 0 = perfectly linear in N
+    lin_err = (sample_s / max(n_s, 1)) / ((fq + bq) / max(n_q, 1)) - 1.0
+    how = ("the whole view, nothing extrapolated" if Ps == args.P else
+           f"value extrapolated linearly in N to N={n_full_per_view}")
     return {
         "value": 1.0 / (sample_s * scale), "unit": "views/s", "cores": cores, "kind": "port",
-        "sample": f"oracle fwd+bwd on the first {Ps} of {args.P} Gaussians at {args.W}x{args.H}, S={args.S}: "
-                  f"N={f.num_rendered}, fwd {t1 - t0:.2f} s + bwd {t2 - t1:.2f} s; value extrapolated linearly in N "
-                  f"to N={n_full_per_view}",
-        "sample_seconds": sample_s, "sample_num_rendered": int(f.num_rendered),
+        "sample": f"oracle fwd+bwd on {'all' if Ps == args.P else 'the first'} {Ps} of {args.P} Gaussians at "
+                  f"{args.W}x{args.H}, S={args.S}: N={n_s}, fwd {fwd_s:.2f} s + bwd {bwd_s:.2f} s; {how}",
+        "sample_seconds": sample_s, "sample_num_rendered": n_s,
+        "linearity": {"quarter_sample_P": max(1, Ps // 4), "quarter_sample_num_rendered": n_q,
+                      "quarter_sample_seconds": fq + bq, "seconds_per_instance_ratio_minus_1": lin_err},
     }
 
 
@@ -95,8 +113,8 @@ def main():
     from goi_hyperplane_amd.scene import HEADLINE
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=60)  # >= 50: one host hiccup is < 2 % of the timed region
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--P", type=int, default=HEADLINE["P"])
     ap.add_argument("--S", type=int, default=HEADLINE["S"])
     ap.add_argument("--W", type=int, default=HEADLINE["W"])
@@ -112,7 +130,11 @@ def main():
                     help="point_cloud.ply saved by the reference (sem_* columns) instead of the synthetic scene; "
                          "cameras stay synthetic (the data sets are not in this image)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-P", type=int, default=100_000)
+    ap.add_argument("--cpu-sample-P", type=int, default=0,
+                    help="bound the CPU baseline to the first N Gaussians (0 = the whole view, ~20 s on the GPU box)")
+    ap.add_argument("--forward", choices=["speculative", "exact"], default=None,
+                    help="forward mode (default: the package default, speculative = no host round trip)")
+    ap.add_argument("--no-fp32-flush", action="store_true", help="skip the secondary exact-fp32-flush figure")
     ap.add_argument("--no-stage-timing", action="store_true")
     ap.add_argument("--no-semantic-finetune", action="store_true",
                     help="skip the secondary semantics-only-training figure")
@@ -143,8 +165,10 @@ def main():
         else:
             dist.init_process_group(backend="nccl", device_id=dev)
 
-    from goi_hyperplane_amd import _lib
+    from goi_hyperplane_amd import _C, _lib
     from goi_hyperplane_amd import rasterizer
+    if args.forward:
+        rasterizer.set_forward_mode(speculative=args.forward == "speculative")
     from goi_hyperplane_amd.dist import allreduce_gradients, allreduce_gradients_sh_factored
     from goi_hyperplane_amd.render import GaussianSet, PipelineParams, TorchCamera, render
     from goi_hyperplane_amd.scene import make_camera, make_scene
@@ -226,8 +250,12 @@ def main():
     # count -- every tile of every Gaussian's 3-sigma rectangle, what the reference lists and what the algorithmic
     # bytes are charged on (cull_variant 0); N_listed is what this build actually emits, sorts and walks.
     with torch.no_grad():
-        from goi_hyperplane_amd import _C
         stats["N_listed"] = 0
+        # (exact frames, and what they teach the capacity policy is forgotten again: the un-culled lists counted here
+        # are 1.6x what the timed steps emit)
+        fwd_mode = _C._FWD["mode"]
+        spec_saved = {k: dict(v, pending=v["pending"]) for k, v in _C._SPEC.items()}
+        _C.set_forward_mode(speculative=False)
         for i in range(min(args.steps, len(cams))):
             cam = cams[((args.warmup + i) * world + rank) % len(cams)]
             for variant in (0, 1):
@@ -243,6 +271,9 @@ def main():
                 else:
                     stats["N_listed"] += n
                 del _r
+        _C._SPEC.clear()
+        _C._SPEC.update(spec_saved)
+        _C.set_forward_mode(speculative=fwd_mode == "speculative")
     V = stats["V"] / stats["views"]
     N = stats["N"] / stats["views"]
 
@@ -271,6 +302,7 @@ def main():
     # host time of every step's enqueue (a clock read per step, no synchronisation: the timed region is unchanged).
     # Informational only -- `value` is K steps over the barrier-bracketed time -- it separates a host stall
     # (max >> median; see profiles/r01_n0_bench_anomalous.json) from a run that is uniformly slow.
+    spec0 = rasterizer.speculation_stats()
     marks = [0.0] * (args.steps + 1)
     t0 = marks[0] = time.perf_counter()
     for i in range(args.steps):
@@ -278,6 +310,7 @@ def main():
         marks[i + 1] = time.perf_counter()
     barrier()
     elapsed = time.perf_counter() - t0
+    spec1 = rasterizer.speculation_stats()
     enq = sorted((marks[i + 1] - marks[i]) * 1e3 for i in range(args.steps))
     step_enqueue_ms = {"median": round(enq[len(enq) // 2], 4), "max": round(enq[-1], 4),
                        "drain": round((elapsed - (marks[-1] - t0)) * 1e3, 4)} if enq else None
@@ -356,6 +389,32 @@ def main():
         for p in params:
             p.requires_grad_(True)
 
+    # Secondary figure: the same step with the EXACT-fp32 flush of the backward's per-Gaussian sums (bwd_variant 2).  The
+    # default flush forms those products from split-bf16 operands (hi*hi + lo*hi + hi*lo, ~2^-16 relative; the six
+    # moments carry a third plane): storage and accumulation are fp32 either way, this is the figure with fp32 products.
+    fp32_flush = None
+    if not args.no_fp32_flush:
+        _lib.set_option("bwd_variant", 2)
+        try:
+            for i in range(2):
+                step(i)
+            barrier()
+            f0 = time.perf_counter()
+            nf = max(5, min(args.steps, 30))
+            for i in range(nf):
+                step(args.warmup + i)
+            barrier()
+            f_elapsed = time.perf_counter() - f0
+        finally:
+            _lib.set_option("bwd_variant", 0)
+        if dist is not None:
+            tt = torch.tensor([f_elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            f_elapsed = float(tt.item())
+        fp32_flush = {"views_per_s": nf * world / f_elapsed, "ms_per_step": f_elapsed / nf * 1e3, "steps": nf,
+                      "what": "bwd_variant 2: per-Gaussian sums of the backward on v_mfma_f32_16x16x4_f32 (exact fp32 "
+                              "products) instead of split-bf16 operands"}
+
     if rank == 0:
         sb = stage_bytes(args.P, V, N, T, HW, args.S)
         b_fwd, b_bwd = survey_bytes(args.P, V, N, T, HW, args.S)
@@ -389,6 +448,8 @@ def main():
                 k = tj["kernels"].get(tj["stage_kernel"].get(dominant, ""))
                 if k:
                     roofline["traffic"] = k["hbm_bytes_corrected"]
+                    # counter bytes / this run's duration / peak: the fraction of the HBM peak the kernel actually draws
+                    roofline["frac_counter"] = round(k["hbm_bytes_corrected"] / (d["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                     roofline["traffic_source"] = ("profiles/" + os.path.basename(pmc) + ": 2*FETCH_SIZE + WRITE_SIZE of "
                                                   + tj["stage_kernel"][dominant] + ", separate rocprofv3 --pmc passes")
         gpu_ms = sum(v["ms"] for v in stage_out.values())
@@ -412,6 +473,12 @@ def main():
             "gui_frame_ms": gui_ms,  # render + fused semantic decode (300 codes)
             "step_enqueue_ms": step_enqueue_ms,  # host-side, informational (stall detector; not used for value)
             "semantic_finetune": sem_only,
+            "value_fp32_flush": None if fp32_flush is None else fp32_flush["views_per_s"],
+            "fp32_flush": fp32_flush,
+            # forward mode of the timed region and what the speculation did in it (exact_frames / waits / overflows
+            # should all be 0: nothing in the timed steps waited for the device)
+            "forward_mode": _C._FWD["mode"],
+            "speculation": {k: spec1[k] - spec0[k] for k in spec1},
             "roofline": roofline,
             "whole_view": {"alg_bytes_fwd": b_fwd, "alg_bytes_bwd": b_bwd,
                            "alg_GBps_over_step": (b_fwd + b_bwd) / (ms_per_step * 1e-3) / 1e9,

@@ -7,7 +7,10 @@ pointers, sizes and the current HIP stream cross into the library.
 """
 from __future__ import annotations
 
+import collections
 import ctypes as C
+import os
+import warnings
 
 import torch
 
@@ -97,6 +100,224 @@ def release_scratch(device=None) -> int:
     return freed
 
 
+# ---- speculative forward ---------------------------------------------------------------------------------------------
+# The reference's forward blocks on num_rendered (cuda_rasterizer/rasterizer_impl.cu:285) to size the binning workspace;
+# a 1.6 ms training step cannot afford a synchronous host hop (every host hiccup idles the GPU one for one).  In
+# speculative mode (the default) the forward is enqueued whole against a binning buffer sized from the counts seen so
+# far (headroom x the high-water mark), the count comes back through an asynchronous ticket, and `num_rendered` is
+# returned as a LazyCount that only waits when somebody reads it.  See include/goi_raster.h, goi_raster_forward_async.
+#
+#   * the first frame on a device (no history), P == 0, debug=True, sort_variant != 1 and mode "exact" take the exact,
+#     synchronous path;
+#   * a frame whose count fits its capacity is bit-identical to the exact path's (outputs, lists, gradients);
+#   * OVERFLOW (count > capacity): the frame was rendered from a truncated instance list.  Whoever reads the count
+#     (int(num_rendered), .resolve()) BEFORE consuming the outputs gets the frame redone in place -- bit-identical to the
+#     exact path.  If nobody asks, the overflow is found by the poll at a later forward: the frame cannot be repaired
+#     any more (its consumers are already enqueued), a RasterOverflowWarning is issued (GOI_OVERFLOW=raise: a
+#     RasterOverflowError), and the capacity is raised.  Its backward stays consistent with what was rendered.
+#   * at most `max_ahead` frames stay unresolved per device; the oldest is waited for beyond that.
+class RasterOverflowWarning(UserWarning):
+    pass
+
+
+class RasterOverflowError(RuntimeError):
+    pass
+
+
+def _env_forward_mode():
+    v = os.environ.get("GOI_FORWARD", "speculative").strip().lower()
+    if v not in ("speculative", "exact"):
+        raise ValueError(f"GOI_FORWARD={v!r}: expected speculative or exact")
+    return v
+
+
+_FWD = {"mode": _env_forward_mode(), "headroom": float(os.environ.get("GOI_BINNING_HEADROOM", "2.0")),
+        "capacity": None, "on_overflow": os.environ.get("GOI_OVERFLOW", "warn").strip().lower(), "max_ahead": 16}
+_SPEC = {}  # device index -> {"high_water": int, "P": int, "pending": deque of LazyCount}
+SPECULATION_STATS = {"exact_frames": 0, "speculative_frames": 0, "overflows": 0, "redone": 0, "waits": 0}
+_MIN_CAPACITY = 1 << 16
+
+
+def set_forward_mode(speculative=None, headroom=None, capacity="keep", on_overflow=None, max_ahead=None):
+    """speculative: True / False (exact, the reference's synchronous forward).  headroom: capacity = headroom x the
+    largest num_rendered seen on the device.  capacity: an int forces that capacity for every frame (tests), None returns
+    to the policy.  on_overflow: "warn" | "raise" for overflows found after the fact.  max_ahead: unresolved frames
+    allowed per device."""
+    if speculative is not None:
+        _FWD["mode"] = "speculative" if speculative else "exact"
+    if headroom is not None:
+        if not headroom >= 1.0:
+            raise ValueError("headroom must be >= 1")
+        _FWD["headroom"] = float(headroom)
+    if capacity != "keep":
+        _FWD["capacity"] = None if capacity is None else max(1, int(capacity))
+    if on_overflow is not None:
+        if on_overflow not in ("warn", "raise"):
+            raise ValueError("on_overflow must be 'warn' or 'raise'")
+        _FWD["on_overflow"] = on_overflow
+    if max_ahead is not None:
+        _FWD["max_ahead"] = max(1, int(max_ahead))
+
+
+def _spec_state(dev):
+    st = _SPEC.get(dev.index)
+    if st is None:
+        st = _SPEC[dev.index] = {"high_water": 0, "P": 0, "pending": collections.deque()}
+    return st
+
+
+def _note_count(dev, P, n):
+    st = _spec_state(dev)
+    if P > 2 * st["P"] or 2 * P < st["P"]:  # another scene: forget what the previous one needed
+        st["high_water"] = 0
+    st["P"] = P
+    st["high_water"] = max(st["high_water"], int(n))
+
+
+def _pick_capacity(dev, P, debug, prefiltered):
+    """Instances to size a speculative frame for, or None for an exact frame.  (prefiltered=True promises something the
+    kernel checks and the reference traps on: that error must surface in THIS call, so such frames stay exact.)"""
+    if (P == 0 or debug or prefiltered or _FWD["mode"] != "speculative"
+            or _lib.OPTIONS.get("sort_variant", 1) != 1):
+        return None
+    if _FWD["capacity"] is not None:
+        return _FWD["capacity"]
+    st = _spec_state(dev)
+    if st["high_water"] <= 0 or P > 2 * st["P"] or 2 * P < st["P"]:
+        return None  # nothing to go by yet: this frame is exact and teaches the policy
+    return max(_MIN_CAPACITY, int(_FWD["headroom"] * st["high_water"]) + 4096)
+
+
+def poll_counts(dev=None, wait=False):
+    """Resolve what can be resolved without waiting (wait=True: everything) on one device or all.  Called at the start
+    of every forward; an overflow found here is reported per set_forward_mode(on_overflow=...)."""
+    for idx, st in list(_SPEC.items()):
+        if dev is not None and torch.device(dev).index != idx:
+            continue
+        pend = st["pending"]
+        while pend:
+            if not pend[0]._resolve(wait=wait or len(pend) > _FWD["max_ahead"], lazy=True):
+                break
+
+
+class LazyCount:
+    """`num_rendered` of a speculative frame: behaves like the int the reference returns, but the value only crosses to
+    the host when it is read.  Reading it (int(), comparisons, arithmetic, .resolve()) waits for the frame's counters
+    and, if the frame overflowed its capacity, redoes it in place first."""
+
+    __slots__ = ("dev", "ticket", "capacity", "layout", "binning", "overflowed", "redone", "_n", "_redo", "_stream",
+                 "_error", "P")
+
+    def __init__(self, dev, ticket, capacity, binning, stream, redo, P):
+        self.dev, self.ticket, self.capacity, self.layout, self.binning = dev, ticket, capacity, capacity, binning
+        self.overflowed = self.redone = False
+        self._n, self._redo, self._stream, self._error, self.P = None, redo, stream, None, P
+        _spec_state(dev)["pending"].append(self)
+
+    @property
+    def resolved(self):
+        return self._n is not None or self._error is not None
+
+    def _resolve(self, wait, lazy):
+        if self._error is not None:
+            if lazy:
+                return True
+            raise self._error
+        if self._n is not None:
+            return True
+        lib = _lib.load()
+        n = C.c_int(0)
+        if wait:
+            SPECULATION_STATS["waits"] += 1
+        r = lib.goi_raster_ticket_result(self.ticket, 1 if wait else 0, C.byref(n))
+        if r == 0:
+            return False
+        self.ticket = None
+        try:
+            _spec_state(self.dev)["pending"].remove(self)
+        except ValueError:
+            pass
+        if r < 0:
+            self._redo = None
+            self._error = RuntimeError(_lib.last_error())
+            raise self._error
+        self._n = int(n.value)
+        _note_count(self.dev, self.P, self._n)
+        if self._n > self.capacity:
+            self.overflowed = True
+            SPECULATION_STATS["overflows"] += 1
+            if lazy:
+                # found after the fact: whatever consumed the outputs is already enqueued, nothing to repair
+                self._redo = None
+                msg = (f"goi_hyperplane_amd: a speculative forward overflowed its binning capacity (num_rendered = "
+                       f"{self._n} > {self.capacity}); that frame was rendered from a truncated instance list and "
+                       f"nobody read num_rendered before using it. The capacity has been raised; use "
+                       f"GOI_BINNING_HEADROOM / set_forward_mode(headroom=...) or GOI_FORWARD=exact to avoid this.")
+                if _FWD["on_overflow"] == "raise":
+                    raise RasterOverflowError(msg)
+                warnings.warn(msg, RasterOverflowWarning, stacklevel=3)
+            else:
+                self._redo_frame()
+        self._redo = None
+        return True
+
+    def _redo_frame(self):
+        lib = _lib.load()
+        sc, keep, geom, img, outs, radii = self._redo
+        stream = torch.cuda.ExternalStream(self._stream, device=self.dev)
+        with torch.cuda.device(self.dev), torch.cuda.stream(stream):
+            step = 16 << 20
+            need = int(lib.goi_raster_binning_bytes(self._n))
+            binning = torch.empty((need + step - 1) // step * step, dtype=torch.uint8, device=self.dev)
+            r = lib.goi_raster_forward_redo(C.byref(sc), self._n, _ptr(geom), _ptr(img), _ptr(binning),
+                                            *[_ptr(o) for o in outs], _ptr(radii), C.c_void_p(self._stream))
+        if r < 0:
+            raise RuntimeError(_lib.last_error())
+        self.binning, self.layout, self.redone = binning, self._n, True
+        SPECULATION_STATS["redone"] += 1
+
+    def resolve(self) -> int:
+        """Waits for the count; an overflowed frame is redone in place (exact outputs from here on)."""
+        self._resolve(wait=True, lazy=False)
+        return self._n
+
+    def ready(self) -> bool:
+        return self._resolve(wait=False, lazy=False)
+
+    __int__ = __index__ = lambda self: self.resolve()
+    __bool__ = lambda self: self.resolve() != 0
+    __eq__ = lambda self, o: self.resolve() == o
+    __ne__ = lambda self, o: self.resolve() != o
+    __lt__ = lambda self, o: self.resolve() < o
+    __le__ = lambda self, o: self.resolve() <= o
+    __gt__ = lambda self, o: self.resolve() > o
+    __ge__ = lambda self, o: self.resolve() >= o
+    __add__ = __radd__ = lambda self, o: self.resolve() + o
+    __sub__ = lambda self, o: self.resolve() - o
+    __rsub__ = lambda self, o: o - self.resolve()
+    __mul__ = __rmul__ = lambda self, o: self.resolve() * o
+    __truediv__ = lambda self, o: self.resolve() / o
+    __floordiv__ = lambda self, o: self.resolve() // o
+    __hash__ = lambda self: id(self)
+    __float__ = lambda self: float(self.resolve())
+
+    def __repr__(self):
+        return str(self._n) if self._n is not None else f"<LazyCount pending, capacity {self.capacity}>"
+
+    __str__ = __repr__
+    __format__ = lambda self, spec: format(self.resolve(), spec)
+
+
+def _layout_of(R):
+    """(instances the binning buffer of this frame was laid out for, that buffer or None) for the R a caller hands to
+    the backward: a plain int (exact frame) or the LazyCount of a speculative one -- which is NOT resolved here."""
+    if isinstance(R, LazyCount):
+        if not R.resolved:
+            R._resolve(wait=False, lazy=True)  # free look: keeps the statistics and the capacity policy current
+        return R.layout, R.binning
+    return int(R), None
+
+
 def _scene(P, S, H, W, bg, means3D, sh, colors, semantics, opacity, scales, rotations, scale_modifier, cov3D,
            viewmatrix, projmatrix, tan_fovx, tan_fovy, degree, campos, prefiltered, debug):
     M = 0 if (sh is None or sh.numel() == 0) else int(sh.size(1))
@@ -141,16 +362,35 @@ def rasterize_gaussians(background, means3D, colors, semantics, opacity, scales,
                    projmatrix=_prep(projmatrix, "projmatrix", dev), campos=_prep(campos, "campos", dev))
         geom = torch.empty(lib.goi_raster_geom_bytes(P) if P > 0 else 0, dtype=torch.uint8, device=dev)
         img = torch.empty(lib.goi_raster_image_bytes(W, H) if P > 0 else 0, dtype=torch.uint8, device=dev)
-        alloc = _BinningAllocator(dev)
         sc = _scene(P, S, H, W, ten["bg"], ten["means3D"], ten["sh"], ten["colors"], ten["semantics"], ten["opacity"],
                     ten["scales"], ten["rotations"], scale_modifier, ten["cov3D"], ten["viewmatrix"],
                     ten["projmatrix"], tan_fovx, tan_fovy, degree, ten["campos"], prefiltered, debug)
+        poll_counts(dev)
+        cap = _pick_capacity(dev, P, debug, prefiltered)
+        if cap is not None:
+            # speculative frame: everything is enqueued now, the count arrives through the ticket
+            step = 16 << 20
+            binning = torch.empty((int(lib.goi_raster_binning_bytes(cap)) + step - 1) // step * step, dtype=torch.uint8,
+                                  device=dev)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            outs = (out_color, out_sem, out_depth, out_alpha)
+            ticket = lib.goi_raster_forward_async(C.byref(sc), _ptr(geom), _ptr(img), _ptr(binning), cap,
+                                                  *[_ptr(o) for o in outs], _ptr(radii), C.c_void_p(stream))
+            if ticket < 0:
+                raise RuntimeError(_lib.last_error())
+            SPECULATION_STATS["speculative_frames"] += 1
+            n = LazyCount(dev, ticket, cap, binning, stream, (sc, ten, geom, img, outs, radii), P)
+            return n, out_color, out_sem, out_depth, out_alpha, radii, geom, binning, img
+        alloc = _BinningAllocator(dev)
         n = lib.goi_raster_forward(C.byref(sc), _ptr(geom), _ptr(img), alloc.cb, None, _ptr(out_color), _ptr(out_sem),
                                    _ptr(out_depth), _ptr(out_alpha), _ptr(radii), _stream(dev))
         if alloc.error is not None:
             raise alloc.error
         if n < 0:
             raise RuntimeError(_lib.last_error())
+        if P > 0:
+            SPECULATION_STATS["exact_frames"] += 1
+            _note_count(dev, P, n)
     return n, out_color, out_sem, out_depth, out_alpha, radii, geom, alloc.tensor, img
 
 
@@ -220,9 +460,12 @@ def _backward_impl(background, means3D, radii, colors, semantics, scales, rotati
             sc = _scene(P, S, H, W, ten["bg"], ten["means3D"], ten["sh"], ten["colors"], ten["semantics"], None,
                         ten["scales"], ten["rotations"], scale_modifier, ten["cov3D"], ten["viewmatrix"],
                         ten["projmatrix"], tan_fovx, tan_fovy, degree, ten["campos"], False, debug)
-            scratch = _backward_scratch(lib.goi_raster_backward_scratch_bytes(int(R), S), dev)
+            R_layout, lazy_binning = _layout_of(R)
+            if lazy_binning is not None:
+                binningBuffer = lazy_binning  # (a redone frame has a new buffer)
+            scratch = _backward_scratch(lib.goi_raster_backward_scratch_bytes(R_layout, S), dev)
             r = lib.goi_raster_backward(
-                C.byref(sc), int(R), _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(ten["radii"]),
+                C.byref(sc), R_layout, _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(ten["radii"]),
                 _ptr(ten["alphas"]), _ptr(ten["g_c"]), _ptr(ten["g_s"]), _ptr(ten["g_d"]), _ptr(ten["g_a"]),
                 _ptr(dL_dmeans2D), _ptr(dL_dconic), _ptr(dL_dopacity), _ptr(dL_dcolors), _ptr(dL_dsemantics),
                 _ptr(dL_ddepths), _ptr(dL_dmeans3D), _ptr(dL_dcov3D), _ptr(dL_dsh), _ptr(dL_dscales),
@@ -297,8 +540,11 @@ def rasterize_gaussians_backward_semantics(background, means3D, radii, semantics
             sc = _scene(P, S, H, W, ten["bg"], ten["means3D"], None, ten["means3D"], ten["semantics"], None,
                         None, None, 1.0, ten["means3D"], ten["viewmatrix"], ten["projmatrix"], tan_fovx, tan_fovy,
                         sh_degree, ten["campos"], False, debug)
-            scratch = _backward_scratch(lib.goi_raster_backward_scratch_bytes(int(R), S), dev)
-            r = lib.goi_raster_backward_semantics(C.byref(sc), int(R), _ptr(geomBuffer), _ptr(binningBuffer),
+            R_layout, lazy_binning = _layout_of(R)
+            if lazy_binning is not None:
+                binningBuffer = lazy_binning
+            scratch = _backward_scratch(lib.goi_raster_backward_scratch_bytes(R_layout, S), dev)
+            r = lib.goi_raster_backward_semantics(C.byref(sc), R_layout, _ptr(geomBuffer), _ptr(binningBuffer),
                                                   _ptr(imageBuffer), _ptr(ten["radii"]), _ptr(ten["alphas"]),
                                                   _ptr(ten["g_s"]), _ptr(dL_dsemantics), _ptr(scratch), _stream(dev))
             if r < 0:
@@ -340,6 +586,8 @@ def rasterize_gaussians_trace(background, means3D, colors, img_sem, opacity, sca
             raise alloc.error
         if n < 0:
             raise RuntimeError(_lib.last_error())
+        if P > 0:
+            _note_count(dev, P, n)
     return n, out_color, gau_sem, num_gsem, geom, alloc.tensor, img
 
 
@@ -364,6 +612,10 @@ def debug_views(P, W, H, R, geomBuffer, binningBuffer, imgBuffer):
     """Tests only: decoded copies of the opaque workspaces as a dict of tensors."""
     lib = _lib.load()
     dev = geomBuffer.device
+    n_true = int(R)  # (resolves -- and, after an overflow, redoes -- a speculative frame)
+    R, lazy_binning = _layout_of(R)
+    if lazy_binning is not None:
+        binningBuffer = lazy_binning
     T = ((W + 15) // 16) * ((H + 15) // 16)
     with torch.cuda.device(dev):
         out = dict(depths=torch.zeros(P, device=dev), means2D=torch.zeros(P, 2, device=dev),
@@ -379,4 +631,5 @@ def debug_views(P, W, H, R, geomBuffer, binningBuffer, imgBuffer):
         if r < 0:
             raise RuntimeError(_lib.last_error())
         torch.cuda.synchronize(dev)
+    out["point_list"] = out["point_list"][:n_true]  # (the workspace of a speculative frame holds `capacity` slots)
     return out

@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libgoi_raster.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 STAGES = ("preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges", "blend_fwd", "blend_bwd",
           "preprocess_bwd")
@@ -42,6 +42,11 @@ SYMBOLS = {
     "goi_raster_backward_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "goi_raster_forward": (C.c_int, [C.POINTER(GoiRasterScene), C.c_void_p, C.c_void_p, ALLOC_FN, C.c_void_p]
                            + [C.c_void_p] * 5 + [C.c_void_p]),
+    "goi_raster_forward_async": (C.c_int, [C.POINTER(GoiRasterScene), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+                                 + [C.c_void_p] * 5 + [C.c_void_p]),
+    "goi_raster_ticket_result": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "goi_raster_forward_redo": (C.c_int, [C.POINTER(GoiRasterScene), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+                                + [C.c_void_p] * 5 + [C.c_void_p]),
     "goi_raster_backward": (C.c_int, [C.POINTER(GoiRasterScene), C.c_int] + [C.c_void_p] * 3 + [C.c_void_p] * 6
                             + [C.c_void_p] * 11 + [C.c_void_p, C.c_void_p]),
     "goi_raster_backward_semantics": (C.c_int, [C.POINTER(GoiRasterScene), C.c_int] + [C.c_void_p] * 9),
@@ -96,6 +101,7 @@ def load():
             name, _, value = item.partition("=")
             if lib.goi_raster_set_option(name.strip().encode(), int(value)) < 0:
                 raise RuntimeError(lib.goi_raster_last_error().decode())
+            OPTIONS[name.strip()] = int(value)
     return _lib
 
 
@@ -112,9 +118,13 @@ class GoiAdamGroup(C.Structure):
 ADAM_MAX_GROUPS = 8
 
 
+OPTIONS = {}  # the switches set through set_option / GOI_OPTIONS in this process (name -> value)
+
+
 def set_option(name: str, value: int) -> None:
     if load().goi_raster_set_option(name.encode(), int(value)) < 0:
         raise RuntimeError(last_error())
+    OPTIONS[name] = int(value)
 
 
 def profile_enable(on: bool) -> None:

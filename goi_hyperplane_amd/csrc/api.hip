@@ -3,6 +3,8 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <atomic>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -43,15 +45,21 @@ struct StageEvents {
     int stage;
     hipEvent_t a, b;
 };
-unsigned g_profile_mask = 0;  // bit i = record HIP events around GOI_STAGE_i
+// (process-wide and shared by every calling thread: the mask is atomic, the event lists sit behind a mutex.  Stage timing
+// is a single-device measurement aid: events are created on whichever device is current when they are first needed.)
+std::atomic<unsigned> g_profile_mask{0};  // bit i = record HIP events around GOI_STAGE_i
+std::mutex g_profile_mu;
 std::vector<StageEvents> g_events;
 std::vector<hipEvent_t> g_pool;
 
 hipEvent_t get_event() {
-    if (!g_pool.empty()) {
-        hipEvent_t e = g_pool.back();
-        g_pool.pop_back();
-        return e;
+    {
+        std::lock_guard<std::mutex> lk(g_profile_mu);
+        if (!g_pool.empty()) {
+            hipEvent_t e = g_pool.back();
+            g_pool.pop_back();
+            return e;
+        }
     }
     hipEvent_t e;
     (void)hipEventCreate(&e);
@@ -62,7 +70,7 @@ struct StageTimer {
     hipStream_t s;
     bool on;
     StageEvents ev{};
-    StageTimer(int stage, hipStream_t st) : s(st), on((g_profile_mask >> stage) & 1u) {
+    StageTimer(int stage, hipStream_t st) : s(st), on((g_profile_mask.load(std::memory_order_relaxed) >> stage) & 1u) {
         if (on) {
             ev.stage = stage;
             ev.a = get_event();
@@ -73,6 +81,7 @@ struct StageTimer {
     ~StageTimer() {
         if (on) {
             (void)hipEventRecord(ev.b, s);
+            std::lock_guard<std::mutex> lk(g_profile_mu);
             g_events.push_back(ev);
         }
     }
@@ -109,10 +118,88 @@ int validate(const GoiRasterScene* sc, bool need_sem, bool need_opacity = true) 
 
 static inline size_t round_up_256(size_t n) { return (n + 255) & ~(size_t)255; }
 
-// Shared front end of forward and trace: preprocess -> depth sort -> scan -> emit -> tile sort ->
-// ranges.  Returns num_rendered (>= 0) and the final point list through *plist.
-int geometry_and_binning(const GoiRasterScene& sc, GeomView& g, ImageView& im, goi_alloc_fn alloc, void* user,
-                         int* radii, const uint32_t** plist, hipStream_t s) {
+// ---- read-back tickets ---------------------------------------------------------------------------
+// num_rendered (and the "prefiltered" error flag) reach the host through a pinned copy of the frame's counters plus an
+// event recorded right behind the copy.  A ticket is one such (pinned words, event) pair; they are pooled per DEVICE
+// (events and pinned allocations belong to the device that was current when they were made) under a mutex, so
+// concurrent callers on different streams / threads / GPUs each get their own.
+struct Ticket {
+    int dev = -1;
+    uint32_t* pinned = nullptr;
+    hipEvent_t ev = nullptr;
+    bool busy = false;
+    int capacity = 0;  // instances the frame's binning buffer holds (speculative frames); 0: exact frame
+};
+std::mutex g_ticket_mu;
+std::vector<Ticket> g_tickets;
+constexpr int MAX_TICKETS = 4096;
+
+int ticket_acquire(int capacity) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return fail("hipGetDevice failed");
+    std::lock_guard<std::mutex> lk(g_ticket_mu);
+    for (size_t i = 0; i < g_tickets.size(); i++)
+        if (!g_tickets[i].busy && g_tickets[i].dev == dev) {
+            g_tickets[i].busy = true;
+            g_tickets[i].capacity = capacity;
+            return (int)i;
+        }
+    if ((int)g_tickets.size() >= MAX_TICKETS)
+        return fail("too many unresolved speculative forwards (goi_raster_ticket_result was never called for them)");
+    Ticket t;
+    t.dev = dev;
+    GOI_HIP(hipHostMalloc(reinterpret_cast<void**>(&t.pinned), COUNTER_WORDS * sizeof(uint32_t), hipHostMallocDefault));
+    GOI_HIP(hipEventCreateWithFlags(&t.ev, hipEventDisableTiming));
+    t.busy = true;
+    t.capacity = capacity;
+    g_tickets.push_back(t);
+    return (int)g_tickets.size() - 1;
+}
+
+void ticket_release(int id) {
+    std::lock_guard<std::mutex> lk(g_ticket_mu);
+    if (id >= 0 && id < (int)g_tickets.size()) g_tickets[id].busy = false;
+}
+
+// wait != 0: block until the frame's counters have arrived.  Returns 1 (done: *n = num_rendered), 0 (not yet; only
+// when wait == 0) or -1 (error; the ticket is released).  A finished ticket is released.
+int ticket_result(int id, int wait, long long* n) {
+    Ticket t;
+    {
+        std::lock_guard<std::mutex> lk(g_ticket_mu);
+        if (id < 0 || id >= (int)g_tickets.size() || !g_tickets[id].busy) return fail("invalid or already resolved ticket");
+        t = g_tickets[id];
+    }
+    if (wait) {
+        hipError_t e = hipEventSynchronize(t.ev);
+        if (e != hipSuccess) {
+            ticket_release(id);
+            return fail("hipEventSynchronize(num_rendered read-back)", e);
+        }
+    } else {
+        hipError_t e = hipEventQuery(t.ev);
+        if (e == hipErrorNotReady) return 0;
+        if (e != hipSuccess) {
+            ticket_release(id);
+            return fail("hipEventQuery(num_rendered read-back)", e);
+        }
+    }
+    unsigned long long total = 0;  // 64-bit: 32 stripes of up to 2^32-1 each
+    for (int i = 0; i < NR_STRIPES; i++) total += t.pinned[NR_BASE + NR_STRIDE * i];
+    const bool filtered = t.pinned[1] != 0;
+    ticket_release(id);
+    if (filtered) return fail("Point is filtered although prefiltered is set. This shouldn't happen!");
+    if (total > 0x7FFFFFFFull) return fail("num_rendered overflows int32");
+    *n = (long long)total;
+    return 1;
+}
+
+// Front half of the forward -- everything that does not depend on num_rendered: preprocess, the read-back of the
+// counters (queued BEFORE the depth sort: preprocess has already summed num_rendered, so a host that waits for it wakes
+// up while the GPU is still sorting), depth sort, scan.  The scan also leaves num_rendered in counters[COUNTER_N] for
+// the kernels of the back half.
+int enqueue_front(const GoiRasterScene& sc, GeomView& g, ImageView& im, int* radii, int ticket, const uint32_t** order_out,
+                  hipStream_t s) {
     const int P = sc.P;
     const int gx = (sc.W + TILE - 1) / TILE, gy = (sc.H + TILE - 1) / TILE;
     // one memset: the counters and, right behind them, the control words of the depth sort
@@ -127,75 +214,95 @@ int geometry_and_binning(const GoiRasterScene& sc, GeomView& g, ImageView& im, g
         launch_preprocess_fwd(sc, g, radii, im.ranges, gx * gy, s);  // also zeroes the tile ranges
     }
     if (check_stage(sc, s, "preprocess")) return -1;
-    // The one host read-back of the forward (num_rendered sizes the binning workspace, as in the reference,
-    // CR/rasterizer_impl.cu:285).  preprocess has already summed it, so the copy is queued BEFORE the depth sort and
-    // the host waits on an event recorded right behind it: it wakes up, allocates and enqueues emit / tile sort /
-    // blend while the GPU is still busy with the depth sort and the scan -- no idle gap on the device.
-    static thread_local uint32_t* pinned = nullptr;
-    static thread_local hipEvent_t n_ready = nullptr;
-    if (!pinned) GOI_HIP(hipHostMalloc(reinterpret_cast<void**>(&pinned), COUNTER_WORDS * sizeof(uint32_t), hipHostMallocDefault));
-    if (!n_ready) GOI_HIP(hipEventCreateWithFlags(&n_ready, hipEventDisableTiming));
-    GOI_HIP(hipMemcpyAsync(pinned, g.counters, COUNTER_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    GOI_HIP(hipEventRecord(n_ready, s));
+    {
+        std::lock_guard<std::mutex> lk(g_ticket_mu);
+        const Ticket& t = g_tickets[ticket];
+        GOI_HIP(hipMemcpyAsync(t.pinned, g.counters, COUNTER_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        GOI_HIP(hipEventRecord(t.ev, s));
+    }
     int order_idx;
     {
         StageTimer t(GOI_STAGE_DEPTH_SORT, s);
         order_idx = radix_sort_pairs(g.sort_keys, g.sort_vals, (size_t)P, 0, 32, g.scratch, s, /*cleared=*/true);
     }
     if (check_stage(sc, s, "depth sort")) return -1;
-    const uint32_t* order = g.sort_vals[order_idx];
-    uint32_t host_counters[2] = {0, 0};
+    *order_out = g.sort_vals[order_idx];
     {
         StageTimer t(GOI_STAGE_SCAN, s);
-        exclusive_scan_u32(g.tiles_touched, order, g.offsets, (size_t)P, nullptr, g.scratch, s);
+        exclusive_scan_u32(g.tiles_touched, *order_out, g.offsets, (size_t)P, g.counters + COUNTER_N, g.scratch, s);
     }
-    GOI_HIP(hipEventSynchronize(n_ready));
-    for (int i = 0; i < NR_STRIPES; i++) host_counters[0] += pinned[NR_BASE + NR_STRIDE * i];
-    host_counters[1] = pinned[1];
-    if (host_counters[1] != 0)
-        return fail("Point is filtered although prefiltered is set. This shouldn't happen!");
-    const int N = (int)host_counters[0];
-    if (N < 0) return fail("num_rendered overflows int32");
-    const size_t need = goi_raster_binning_bytes(N);
-    char* bin_mem = static_cast<char*>(alloc(user, need));
-    if (!bin_mem && need > 0) return fail("binning allocation callback returned NULL");
-    BinView bv;
-    binning_layout(N, bin_mem, &bv);
+    return 0;
+}
+
+// Back half: emit -> tile ranges -> tile sort, for a binning buffer that holds `cap` instances.  exact: cap IS
+// num_rendered (known to the host); otherwise cap is a capacity and every kernel takes the count from
+// counters[COUNTER_N], clamped to cap (an overflowed frame is truncated but memory-safe; the host redoes it).
+int enqueue_back(const GoiRasterScene& sc, GeomView& g, ImageView& im, const BinView& bv_in, int cap, bool exact,
+                 const uint32_t* order, const int* radii, const uint32_t** plist, hipStream_t s) {
+    BinView bv = bv_in;
+    const int P = sc.P;
+    const int gx = (sc.W + TILE - 1) / TILE, gy = (sc.H + TILE - 1) / TILE;
+    const uint32_t* n_dev = exact ? nullptr : g.counters + COUNTER_N;
     // Tile counting fused into emit (onesweep sort, tile grid small enough for an LDS histogram): the counts give
     // the tile ranges and the sort's digit histograms, so neither the keys nor the sorted keys are re-read for them.
-    const bool counting = N > 0 && g_options.sort_variant == 1 && emit_can_count_tiles(sc.W, sc.H);
+    const bool counting = cap > 0 && g_options.sort_variant == 1 && emit_can_count_tiles(sc.W, sc.H);
     const int tile_bits = tile_key_bits((uint32_t)(gx * gy));
     {
         StageTimer t(GOI_STAGE_EMIT, s);
         if (counting) {
             // emit also clears the control words of the tile sort (status words, histograms, tickets): one launch less
             launch_emit_counting(P, sc.W, sc.H, g, order, radii, bv.keys[0], bv.vals[0], im.ranges, bv.scratch,
-                                 radix_sort_control_words((size_t)N, 0, tile_bits), s);
+                                 radix_sort_control_words((size_t)cap, 0, tile_bits), (uint32_t)cap, s);
         }
-        else if (N > 0)
-            launch_emit(P, sc.W, sc.H, g, order, radii, bv.keys[0], bv.vals[0], s);
+        else if (cap > 0)
+            launch_emit(P, sc.W, sc.H, g, order, radii, bv.keys[0], bv.vals[0], (uint32_t)cap, s);
     }
     if (check_stage(sc, s, "emit")) return -1;
     int fin;
     if (counting) {
         {
             StageTimer t(GOI_STAGE_RANGES, s);
-            launch_tile_ranges_hist(sc.W, sc.H, im.ranges, radix_sort_ghist(bv.scratch, (size_t)N, 0, tile_bits), s);
+            launch_tile_ranges_hist(sc.W, sc.H, im.ranges, radix_sort_ghist(bv.scratch, (size_t)cap, 0, tile_bits), s);
         }
         StageTimer t(GOI_STAGE_TILE_SORT, s);
-        fin = radix_sort_pairs(bv.keys, bv.vals, (size_t)N, 0, tile_bits, bv.scratch, s, /*cleared=*/true,
-                               /*ghist_ready=*/true);
+        fin = radix_sort_pairs(bv.keys, bv.vals, (size_t)cap, 0, tile_bits, bv.scratch, s, /*cleared=*/true,
+                               /*ghist_ready=*/true, n_dev);
     } else {
         {
             StageTimer t(GOI_STAGE_TILE_SORT, s);
-            fin = radix_sort_pairs(bv.keys, bv.vals, (size_t)N, 0, tile_bits, bv.scratch, s);
+            fin = radix_sort_pairs(bv.keys, bv.vals, (size_t)cap, 0, tile_bits, bv.scratch, s, false, false, n_dev);
         }
         if (check_stage(sc, s, "tile sort")) return -1;
         StageTimer t(GOI_STAGE_RANGES, s);
-        launch_ranges(N, bv.keys[fin], im.ranges, gx * gy, s);
+        launch_ranges(cap, n_dev, bv.keys[fin], im.ranges, gx * gy, s);
     }
     if (check_stage(sc, s, "tile sort / ranges")) return -1;
     *plist = bv.vals[fin];
+    return 0;
+}
+
+// The exact front end shared by goi_raster_forward and goi_raster_trace: the host waits for num_rendered (the one
+// read-back of the reference, CR/rasterizer_impl.cu:285), sizes the binning workspace through the allocation callback
+// and enqueues the back half while the GPU is still busy with the depth sort and the scan -- no idle gap on the device.
+// Returns num_rendered (>= 0) and the final point list through *plist.
+int geometry_and_binning(const GoiRasterScene& sc, GeomView& g, ImageView& im, goi_alloc_fn alloc, void* user,
+                         int* radii, const uint32_t** plist, hipStream_t s) {
+    const int ticket = ticket_acquire(0);
+    if (ticket < 0) return -1;
+    const uint32_t* order = nullptr;
+    if (enqueue_front(sc, g, im, radii, ticket, &order, s)) {
+        ticket_release(ticket);
+        return -1;
+    }
+    long long n64 = 0;
+    if (ticket_result(ticket, 1, &n64) < 0) return -1;
+    const int N = (int)n64;
+    const size_t need = goi_raster_binning_bytes(N);
+    char* bin_mem = static_cast<char*>(alloc(user, need));
+    if (!bin_mem && need > 0) return fail("binning allocation callback returned NULL");
+    BinView bv;
+    binning_layout(N, bin_mem, &bv);
+    if (enqueue_back(sc, g, im, bv, N, /*exact=*/true, order, radii, plist, s)) return -1;
     return N;
 }
 
@@ -312,6 +419,79 @@ int goi_raster_forward(const GoiRasterScene* scene, void* geom_buffer, void* ima
     if (check_stage(sc, s, "forward blend")) return -1;
     GOI_HIP(hipGetLastError());
     return N;
+}
+
+int goi_raster_forward_async(const GoiRasterScene* scene, void* geom_buffer, void* image_buffer, void* binning_buffer,
+                             int capacity, float* out_color, float* out_semantic, float* out_depth, float* out_alpha,
+                             int* radii, void* stream) {
+    if (validate(scene, true)) return -1;
+    const GoiRasterScene& sc = *scene;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (sc.P == 0) return fail("goi_raster_forward_async: P == 0 has nothing to speculate on; use goi_raster_forward");
+    if (sc.debug) return fail("goi_raster_forward_async: debug mode synchronises after every stage; use goi_raster_forward");
+    if (g_options.sort_variant != 1) return fail("goi_raster_forward_async needs the onesweep sort (sort_variant 1)");
+    if (capacity <= 0) return fail("goi_raster_forward_async: capacity must be positive");
+    if (!geom_buffer || !image_buffer || !binning_buffer) return fail("workspace pointer is NULL");
+    GeomView g;
+    ImageView im;
+    BinView bv;
+    geom_layout(sc.P, static_cast<char*>(geom_buffer), &g);
+    image_layout(sc.W, sc.H, static_cast<char*>(image_buffer), &im);
+    binning_layout(capacity, static_cast<char*>(binning_buffer), &bv);
+    const int ticket = ticket_acquire(capacity);
+    if (ticket < 0) return -1;
+    const uint32_t* order = nullptr;
+    const uint32_t* plist = nullptr;
+    if (enqueue_front(sc, g, im, radii, ticket, &order, s) ||
+        enqueue_back(sc, g, im, bv, capacity, /*exact=*/false, order, radii, &plist, s)) {
+        ticket_release(ticket);
+        return -1;
+    }
+    {
+        StageTimer t(GOI_STAGE_BLEND_FWD, s);
+        launch_render_fwd(sc, g, im, plist, out_color, out_semantic, out_depth, out_alpha, s);
+    }
+    if (hipGetLastError() != hipSuccess) {
+        ticket_release(ticket);
+        return fail("goi_raster_forward_async: a launch failed");
+    }
+    return ticket;
+}
+
+int goi_raster_ticket_result(int ticket, int wait, int* num_rendered) {
+    long long n = 0;
+    const int r = ticket_result(ticket, wait, &n);
+    if (r == 1 && num_rendered) *num_rendered = (int)n;
+    return r;
+}
+
+int goi_raster_forward_redo(const GoiRasterScene* scene, int num_rendered, void* geom_buffer, void* image_buffer,
+                            void* binning_buffer, float* out_color, float* out_semantic, float* out_depth,
+                            float* out_alpha, const int* radii, void* stream) {
+    if (validate(scene, true)) return -1;
+    const GoiRasterScene& sc = *scene;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (sc.P == 0 || num_rendered < 0) return fail("goi_raster_forward_redo: nothing to redo");
+    if (!geom_buffer || !image_buffer || (num_rendered > 0 && !binning_buffer)) return fail("workspace pointer is NULL");
+    GeomView g;
+    ImageView im;
+    BinView bv;
+    geom_layout(sc.P, static_cast<char*>(geom_buffer), &g);
+    image_layout(sc.W, sc.H, static_cast<char*>(image_buffer), &im);
+    binning_layout(num_rendered, static_cast<char*>(binning_buffer), &bv);
+    const int gx = (sc.W + TILE - 1) / TILE, gy = (sc.H + TILE - 1) / TILE;
+    // the geometry state of the first attempt (records, depth order, offsets) does not depend on the capacity and is
+    // still in the geometry buffer; the per-tile counts the first emit accumulated are not wanted
+    GOI_HIP(hipMemsetAsync(im.ranges, 0, sizeof(uint2) * (size_t)gx * gy, s));
+    const uint32_t* order = g.sort_vals[depth_sort_result_index()];
+    const uint32_t* plist = nullptr;
+    if (enqueue_back(sc, g, im, bv, num_rendered, /*exact=*/true, order, radii, &plist, s)) return -1;
+    {
+        StageTimer t(GOI_STAGE_BLEND_FWD, s);
+        launch_render_fwd(sc, g, im, plist, out_color, out_semantic, out_depth, out_alpha, s);
+    }
+    GOI_HIP(hipGetLastError());
+    return 0;
 }
 
 int goi_raster_trace(const GoiRasterScene* scene, const float* img_sem, void* geom_buffer, void* image_buffer,
@@ -525,9 +705,9 @@ int goi_knn_dist2(int P, const float* points, float* mean_dist2, void* workspace
     return 0;
 }
 
-void goi_raster_profile_enable(int on) { g_profile_mask = on ? ~0u : 0u; }
+void goi_raster_profile_enable(int on) { g_profile_mask.store(on ? ~0u : 0u); }
 
-void goi_raster_profile_stages(unsigned stage_mask) { g_profile_mask = stage_mask; }
+void goi_raster_profile_stages(unsigned stage_mask) { g_profile_mask.store(stage_mask); }
 
 int goi_raster_set_option(const char* name, int value) {
     if (!name) return fail("option name is NULL");
@@ -547,16 +727,21 @@ int goi_raster_set_option(const char* name, int value) {
 }
 
 int goi_raster_profile_collect(double* ms, int* calls) {
-    for (auto& ev : g_events) {
+    std::vector<StageEvents> events;
+    {
+        std::lock_guard<std::mutex> lk(g_profile_mu);
+        events.swap(g_events);
+    }
+    for (auto& ev : events) {
         GOI_HIP(hipEventSynchronize(ev.b));
         float t = 0.f;
         GOI_HIP(hipEventElapsedTime(&t, ev.a, ev.b));
         if (ms) ms[ev.stage] += (double)t;
         if (calls) calls[ev.stage] += 1;
+        std::lock_guard<std::mutex> lk(g_profile_mu);
         g_pool.push_back(ev.a);
         g_pool.push_back(ev.b);
     }
-    g_events.clear();
     return 0;
 }
 

@@ -87,21 +87,24 @@ void exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* ou
 //                 neighbouring counters in one memset) -- otherwise the sort clears them itself;
 //   ghist_ready : after that clear the caller has written the per-pass global digit histograms
 //                 ([pass][256] words at radix_sort_ghist(...)), so the sort's histogram kernel is skipped.
+//   n_dev       : (onesweep only) the element count lives on the DEVICE and `n` is a capacity: grids and control words
+//                 are sized for n, the kernels sort min(*n_dev, n) elements (speculative forward, api.hip).
 int radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], size_t n, int lo, int hi, uint32_t* scratch,
-                     hipStream_t s, bool cleared = false, bool ghist_ready = false);
+                     hipStream_t s, bool cleared = false, bool ghist_ready = false, const uint32_t* n_dev = nullptr);
 size_t radix_sort_control_words(size_t n, int lo, int hi);
 uint32_t* radix_sort_ghist(uint32_t* scratch, size_t n, int lo, int hi);
 
 // ---- stages ---------------------------------------------------------------------------------------
 void launch_preprocess_fwd(const GoiRasterScene& sc, const GeomView& g, int* radii, uint2* ranges, int n_tiles,
                            hipStream_t s);
+// cap: instances keys[] / vals[] can hold (instances past it are dropped: only an overflowed speculative frame has any)
 void launch_emit(int P, int W, int H, const GeomView& g, const uint32_t* order, const int* radii, uint32_t* keys,
-                 uint32_t* vals, hipStream_t s);
+                 uint32_t* vals, uint32_t cap, hipStream_t s);
 bool emit_can_count_tiles(int W, int H);
 void launch_emit_counting(int P, int W, int H, const GeomView& g, const uint32_t* order, const int* radii, uint32_t* keys,
-                          uint32_t* vals, uint2* ranges, uint32_t* clear, size_t clear_words, hipStream_t s);
+                          uint32_t* vals, uint2* ranges, uint32_t* clear, size_t clear_words, uint32_t cap, hipStream_t s);
 void launch_tile_ranges_hist(int W, int H, uint2* ranges, uint32_t* ghist, hipStream_t s);
-void launch_ranges(int N, const uint32_t* sorted_keys, uint2* ranges, int T, hipStream_t s);
+void launch_ranges(int N, const uint32_t* n_dev, const uint32_t* sorted_keys, uint2* ranges, int T, hipStream_t s);
 void launch_render_fwd(const GoiRasterScene& sc, const GeomView& g, const ImageView& im, const uint32_t* point_list,
                        float* out_color, float* out_sem, float* out_depth, float* out_alpha, hipStream_t s);
 void launch_trace_fwd(const GoiRasterScene& sc, const float* img_sem, const GeomView& g, const ImageView& im,
@@ -185,6 +188,8 @@ __device__ __forceinline__ void listed_rect(float px, float py, int r, float hx,
 constexpr int NR_STRIPES = 32, NR_STRIDE = 32, NR_BASE = 32;
 constexpr int COUNTER_WORDS = NR_BASE + NR_STRIPES * NR_STRIDE;
 constexpr int COUNTER_CULL = 2;  // GeomView::counters[COUNTER_CULL]: the forward's cull_variant, read by emit / backward
+constexpr int COUNTER_N = 3;     // num_rendered as ONE device word (the scan's total): what the tile sort, the ranges pass and
+                                 // the backward's row reduction read when the host sized the frame from a capacity
 
 // The depth sort runs ceil(32/8) = 4 ping-pong passes from buffer 0, so its result is in buffer 0.
 inline int depth_sort_result_index() { return ((32 + 7) / 8) & 1; }

@@ -592,7 +592,8 @@ __global__ __launch_bounds__(256) void mark_visible_k(int P, const float* __rest
 // slots of the chunk are packed into a 64-bit mask (quadrant-major), and up to 16 rows are requested
 // back to back before the first is consumed (lane e reads row elements e, e+16, ...: coalesced).
 template <int K>  // K = row_floats / 16
-__global__ __launch_bounds__(256) void reduce_rows_k(int P, int S, int nch, uint32_t N, const uint32_t* __restrict__ order,
+__global__ __launch_bounds__(256) void reduce_rows_k(int P, int S, int nch, uint32_t N_cap, const uint32_t* __restrict__ n_dev,
+                                                     const uint32_t* __restrict__ order,
                                                      const uint32_t* __restrict__ offsets,
                                                      const float* __restrict__ rows, const uint8_t* __restrict__ flags,
                                                      float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic,
@@ -600,6 +601,10 @@ __global__ __launch_bounds__(256) void reduce_rows_k(int P, int S, int nch, uint
                                                      float* __restrict__ dL_dsemantic, float* __restrict__ dL_ddepth) {
     constexpr int RF = 16 * K;
     constexpr int INFLIGHT = 16;
+    // N_cap: the slot capacity the scratch was laid out for; n_dev: the forward's instance count on the device (the
+    // exact forward passes N_cap = num_rendered; the speculative one a capacity, and an overflowed frame stored only
+    // the first N_cap instances)
+    const uint32_t N = min(N_cap, *n_dev);
     const int lane = threadIdx.x & 63, quarter = lane >> 4, e = lane & 15;
     // Gaussians are visited in DEPTH order: that is the order of the slot space, so consecutive quarter
     // waves stream through rows[] and flags[] front to back (DRAM-page and TLB friendly); only the
@@ -609,8 +614,8 @@ __global__ __launch_bounds__(256) void reduce_rows_k(int P, int S, int nch, uint
     // slots of the i-th Gaussian in depth order: [offsets[i], offsets[i+1]) -- straight from the prefix sum, so the
     // chain of dependent loads is offsets -> flags -> rows; the Gaussian's id is only needed for the final store
     const uint32_t g = live ? order[i] : 0u;
-    const uint32_t off0 = live ? offsets[i] : 0u;
-    const uint32_t off1 = live ? (i + 1 < P ? offsets[i + 1] : N) : 0u;
+    const uint32_t off0 = live ? min(offsets[i], N) : 0u;
+    const uint32_t off1 = live ? (i + 1 < P ? min(offsets[i + 1], N) : N) : 0u;
     const uint32_t cnt = off1 - off0;
     const size_t inst0 = off0;
     const uint32_t* flags32 = reinterpret_cast<const uint32_t*>(flags);
@@ -696,7 +701,10 @@ __global__ __launch_bounds__(256) void emit_k(int P, int gx, int gy, const Gauss
                                               const uint32_t* __restrict__ offsets, uint32_t* __restrict__ goff,
                                               uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
                                               uint32_t* __restrict__ tile_count, const uint32_t* __restrict__ counters,
-                                              uint32_t* __restrict__ clear, uint32_t clear_words) {
+                                              uint32_t* __restrict__ clear, uint32_t clear_words, uint32_t cap) {
+    // cap: number of instances keys[] / vals[] can hold.  The exact forward sizes them for num_rendered, so the
+    // guard below never fires; the speculative forward sizes them from a guess, and a frame that overflows must
+    // stay memory-safe and self-consistent (the tile counts only count what was stored) until the host notices.
     const bool cull = counters[COUNTER_CULL] != 0;
     // COUNT: the blocks also zero the control words of the tile sort that follows (its own memset launch otherwise)
     if (COUNT)
@@ -762,9 +770,12 @@ __global__ __launch_bounds__(256) void emit_k(int P, int gx, int gy, const Gauss
             row += ((row + 1) * wl <= k);
             const int col = k - row * wl;
             const uint32_t key = (uint32_t)(((int)(info.x >> 16) + row) * gx + (int)(info.x & 0xFFFFu) + col);
-            keys[info.z + (uint32_t)t] = key;
-            vals[info.z + (uint32_t)t] = info.w;
-            if (COUNT) atomicAdd(&s_cnt[key], 1u);
+            const uint32_t pos = info.z + (uint32_t)t;
+            if (pos < cap) {
+                keys[pos] = key;
+                vals[pos] = info.w;
+                if (COUNT) atomicAdd(&s_cnt[key], 1u);
+            }
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -822,7 +833,9 @@ __global__ __launch_bounds__(1024) void tile_ranges_hist_k(int T, uint2* __restr
 }
 
 // Per-tile [start,end) from the tile-sorted key list (CR/rasterizer_impl.cu:116-138).
-__global__ __launch_bounds__(256) void ranges_k(int N, const uint32_t* __restrict__ keys, uint2* __restrict__ ranges) {
+__global__ __launch_bounds__(256) void ranges_k(int N_cap, const uint32_t* __restrict__ n_dev,
+                                                const uint32_t* __restrict__ keys, uint2* __restrict__ ranges) {
+    const int N = n_dev ? (int)min((uint32_t)N_cap, *n_dev) : N_cap;  // (speculative forward: the count is on the device)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     const uint32_t cur = keys[i];
@@ -892,13 +905,13 @@ void launch_reduce_rows(const GoiRasterScene& sc, const GeomView& g, int N, cons
     const dim3 grid((sc.P + 15) / 16);
     const uint32_t* order = g.sort_vals[depth_sort_result_index()];
     if (rf == 32)
-        reduce_rows_k<2><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, order, g.offsets, scr.rows, scr.flags,
+        reduce_rows_k<2><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, scr.rows, scr.flags,
                                                     dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dsemantic, dL_ddepth);
     else if (rf == 16)
-        reduce_rows_k<1><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, order, g.offsets, scr.rows, scr.flags,
+        reduce_rows_k<1><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, scr.rows, scr.flags,
                                                     dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dsemantic, dL_ddepth);
     else
-        reduce_rows_k<3><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, order, g.offsets, scr.rows, scr.flags,
+        reduce_rows_k<3><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, scr.rows, scr.flags,
                                                     dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dsemantic, dL_ddepth);
 }
 
@@ -909,18 +922,18 @@ void launch_reduce_sem_rows(const GoiRasterScene& sc, const GeomView& g, int N, 
     const dim3 grid((sc.P + 15) / 16);
     const uint32_t* order = g.sort_vals[depth_sort_result_index()];
     if (row_floats == 16)
-        reduce_rows_k<1><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, order, g.offsets, rows, flags, nullptr,
+        reduce_rows_k<1><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, rows, flags, nullptr,
                                                     nullptr, nullptr, nullptr, dL_dsemantic, nullptr);
     else
-        reduce_rows_k<2><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, order, g.offsets, rows, flags, nullptr,
+        reduce_rows_k<2><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, rows, flags, nullptr,
                                                     nullptr, nullptr, nullptr, dL_dsemantic, nullptr);
 }
 
 void launch_emit(int P, int W, int H, const GeomView& g, const uint32_t* order, const int* radii, uint32_t* keys,
-                 uint32_t* vals, hipStream_t s) {
+                 uint32_t* vals, uint32_t cap, hipStream_t s) {
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     emit_k<false><<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, gx, gy, g.rec, radii, order, g.offsets, g.goff, keys, vals,
-                                                              nullptr, g.counters, nullptr, 0u);
+                                                              nullptr, g.counters, nullptr, 0u, cap);
 }
 
 bool emit_can_count_tiles(int W, int H) {
@@ -930,12 +943,12 @@ bool emit_can_count_tiles(int W, int H) {
 
 // emit + per-tile counts; ranges must be zeroed by the caller's stream order (done here)
 void launch_emit_counting(int P, int W, int H, const GeomView& g, const uint32_t* order, const int* radii, uint32_t* keys,
-                          uint32_t* vals, uint2* ranges, uint32_t* clear, size_t clear_words, hipStream_t s) {
+                          uint32_t* vals, uint2* ranges, uint32_t* clear, size_t clear_words, uint32_t cap, hipStream_t s) {
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     // `ranges` was zeroed by preprocess_fwd_k
     emit_k<true><<<dim3((P + 256 * EMIT_ROUNDS - 1) / (256 * EMIT_ROUNDS)), dim3(256), (size_t)gx * gy * sizeof(uint32_t), s>>>(
         P, gx, gy, g.rec, radii, order, g.offsets, g.goff, keys, vals, reinterpret_cast<uint32_t*>(ranges) + 1, g.counters,
-        clear, (uint32_t)clear_words);
+        clear, (uint32_t)clear_words, cap);
 }
 
 // per-tile counts -> ranges and the two digit histograms (written to ghist[0..511]) of a sort on
@@ -948,9 +961,9 @@ void launch_tile_ranges_hist(int W, int H, uint2* ranges, uint32_t* ghist, hipSt
     tile_ranges_hist_k<<<dim3(1), dim3(1024), 0, s>>>(gx * gy, ranges, passes, 0, n0, n0, n1 > 0 ? n1 : 1, ghist);
 }
 
-void launch_ranges(int N, const uint32_t* sorted_keys, uint2* ranges, int T, hipStream_t s) {
+void launch_ranges(int N, const uint32_t* n_dev, const uint32_t* sorted_keys, uint2* ranges, int T, hipStream_t s) {
     (void)hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)T, s);
-    if (N > 0) ranges_k<<<dim3((N + 255) / 256), dim3(256), 0, s>>>(N, sorted_keys, ranges);
+    if (N > 0) ranges_k<<<dim3((N + 255) / 256), dim3(256), 0, s>>>(N, n_dev, sorted_keys, ranges);
 }
 
 void launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s) {

@@ -10,6 +10,8 @@
 // digit-major [RADIX][blocks] table, (c) stable scatter.  Stability inside a block comes from
 // wave-level match-any ranking (ballots over the digit bits) with elements laid out so that
 // (wave, round, lane) order equals index order.
+#include <atomic>
+
 #include "common.h"
 
 namespace goi {
@@ -232,8 +234,19 @@ struct SweepPlan {
     int nbits[MAX_PASSES];
 };
 
-__global__ __launch_bounds__(SORT_THREADS) void sweep_hist_k(const uint32_t* __restrict__ keys, size_t n, SweepPlan plan,
+// n_dev (may be NULL): the element count lives on the device (speculative forward: the host sized grids and buffers for
+// a CAPACITY `n` and never learned the count); the kernels then work on min(*n_dev, n) elements and surplus blocks exit.
+__device__ __forceinline__ size_t effective_n(size_t n, const uint32_t* __restrict__ n_dev) {
+    if (!n_dev) return n;
+    const size_t m = (size_t)__builtin_nontemporal_load(n_dev);
+    return m < n ? m : n;
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void sweep_hist_k(const uint32_t* __restrict__ keys, size_t n_cap,
+                                                             const uint32_t* __restrict__ n_dev, SweepPlan plan,
                                                              uint32_t* __restrict__ ghist) {
+    const size_t n = effective_n(n_cap, n_dev);
+    if ((size_t)blockIdx.x * SORT_TILE >= n) return;
     __shared__ uint32_t h[MAX_PASSES][RADIX_MAX];
     for (int i = threadIdx.x; i < MAX_PASSES * RADIX_MAX; i += SORT_THREADS) (&h[0][0])[i] = 0;
     __syncthreads();
@@ -262,10 +275,12 @@ template <int THREADS, int ITEMS>
 __global__ __launch_bounds__(THREADS) void sweep_pass_k(const uint32_t* __restrict__ keys_in,
                                                              const uint32_t* __restrict__ vals_in,
                                                              uint32_t* __restrict__ keys_out,
-                                                             uint32_t* __restrict__ vals_out, size_t n, int shift,
+                                                             uint32_t* __restrict__ vals_out, size_t n_cap,
+                                                             const uint32_t* __restrict__ n_dev, int shift,
                                                              int nbits, const uint32_t* __restrict__ ghist,
                                                              uint32_t* status, uint32_t* ticket, uint32_t* error) {
     constexpr int TILE_KEYS = THREADS * ITEMS, WAVES = THREADS / WAVE, WAVE_ITEMS = TILE_KEYS / WAVES;
+    const size_t n = effective_n(n_cap, n_dev);
     __shared__ uint32_t cnt[WAVES][RADIX_MAX];  // per-wave digit counts -> per-wave local offsets
     __shared__ uint32_t gbase[RADIX_MAX];            // global position of this block's first element of digit d
     __shared__ uint32_t lbase[RADIX_MAX];            // local (in-block) exclusive offset of digit d
@@ -278,6 +293,9 @@ __global__ __launch_bounds__(THREADS) void sweep_pass_k(const uint32_t* __restri
     for (int i = threadIdx.x; i < WAVES * RADIX_MAX; i += THREADS) (&cnt[0][0])[i] = 0;
     __syncthreads();
     const uint32_t bid = s_bid;
+    // the grid covers the capacity: tickets past the last tile of the real count have nothing to rank and nobody
+    // looks back at them (tickets are dealt in order, so every tile below is owned by a running block)
+    if ((size_t)bid * TILE_KEYS >= n) return;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint64_t lt = (1ull << lane) - 1ull;
     const size_t tile_base = (size_t)bid * TILE_KEYS;
@@ -436,7 +454,7 @@ uint32_t* radix_sort_ghist(uint32_t* scratch, size_t n, int lo, int hi) {
 }
 
 int radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], size_t n, int lo, int hi, uint32_t* scratch,
-                     hipStream_t s, bool cleared, bool ghist_ready) {
+                     hipStream_t s, bool cleared, bool ghist_ready, const uint32_t* n_dev) {
     int cur = 0;
     if (n == 0) return cur;
     const uint32_t nblk = (uint32_t)div_up(n, SORT_TILE);
@@ -462,24 +480,28 @@ int radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], size_t n, int lo, int
             sh += plan.nbits[p];
         }
         for (int p = passes; p < MAX_PASSES; p++) plan.shift[p] = plan.nbits[p] = 0;
-        if (!ghist_ready) sweep_hist_k<<<dim3(nblk), dim3(SORT_THREADS), 0, s>>>(keys[0], n, plan, ghist);
+        if (!ghist_ready) sweep_hist_k<<<dim3(nblk), dim3(SORT_THREADS), 0, s>>>(keys[0], n, n_dev, plan, ghist);
         const size_t tile = sweep_tile_keys(n);
         const uint32_t nt = (uint32_t)div_up(n, tile);
         const size_t lds = 2 * tile * sizeof(uint32_t);  // the tile's keys and values in digit order
-        static bool attr_set = false;
-        if (!attr_set) {
+        // (the attribute is per device: set it once on each device this process sorts on)
+        static std::atomic<uint64_t> attr_set{0};
+        int dev_id = 0;
+        (void)hipGetDevice(&dev_id);
+        const uint64_t dev_bit = 1ull << (dev_id & 63);
+        if (!(attr_set.load(std::memory_order_relaxed) & dev_bit)) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sweep_pass_k<512, 16>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8192 * (int)sizeof(uint32_t));
-            attr_set = true;
+            attr_set.fetch_or(dev_bit, std::memory_order_relaxed);
         }
         for (int p = 0; p < passes; p++) {
             if (tile == 4096)
                 sweep_pass_k<1024, 4><<<dim3(nt), dim3(1024), lds, s>>>(
-                    keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, plan.shift[p], plan.nbits[p],
+                    keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, n_dev, plan.shift[p], plan.nbits[p],
                     ghist + (size_t)p * RADIX_MAX, status + (size_t)p * nt * RADIX_MAX, ticket + p, error);
             else
                 sweep_pass_k<512, 16><<<dim3(nt), dim3(512), lds, s>>>(
-                    keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, plan.shift[p], plan.nbits[p],
+                    keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, n_dev, plan.shift[p], plan.nbits[p],
                     ghist + (size_t)p * RADIX_MAX, status + (size_t)p * nt * RADIX_MAX, ticket + p, error);
             cur ^= 1;
         }

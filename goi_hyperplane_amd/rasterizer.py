@@ -108,6 +108,29 @@ def set_backward_mode(semantics_only=None, sh_factored: bool = None) -> None:
         _SH_FACTOR["last"] = None
 
 
+def set_forward_mode(speculative=None, headroom=None, capacity="keep", on_overflow=None, max_ahead=None) -> None:
+    """Forward without the host round trip (default) or the reference's synchronous forward: see _C.set_forward_mode
+    and include/goi_raster.h (goi_raster_forward_async).  GOI_FORWARD=exact|speculative, GOI_BINNING_HEADROOM,
+    GOI_OVERFLOW=warn|raise set the process defaults."""
+    _C.set_forward_mode(speculative, headroom, capacity, on_overflow, max_ahead)
+
+
+def speculation_stats() -> dict:
+    """Counters of the speculative forward since import: exact_frames, speculative_frames, overflows, redone, waits."""
+    return dict(_C.SPECULATION_STATS)
+
+
+_LAST_FORWARD = {"num_rendered": None}
+
+
+def last_num_rendered():
+    """`num_rendered` of the most recent forward of this process: an int (exact frame) or a _C.LazyCount (speculative
+    frame).  int(last_num_rendered()) right after a render is the "read before use" hook of the speculative forward:
+    it waits for the frame's count and, had the frame overflowed its capacity, redoes it in place before anything
+    consumes the outputs."""
+    return _LAST_FORWARD["num_rendered"]
+
+
 def last_backward_kernel():
     """Which backward path the most recent _RasterizeGaussians.backward took (tests, bench reporting)."""
     return _LAST_BACKWARD["kernel"]
@@ -129,7 +152,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         (num_rendered, color, semant, depth, alpha, radii, geomBuffer, binningBuffer, imgBuffer) = _call_with_snapshot(
             _C.rasterize_gaussians, args, raster_settings.debug, "snapshot_fw.dump", "forward")
         ctx.raster_settings = raster_settings
-        ctx.num_rendered = num_rendered
+        ctx.num_rendered = num_rendered  # an int, or the LazyCount of a speculative frame (never forced here)
+        _LAST_FORWARD["num_rendered"] = num_rendered
         ctx.set_materialize_grads(False)  # unused outputs (depth, alpha, ...) reach backward as None, not as zero tensors
         ctx.save_for_backward(colors_precomp, semantics, means3D, scales, rotations, cov3Ds_precomp, radii, sh,
                               geomBuffer, binningBuffer, imgBuffer, alpha)

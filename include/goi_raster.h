@@ -27,7 +27,10 @@
  *   - outputs need not be initialised by the caller; every element is written;
  *   - `stream` is a hipStream_t (NULL = the default stream); all work is enqueued on it; the only
  *     host synchronisation is the read-back of num_rendered inside forward/trace (the reference
- *     has the same one, cuda_rasterizer/rasterizer_impl.cu:285);
+ *     has the same one, cuda_rasterizer/rasterizer_impl.cu:285); goi_raster_forward_async has none;
+ *   - entry points may be called concurrently from several host threads on different streams / devices
+ *     (read-back tickets are pooled per device under a mutex; last_error is per thread); the
+ *     goi_raster_set_option switches and the stage profile are process-wide;
  *   - return value: >= 0 on success (forward/trace: num_rendered), < 0 on error with the message
  *     available from goi_raster_last_error() (thread-local).
  *   - supported S (semantic channels): any 1..32; fast paths are instantiated for 10 and 16.
@@ -42,7 +45,7 @@
 extern "C" {
 #endif
 
-#define GOI_RASTER_ABI_VERSION 1
+#define GOI_RASTER_ABI_VERSION 2
 
 typedef struct GoiRasterScene {
     int P;                       /* number of Gaussians */
@@ -89,7 +92,38 @@ int goi_raster_forward(const GoiRasterScene* scene, void* geom_buffer, void* ima
                        float* out_color, float* out_semantic, float* out_depth, float* out_alpha,
                        int* radii, void* stream);
 
-/* Backward of the forward that filled the three workspaces.  R = that forward's return value.
+/* ---- Speculative forward: the same frame WITHOUT the host round trip -----------------------------------------------
+ * (no counterpart in the reference: CudaRasterizer::Rasterizer::forward blocks on num_rendered at
+ * cuda_rasterizer/rasterizer_impl.cu:285 to size the binning workspace; SURVEY.md section 7 "no host sync").
+ *
+ * goi_raster_forward_async enqueues the WHOLE frame and returns at once.  The caller supplies the binning workspace
+ * up front, sized by goi_raster_binning_bytes(capacity) for a capacity it believes to be >= num_rendered (e.g. twice
+ * the largest count seen so far); on the device every kernel takes the true count from the geometry workspace and
+ * clamps it to `capacity`.  The return value is a TICKET (>= 0) for the asynchronous read-back of the count:
+ *
+ *   goi_raster_ticket_result(ticket, wait, &n): 1 = the count has arrived (n = num_rendered; the ticket is released),
+ *       0 = not yet (only with wait == 0), -1 = error (e.g. the "prefiltered" trap; ticket released).
+ *   n <= capacity : the frame is exactly what goi_raster_forward would have produced (bit-identical outputs; the
+ *       tile lists are identical, only the workspace is larger).  Pass R = capacity to goi_raster_backward.
+ *   n >  capacity : OVERFLOW.  The frame was rendered from the first `capacity` instances in emit (depth) order --
+ *       memory-safe and self-consistent with a backward called with R = capacity, but not the right image.
+ *       goi_raster_forward_redo re-runs emit -> tile sort -> blend from the geometry state that is still in the
+ *       workspace, into a binning buffer of goi_raster_binning_bytes(n) bytes: afterwards outputs and workspaces are
+ *       bit-identical to goi_raster_forward's, and R = n.
+ *
+ * Nothing here waits for the device unless asked to (wait != 0).  Every ticket must be resolved exactly once.
+ * Not available with scene->debug (which synchronises after every stage) or for P == 0. */
+int goi_raster_forward_async(const GoiRasterScene* scene, void* geom_buffer, void* image_buffer, void* binning_buffer,
+                             int capacity, float* out_color, float* out_semantic, float* out_depth, float* out_alpha,
+                             int* radii, void* stream);
+int goi_raster_ticket_result(int ticket, int wait, int* num_rendered);
+int goi_raster_forward_redo(const GoiRasterScene* scene, int num_rendered, void* geom_buffer, void* image_buffer,
+                            void* binning_buffer, float* out_color, float* out_semantic, float* out_depth,
+                            float* out_alpha, const int* radii, void* stream);
+
+/* Backward of the forward that filled the three workspaces.  R = the instance count the binning workspace was laid out
+ * for: goi_raster_forward's return value, or the `capacity` of a goi_raster_forward_async frame (the kernels read the
+ * true count from the geometry workspace), or num_rendered after goi_raster_forward_redo.
  * Any of the four upstream gradients dL_dout_* may be NULL (= zero).  dL_dconic is [P,4] (x: a, y: b, z: unused, w: c), dL_dsh [P,M,3] (may be NULL when M == 0).
  * FACTORED mode: dL_dsh == NULL while the scene has SH colours.  dL/dSH is not formed (192 of the 300 bytes of
  * gradient per Gaussian at degree 3); dL_dcolor returns the colour gradient with the forward's clamp mask applied

@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared == set(_lib.SYMBOLS), "ctypes table and header disagree"
     for name in declared:
         assert hasattr(lib, name), f"{name} is declared in goi_raster.h but not exported"
-    assert lib.goi_raster_abi_version() == 1
+    assert lib.goi_raster_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define GOI_RASTER_ABI_VERSION (\d+)", hdr).group(1))
 
 
 def test_scene_struct_layout_matches_c(tmp_path):

@@ -54,7 +54,7 @@ def test_config5_masked_edit_step_properties(dev):
     o2, g2 = edit_step(pc, keep)
     for k in ("image", "semantics", "depth", "alpha"):
         assert torch.equal(o1[k], o2[k]), f"forward {k} not reproducible"
-    assert float(o1["alpha"].mean()) > 0.5
+    assert float(o1["alpha"].detach().mean()) > 0.5
     for n in g1:
         assert torch.equal(g1[n], g2[n]), f"gradient {n} not bit-reproducible"
         assert torch.isfinite(g1[n]).all()

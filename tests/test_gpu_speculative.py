@@ -1,0 +1,194 @@
+"""The forward without the host round trip (goi_raster_forward_async, SURVEY.md section 7 "no host sync"; the
+reference blocks at cuda_rasterizer/rasterizer_impl.cu:285).  A speculative frame is sized from a capacity guess and
+returns `num_rendered` lazily; these tests pin down that it changes no result:
+
+  * capacity >= count (any capacity): outputs, sorted lists, ranges and every gradient are BIT-identical to the exact,
+    synchronous path;
+  * capacity < count (forced): reading the count before the outputs redoes the frame in place -> bit-identical again,
+    forward and backward; not reading it leaves a truncated-but-consistent frame that is reported at the next forward;
+  * the default policy: first frame exact, later frames speculative, nothing waits."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from goi_hyperplane_amd.scene import make_camera, make_scene
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    from goi_hyperplane_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _restore_mode():
+    from goi_hyperplane_amd import _C
+    yield
+    _C.poll_counts(wait=True)
+    _C.set_forward_mode(speculative=True, headroom=2.0, capacity=None, on_overflow="warn", max_ahead=16)
+
+
+def _args(sc, cam, dev, bg):
+    from goi_hyperplane_amd.render import TorchCamera
+    tc = TorchCamera(cam, dev)
+    t = lambda a: torch.tensor(a, device=dev)  # noqa: E731
+    return (torch.tensor(bg, device=dev), t(sc.means3D), torch.Tensor([]), t(sc.semantics), t(sc.opacities), t(sc.scales),
+            t(sc.rotations), 1.0, torch.Tensor([]), tc.world_view_transform, tc.full_proj_transform, cam.tanfovx,
+            cam.tanfovy, cam.image_height, cam.image_width, t(sc.shs), sc.sh_degree, tc.camera_center, False, False)
+
+
+def _raw(dev, sc, cam, bg, **mode):
+    """raw op forward (+ workspace views) under a forward mode; returns (n, outputs, views)"""
+    from goi_hyperplane_amd import _C
+    _C.set_forward_mode(**mode)
+    n, color, sem, depth, alpha, radii, geom, binning, img = _C.rasterize_gaussians(*_args(sc, cam, dev, bg))
+    return n, (color, sem, depth, alpha, radii), (geom, binning, img)
+
+
+@pytest.mark.parametrize("P,S,W,H,mu", [(3000, 16, 160, 120, -2.8), (20000, 16, 400, 300, -3.5), (800, 10, 123, 77, -1.6),
+                                         (1500, 4, 3840, 2160, -2.0)])
+def test_speculative_frames_are_bit_identical_to_exact_ones(dev, P, S, W, H, mu):
+    from goi_hyperplane_amd import _C
+    sc = make_scene(P, S=S, seed=3, log_scale_mean=mu)
+    cam = make_camera(W, H, yaw=0.2, pitch=-0.1)
+    bg = np.array([0.1, 0.3, 0.6], np.float32)
+    n0, o0, w0 = _raw(dev, sc, cam, bg, speculative=False)
+    assert isinstance(n0, int) and n0 > 0
+    v0 = _C.debug_views(P, W, H, n0, *w0)
+    for cap in (n0, n0 + 1, 2 * n0 + 12345, 7 * n0):  # exactly full, barely, the default headroom, far too large
+        n1, o1, w1 = _raw(dev, sc, cam, bg, speculative=True, capacity=cap)
+        assert isinstance(n1, _C.LazyCount) and not n1.resolved
+        for a, b in zip(o0, o1):
+            assert torch.equal(a, b)
+        assert int(n1) == n0 and not n1.overflowed and n1.layout == cap
+        v1 = _C.debug_views(P, W, H, n1, *w1)
+        for k in v0:
+            assert torch.equal(v0[k], v1[k]), (cap, k)
+
+
+@pytest.mark.parametrize("frac", [0.05, 0.5, 0.999])
+def test_overflow_is_redone_bit_identically_when_the_count_is_read_first(dev, frac):
+    from goi_hyperplane_amd import _C
+    P, S, W, H = 4000, 16, 208, 160
+    sc = make_scene(P, S=S, seed=8, log_scale_mean=-2.7)
+    cam = make_camera(W, H, yaw=-0.1)
+    bg = np.array([0.2, 0.1, 0.0], np.float32)
+    n0, o0, w0 = _raw(dev, sc, cam, bg, speculative=False)
+    v0 = _C.debug_views(P, W, H, n0, *w0)
+    before = dict(_C.SPECULATION_STATS)
+    cap = max(1, int(frac * n0))
+    n1, o1, w1 = _raw(dev, sc, cam, bg, speculative=True, capacity=cap)
+    torch.cuda.synchronize()
+    # the truncated frame differs (that is what an overflow is) but is finite and was memory-safe
+    assert not torch.equal(o0[0], o1[0]) and all(torch.isfinite(x.float()).all() for x in o1)
+    assert int(n1) == n0 and n1.overflowed and n1.redone and n1.layout == n0  # reading the count repaired the frame
+    for a, b in zip(o0, o1):
+        assert torch.equal(a, b)
+    v1 = _C.debug_views(P, W, H, n1, w1[0], n1.binning, w1[2])
+    for k in v0:
+        assert torch.equal(v0[k], v1[k]), k
+    after = _C.SPECULATION_STATS
+    assert after["overflows"] == before["overflows"] + 1 and after["redone"] == before["redone"] + 1
+
+
+def test_overflow_through_autograd_read_before_use_gives_exact_gradients(dev):
+    """The autograd path: an overflowed frame whose count is read (LazyCount.resolve, here through
+    rasterizer.last_num_rendered) before the loss is formed has the exact path's outputs AND gradients."""
+    from goi_hyperplane_amd import _C, rasterizer
+    from goi_hyperplane_amd.render import GaussianSet, PipelineParams, TorchCamera, render
+    sc = make_scene(5000, S=16, seed=12, log_scale_mean=-2.9)
+    cam = TorchCamera(make_camera(208, 160, yaw=0.05), dev)
+    pc = GaussianSet.from_scene(sc, dev)
+    bg = torch.zeros(3, device=dev)
+    g = torch.Generator(device=dev).manual_seed(4)
+    up = [torch.randn(s, device=dev, generator=g) for s in ((3, 160, 208), (16, 160, 208))]
+
+    def step(read_count, **mode):
+        _C.set_forward_mode(**mode)
+        for p in pc.parameters():
+            p.grad = None
+        out = render(cam, pc, PipelineParams(), bg)
+        n = rasterizer.last_num_rendered()
+        if read_count:
+            n = int(n)
+        torch.autograd.backward((out["render"], out["semantics"]), up)
+        return n, {k: out[k].detach().clone() for k in ("render", "semantics", "depth", "alpha")}, \
+            {k: p.grad.clone() for k, p in pc.named_parameters()}, out["viewspace_points"].grad.clone()
+
+    n0, o0, g0, v0 = step(True, speculative=False)
+    n1, o1, g1, v1 = step(True, speculative=True, capacity=n0 // 3)  # overflow, repaired before use
+    assert n1 == n0
+    for k in o0:
+        assert torch.equal(o0[k], o1[k]), k
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k
+    assert torch.equal(v0, v1)
+    n2, o2, g2, v2 = step(False, speculative=True, capacity=3 * n0)  # fits: nothing is ever read back in time
+    for k in o0:
+        assert torch.equal(o0[k], o2[k]), k
+    for k in g0:
+        assert torch.equal(g0[k], g2[k]), k
+    assert torch.equal(v0, v2)
+
+
+def test_unread_overflow_is_reported_at_a_later_forward_and_stays_consistent(dev):
+    from goi_hyperplane_amd import _C
+    from goi_hyperplane_amd.render import GaussianSet, PipelineParams, TorchCamera, render
+    sc = make_scene(4000, S=16, seed=5, log_scale_mean=-2.7)
+    cam = TorchCamera(make_camera(160, 128), dev)
+    pc = GaussianSet.from_scene(sc, dev)
+    bg = torch.zeros(3, device=dev)
+    _C.set_forward_mode(speculative=True, capacity=2000)
+    out = render(cam, pc, PipelineParams(), bg)
+    (out["render"].sum() + out["semantics"].sum()).backward()  # backward of the truncated frame: consistent, finite
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(p.grad).all() for p in pc.parameters())
+    _C.set_forward_mode(capacity=None)
+    with pytest.warns(_C.RasterOverflowWarning, match="overflowed its binning capacity"):
+        render(cam, pc, PipelineParams(), bg)  # the poll at the start of this forward finds it
+    # ... and the policy has learned: the next frames are speculative with room to spare, no warning, no wait
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        waits = _C.SPECULATION_STATS["waits"]
+        outs = [render(cam, pc, PipelineParams(), bg) for _ in range(5)]
+        assert _C.SPECULATION_STATS["waits"] == waits
+    torch.cuda.synchronize()
+    _C.set_forward_mode(speculative=False)
+    ref = render(cam, pc, PipelineParams(), bg)
+    assert all(torch.equal(o["render"], ref["render"]) for o in outs)
+    # raise instead of warn
+    _C.set_forward_mode(speculative=True, capacity=2000, on_overflow="raise")
+    render(cam, pc, PipelineParams(), bg)
+    torch.cuda.synchronize()
+    _C.set_forward_mode(capacity=None)
+    with pytest.raises(_C.RasterOverflowError):
+        render(cam, pc, PipelineParams(), bg)
+
+
+def test_default_policy_first_frame_exact_then_nothing_waits(dev):
+    from goi_hyperplane_amd import _C
+    from goi_hyperplane_amd.render import GaussianSet, PipelineParams, TorchCamera, render
+    _C._SPEC.clear()  # a fresh process
+    sc = make_scene(30000, S=16, seed=2, log_scale_mean=-3.4)
+    pc = GaussianSet.from_scene(sc, dev)
+    cams = [TorchCamera(make_camera(400, 304, yaw=0.03 * i), dev) for i in range(8)]
+    bg = torch.zeros(3, device=dev)
+    s0 = dict(_C.SPECULATION_STATS)
+    for i in range(24):
+        for p in pc.parameters():
+            p.grad = None
+        out = render(cams[i % 8], pc, PipelineParams(), bg)
+        (out["render"].mean() + out["semantics"].mean()).backward()
+    torch.cuda.synchronize()
+    _C.poll_counts(wait=True)
+    s1 = _C.SPECULATION_STATS
+    assert s1["exact_frames"] - s0["exact_frames"] == 1
+    assert s1["speculative_frames"] - s0["speculative_frames"] == 23
+    assert s1["overflows"] == s0["overflows"]
+    assert len(_C._SPEC[dev.index]["pending"]) == 0
