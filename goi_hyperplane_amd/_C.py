@@ -11,6 +11,7 @@ import collections
 import ctypes as C
 import os
 import warnings
+import weakref
 
 import torch
 
@@ -115,7 +116,10 @@ def release_scratch(device=None) -> int:
 #     exact path.  If nobody asks, the overflow is found by the poll at a later forward: the frame cannot be repaired
 #     any more (its consumers are already enqueued), a RasterOverflowWarning is issued (GOI_OVERFLOW=raise: a
 #     RasterOverflowError), and the capacity is raised.  Its backward stays consistent with what was rendered.
-#   * at most `max_ahead` frames stay unresolved per device; the oldest is waited for beyond that.
+#   * at most `max_ahead` frames stay unresolved per device; the oldest is waited for beyond that (flow control: the
+#     host may run that far ahead of the GPU, which is what absorbs a host stall).  A pending frame pins no device
+#     memory: the LazyCount refers to the frame's tensors weakly (a frame whose outputs have died has no consumer
+#     left to repair for).
 class RasterOverflowWarning(UserWarning):
     pass
 
@@ -132,7 +136,8 @@ def _env_forward_mode():
 
 
 _FWD = {"mode": _env_forward_mode(), "headroom": float(os.environ.get("GOI_BINNING_HEADROOM", "2.0")),
-        "capacity": None, "on_overflow": os.environ.get("GOI_OVERFLOW", "warn").strip().lower(), "max_ahead": 16}
+        "capacity": None, "on_overflow": os.environ.get("GOI_OVERFLOW", "warn").strip().lower(),
+        "max_ahead": int(os.environ.get("GOI_MAX_AHEAD", "64"))}
 _SPEC = {}  # device index -> {"high_water": int, "P": int, "pending": deque of LazyCount}
 SPECULATION_STATS = {"exact_frames": 0, "speculative_frames": 0, "overflows": 0, "redone": 0, "waits": 0}
 _MIN_CAPACITY = 1 << 16
@@ -206,7 +211,7 @@ class LazyCount:
     and, if the frame overflowed its capacity, redoes it in place first."""
 
     __slots__ = ("dev", "ticket", "capacity", "layout", "binning", "overflowed", "redone", "_n", "_redo", "_stream",
-                 "_error", "P")
+                 "_error", "P", "__weakref__")
 
     def __init__(self, dev, ticket, capacity, binning, stream, redo, P):
         self.dev, self.ticket, self.capacity, self.layout, self.binning = dev, ticket, capacity, capacity, binning
@@ -263,7 +268,13 @@ class LazyCount:
 
     def _redo_frame(self):
         lib = _lib.load()
-        sc, keep, geom, img, outs, radii = self._redo
+        sc, refs, _inputs = self._redo
+        live = [r() for r in refs]
+        if any(t is None for t in live):
+            raise RasterOverflowError(
+                f"a speculative forward overflowed its binning capacity (num_rendered = {self._n} > {self.capacity}) and "
+                "cannot be redone: its outputs / workspaces have already been released")
+        geom, img, radii, outs = live[0], live[1], live[2], live[3:7]
         stream = torch.cuda.ExternalStream(self._stream, device=self.dev)
         with torch.cuda.device(self.dev), torch.cuda.stream(stream):
             step = 16 << 20
@@ -379,7 +390,11 @@ def rasterize_gaussians(background, means3D, colors, semantics, opacity, scales,
             if ticket < 0:
                 raise RuntimeError(_lib.last_error())
             SPECULATION_STATS["speculative_frames"] += 1
-            n = LazyCount(dev, ticket, cap, binning, stream, (sc, ten, geom, img, outs, radii), P)
+            # what a redo needs: workspaces and outputs (weakly: dead outputs have no consumer left to repair for) and the
+            # two inputs the back half of the frame reads, the semantic rows and the background (strongly: they may be
+            # temporaries of the caller, e.g. pc.get_semantics under a mask)
+            refs = [weakref.ref(t) for t in (geom, img, radii) + outs]
+            n = LazyCount(dev, ticket, cap, binning, stream, (sc, refs, (ten["semantics"], ten["bg"])), P)
             return n, out_color, out_sem, out_depth, out_alpha, radii, geom, binning, img
         alloc = _BinningAllocator(dev)
         n = lib.goi_raster_forward(C.byref(sc), _ptr(geom), _ptr(img), alloc.cb, None, _ptr(out_color), _ptr(out_sem),

@@ -31,7 +31,7 @@ def _restore_mode():
     from goi_hyperplane_amd import _C
     yield
     _C.poll_counts(wait=True)
-    _C.set_forward_mode(speculative=True, headroom=2.0, capacity=None, on_overflow="warn", max_ahead=16)
+    _C.set_forward_mode(speculative=True, headroom=2.0, capacity=None, on_overflow="warn", max_ahead=64)
 
 
 def _args(sc, cam, dev, bg):
@@ -145,13 +145,14 @@ def test_unread_overflow_is_reported_at_a_later_forward_and_stays_consistent(dev
     pc = GaussianSet.from_scene(sc, dev)
     bg = torch.zeros(3, device=dev)
     _C.set_forward_mode(speculative=True, capacity=2000)
-    out = render(cam, pc, PipelineParams(), bg)
-    (out["render"].sum() + out["semantics"].sum()).backward()  # backward of the truncated frame: consistent, finite
-    torch.cuda.synchronize()
-    assert all(torch.isfinite(p.grad).all() for p in pc.parameters())
-    _C.set_forward_mode(capacity=None)
     with pytest.warns(_C.RasterOverflowWarning, match="overflowed its binning capacity"):
-        render(cam, pc, PipelineParams(), bg)  # the poll at the start of this forward finds it
+        out = render(cam, pc, PipelineParams(), bg)
+        (out["render"].sum() + out["semantics"].sum()).backward()  # backward of the truncated frame: consistent, finite
+        torch.cuda.synchronize()
+        assert all(torch.isfinite(p.grad).all() for p in pc.parameters())
+        _C.set_forward_mode(capacity=None)
+        # found by whichever looks first without waiting: the backward's free look, or the poll of the next forward
+        render(cam, pc, PipelineParams(), bg)
     # ... and the policy has learned: the next frames are speculative with room to spare, no warning, no wait
     with warnings.catch_warnings():
         warnings.simplefilter("error")
