@@ -19,6 +19,50 @@ from . import _lib
 from ._lib import ALLOC_FN, GoiRasterScene
 
 
+# ---- which binding crosses into libgoi_raster.so ----------------------------------------------------------------------
+# "compiled": goi_hyperplane_amd/lib/_goi_C.so, the pybind/torch C++ binding a maintainer of the reference would build in
+# place of rasterize_points.cu (csrc/torch_binding.cpp; host C++ only) -- tensor allocation, checks and the C-ABI call
+# happen in C++, one Python->C++ transition per operator call.  "ctypes": this file's own ctypes calls.  Same library,
+# same kernels, bit-identical results; the compiled one costs less host time per call and is the default when it has
+# been built (GOI_BINDING=ctypes|compiled, set_binding()).
+_EXT = {"mod": None, "tried": False, "want": os.environ.get("GOI_BINDING", "compiled").strip().lower()}
+_EMPTY = torch.Tensor([])
+
+
+def _ext():
+    if not _EXT["tried"]:
+        _EXT["tried"] = True
+        path = os.path.join(os.path.dirname(_lib.LIB_PATH), "_goi_C.so")
+        if _EXT["want"] == "compiled" and os.path.exists(path):
+            import importlib.util
+            _lib.load()  # same libgoi_raster.so instance (tickets, options and last_error are shared)
+            spec = importlib.util.spec_from_file_location("_goi_C", path)
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            if mod.abi_version() != _lib.ABI_VERSION:
+                raise ImportError(f"{path}: built against ABI {mod.abi_version()}, expected {_lib.ABI_VERSION}; rebuild")
+            _EXT["mod"] = mod
+    return _EXT["mod"]
+
+
+def set_binding(name: str) -> None:
+    """"compiled" (needs goi_hyperplane_amd/lib/_goi_C.so) or "ctypes"."""
+    if name not in ("compiled", "ctypes"):
+        raise ValueError("binding must be 'compiled' or 'ctypes'")
+    _EXT.update(want=name, tried=False, mod=None)
+    if name == "compiled" and _ext() is None:
+        raise ImportError("the compiled binding has not been built (python -m goi_hyperplane_amd.build)")
+
+
+def binding() -> str:
+    return "compiled" if _ext() is not None else "ctypes"
+
+
+def _e(t):
+    """None -> the reference's marker for an absent tensor argument (an empty tensor)"""
+    return _EMPTY if t is None else t
+
+
 def _ptr(t):
     """Device pointer of a tensor, or None for the reference's 'empty tensor means absent'."""
     if t is None or t.numel() == 0:
@@ -98,6 +142,8 @@ def release_scratch(device=None) -> int:
     freed = 0
     for key in [k for k in _SCRATCH if device is None or k[0] == torch.device(device).index]:
         freed += _SCRATCH.pop(key).numel()
+    if _EXT["mod"] is not None:
+        freed += int(_EXT["mod"].release_scratch())  # (the compiled binding keeps its own; all devices)
     return freed
 
 
@@ -268,7 +314,8 @@ class LazyCount:
 
     def _redo_frame(self):
         lib = _lib.load()
-        sc, refs, _inputs = self._redo
+        make_scene, refs = self._redo
+        sc, _keep = make_scene()
         live = [r() for r in refs]
         if any(t is None for t in live):
             raise RasterOverflowError(
@@ -358,6 +405,29 @@ def rasterize_gaussians(background, means3D, colors, semantics, opacity, scales,
         S = int(semantics.size(1))
     if not (1 <= S <= 32):
         raise RuntimeError(f"unsupported number of semantic channels S={S} (1..32)")
+    ext = _ext()
+    if ext is not None:
+        poll_counts(dev)
+        args = (background, means3D, _e(colors), _e(semantics), _e(opacity), _e(scales), _e(rotations),
+                float(scale_modifier), _e(cov3D_precomp), viewmatrix, projmatrix, float(tan_fovx), float(tan_fovy), H, W,
+                _e(sh), int(degree), campos, bool(prefiltered), bool(debug))
+        cap = _pick_capacity(dev, P, debug, prefiltered)
+        if cap is None:
+            res = ext.rasterize_gaussians(*args)
+            if P > 0:
+                SPECULATION_STATS["exact_frames"] += 1
+                _note_count(dev, P, res[0])
+            return res
+        ticket, out_color, out_sem, out_depth, out_alpha, radii, geom, binning, img = ext.rasterize_gaussians_async(*args, cap)
+        SPECULATION_STATS["speculative_frames"] += 1
+        refs = [weakref.ref(t) for t in (geom, img, radii, out_color, out_sem, out_depth, out_alpha)]
+
+        def make_scene(bg=background, sem=semantics):  # only what a redo reads (include/goi_raster.h)
+            bg_c, sem_c = bg.contiguous(), sem.contiguous()
+            return _scene(P, S, H, W, bg_c, None, None, None, sem_c, None, None, None, 1.0, None, None, None, 0.0, 0.0, 0,
+                          None, False, False), (bg_c, sem_c)
+        n = LazyCount(dev, ticket, cap, binning, torch.cuda.current_stream(dev).cuda_stream, (make_scene, refs), P)
+        return n, out_color, out_sem, out_depth, out_alpha, radii, geom, binning, img
     f32 = dict(dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         out_color = torch.empty((3, H, W), **f32)
@@ -394,7 +464,8 @@ def rasterize_gaussians(background, means3D, colors, semantics, opacity, scales,
             # two inputs the back half of the frame reads, the semantic rows and the background (strongly: they may be
             # temporaries of the caller, e.g. pc.get_semantics under a mask)
             refs = [weakref.ref(t) for t in (geom, img, radii) + outs]
-            n = LazyCount(dev, ticket, cap, binning, stream, (sc, refs, (ten["semantics"], ten["bg"])), P)
+            keep = (ten["semantics"], ten["bg"])
+            n = LazyCount(dev, ticket, cap, binning, stream, (lambda: (sc, keep), refs), P)
             return n, out_color, out_sem, out_depth, out_alpha, radii, geom, binning, img
         alloc = _BinningAllocator(dev)
         n = lib.goi_raster_forward(C.byref(sc), _ptr(geom), _ptr(img), alloc.cb, None, _ptr(out_color), _ptr(out_sem),
@@ -421,6 +492,15 @@ def _backward_impl(background, means3D, radii, colors, semantics, scales, rotati
     dL/dSH[k] = basis_k(view direction) * g -- see sh_grad_from_views and dist.allreduce_gradients_sh_factored."""
     lib = _lib.load()
     dev = _check_device(means3D)
+    ext = _ext()
+    if ext is not None:
+        R_layout, lazy_binning = _layout_of(R)
+        return ext.backward_ex(background, means3D, radii, _e(colors), semantics, _e(scales), _e(rotations),
+                               float(scale_modifier), _e(cov3D_precomp), viewmatrix, projmatrix, float(tan_fovx),
+                               float(tan_fovy), dL_dout_color, dL_dout_semantic, dL_dout_depth, dL_dout_alpha, _e(sh),
+                               int(degree), campos, geomBuffer, R_layout,
+                               binningBuffer if lazy_binning is None else lazy_binning, imageBuffer, alphas, bool(debug),
+                               bool(sh_factored))
     P = int(means3D.size(0))
     # the reference reads H, W off dL_dout_color (rasterize_points.cu:243-244); here any upstream gradient may be
     # None (an output the loss does not use), so the sizes come from tensors that always exist
@@ -539,6 +619,13 @@ def rasterize_gaussians_backward_semantics(background, means3D, radii, semantics
     dL_dsemantics of rasterize_gaussians_backward."""
     lib = _lib.load()
     dev = _check_device(means3D)
+    ext = _ext()
+    if ext is not None:
+        R_layout, lazy_binning = _layout_of(R)
+        return ext.backward_semantics(background, means3D, radii, semantics, viewmatrix, projmatrix, float(tan_fovx),
+                                      float(tan_fovy), dL_dout_semantic, campos, geomBuffer, R_layout,
+                                      binningBuffer if lazy_binning is None else lazy_binning, imageBuffer, alphas,
+                                      int(sh_degree), bool(debug))
     P = int(means3D.size(0))
     S = int(dL_dout_semantic.size(0))
     H, W = int(dL_dout_semantic.size(1)), int(dL_dout_semantic.size(2))
@@ -576,6 +663,15 @@ def rasterize_gaussians_trace(background, means3D, colors, img_sem, opacity, sca
     P, H, W = int(means3D.size(0)), int(image_height), int(image_width)
     if img_sem is None or img_sem.numel() == 0:
         raise RuntimeError("img_sem [S,H,W] is required")
+    ext = _ext()
+    if ext is not None:
+        res = ext.rasterize_gaussians_trace(background, means3D, _e(colors), img_sem, _e(opacity), _e(scales),
+                                            _e(rotations), float(scale_modifier), _e(cov3D_precomp), viewmatrix,
+                                            projmatrix, float(tan_fovx), float(tan_fovy), H, W, _e(sh), int(degree),
+                                            campos, bool(prefiltered), bool(debug))
+        if P > 0:
+            _note_count(dev, P, res[0])
+        return res
     S = int(img_sem.size(0))
     f32 = dict(dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
@@ -610,6 +706,9 @@ def mark_visible(means3D, viewmatrix, projmatrix):
     """-> bool[P]: view-space z > 0.2 (cuda_rasterizer/auxiliary.h:139-164)."""
     lib = _lib.load()
     dev = _check_device(means3D)
+    ext = _ext()
+    if ext is not None:
+        return ext.mark_visible(means3D, viewmatrix, projmatrix)
     P = int(means3D.size(0))
     with torch.cuda.device(dev):
         present = torch.zeros((P,), dtype=torch.bool, device=dev)

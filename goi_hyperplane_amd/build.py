@@ -39,6 +39,33 @@ UNITS = {
 }
 
 
+EXT = os.path.join(LIBDIR, "_goi_C.so")  # the compiled torch binding (csrc/torch_binding.cpp), host C++ only
+EXT_SRC = os.path.join(CSRC, "torch_binding.cpp")
+
+
+def build_torch_binding(force: bool = False, verbose: bool = False) -> str:
+    """g++ against the torch headers, linked with libgoi_raster.so (rpath $ORIGIN).  No hipcc, no hipify: the file
+    contains no device code.  This is the binding a maintainer of the reference would build in place of
+    submodules/diff-gaussian-rasterization (rasterize_points.cu + ext.cpp); _C.py uses it when it is there."""
+    import sysconfig
+    import torch
+    hdr = os.path.join(ROOT, "include", "goi_raster.h")
+    if not force and os.path.exists(EXT) and all(os.path.getmtime(f) <= os.path.getmtime(EXT) for f in (EXT_SRC, hdr, LIB)):
+        return EXT
+    tdir = os.path.dirname(torch.__file__)
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1",
+           "-DUSE_ROCM=1", "-DTORCH_EXTENSION_NAME=_goi_C", "-DTORCH_API_INCLUDE_EXTENSION_H",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}",
+           "-I" + os.path.join(tdir, "include"), "-I" + os.path.join(tdir, "include", "torch", "csrc", "api", "include"),
+           "-I" + sysconfig.get_paths()["include"], "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"),
+           EXT_SRC, "-o", EXT, "-L" + os.path.join(tdir, "lib"), "-ltorch", "-ltorch_cpu", "-ltorch_python", "-lc10",
+           "-lc10_hip", "-ltorch_hip", "-L" + LIBDIR, "-lgoi_raster", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return EXT
+
+
 def _newer(src: str, dst: str) -> bool:
     return (not os.path.exists(dst)) or os.path.getmtime(src) > os.path.getmtime(dst)
 
@@ -71,6 +98,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+    build_torch_binding(force=force, verbose=verbose)
     return LIB
 
 

@@ -468,10 +468,14 @@ int goi_raster_ticket_result(int ticket, int wait, int* num_rendered) {
 int goi_raster_forward_redo(const GoiRasterScene* scene, int num_rendered, void* geom_buffer, void* image_buffer,
                             void* binning_buffer, float* out_color, float* out_semantic, float* out_depth,
                             float* out_alpha, const int* radii, void* stream) {
-    if (validate(scene, true)) return -1;
+    // (the back half of a frame reads P, S, W, H, the semantic rows and the background from the scene; everything else
+    // comes from the geometry workspace of the first attempt, so only those fields are checked)
+    if (!scene) return fail("scene is NULL");
     const GoiRasterScene& sc = *scene;
+    if (sc.P <= 0 || sc.W <= 0 || sc.H <= 0 || sc.S < 1 || sc.S > 32) return fail("goi_raster_forward_redo: bad P/W/H/S");
+    if (!sc.semantics || !sc.bg || !radii) return fail("goi_raster_forward_redo: semantics, bg and radii are required");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (sc.P == 0 || num_rendered < 0) return fail("goi_raster_forward_redo: nothing to redo");
+    if (num_rendered < 0) return fail("goi_raster_forward_redo: nothing to redo");
     if (!geom_buffer || !image_buffer || (num_rendered > 0 && !binning_buffer)) return fail("workspace pointer is NULL");
     GeomView g;
     ImageView im;

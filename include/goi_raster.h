@@ -111,6 +111,7 @@ int goi_raster_forward(const GoiRasterScene* scene, void* geom_buffer, void* ima
  *       workspace, into a binning buffer of goi_raster_binning_bytes(n) bytes: afterwards outputs and workspaces are
  *       bit-identical to goi_raster_forward's, and R = n.
  *
+ * goi_raster_forward_redo reads only P, S, W, H, semantics and bg from `scene` (the other fields may be NULL).
  * Nothing here waits for the device unless asked to (wait != 0).  Every ticket must be resolved exactly once.
  * Not available with scene->debug (which synchronises after every stage) or for P == 0. */
 int goi_raster_forward_async(const GoiRasterScene* scene, void* geom_buffer, void* image_buffer, void* binning_buffer,

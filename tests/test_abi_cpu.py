@@ -39,6 +39,23 @@ def test_library_exports_every_declared_symbol(lib):
     assert lib.goi_raster_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define GOI_RASTER_ABI_VERSION (\d+)", hdr).group(1))
 
 
+def test_compiled_binding_is_built_and_exports_the_reference_surface(lib):
+    """lib/_goi_C.so (csrc/torch_binding.cpp, host C++ against the torch headers): the four functions of the reference's
+    pybind module (ext.cpp:15-20) under the reference's names, built against the same ABI version."""
+    from goi_hyperplane_amd import _C, _lib
+    from goi_hyperplane_amd.build import EXT
+    assert os.path.exists(EXT), "build() must produce the compiled binding"
+    _C.set_binding("compiled")
+    ext = _C._ext()
+    for name in ("rasterize_gaussians", "rasterize_gaussians_backward", "rasterize_gaussians_trace", "mark_visible"):
+        assert callable(getattr(ext, name)), name
+    assert ext.abi_version() == _lib.ABI_VERSION
+    assert _C.binding() == "compiled"
+    import torch
+    with pytest.raises(RuntimeError, match="no CPU fallback"):  # the loud CPU refusal survives the binding
+        ext.mark_visible(torch.zeros(4, 3), torch.eye(4), torch.eye(4))
+
+
 def test_scene_struct_layout_matches_c(tmp_path):
     """The ctypes mirror must have exactly the layout gcc gives `struct GoiRasterScene`."""
     import subprocess
