@@ -135,6 +135,9 @@ def main():
     ap.add_argument("--forward", choices=["speculative", "exact"], default=None,
                     help="forward mode (default: the package default, speculative = no host round trip)")
     ap.add_argument("--no-fp32-flush", action="store_true", help="skip the secondary exact-fp32-flush figure")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="--gpus > 1: wait for each step's gradient exchange inside the step instead of letting it run "
+                         "behind the next step's render + backward")
     ap.add_argument("--no-stage-timing", action="store_true")
     ap.add_argument("--no-semantic-finetune", action="store_true",
                     help="skip the secondary semantics-only-training figure")
@@ -169,7 +172,8 @@ def main():
     from goi_hyperplane_amd import rasterizer
     if args.forward:
         rasterizer.set_forward_mode(speculative=args.forward == "speculative")
-    from goi_hyperplane_amd.dist import allreduce_gradients, allreduce_gradients_sh_factored
+    from goi_hyperplane_amd.dist import (allreduce_gradients, allreduce_gradients_async,
+                                         allreduce_gradients_sh_factored, allreduce_gradients_sh_factored_async)
     from goi_hyperplane_amd.render import GaussianSet, PipelineParams, TorchCamera, render
     from goi_hyperplane_amd.scene import make_camera, make_scene
     _lib.load()
@@ -202,17 +206,40 @@ def main():
     exchange = {"mode": "allreduce", "note": None}
     non_sh_params = [pc._xyz, pc._semantics, pc._opacity, pc._scaling, pc._rotation]
 
-    def step(i, record=False):
+    # Gradient exchange in flight: the collective of step k is issued after its backward and waited for after step
+    # k+1's backward, so it is on the wire while the next view renders.  Every step's gradients are
+    # reduced, and the last exchange is drained inside the timed region.  --no-overlap keeps it inside the step.
+    overlap_default = not args.no_overlap
+    inflight = {"h": None}
+
+    def drain():
+        if inflight["h"] is not None:
+            inflight["h"].wait()
+            inflight["h"] = None
+
+    def step(i, record=False, overlap=None):
+        overlap = overlap_default if overlap is None else overlap
         cam = cams[(i * world + rank) % len(cams)]  # rank r takes views r, r+G, ... of the cycle
         for p in params:
             p.grad = None
         out = render(cam, pc, pipe, bg)
         torch.autograd.backward((out["render"], out["semantics"]), (g_color, g_sem))
         if dist is not None:
-            if exchange["mode"] == "factored":
-                allreduce_gradients_sh_factored(non_sh_params, (pc._features,), pc._xyz, rasterizer.take_sh_factor(), dist)
+            if not overlap:
+                drain()
+                if exchange["mode"] == "factored":
+                    allreduce_gradients_sh_factored(non_sh_params, (pc._features,), pc._xyz, rasterizer.take_sh_factor(), dist)
+                else:
+                    allreduce_gradients(reduce_params, dist)
             else:
-                allreduce_gradients(reduce_params, dist)
+                prev = inflight["h"]
+                if exchange["mode"] == "factored":
+                    inflight["h"] = allreduce_gradients_sh_factored_async(non_sh_params, (pc._features,), pc._xyz,
+                                                                          rasterizer.take_sh_factor(), dist)
+                else:
+                    inflight["h"] = allreduce_gradients_async(reduce_params, dist)
+                if prev is not None:
+                    prev.wait()
         if record:
             stats["radii"] = out["radii"]
         return out
@@ -223,11 +250,11 @@ def main():
         # failure falls back to the plain all-reduce and is reported in config.exchange.
         local_ok, why = True, ""
         try:
-            step(0)
+            step(0, overlap=False)
             want = pc._features.grad.clone()
             exchange["mode"] = "factored"
             rasterizer.set_backward_mode(sh_factored=True)
-            step(0)
+            step(0, overlap=False)
             err = float((pc._features.grad - want).abs().max())
             scale = float(want.abs().max())
             if not err <= 1e-5 * scale + 1e-12:
@@ -246,6 +273,7 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    drain()
     # workload statistics of the views this rank will time (outside the timed region).  N is SURVEY 8(d)'s instance
     # count -- every tile of every Gaussian's 3-sigma rectangle, what the reference lists and what the algorithmic
     # bytes are charged on (cull_variant 0); N_listed is what this build actually emits, sorts and walks.
@@ -292,6 +320,7 @@ def main():
         _lib.profile_enable(True)
         for i in range(min(args.steps, 10)):
             step(args.warmup + i)
+        drain()
         barrier()
         _lib.profile_enable(False)
         stages = _lib.profile_collect()
@@ -308,6 +337,7 @@ def main():
     for i in range(args.steps):
         step(args.warmup + i)
         marks[i + 1] = time.perf_counter()
+    drain()  # the last step's exchange completes inside the timed region
     barrier()
     elapsed = time.perf_counter() - t0
     spec1 = rasterizer.speculation_stats()
@@ -317,10 +347,35 @@ def main():
     if timing:
         _lib.profile_enable(False)
         stages[dominant] = _lib.profile_collect()[dominant]
+    own_elapsed = elapsed
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # the same steps with the exchange waited for inside every step (what a one-view-per-optimizer-step loop pays)
+    serialized = None
+    if dist is not None and overlap_default and world > 1:
+        for i in range(2):
+            step(i, overlap=False)
+        barrier()
+        z0 = time.perf_counter()
+        nz = max(5, min(args.steps, 20))
+        for i in range(nz):
+            step(args.warmup + i, overlap=False)
+        barrier()
+        tz = torch.tensor([time.perf_counter() - z0], dtype=torch.float64, device=dev)
+        dist.all_reduce(tz, op=dist.ReduceOp.MAX)
+        serialized = {"views_per_s": nz * world / float(tz.item()), "ms_per_step": float(tz.item()) / nz * 1e3, "steps": nz}
+    # one line per rank, so that a scaling run explains itself: is a rank slow on the GPU, or waiting for the wire?
+    per_rank = None
+    if dist is not None:
+        mine = {"rank": rank, "ms_per_step": own_elapsed / args.steps * 1e3,
+                "gpu_stage_ms_sum": (sum(ms / max(c, 1) for ms, c in stages.values()) if stages else None),
+                "dominant_stage": dominant, "dominant_ms": (stages[dominant][0] / max(stages[dominant][1], 1)
+                                                            if stages and dominant else None),
+                "step_enqueue_ms_median": step_enqueue_ms["median"] if step_enqueue_ms else None}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
 
     # render ms/frame: forward only, no_grad (the GUI path, gui/main.py:556-602), outside the step timing
     with torch.no_grad():
@@ -398,11 +453,13 @@ def main():
         try:
             for i in range(2):
                 step(i)
+            drain()
             barrier()
             f0 = time.perf_counter()
             nf = max(5, min(args.steps, 30))
             for i in range(nf):
                 step(args.warmup + i)
+            drain()
             barrier()
             f_elapsed = time.perf_counter() - f0
         finally:
@@ -477,6 +534,11 @@ def main():
             "fp32_flush": fp32_flush,
             # forward mode of the timed region and what the speculation did in it (exact_frames / waits / overflows
             # should all be 0: nothing in the timed steps waited for the device)
+            "exchange_overlap": (None if world <= 1 else
+                                 ("in flight behind the next step's render + backward" if overlap_default else "inside the step")),
+            "serialized_exchange": serialized,  # same steps, exchange waited for inside each step
+            "per_rank": per_rank,
+            "binding": _C.binding(),
             "forward_mode": _C._FWD["mode"],
             "speculation": {k: spec1[k] - spec0[k] for k in spec1},
             "roofline": roofline,

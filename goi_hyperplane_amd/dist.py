@@ -157,3 +157,78 @@ def allreduce_gradients_sh_factored(params, sh_leaves, means3D, factor, dist, re
         raise ValueError(f"sh_leaves hold {k} coefficients, the rasterizer was given {dsh.shape[1]}")
     for w in works:
         w.wait()
+
+
+# ---- exchange in flight: overlap the collective with the next view's render ---------------------------------------------
+class PendingExchange:
+    """Handle of a gradient exchange that is on the wire.  It owns the gradient tensors being reduced (so the caller
+    may drop or replace `.grad` at once) and finishes the exchange in wait(): the collectives are waited for on the
+    current stream and, for the factored form, dL/dSH is rebuilt and handed to the SH leaves."""
+
+    def __init__(self, works, keep, finish=None):
+        self.works, self.keep, self._finish, self.done = list(works), keep, finish, False
+
+    def wait(self):
+        if self.done:
+            return
+        for w in self.works:
+            w.wait()
+        if self._finish is not None:
+            self._finish()
+        self.done, self.works, self._finish = True, [], None
+
+
+def allreduce_gradients_async(params, dist) -> PendingExchange:
+    """allreduce_gradients without the wait: the collectives are issued (RCCL runs them on its own stream, ordered
+    after the work already queued on the current one) and the handle is returned at once.  The next view's forward and
+    backward can be enqueued while the reduction is on the wire -- the backward writes its gradients into a fresh flat
+    buffer every call, so the buffer in flight is never touched ("double buffering" by allocation).  Legal wherever
+    the reduced gradient is consumed later than the next render starts: several views accumulated per optimizer step,
+    or one-step-delayed updates.  wait() before reading the reduced `.grad` tensors (they are the ones the parameters
+    held when this was called)."""
+    grads = [p.grad for p in params if p.grad is not None]
+    spans = coalesce_shared_storage(grads) if grads else []
+    works = [dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True) for g in spans]
+    return PendingExchange(works, (grads, spans))
+
+
+def allreduce_gradients_sh_factored_async(params, sh_leaves, means3D, factor, dist, reconstruct=None) -> PendingExchange:
+    """allreduce_gradients_sh_factored with the collectives left in flight; wait() rebuilds dL/dSH from the gathered
+    factors and assigns / accumulates it into the SH leaves."""
+    if factor is None:
+        raise RuntimeError("no SH factor: run the backward with rasterizer.set_backward_mode(sh_factored=True)")
+    if reconstruct is None:
+        from . import _C
+        reconstruct = _C.sh_grad_from_views
+    world = dist.get_world_size()
+    gcol = factor["gcol"].detach().contiguous()
+    campos = factor["campos"].detach().reshape(1, 3).to(gcol.dtype).contiguous()
+    all_g = torch.empty((world,) + tuple(gcol.shape), dtype=gcol.dtype, device=gcol.device)
+    all_c = torch.empty((world, 3), dtype=gcol.dtype, device=gcol.device)
+    try:
+        works = [dist.all_gather_into_tensor(all_g, gcol, async_op=True),
+                 dist.all_gather_into_tensor(all_c, campos, async_op=True)]
+    except (RuntimeError, AttributeError, NotImplementedError):  # a backend without the flat form
+        works = [dist.all_gather(list(all_g.unbind(0)), gcol, async_op=True),
+                 dist.all_gather(list(all_c.unbind(0)), campos.reshape(3), async_op=True)]
+    grads = [p.grad for p in params if p.grad is not None]
+    spans = coalesce_shared_storage(grads) if grads else []
+    works += [dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True) for g in spans]
+    means = means3D.detach()
+    degree, M = int(factor["degree"]), int(factor["M"])
+    result = {}
+
+    def finish():
+        dsh = reconstruct(means, all_c, all_g, degree, M)
+        k = 0
+        for leaf in sh_leaves:
+            n = int(leaf.shape[1])
+            part = dsh[:, k:k + n, :].contiguous() if (k or n != dsh.shape[1]) else dsh
+            result[id(leaf)] = part
+            k += n
+        if k != dsh.shape[1]:
+            raise ValueError(f"sh_leaves hold {k} coefficients, the rasterizer was given {dsh.shape[1]}")
+
+    h = PendingExchange(works, (grads, spans, gcol, campos, all_g, all_c), finish)
+    h.sh_grads = result  # id(leaf) -> its reduced dL/dSH part, filled by wait() (the leaves' .grad may have moved on)
+    return h

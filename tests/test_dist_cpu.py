@@ -66,7 +66,17 @@ def _worker(rank, world, port, bucket_bytes, q):
         off += (g[n].size + 63) // 64 * 64
         params.append(p)
     local = [p.grad.clone() for p in params]
-    allreduce_gradients(params, dist, bucket_bytes=bucket_bytes)
+    if bucket_bytes == -1:  # the exchange left in flight: the handle owns the gradients, the parameters move on
+        from goi_hyperplane_amd.dist import allreduce_gradients_async
+        held = [p.grad for p in params]
+        h = allreduce_gradients_async(params, dist)
+        for p in params:
+            p.grad = None  # what a training loop does before the next view
+        h.wait()
+        for p, g_ in zip(params, held):
+            p.grad = g_
+    else:
+        allreduce_gradients(params, dist, bucket_bytes=bucket_bytes)
     q.put((rank, views[0], [x.numpy() for x in local], [p.grad.numpy() for p in params]))
     dist.barrier()
     dist.destroy_process_group()
@@ -120,13 +130,18 @@ def test_allreduce_equals_sum_of_single_view_gradients_bucketed():
     _run(1 << 12)
 
 
+def test_exchange_in_flight_equals_sum_of_single_view_gradients():
+    """allreduce_gradients_async: same sums as the blocking form, with the parameters' .grad released in between."""
+    _run(-1)
+
+
 def test_eight_ranks_allreduce_equals_sum_of_eight_single_view_gradients():
     """BASELINE config 4's exchange step at its real width (8-view batch over 8 ranks): the
     all-reduced gradient on every rank == the sum of the 8 single-view oracle gradients."""
     _run(0, world=8)
 
 
-def _worker_factored(rank, world, port, q):
+def _worker_factored(rank, world, port, q, in_flight=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -152,22 +167,32 @@ def _worker_factored(rank, world, port, q):
     dc = torch.nn.Parameter(torch.zeros(dsh.shape[0], 1, 3))
     rest = torch.nn.Parameter(torch.zeros(dsh.shape[0], 15, 3))
     local = [p.grad.clone().numpy() for p in params]
-    allreduce_gradients_sh_factored(params, (dc, rest), torch.tensor(np.asarray(sc.means3D, np.float32)), factor, dist,
-                                    reconstruct=sh_grad_from_views)
+    means = torch.tensor(np.asarray(sc.means3D, np.float32))
+    if in_flight:
+        from goi_hyperplane_amd.dist import allreduce_gradients_sh_factored_async
+        h = allreduce_gradients_sh_factored_async(params, (dc, rest), means, factor, dist, reconstruct=sh_grad_from_views)
+        h.wait()
+        dc.grad, rest.grad = h.sh_grads[id(dc)], h.sh_grads[id(rest)]
+    else:
+        allreduce_gradients_sh_factored(params, (dc, rest), means, factor, dist, reconstruct=sh_grad_from_views)
     q.put((rank, local, dsh.numpy(), [p.grad.numpy() for p in params],
            torch.cat([dc.grad, rest.grad], dim=1).numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_sh_factored_exchange_equals_sum_of_single_view_gradients():
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("in_flight", [False, True])
+def test_sh_factored_exchange_equals_sum_of_single_view_gradients(in_flight):
     """SURVEY.md 8(e) with the SH gradient exchanged as factors (all-gather of the masked colour gradients + local
-    reconstruction): same sums as the plain all-reduce, on every rank."""
+    reconstruction): same sums as the plain all-reduce, on every rank; blocking and in-flight forms."""
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_factored, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker_factored, args=(r, world, port, q, in_flight)) for r in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=120) for _ in range(world)]

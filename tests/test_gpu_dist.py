@@ -41,3 +41,26 @@ def test_two_ranks_on_one_gpu(exchange):
         assert d["config"]["allreduce_bytes"] == 20000 * 27 * 4
     else:
         assert d["config"]["allreduce_bytes"] == 20000 * 75 * 4
+
+
+@pytest.mark.parametrize("exchange", ["factored", "allreduce"])
+def test_single_rank_rccl_path_runs_on_hardware(exchange):
+    """RCCL itself (torch.distributed backend "nccl"), one rank: the process group is created on the GPU, the gradient
+    exchange of every step goes through real RCCL collectives (all-reduce; all-gather + all-reduce for the factored
+    form) issued in flight behind the next step -- the code path the 8-GPU scaling run takes, on the one GPU a test box
+    has.  (GOI_BENCH_FORCE_DIST=1: bench.py's hook for exactly this.)"""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    env = dict(os.environ, GOI_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0",
+               WORLD_SIZE="1", LOCAL_RANK="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--P", "50000",
+           "--W", "400", "--H", "304", "--no-cpu-baseline", "--no-semantic-finetune", "--no-fp32-flush", "--exchange",
+           exchange]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["value"] > 0
+    assert isinstance(d["per_rank"], list) and len(d["per_rank"]) == 1 and d["per_rank"][0]["rank"] == 0
+    assert d["per_rank"][0]["gpu_stage_ms_sum"] > 0 and d["per_rank"][0]["dominant_stage"] in d["stages"]
+    assert d["speculation"]["overflows"] == 0
