@@ -198,6 +198,16 @@ int ticket_result(int id, int wait, long long* n) {
 // counters (queued BEFORE the depth sort: preprocess has already summed num_rendered, so a host that waits for it wakes
 // up while the GPU is still sorting), depth sort, scan.  The scan also leaves num_rendered in counters[COUNTER_N] for
 // the kernels of the back half.
+int enqueue_readback(const GeomView& g, int ticket, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_ticket_mu);
+    const Ticket& t = g_tickets[ticket];
+    GOI_HIP(hipMemcpyAsync(t.pinned, g.counters, COUNTER_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    GOI_HIP(hipEventRecord(t.ev, s));
+    return 0;
+}
+
+// ticket < 0: no read-back here (the speculative forward queues it behind the blend instead: nobody is waiting for it,
+// and a device-to-host copy in the middle of the frame costs the stream a ~10 us bubble)
 int enqueue_front(const GoiRasterScene& sc, GeomView& g, ImageView& im, int* radii, int ticket, const uint32_t** order_out,
                   hipStream_t s) {
     const int P = sc.P;
@@ -214,12 +224,7 @@ int enqueue_front(const GoiRasterScene& sc, GeomView& g, ImageView& im, int* rad
         launch_preprocess_fwd(sc, g, radii, im.ranges, gx * gy, s);  // also zeroes the tile ranges
     }
     if (check_stage(sc, s, "preprocess")) return -1;
-    {
-        std::lock_guard<std::mutex> lk(g_ticket_mu);
-        const Ticket& t = g_tickets[ticket];
-        GOI_HIP(hipMemcpyAsync(t.pinned, g.counters, COUNTER_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        GOI_HIP(hipEventRecord(t.ev, s));
-    }
+    if (ticket >= 0 && enqueue_readback(g, ticket, s)) return -1;
     int order_idx;
     {
         StageTimer t(GOI_STAGE_DEPTH_SORT, s);
@@ -442,7 +447,7 @@ int goi_raster_forward_async(const GoiRasterScene* scene, void* geom_buffer, voi
     if (ticket < 0) return -1;
     const uint32_t* order = nullptr;
     const uint32_t* plist = nullptr;
-    if (enqueue_front(sc, g, im, radii, ticket, &order, s) ||
+    if (enqueue_front(sc, g, im, radii, /*ticket=*/-1, &order, s) ||
         enqueue_back(sc, g, im, bv, capacity, /*exact=*/false, order, radii, &plist, s)) {
         ticket_release(ticket);
         return -1;
@@ -450,6 +455,10 @@ int goi_raster_forward_async(const GoiRasterScene* scene, void* geom_buffer, voi
     {
         StageTimer t(GOI_STAGE_BLEND_FWD, s);
         launch_render_fwd(sc, g, im, plist, out_color, out_semantic, out_depth, out_alpha, s);
+    }
+    if (enqueue_readback(g, ticket, s)) {
+        ticket_release(ticket);
+        return -1;
     }
     if (hipGetLastError() != hipSuccess) {
         ticket_release(ticket);

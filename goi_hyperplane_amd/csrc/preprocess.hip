@@ -591,7 +591,13 @@ __global__ __launch_bounds__(256) void mark_visible_k(int P, const float* __rest
 // is what matters here: the lanes fetch 16 instances x 4 validity bytes in one load, the flagged
 // slots of the chunk are packed into a 64-bit mask (quadrant-major), and up to 16 rows are requested
 // back to back before the first is consumed (lane e reads row elements e, e+16, ...: coalesced).
-template <int K>  // K = row_floats / 16
+// The kernel is LATENCY bound, not bandwidth bound: a Gaussian costs a chain of three dependent memory round trips
+// (slot range -> validity bytes -> rows) for ~8 rows of payload, and with one Gaussian per quarter wave the chip works
+// through 250 K short-lived waves in ~30 rounds of that chain (223 us for 0.5 GB).  So every quarter wave walks GPQ
+// Gaussians in a software pipeline: while the rows of Gaussian k are summed, the validity word of k+1 and the slot
+// range of k+2 are already on their way -- one exposed round trip per Gaussian instead of three, 1/GPQ of the waves.
+// The order in which a Gaussian's rows are added is unchanged (bit-identical gradients).
+template <int K, int GPQ>  // K = row_floats / 16; GPQ = Gaussians per quarter wave
 __global__ __launch_bounds__(256) void reduce_rows_k(int P, int S, int nch, uint32_t N_cap, const uint32_t* __restrict__ n_dev,
                                                      const uint32_t* __restrict__ order,
                                                      const uint32_t* __restrict__ offsets,
@@ -606,80 +612,114 @@ __global__ __launch_bounds__(256) void reduce_rows_k(int P, int S, int nch, uint
     // the first N_cap instances)
     const uint32_t N = min(N_cap, *n_dev);
     const int lane = threadIdx.x & 63, quarter = lane >> 4, e = lane & 15;
+    const uint32_t* flags32 = reinterpret_cast<const uint32_t*>(flags);
+    const int nsem = nch - 4;
     // Gaussians are visited in DEPTH order: that is the order of the slot space, so consecutive quarter
     // waves stream through rows[] and flags[] front to back (DRAM-page and TLB friendly); only the
-    // per-Gaussian outputs are scattered
-    const int i = blockIdx.x * 16 + (threadIdx.x >> 4);
-    const bool live = i < P;
-    // slots of the i-th Gaussian in depth order: [offsets[i], offsets[i+1]) -- straight from the prefix sum, so the
-    // chain of dependent loads is offsets -> flags -> rows; the Gaussian's id is only needed for the final store
-    const uint32_t g = live ? order[i] : 0u;
-    const uint32_t off0 = live ? min(offsets[i], N) : 0u;
-    const uint32_t off1 = live ? (i + 1 < P ? min(offsets[i + 1], N) : N) : 0u;
-    const uint32_t cnt = off1 - off0;
-    const size_t inst0 = off0;
-    const uint32_t* flags32 = reinterpret_cast<const uint32_t*>(flags);
-    float sum[K];
-#pragma unroll
-    for (int k = 0; k < K; k++) sum[k] = 0.f;
-    // every lane of the wave must reach the ballots: loop to the wave's largest count
-    uint32_t cmax = cnt;
-#pragma unroll
-    for (int d = 32; d >= 16; d >>= 1) cmax = max(cmax, (uint32_t)__shfl_xor((int)cmax, d, 64));
-    for (uint32_t c = 0; c < cmax; c += 16) {
-        const uint32_t w = (c + e < cnt) ? flags32[inst0 + c + e] : 0u;  // 4 quadrant bytes of instance c+e
-        unsigned long long m = 0;  // bit 16q + i: quadrant q of instance c+i is valid
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const unsigned long long bal = __ballot(((w >> (8 * q)) & 0xFFu) != 0);
-            m |= ((bal >> (16 * quarter)) & 0xFFFFull) << (16 * q);
+    // per-Gaussian outputs are scattered.  Step k of the block covers 16 consecutive Gaussians.
+    const int i0 = blockIdx.x * (16 * GPQ) + (threadIdx.x >> 4);
+    struct Meta {
+        uint32_t g, off0, off1;
+    };
+    // slots of the i-th Gaussian in depth order: [offsets[i], offsets[i+1]) -- straight from the prefix sum; the
+    // Gaussian's id is only needed for the final store
+    auto load_meta = [&](int k) {
+        const int i = i0 + 16 * k;
+        Meta m{0u, 0u, 0u};
+        if (k < GPQ && i < P) {
+            m.g = order[i];
+            m.off0 = min(offsets[i], N);
+            m.off1 = i + 1 < P ? min(offsets[i + 1], N) : N;
         }
-        const float* chunk = rows + (inst0 + c) * 4 * RF;
-        while (m) {
-            float v[INFLIGHT][K];
+        return m;
+    };
+    // the 4 quadrant bytes of instance off0 + c + e (first chunk of a Gaussian: c = 0)
+    auto load_flags = [&](const Meta& m, uint32_t c) { return (c + e < m.off1 - m.off0) ? flags32[m.off0 + c + e] : 0u; };
+
+    Meta cur = load_meta(0), nxt = load_meta(1);
+    uint32_t w_cur = load_flags(cur, 0);
+#pragma unroll 1
+    for (int k = 0; k < GPQ; k++) {
+        if (i0 + 16 * k - (int)(threadIdx.x >> 4) >= P) break;  // (block-uniform: nothing left for any quarter wave)
+        const Meta nn = load_meta(k + 2);        // two Gaussians ahead: slot range
+        const uint32_t w_nxt = load_flags(nxt, 0);  // one ahead: validity bytes of its first 16 instances
+        const bool live = i0 + 16 * k < P;
+        const uint32_t cnt = cur.off1 - cur.off0;
+        const size_t inst0 = cur.off0;
+        float sum[K];
 #pragma unroll
-            for (int i = 0; i < INFLIGHT; i++) {
-                const bool have = m != 0;
-                const int bit = have ? __builtin_ctzll(m) : 0;
-                if (have) m &= m - 1;
-                const float* r = chunk + (size_t)((bit & 15) * 4 + (bit >> 4)) * RF;
-                if (K == 2) {  // one 8-byte load per lane: the quarter wave reads the 128-byte row in one request
-                    const float2 t = have ? reinterpret_cast<const float2*>(r)[e] : make_float2(0.f, 0.f);
-                    v[i][0] = t.x;
-                    v[i][K - 1] = t.y;
-                } else {
+        for (int kk = 0; kk < K; kk++) sum[kk] = 0.f;
+        // every lane of the wave must reach the ballots: loop to the wave's largest count
+        uint32_t cmax = cnt;
 #pragma unroll
-                    for (int k = 0; k < K; k++) v[i][k] = have ? r[e + 16 * k] : 0.f;
+        for (int d = 32; d >= 16; d >>= 1) cmax = max(cmax, (uint32_t)__shfl_xor((int)cmax, d, 64));
+        for (uint32_t c = 0; c < cmax; c += 16) {
+            const uint32_t w = c == 0 ? w_cur : load_flags(cur, c);  // 4 quadrant bytes of instance c+e
+            unsigned long long m = 0;  // bit 16q + i: quadrant q of instance c+i is valid
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const unsigned long long bal = __ballot(((w >> (8 * q)) & 0xFFu) != 0);
+                m |= ((bal >> (16 * quarter)) & 0xFFFFull) << (16 * q);
+            }
+            const float* chunk = rows + (inst0 + c) * 4 * RF;
+#ifdef GOI_EXP_DENSE2
+            int dense_j = 0;  // TIMING EXPERIMENT (wrong results): the j-th valid row of a Gaussian is read from a compact,
+                              // contiguous position -- what a densely packed row store would look like to this kernel
+#endif
+            while (m) {
+                float v[INFLIGHT][K];
+#pragma unroll
+                for (int i = 0; i < INFLIGHT; i++) {
+                    const bool have = m != 0;
+                    const int bit = have ? __builtin_ctzll(m) : 0;
+                    if (have) m &= m - 1;
+#ifdef GOI_EXP_DENSE2
+                    const float* r = rows + ((inst0 + c) * 4 / 5 + (size_t)(dense_j++)) * RF;
+#else
+                    const float* r = chunk + (size_t)((bit & 15) * 4 + (bit >> 4)) * RF;
+#endif
+                    if (K == 2) {  // one 8-byte load per lane: the quarter wave reads the 128-byte row in one request
+                        const float2 t = have ? reinterpret_cast<const float2*>(r)[e] : make_float2(0.f, 0.f);
+                        v[i][0] = t.x;
+                        v[i][K - 1] = t.y;
+                    } else {
+#pragma unroll
+                        for (int kk = 0; kk < K; kk++) v[i][kk] = have ? r[e + 16 * kk] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < INFLIGHT; i++)
+#pragma unroll
+                    for (int kk = 0; kk < K; kk++) sum[kk] += v[i][kk];
+            }
+        }
+        if (live) {
+            const uint32_t g = cur.g;
+#pragma unroll
+            for (int kk = 0; kk < K; kk++) {
+                const float v = sum[kk];
+                const int el = K == 2 ? 2 * e + kk : e + 16 * kk;  // element of the row this lane summed
+                if (el < nsem) {
+                    if (el < S) dL_dsemantic[(size_t)g * S + el] = v;
+                } else if (el < nsem + 3) {
+                    dL_dcolor[(size_t)g * 3 + (el - nsem)] = v;
+                } else if (el == nsem + 3) {
+                    dL_ddepth[g] = v;
+                } else if (el < nch + 2) {
+                    dL_dmean2D[(size_t)g * 3 + (el - nch)] = v;
+                    if (el == nch + 1) dL_dmean2D[(size_t)g * 3 + 2] = 0.f;
+                } else if (el < nch + 5) {
+                    const int c = el - nch - 2;  // a, b, c -> x, y, w of the [P,2,2] conic gradient
+                    dL_dconic[(size_t)g * 4 + (c == 2 ? 3 : c)] = v;
+                    if (c == 2) dL_dconic[(size_t)g * 4 + 2] = 0.f;
+                } else if (el == nch + 5) {
+                    dL_dopacity[g] = v;
                 }
             }
-#pragma unroll
-            for (int i = 0; i < INFLIGHT; i++)
-#pragma unroll
-                for (int k = 0; k < K; k++) sum[k] += v[i][k];
         }
-    }
-    if (!live) return;
-    const int nsem = nch - 4;
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-        const float v = sum[k];
-        const int el = K == 2 ? 2 * e + k : e + 16 * k;  // element of the row this lane summed
-        if (el < nsem) {
-            if (el < S) dL_dsemantic[(size_t)g * S + el] = v;
-        } else if (el < nsem + 3) {
-            dL_dcolor[(size_t)g * 3 + (el - nsem)] = v;
-        } else if (el == nsem + 3) {
-            dL_ddepth[g] = v;
-        } else if (el < nch + 2) {
-            dL_dmean2D[(size_t)g * 3 + (el - nch)] = v;
-            if (el == nch + 1) dL_dmean2D[(size_t)g * 3 + 2] = 0.f;
-        } else if (el < nch + 5) {
-            const int c = el - nch - 2;  // a, b, c -> x, y, w of the [P,2,2] conic gradient
-            dL_dconic[(size_t)g * 4 + (c == 2 ? 3 : c)] = v;
-            if (c == 2) dL_dconic[(size_t)g * 4 + 2] = 0.f;
-        } else if (el == nch + 5) {
-            dL_dopacity[g] = v;
-        }
+        cur = nxt;
+        nxt = nn;
+        w_cur = w_nxt;
     }
 }
 
@@ -898,20 +938,25 @@ void launch_sh_grad_from_views(int P, int D, int M, int V, const float* means3D,
     sh_grad_from_views_k<<<dim3((P + 255) / 256), dim3(256), lds, s>>>(P, D, M, V, means3D, campos, gcol, dL_dsh);
 }
 
+#ifndef GOI_REDUCE_GPQ
+#define GOI_REDUCE_GPQ 2
+#endif
+constexpr int REDUCE_GPQ = GOI_REDUCE_GPQ;  // Gaussians per quarter wave of reduce_rows_k
+
 void launch_reduce_rows(const GoiRasterScene& sc, const GeomView& g, int N, const BwdScratchView& scr, float* dL_dmean2D,
                         float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dsemantic, float* dL_ddepth,
                         hipStream_t s) {
     const int rf = bwd_row_floats(sc.S), nch = 4 * ((sc.S + 3) / 4) + 4;
-    const dim3 grid((sc.P + 15) / 16);
+    const dim3 grid((sc.P + 16 * REDUCE_GPQ - 1) / (16 * REDUCE_GPQ));
     const uint32_t* order = g.sort_vals[depth_sort_result_index()];
     if (rf == 32)
-        reduce_rows_k<2><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, scr.rows, scr.flags,
+        reduce_rows_k<2, REDUCE_GPQ><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, scr.rows, scr.flags,
                                                     dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dsemantic, dL_ddepth);
     else if (rf == 16)
-        reduce_rows_k<1><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, scr.rows, scr.flags,
+        reduce_rows_k<1, REDUCE_GPQ><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, scr.rows, scr.flags,
                                                     dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dsemantic, dL_ddepth);
     else
-        reduce_rows_k<3><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, scr.rows, scr.flags,
+        reduce_rows_k<3, REDUCE_GPQ><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, scr.rows, scr.flags,
                                                     dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dsemantic, dL_ddepth);
 }
 
@@ -919,13 +964,13 @@ void launch_reduce_sem_rows(const GoiRasterScene& sc, const GeomView& g, int N, 
                             int row_floats, float* dL_dsemantic, hipStream_t s) {
     // rows hold semantic channels only: with nch = row_floats + 4 every element index is a semantic one
     const int nch = row_floats + 4;
-    const dim3 grid((sc.P + 15) / 16);
+    const dim3 grid((sc.P + 16 * REDUCE_GPQ - 1) / (16 * REDUCE_GPQ));
     const uint32_t* order = g.sort_vals[depth_sort_result_index()];
     if (row_floats == 16)
-        reduce_rows_k<1><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, rows, flags, nullptr,
+        reduce_rows_k<1, REDUCE_GPQ><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, rows, flags, nullptr,
                                                     nullptr, nullptr, nullptr, dL_dsemantic, nullptr);
     else
-        reduce_rows_k<2><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, rows, flags, nullptr,
+        reduce_rows_k<2, REDUCE_GPQ><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, rows, flags, nullptr,
                                                     nullptr, nullptr, nullptr, dL_dsemantic, nullptr);
 }
 

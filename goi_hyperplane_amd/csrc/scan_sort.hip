@@ -251,6 +251,9 @@ __global__ __launch_bounds__(SORT_THREADS) void sweep_hist_k(const uint32_t* __r
     for (int i = threadIdx.x; i < MAX_PASSES * RADIX_MAX; i += SORT_THREADS) (&h[0][0])[i] = 0;
     __syncthreads();
     const size_t base = (size_t)blockIdx.x * SORT_TILE;
+    // (one LDS atomic per key and pass.  The keys are far from uniform -- float bits with a handful of exponents, half of
+    // them the 0xFFFFFFFF of culled Gaussians -- but counting lanes that share a digit with ballots and adding once per
+    // group was SLOWER than letting the LDS serialise the same-address atomics: depth sort 0.098 -> 0.118 ms.)
 #pragma unroll 4
     for (int k = 0; k < SORT_ITEMS; k++) {
         size_t i = base + (size_t)k * SORT_THREADS + threadIdx.x;

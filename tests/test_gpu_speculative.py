@@ -193,3 +193,62 @@ def test_default_policy_first_frame_exact_then_nothing_waits(dev):
     assert s1["speculative_frames"] - s0["speculative_frames"] == 23
     assert s1["overflows"] == s0["overflows"]
     assert len(_C._SPEC[dev.index]["pending"]) == 0
+
+
+@pytest.mark.parametrize("binding", ["ctypes", "compiled"])
+def test_two_host_threads_on_two_streams(dev, binding):
+    """concurrent calls on different streams are legal for a drop-in.  Two Python threads, each with its
+    own stream and scene, render + backpropagate concurrently (speculative forwards: tickets, the capacity policy and the
+    stage-profile state are shared process-wide behind locks); every result equals the single-threaded one bit for bit."""
+    import threading
+    from goi_hyperplane_amd import _C
+    from goi_hyperplane_amd.render import GaussianSet, PipelineParams, TorchCamera, render
+    _C.set_binding(binding)
+    try:
+        jobs = []
+        for seed, (P, W, H) in enumerate([(20000, 320, 208), (12000, 256, 192)]):
+            sc = make_scene(P, S=16, seed=40 + seed, log_scale_mean=-3.2)
+            jobs.append((GaussianSet.from_scene(sc, dev), [TorchCamera(make_camera(W, H, yaw=0.05 * i), dev) for i in range(4)]))
+        bg = torch.zeros(3, device=dev)
+
+        def run(job, stream, out, n=12):
+            pc, cams = job
+            res = []
+            with torch.cuda.stream(stream):
+                for i in range(n):
+                    for p in pc.parameters():
+                        p.grad = None
+                    o = render(cams[i % 4], pc, PipelineParams(), bg)
+                    (o["render"].sum() + o["semantics"].sum()).backward()
+                    res.append((o["render"].detach().clone(), pc._xyz.grad.clone(), pc._semantics.grad.clone()))
+            stream.synchronize()
+            out.append(res)
+
+        serial = []
+        for job in jobs:
+            run(job, torch.cuda.current_stream(dev), serial)
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream(device=dev) for _ in jobs]
+        for s in streams:
+            s.wait_stream(torch.cuda.current_stream(dev))
+        outs = [[] for _ in jobs]
+        errors = []
+
+        def guarded(*a):
+            try:
+                run(*a)
+            except Exception as ex:  # noqa: BLE001
+                errors.append(ex)
+        threads = [threading.Thread(target=guarded, args=(job, s, o)) for job, s, o in zip(jobs, streams, outs)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors
+        for want, got in zip(serial, outs):
+            for a, b in zip(want, got[0]):
+                for x, y in zip(a, b):
+                    assert torch.equal(x, y)
+    finally:
+        _C.poll_counts(wait=True)
+        _C.set_binding("compiled")
