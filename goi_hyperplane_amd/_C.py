@@ -10,6 +10,7 @@ from __future__ import annotations
 import collections
 import ctypes as C
 import os
+import threading
 import warnings
 import weakref
 
@@ -185,6 +186,7 @@ _FWD = {"mode": _env_forward_mode(), "headroom": float(os.environ.get("GOI_BINNI
         "capacity": None, "on_overflow": os.environ.get("GOI_OVERFLOW", "warn").strip().lower(),
         "max_ahead": int(os.environ.get("GOI_MAX_AHEAD", "64"))}
 _SPEC = {}  # device index -> {"high_water": int, "P": int, "pending": deque of LazyCount}
+_SPEC_LOCK = threading.RLock()
 SPECULATION_STATS = {"exact_frames": 0, "speculative_frames": 0, "overflows": 0, "redone": 0, "waits": 0}
 _MIN_CAPACITY = 1 << 16
 
@@ -242,13 +244,14 @@ def _pick_capacity(dev, P, debug, prefiltered):
 def poll_counts(dev=None, wait=False):
     """Resolve what can be resolved without waiting (wait=True: everything) on one device or all.  Called at the start
     of every forward; an overflow found here is reported per set_forward_mode(on_overflow=...)."""
-    for idx, st in list(_SPEC.items()):
-        if dev is not None and torch.device(dev).index != idx:
-            continue
-        pend = st["pending"]
-        while pend:
-            if not pend[0]._resolve(wait=wait or len(pend) > _FWD["max_ahead"], lazy=True):
-                break
+    with _SPEC_LOCK:
+        for idx, st in list(_SPEC.items()):
+            if dev is not None and torch.device(dev).index != idx:
+                continue
+            pend = st["pending"]
+            while pend:
+                if not pend[0]._resolve(wait=wait or len(pend) > _FWD["max_ahead"], lazy=True):
+                    break
 
 
 class LazyCount:
@@ -270,6 +273,10 @@ class LazyCount:
         return self._n is not None or self._error is not None
 
     def _resolve(self, wait, lazy):
+        with _SPEC_LOCK:  # (several host threads may poll the same pending frame)
+            return self._resolve_locked(wait, lazy)
+
+    def _resolve_locked(self, wait, lazy):
         if self._error is not None:
             if lazy:
                 return True
@@ -284,10 +291,11 @@ class LazyCount:
         if r == 0:
             return False
         self.ticket = None
-        try:
-            _spec_state(self.dev)["pending"].remove(self)
-        except ValueError:
-            pass
+        pend = _spec_state(self.dev)["pending"]
+        for idx, item in enumerate(pend):  # by IDENTITY: deque.remove() compares with ==, which on a LazyCount means
+            if item is self:                # "resolve and compare the counts"
+                del pend[idx]
+                break
         if r < 0:
             self._redo = None
             self._error = RuntimeError(_lib.last_error())

@@ -41,11 +41,56 @@ __device__ __forceinline__ bool any_all(bool a, bool b, bool c) {
 // only be a rounding artefact next to the Gaussian's centre, where the exact exponent is ~0; the expanded form
 // rounds differently there, so the guard is applied with a tolerance: power <= kPowerTol contributes (with
 // exp(power) <= 1.0001).  In the folded form the guard reads  A0 + ... <= lim = log2(opacity) + kPowerTol log2(e).
+//
+// BUILD SWITCH  GOI_EXTRA_FLAGS=-DGOI_ALPHA_DIRECT  (python -m goi_hyperplane_amd.build --force): every kernel
+// evaluates alpha in the REFERENCE'S OWN FORM instead -- power = -1/2 (a dx^2 + c dy^2) - b dx dy, skip power > 0 exactly,
+// alpha = min(0.99, o exp(power)), CR/forward.cu:341-350 -- through the same two functions (the five staged words then
+// hold a, c, Dx, Dy, o, b).  Slower; it exists to A/B a configuration on which the folded polynomial and the oracle
+// disagree (guard flips, needles): tests/test_gpu_fuzz.py passes with either build.
 struct PolyCoef {
     f32x2 A35, A12;  // (A3, A5), (A1, A2): operands of the packed FMA
     float A0, A4, lim;
 };
 constexpr float kLog2e = 1.4426950408889634f;
+#ifdef GOI_ALPHA_DIRECT
+__device__ __forceinline__ PolyCoef poly_coefs(float gx_, float gy_, float ca, float cb, float cc, float o, float qcx,
+                                               float qcy) {
+    PolyCoef p;
+    p.A35 = f32x2{ca, cc};
+    p.A12 = f32x2{gx_ - qcx, gy_ - qcy};  // dx = Dx - u, dy = Dy - v
+    p.A0 = o;
+    p.A4 = cb;
+    p.lim = 0.f;
+    return p;
+}
+__device__ __forceinline__ PairEval eval_poly(f32x2 A35, f32x2 A12, float A0, float A4, float lim, f32x2 uv) {
+    (void)lim;
+    PairEval e;
+    const float dx = A12.x - uv.x, dy = A12.y - uv.y;
+    const float power = -0.5f * (A35.x * dx * dx + A35.y * dy * dy) - A4 * dx * dy;
+    e.E = A0 * __expf(power);
+    e.alpha = fminf(kAlphaMax, e.E);
+    e.below = !(power > 0.0f);
+    e.seen = e.alpha >= kAlphaMin;
+    e.hit = e.below && e.seen;
+    return e;
+}
+// what the backward's flush reads back from the staged words: the conic and 1 / opacity
+__device__ __forceinline__ void coef_decode(f32x4 g, f32x4 g2, float& ca, float& cb, float& cc, float& inv_o) {
+    ca = g.x;
+    cc = g.y;
+    cb = g2.y;
+    inv_o = __builtin_amdgcn_rcpf(g2.x);
+}
+#else
+__device__ __forceinline__ void coef_decode(f32x4 g, f32x4 g2, float& ca, float& cb, float& cc, float& inv_o) {
+    // conic back from A3, A4, A5 (= -log2e/2 a, -log2e b, -log2e/2 c) and 1/opacity from lim
+    constexpr float kLn2 = 0.6931471805599453f;
+    ca = (-2.f * kLn2) * g.x;
+    cb = -kLn2 * g2.y;
+    cc = (-2.f * kLn2) * g.y;
+    inv_o = __builtin_amdgcn_exp2f(1e-4f * 1.4426950408889634f - g2.z);  // lim = log2(o) + kPowerTol log2(e)
+}
 __device__ __forceinline__ PolyCoef poly_coefs(float gx_, float gy_, float ca, float cb, float cc, float o, float qcx,
                                                float qcy) {
     // A0 and A1, A2 are differences of terms of size a Dx^2 and a Dx, which for a long thin Gaussian (thin across,
@@ -95,6 +140,7 @@ __device__ __forceinline__ PairEval eval_poly(f32x2 A35, f32x2 A12, float A0, fl
     e.hit = e.below && e.seen;
     return e;
 }
+#endif  // GOI_ALPHA_DIRECT
 
 // ---- split-bf16 operands of the backward kernels' MFMA reductions (render_bwd.hip, "Two flushes")
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));

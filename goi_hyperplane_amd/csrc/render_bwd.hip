@@ -317,10 +317,8 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
             const float2 cen = s_cen[idx];
             const uint32_t slot = __float_as_uint(g2.w);  // (emit-order instance) * 4 + quadrant
             const float Dx = cen.x, Dy = cen.y;           // centre - quadrant centre: dx = Dx - u, dy = Dy - v
-            // conic back from A3, A4, A5 (= -log2e/2 a, -log2e b, -log2e/2 c) and 1/opacity from lim
-            constexpr float kLn2 = 0.6931471805599453f;
-            const float ca = (-2.f * kLn2) * g.x, cb = -kLn2 * g2.y, cc = (-2.f * kLn2) * g.y;
-            const float inv_o = __builtin_amdgcn_exp2f(kPowerTol * kLog2e - g2.z);
+            float ca, cb, cc, inv_o;  // the conic and 1 / opacity, back from the staged words
+            coef_decode(g, g2, ca, cb, cc, inv_o);
             const float m0 = m03.x, mu = m03.y, mv = m03.z, muu = m03.w, muv = m45.x, mvv = m45.y;
             const float sx = Dx * m0 - mu;                             // sum h dx
             const float sy = Dy * m0 - mv;                             // sum h dy
