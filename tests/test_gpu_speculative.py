@@ -252,3 +252,55 @@ def test_two_host_threads_on_two_streams(dev, binding):
     finally:
         _C.poll_counts(wait=True)
         _C.set_binding("compiled")
+
+
+def _fuzz_cases(n=36, seed=77):
+    rng = np.random.default_rng(seed)
+    out = []
+    for k in range(n):
+        P = int(rng.choice([1, 7, 64, 65, 300, 1500, 4000, 20000]))
+        W, H = int(rng.integers(17, 260)), int(rng.integers(17, 200))
+        S = int(rng.choice([1, 3, 4, 10, 16, 17, 32]))
+        mu = float(rng.uniform(-4.0, -1.0))
+        frac = float(rng.choice([0.02, 0.3, 0.9, 1.0, 1.0001, 1.5, 4.0]))  # capacity as a fraction of the true count
+        out.append((k, P, S, W, H, mu, frac))
+    return out
+
+
+@pytest.mark.parametrize("k,P,S,W,H,mu,frac", _fuzz_cases())
+def test_random_capacities_forward_and_backward_are_bit_identical_to_exact(dev, k, P, S, W, H, mu, frac):
+    """Seeded sweep over shapes and over capacities below, at and above the true count: a speculative frame whose count is
+    read before its outputs are used (redo on overflow) equals the exact frame bit for bit, outputs and gradients; so does
+    one that fits and is never read."""
+    from goi_hyperplane_amd import _C, rasterizer
+    from goi_hyperplane_amd.render import GaussianSet, PipelineParams, TorchCamera, render
+    sc = make_scene(P, S=S, sh_degree=int(k % 4), seed=300 + k, log_scale_mean=mu)
+    cam = TorchCamera(make_camera(W, H, yaw=0.02 * k - 0.3, pitch=0.01 * (k % 7)), dev)
+    pc = GaussianSet.from_scene(sc, dev)
+    bg = torch.tensor([0.1, 0.2, 0.3], device=dev)
+    g = torch.Generator(device=dev).manual_seed(k)
+    ups = [torch.randn(s, device=dev, generator=g) for s in ((3, H, W), (S, H, W), (1, H, W), (1, H, W))]
+
+    def step(read, **mode):
+        _C.set_forward_mode(**mode)
+        for p in pc.parameters():
+            p.grad = None
+        out = render(cam, pc, PipelineParams(), bg)
+        n = rasterizer.last_num_rendered()
+        if read:
+            n = int(n)
+        torch.autograd.backward((out["render"], out["semantics"], out["depth"], out["alpha"]), ups)
+        return n, [out[x].detach().clone() for x in ("render", "semantics", "depth", "alpha", "radii")], \
+            [p.grad.clone() for p in pc.parameters()] + [out["viewspace_points"].grad.clone()]
+
+    n0, o0, g0 = step(True, speculative=False)
+    cap = max(1, int(np.ceil(frac * max(n0, 1))))
+    n1, o1, g1 = step(True, speculative=True, capacity=cap)
+    assert n1 == n0
+    for a, b in zip(o0 + g0, o1 + g1):
+        assert torch.equal(a, b), (k, cap, n0)
+    if cap >= n0:  # fits: identical even when nobody ever reads the count
+        n2, o2, g2 = step(False, speculative=True, capacity=cap)
+        for a, b in zip(o0 + g0, o2 + g2):
+            assert torch.equal(a, b), (k, cap, n0)
+        assert int(n2) == n0
