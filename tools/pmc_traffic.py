@@ -14,7 +14,7 @@ import json
 import os
 import sys
 
-STAGE_KERNEL_PREFIX = {"blend_bwd": "render_bwd_rows_k<4", "blend_fwd": "render_fwd_k<4, false, true>",
+STAGE_KERNEL_PREFIX = {"blend_bwd": "render_bwd_rows_k<4, 0>", "blend_fwd": "render_fwd_k<4, false, true>",
                        "preprocess": "preprocess_fwd_k", "emit": "emit_k<true>"}
 
 
