@@ -189,6 +189,7 @@ _SPEC = {}  # device index -> {"high_water": int, "P": int, "pending": deque of 
 _SPEC_LOCK = threading.RLock()
 SPECULATION_STATS = {"exact_frames": 0, "speculative_frames": 0, "overflows": 0, "redone": 0, "waits": 0}
 _MIN_CAPACITY = 1 << 16
+_KEEP_WORKSPACES = 2  # pending frames per device whose workspaces stay alive for a possible redo
 
 
 def set_forward_mode(speculative=None, headroom=None, capacity="keep", on_overflow=None, max_ahead=None):
@@ -260,13 +261,20 @@ class LazyCount:
     and, if the frame overflowed its capacity, redoes it in place first."""
 
     __slots__ = ("dev", "ticket", "capacity", "layout", "binning", "overflowed", "redone", "_n", "_redo", "_stream",
-                 "_error", "P", "__weakref__")
+                 "_error", "P", "_hold", "__weakref__")
 
-    def __init__(self, dev, ticket, capacity, binning, stream, redo, P):
+    def __init__(self, dev, ticket, capacity, binning, stream, redo, P, workspaces=None):
         self.dev, self.ticket, self.capacity, self.layout, self.binning = dev, ticket, capacity, capacity, binning
         self.overflowed = self.redone = False
         self._n, self._redo, self._stream, self._error, self.P = None, redo, stream, None, P
-        _spec_state(dev)["pending"].append(self)
+        # The frame's workspaces (geometry / image state, radii) are needed for a redo but belong to nobody once the
+        # operator has returned under no_grad: the newest few pending frames of a device keep them alive (a caller who
+        # reads the count does so right after the forward), older ones let go (a pending frame must not pin memory).
+        self._hold = workspaces
+        pend = _spec_state(dev)["pending"]
+        pend.append(self)
+        if len(pend) > _KEEP_WORKSPACES:
+            pend[-1 - _KEEP_WORKSPACES]._hold = None
 
     @property
     def resolved(self):
@@ -297,7 +305,7 @@ class LazyCount:
                 del pend[idx]
                 break
         if r < 0:
-            self._redo = None
+            self._redo = self._hold = None
             self._error = RuntimeError(_lib.last_error())
             raise self._error
         self._n = int(n.value)
@@ -307,7 +315,7 @@ class LazyCount:
             SPECULATION_STATS["overflows"] += 1
             if lazy:
                 # found after the fact: whatever consumed the outputs is already enqueued, nothing to repair
-                self._redo = None
+                self._redo = self._hold = None
                 msg = (f"goi_hyperplane_amd: a speculative forward overflowed its binning capacity (num_rendered = "
                        f"{self._n} > {self.capacity}); that frame was rendered from a truncated instance list and "
                        f"nobody read num_rendered before using it. The capacity has been raised; use "
@@ -316,19 +324,25 @@ class LazyCount:
                     raise RasterOverflowError(msg)
                 warnings.warn(msg, RasterOverflowWarning, stacklevel=3)
             else:
-                self._redo_frame()
-        self._redo = None
+                try:
+                    self._redo_frame()
+                finally:
+                    self._redo = self._hold = None
+        self._redo = self._hold = None
         return True
 
     def _redo_frame(self):
         lib = _lib.load()
         make_scene, refs = self._redo
-        sc, _keep = make_scene()
         live = [r() for r in refs]
+        if all(t is None for t in live[3:7]):
+            return  # every output has been released: nobody can consume the truncated frame, nothing to repair
         if any(t is None for t in live):
             raise RasterOverflowError(
                 f"a speculative forward overflowed its binning capacity (num_rendered = {self._n} > {self.capacity}) and "
-                "cannot be redone: its outputs / workspaces have already been released")
+                "cannot be redone: its workspaces have already been released (the count was read too late -- the last "
+                f"{_KEEP_WORKSPACES} frames of a device keep theirs)")
+        sc, _keep = make_scene()
         geom, img, radii, outs = live[0], live[1], live[2], live[3:7]
         stream = torch.cuda.ExternalStream(self._stream, device=self.dev)
         with torch.cuda.device(self.dev), torch.cuda.stream(stream):
@@ -434,7 +448,8 @@ def rasterize_gaussians(background, means3D, colors, semantics, opacity, scales,
             bg_c, sem_c = bg.contiguous(), sem.contiguous()
             return _scene(P, S, H, W, bg_c, None, None, None, sem_c, None, None, None, 1.0, None, None, None, 0.0, 0.0, 0,
                           None, False, False), (bg_c, sem_c)
-        n = LazyCount(dev, ticket, cap, binning, torch.cuda.current_stream(dev).cuda_stream, (make_scene, refs), P)
+        n = LazyCount(dev, ticket, cap, binning, torch.cuda.current_stream(dev).cuda_stream, (make_scene, refs), P,
+                      workspaces=(geom, img, radii))
         return n, out_color, out_sem, out_depth, out_alpha, radii, geom, binning, img
     f32 = dict(dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
@@ -473,7 +488,7 @@ def rasterize_gaussians(background, means3D, colors, semantics, opacity, scales,
             # temporaries of the caller, e.g. pc.get_semantics under a mask)
             refs = [weakref.ref(t) for t in (geom, img, radii) + outs]
             keep = (ten["semantics"], ten["bg"])
-            n = LazyCount(dev, ticket, cap, binning, stream, (lambda: (sc, keep), refs), P)
+            n = LazyCount(dev, ticket, cap, binning, stream, (lambda: (sc, keep), refs), P, workspaces=(geom, img, radii))
             return n, out_color, out_sem, out_depth, out_alpha, radii, geom, binning, img
         alloc = _BinningAllocator(dev)
         n = lib.goi_raster_forward(C.byref(sc), _ptr(geom), _ptr(img), alloc.cb, None, _ptr(out_color), _ptr(out_sem),

@@ -304,3 +304,28 @@ def test_random_capacities_forward_and_backward_are_bit_identical_to_exact(dev, 
         for a, b in zip(o0 + g0, o2 + g2):
             assert torch.equal(a, b), (k, cap, n0)
         assert int(n2) == n0
+
+
+def test_overflow_under_no_grad_is_redone_when_the_count_is_read_right_away(dev):
+    """Inference (torch.no_grad): nothing but the LazyCount keeps the frame's workspaces once the operator has returned;
+    the newest pending frames hold on to them, so reading the count right after the render still repairs an overflow."""
+    from goi_hyperplane_amd import _C, rasterizer
+    from goi_hyperplane_amd.render import GaussianSet, PipelineParams, TorchCamera, render
+    sc = make_scene(6000, S=16, seed=15, log_scale_mean=-2.9)
+    cam = TorchCamera(make_camera(224, 160, yaw=0.1), dev)
+    pc = GaussianSet.from_scene(sc, dev)
+    bg = torch.zeros(3, device=dev)
+    with torch.no_grad():
+        _C.set_forward_mode(speculative=False)
+        ref = render(cam, pc, PipelineParams(), bg, scaling_modifier=2.5)
+        n_ref = int(rasterizer.last_num_rendered())
+        _C.set_forward_mode(speculative=True, capacity=n_ref // 4)
+        out = render(cam, pc, PipelineParams(), bg, scaling_modifier=2.5)
+        n = rasterizer.last_num_rendered()
+        assert int(n) == n_ref and n.overflowed and n.redone
+        for k in ("render", "semantics", "depth", "alpha"):
+            assert torch.equal(out[k], ref[k]), k
+        # outputs dropped before the count is read: nothing to repair, no error
+        render(cam, pc, PipelineParams(), bg, scaling_modifier=2.5)
+        n2 = rasterizer.last_num_rendered()
+        assert int(n2) == n_ref and n2.overflowed and not n2.redone
