@@ -374,6 +374,13 @@ def main():
                 "dominant_stage": dominant, "dominant_ms": (stages[dominant][0] / max(stages[dominant][1], 1)
                                                             if stages and dominant else None),
                 "step_enqueue_ms_median": step_enqueue_ms["median"] if step_enqueue_ms else None}
+        # this rank's own views: algorithmic bytes of a view over its step time, as a fraction of the HBM peak, and the
+        # dominant kernel's roofline fraction (SURVEY.md 8(d) accounting on THIS rank's V and N)
+        r_fwd, r_bwd = survey_bytes(args.P, V, N, T, HW, args.S)
+        mine["hbm_frac_over_step"] = (r_fwd + r_bwd) / (mine["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        if mine["dominant_ms"]:
+            mine["dominant_hbm_frac"] = (stage_bytes(args.P, V, N, T, HW, args.S)[dominant] / (mine["dominant_ms"] * 1e-3)
+                                         / 1e9 / HBM_PEAK_GBS)
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
 
