@@ -395,6 +395,19 @@ def main():
             render(cams[(i * world + rank) % len(cams)], pc, pipe, bg)
         barrier()
         render_ms = (time.perf_counter() - r0) / nfr * 1e3
+        # (frames rendered without autograd take the exact forward by default -- their image is the product, and a viewer
+        # hands it to the host every frame anyway; the same loop with the speculative forward, for comparison)
+        render_mode = _C._FWD["inference"]
+        rasterizer.set_forward_mode(inference_speculative=True)
+        for i in range(2):
+            render(cams[i % len(cams)], pc, pipe, bg)
+        barrier()
+        r0 = time.perf_counter()
+        for i in range(nfr):
+            render(cams[(i * world + rank) % len(cams)], pc, pipe, bg)
+        barrier()
+        render_ms_spec = (time.perf_counter() - r0) / nfr * 1e3
+        rasterizer.set_forward_mode(inference_speculative=render_mode == "speculative")
         # GUI frame: render + fused semantic decode (code-book argmax + hyperplane score + mask, gui/main.py:364-386)
         from goi_hyperplane_amd.semantic import LinearSVM, SemanticModel, compute_similarity, svm_score_fn
         torch.manual_seed(0)
@@ -534,6 +547,8 @@ def main():
                        "allgather_bytes": int(args.P * 3 * 4 * world) if (world > 1 and exchange["mode"] == "factored") else 0,
                        "exchange": exchange["mode"] if world > 1 else None, "exchange_note": exchange["note"]},
             "render_ms_per_frame": render_ms,
+            "render_forward_mode": render_mode,  # forward of frames rendered without autograd (package default: exact)
+            "render_ms_per_frame_speculative": render_ms_spec,
             "gui_frame_ms": gui_ms,  # render + fused semantic decode (300 codes)
             "step_enqueue_ms": step_enqueue_ms,  # host-side, informational (stall detector; not used for value)
             "semantic_finetune": sem_only,

@@ -182,7 +182,21 @@ def _env_forward_mode():
     return v
 
 
-_FWD = {"mode": _env_forward_mode(), "headroom": float(os.environ.get("GOI_BINNING_HEADROOM", "2.0")),
+def _env_inference_mode():
+    v = os.environ.get("GOI_FORWARD_INFERENCE", "exact").strip().lower()
+    if v not in ("speculative", "exact"):
+        raise ValueError(f"GOI_FORWARD_INFERENCE={v!r}: expected speculative or exact")
+    return v
+
+
+# A frame nobody can backpropagate through (torch.no_grad(), or no input requires a gradient: a GUI frame, an evaluation
+# render) is rendered for its IMAGE, and the caller usually hands that image to the host right away: such frames take the
+# exact forward by default -- a truncated picture is not worth the host round trip it saves.  The autograd wrapper
+# (rasterizer.rasterize_gaussians) says which kind a frame is; the raw operator called directly counts as a training frame.
+_CALL = threading.local()
+
+_FWD = {"mode": _env_forward_mode(), "inference": _env_inference_mode(),
+        "headroom": float(os.environ.get("GOI_BINNING_HEADROOM", "2.0")),
         "capacity": None, "on_overflow": os.environ.get("GOI_OVERFLOW", "warn").strip().lower(),
         "max_ahead": int(os.environ.get("GOI_MAX_AHEAD", "64"))}
 _SPEC = {}  # device index -> {"high_water": int, "P": int, "pending": deque of LazyCount}
@@ -192,13 +206,17 @@ _MIN_CAPACITY = 1 << 16
 _KEEP_WORKSPACES = 2  # pending frames per device whose workspaces stay alive for a possible redo
 
 
-def set_forward_mode(speculative=None, headroom=None, capacity="keep", on_overflow=None, max_ahead=None):
-    """speculative: True / False (exact, the reference's synchronous forward).  headroom: capacity = headroom x the
+def set_forward_mode(speculative=None, headroom=None, capacity="keep", on_overflow=None, max_ahead=None,
+                     inference_speculative=None):
+    """speculative: True / False (exact, the reference's synchronous forward) for frames a backward may follow.
+    inference_speculative: the same for frames rendered without autograd (default False: exact).  headroom: capacity = headroom x the
     largest num_rendered seen on the device.  capacity: an int forces that capacity for every frame (tests), None returns
     to the policy.  on_overflow: "warn" | "raise" for overflows found after the fact.  max_ahead: unresolved frames
     allowed per device."""
     if speculative is not None:
         _FWD["mode"] = "speculative" if speculative else "exact"
+    if inference_speculative is not None:
+        _FWD["inference"] = "speculative" if inference_speculative else "exact"
     if headroom is not None:
         if not headroom >= 1.0:
             raise ValueError("headroom must be >= 1")
@@ -234,6 +252,8 @@ def _pick_capacity(dev, P, debug, prefiltered):
     if (P == 0 or debug or prefiltered or _FWD["mode"] != "speculative"
             or _lib.OPTIONS.get("sort_variant", 1) != 1):
         return None
+    if getattr(_CALL, "inference", False) and _FWD["inference"] != "speculative" and _FWD["capacity"] is None:
+        return None  # an image-only frame: exact unless asked otherwise (a forced capacity, as in the tests, overrides)
     if _FWD["capacity"] is not None:
         return _FWD["capacity"]
     st = _spec_state(dev)

@@ -108,11 +108,13 @@ def set_backward_mode(semantics_only=None, sh_factored: bool = None) -> None:
         _SH_FACTOR["last"] = None
 
 
-def set_forward_mode(speculative=None, headroom=None, capacity="keep", on_overflow=None, max_ahead=None) -> None:
-    """Forward without the host round trip (default) or the reference's synchronous forward: see _C.set_forward_mode
-    and include/goi_raster.h (goi_raster_forward_async).  GOI_FORWARD=exact|speculative, GOI_BINNING_HEADROOM,
-    GOI_OVERFLOW=warn|raise set the process defaults."""
-    _C.set_forward_mode(speculative, headroom, capacity, on_overflow, max_ahead)
+def set_forward_mode(speculative=None, headroom=None, capacity="keep", on_overflow=None, max_ahead=None,
+                     inference_speculative=None) -> None:
+    """Forward without the host round trip (default for frames a backward may follow) or the reference's synchronous
+    forward (default for frames rendered without autograd: their image is the product): see _C.set_forward_mode and
+    include/goi_raster.h (goi_raster_forward_async).  GOI_FORWARD=exact|speculative, GOI_FORWARD_INFERENCE=exact|speculative,
+    GOI_BINNING_HEADROOM, GOI_OVERFLOW=warn|raise set the process defaults."""
+    _C.set_forward_mode(speculative, headroom, capacity, on_overflow, max_ahead, inference_speculative)
 
 
 def speculation_stats() -> dict:
@@ -218,8 +220,18 @@ class _RasterizeGaussians(torch.autograd.Function):
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, semantics, opacities, scales, rotations, cov3Ds_precomp,
                         raster_settings):
-    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, semantics, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings)
+    # can a backward follow this frame?  (inside Function.forward grad mode is always off, so it is decided here.)  A frame
+    # rendered only for its image takes the exact forward by default, see _C._CALL
+    # (means2D is the caller's gradient SINK -- the reference's harness makes it require a gradient on every call -- so it
+    # does not count)
+    tensors = (means3D, sh, colors_precomp, semantics, opacities, scales, rotations, cov3Ds_precomp)
+    _C._CALL.inference = not (torch.is_grad_enabled()
+                              and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors))
+    try:
+        return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, semantics, opacities, scales, rotations,
+                                         cov3Ds_precomp, raster_settings)
+    finally:
+        _C._CALL.inference = False
 
 
 def trace_gaussians(means3D, means2D, sh, colors_precomp, img_sem, opacities, scales, rotations, cov3Ds_precomp,

@@ -31,7 +31,8 @@ def _restore_mode():
     from goi_hyperplane_amd import _C
     yield
     _C.poll_counts(wait=True)
-    _C.set_forward_mode(speculative=True, headroom=2.0, capacity=None, on_overflow="warn", max_ahead=64)
+    _C.set_forward_mode(speculative=True, headroom=2.0, capacity=None, on_overflow="warn", max_ahead=64,
+                        inference_speculative=False)
 
 
 def _args(sc, cam, dev, bg):
@@ -329,3 +330,31 @@ def test_overflow_under_no_grad_is_redone_when_the_count_is_read_right_away(dev)
         render(cam, pc, PipelineParams(), bg, scaling_modifier=2.5)
         n2 = rasterizer.last_num_rendered()
         assert int(n2) == n_ref and n2.overflowed and not n2.redone
+
+
+def test_image_only_frames_are_exact_by_default(dev):
+    """A frame rendered without autograd (torch.no_grad(), or nothing requires a gradient) is rendered for its image: by
+    default it takes the exact forward (int count, never truncated); with autograd recording the same call is speculative;
+    set_forward_mode(inference_speculative=True) / GOI_FORWARD_INFERENCE=speculative lifts the restriction."""
+    from goi_hyperplane_amd import _C, rasterizer
+    from goi_hyperplane_amd.render import GaussianSet, PipelineParams, TorchCamera, render
+    sc = make_scene(5000, S=16, seed=21, log_scale_mean=-2.9)
+    cam = TorchCamera(make_camera(200, 152), dev)
+    pc = GaussianSet.from_scene(sc, dev)
+    bg = torch.zeros(3, device=dev)
+    render(cam, pc, PipelineParams(), bg)  # teaches the policy
+    a = render(cam, pc, PipelineParams(), bg)
+    assert isinstance(rasterizer.last_num_rendered(), _C.LazyCount)  # training frame: speculative
+    with torch.no_grad():
+        b = render(cam, pc, PipelineParams(), bg)
+        assert isinstance(rasterizer.last_num_rendered(), int)  # image-only frame: exact
+        _C.set_forward_mode(inference_speculative=True)
+        c = render(cam, pc, PipelineParams(), bg)
+        assert isinstance(rasterizer.last_num_rendered(), _C.LazyCount)
+    for p in pc.parameters():
+        p.requires_grad_(False)
+    _C.set_forward_mode(inference_speculative=False)
+    d = render(cam, pc, PipelineParams(), bg)  # grad mode on, but nothing to differentiate: image-only as well
+    assert isinstance(rasterizer.last_num_rendered(), int)
+    for x in (b, c, d):
+        assert torch.equal(a["render"].detach(), x["render"]) and torch.equal(a["semantics"].detach(), x["semantics"])

@@ -40,7 +40,7 @@ warnings.simplefilter("ignore", _C.RasterOverflowWarning)
 for name, cams in seqs.items():
     _C.poll_counts(wait=True)
     _C._SPEC.clear()
-    _C.set_forward_mode(speculative=True, capacity=None)
+    _C.set_forward_mode(speculative=True, capacity=None, inference_speculative=True)  # (image-only frames are exact by default)
     s0 = dict(_C.SPECULATION_STATS)
     counts = []
     with torch.no_grad():
@@ -61,7 +61,7 @@ for name, cams in seqs.items():
           f"frame-to-frame growth x{(ns[1:] / np.maximum(ns[:-1], 1)).max():.2f}")
 # an overflow, read before use: redone == exact
 _C._SPEC.clear()
-_C.set_forward_mode(speculative=True, capacity=None)
+_C.set_forward_mode(speculative=True, capacity=None, inference_speculative=True)
 cam = TorchCamera(make_camera(800, 528, distance=5.0), dev)
 with torch.no_grad():
     render(cam, pc, PipelineParams(), bg, scaling_modifier=0.5)       # exact, teaches a small count
