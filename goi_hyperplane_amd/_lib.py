@@ -55,6 +55,9 @@ SYMBOLS = {
     "goi_raster_mark_visible": (C.c_int, [C.c_int] + [C.c_void_p] * 4 + [C.c_void_p]),
     "goi_codebook_loss_partial_rows": (C.c_int, []),
     "goi_codebook_loss_rows": (C.c_int, [C.c_void_p] * 5 + [C.c_longlong, C.c_int, C.c_int, C.c_float] + [C.c_void_p] * 4),
+    "goi_codebook_sim_workspace_bytes": (C.c_size_t, []),
+    "goi_codebook_sim": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p]),
     "goi_codebook_dlut_partial_blocks": (C.c_int, []),
     "goi_codebook_dlut": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "goi_adam_step": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p]),

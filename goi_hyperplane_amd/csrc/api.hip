@@ -668,6 +668,17 @@ int goi_codebook_loss_rows(const float* sim_raw, const float* inv_gnorm, const f
     return 0;
 }
 
+size_t goi_codebook_sim_workspace_bytes(void) { return codebook_sim_workspace_bytes(); }
+
+int goi_codebook_sim(const float* g, const float* lut1, long long HW, int C, int D, float* sim, float* inv_gnorm,
+                     void* workspace, void* stream) {
+    if (!g || !lut1 || !sim || !inv_gnorm || !workspace) return fail("goi_codebook_sim: a required pointer is NULL");
+    if (launch_codebook_sim(g, lut1, HW, C, D, sim, inv_gnorm, workspace, static_cast<hipStream_t>(stream)) < 0)
+        return fail("goi_codebook_sim: supported shape is D = 256, C <= 304, C % 4 = 0");
+    GOI_HIP(hipGetLastError());
+    return 0;
+}
+
 int goi_codebook_dlut_partial_blocks(void) { return codebook_dlut_blocks(); }
 
 int goi_codebook_dlut(const float* dsim, const float* g, long long HW, int C, int D, float* partial, void* stream) {

@@ -26,7 +26,7 @@
 // order: the losses and gradients are bit-reproducible.
 #include <float.h>
 
-#include "common.h"
+#include "blend_common.h"
 
 namespace goi {
 
@@ -397,6 +397,148 @@ __global__ __launch_bounds__(DL_THREADS) void codebook_dlut_k(const float* __res
         for (int r = 0; r < 4; r++) out[(size_t)(16 * cb + 4 * kq + r) * 256 + dcol] = acc[cb][r];
 }
 
+
+// ---- sim_raw = g^T L1^T: [HW x 256] x [256 x C] on the bf16 matrix rate with SPLIT operands ----------------------------
+// The library GEMM this replaces (hipBLASLt through torch.matmul) runs fp32 MFMAs at 99 TFLOP/s: 2.6 ms at 1600x1056, a
+// third of the fused loss.  Here every fp32 operand is carried as two bf16 numbers (hi = rne(x), lo = rne(x - hi)) and a
+// product is  hi*hi + lo*hi + hi*lo  on v_mfma_f32_16x16x32_bf16 with fp32 accumulation -- the split flush of
+// render_bwd.hip.  The dropped lo*lo term is <= 2^-16 of a product; sim is a sum of 256 such products of either sign, so
+// the error of sim is ~1e-6 of |g||L1_c| (the 1e-5 / 1e-3 parity of the losses and gradients is checked by the tests).
+//
+// Orientation: M = codes (A = L1 [c][k]: 8 consecutive k of a code row per lane), N = pixels (B = g [k][p], channel-major
+// as the ground-truth map is: lane (kq, mm) loads k = 8 kq + i of pixel mm -- 64-byte segments), so D[code 4 kq + r][pixel mm]
+// leaves as one float4 of 4 consecutive codes per lane into the [HW][C] result.  A workgroup of 4 waves owns 128 pixels
+// (a wave: 2 pixel blocks x all 19 code blocks = 152 accumulator VGPRs) and walks K in 8 chunks of 32; the two bf16 planes
+// of the code book's chunk (2 x 304 rows x 64 B) are staged through LDS once per chunk for all four waves, double-buffered
+// and by LDS-DMA, so that the next chunk lands while this one is multiplied: one barrier per chunk.  The same pass over g
+// also yields 1/|g_p| (the separate norm kernel is gone).
+constexpr int SIM_NCB = 19, SIM_NC = SIM_NCB * 16, SIM_K = 256, SIM_KC = 32;
+
+// L1 [C][256] fp32 -> planes[2][304][256] bf16 (hi, lo), rows >= C zero
+__global__ __launch_bounds__(256) void codebook_split_k(const float* __restrict__ l1, int C, uint16_t* __restrict__ planes) {
+    const int i = blockIdx.x * 256 + threadIdx.x;  // pair index
+    if (i >= SIM_NC * SIM_K / 2) return;
+    const int c = (2 * i) / SIM_K;
+    const float a = c < C ? l1[2 * i] : 0.f, b = c < C ? l1[2 * i + 1] : 0.f;
+    uint32_t hi, lo;
+    split_pair(a, b, hi, lo);
+    reinterpret_cast<uint32_t*>(planes)[i] = hi;
+    reinterpret_cast<uint32_t*>(planes + (size_t)SIM_NC * SIM_K)[i] = lo;
+}
+
+#ifndef GOI_SIM_PB
+#define GOI_SIM_PB 2
+#endif
+#ifndef GOI_SIM_NW
+#define GOI_SIM_NW 4
+#endif
+constexpr int SIM_PB = GOI_SIM_PB, SIM_NW = GOI_SIM_NW;  // pixel blocks (of 16) per wave, waves per workgroup
+constexpr int SIM_WG_PIX = 16 * SIM_PB * SIM_NW;
+
+// LDS: two buffers x two planes x [304][32] bf16, rows UNPADDED (64 B) because the staging is LDS-DMA
+// (global_load_lds_dwordx4: a wave instruction lands 64 lanes x 16 B contiguously -- the destination cannot be padded, the
+// per-lane SOURCE address is free).  Bank conflicts of the ds_read_b128 operand reads are avoided by a swizzle instead: the
+// 16-byte piece j of row r sits in slot j ^ ((r >> 2) & 3) of its row; the 16 lanes of a read (rows r0 .. r0+15, one k
+// quarter) then cover 16 different 16-byte slots of the 256-byte bank row.
+constexpr int SIM_PLANE_U = SIM_NC * 64;            // bytes of one unpadded plane chunk
+constexpr int SIM_BUF = 2 * SIM_PLANE_U;            // both planes: 38 KiB = 38 wave pieces of 1 KiB
+constexpr int SIM_PIECES = SIM_BUF / 1024;
+static_assert(SIM_BUF % 1024 == 0, "the staged chunk must be a whole number of 1 KiB wave pieces");
+
+__global__ __launch_bounds__(64 * SIM_NW) void codebook_sim_k(const float* __restrict__ g, const uint16_t* __restrict__ planes,
+                                                               long long HW, int C, float* __restrict__ sim,
+                                                               float* __restrict__ inv_gnorm) {
+    __shared__ __attribute__((aligned(1024))) char s_a[2][SIM_BUF];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, kq = lane >> 4, mm = lane & 15;
+    const long long p0 = (long long)blockIdx.x * SIM_WG_PIX + 16 * SIM_PB * w;  // this wave's pixel blocks p0, p0 + 16, ..
+    f32x4 acc[SIM_PB][SIM_NCB];
+#pragma unroll
+    for (int pb = 0; pb < SIM_PB; pb++)
+#pragma unroll
+        for (int cb = 0; cb < SIM_NCB; cb++) acc[pb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float nrm[SIM_PB];
+#pragma unroll
+    for (int pb = 0; pb < SIM_PB; pb++) nrm[pb] = 0.f;
+    float braw[SIM_PB][8];
+    auto load_b = [&](int kc) {  // g[k = 32 kc + 8 kq + i][pixel p0 + 16 pb + mm]
+#pragma unroll
+        for (int pb = 0; pb < SIM_PB; pb++) {
+            const long long p = p0 + 16 * pb + mm;
+            const float* src = g + (size_t)(SIM_KC * kc + 8 * kq) * HW + (p < HW ? p : HW - 1);
+#pragma unroll
+            for (int i = 0; i < 8; i++) braw[pb][i] = p < HW ? src[(size_t)i * HW] : 0.f;
+        }
+    };
+    // the code book's two planes of K chunk kc -> LDS buffer buf, asynchronously, no registers: wave w moves the 1 KiB
+    // pieces w, w + NW, ...; lane l of piece q fills 16-byte slot 64 q + l
+    auto stage = [&](int kc, int buf) {
+        for (int q = w; q < SIM_PIECES; q += SIM_NW) {
+            const int slot = 64 * q + lane;
+            const int plane = slot / (SIM_NC * 4), rs = slot - plane * (SIM_NC * 4), r = rs >> 2, sp = rs & 3;
+            const int piece = sp ^ ((r >> 2) & 3);
+            const uint16_t* src = planes + ((size_t)plane * SIM_NC + r) * SIM_K + SIM_KC * kc + 8 * piece;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(s_a[buf] + 1024 * q), 16, 0, 0);
+        }
+    };
+    const int a_off = 64 * mm + 16 * (kq ^ ((mm >> 2) & 3));  // this lane's operand in a 16-row block (rows 16 cb + mm)
+    stage(0, 0);
+    load_b(0);
+    for (int kc = 0; kc < SIM_K / SIM_KC; kc++) {
+        // chunk kc has landed for THIS wave's pieces; past the barrier it has for every wave's, and every wave is done
+        // reading the other buffer (chunk kc - 1)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // ---- this chunk's B operands: split, and the running |g|^2
+        bf16x8 Bh[SIM_PB], Bl[SIM_PB];
+#pragma unroll
+        for (int pb = 0; pb < SIM_PB; pb++) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) nrm[pb] = fmaf(braw[pb][i], braw[pb][i], nrm[pb]);
+            split_pack8(braw[pb], Bh[pb], Bl[pb]);
+        }
+        if (kc + 1 < SIM_K / SIM_KC) {  // the next chunk's traffic flies under this chunk's MFMAs
+            stage(kc + 1, (kc + 1) & 1);
+            load_b(kc + 1);
+        }
+        const char* buf = s_a[kc & 1] + a_off;
+#pragma unroll
+        for (int cb = 0; cb < SIM_NCB; cb++) {
+            const bf16x8 Ah = *reinterpret_cast<const bf16x8*>(buf + 1024 * cb);
+            const bf16x8 Al = *reinterpret_cast<const bf16x8*>(buf + 1024 * cb + SIM_PLANE_U);
+#pragma unroll
+            for (int pb = 0; pb < SIM_PB; pb++) {
+                acc[pb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bh[pb], acc[pb][cb], 0, 0, 0);
+                acc[pb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bl[pb], acc[pb][cb], 0, 0, 0);
+                acc[pb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh[pb], acc[pb][cb], 0, 0, 0);
+            }
+        }
+    }
+    // ---- D[code 16 cb + 4 kq + r][pixel mm] -> sim[p][c]: one float4 of 4 consecutive codes per lane (C % 4 == 0)
+#pragma unroll
+    for (int pb = 0; pb < SIM_PB; pb++) {
+        const long long p = p0 + 16 * pb + mm;
+        // |g_p|^2: this lane summed k = 8 kq .. 8 kq + 7 of every chunk; the other three k lanes of the pixel sit 16 lanes apart
+        float n2 = nrm[pb];
+        n2 += __shfl_xor(n2, 16, 64);
+        n2 += __shfl_xor(n2, 32, 64);
+        if (p < HW) {
+            if (kq == 0) inv_gnorm[p] = 1.0f / sqrtf(n2);
+            float* dst = sim + (size_t)p * C;
+#pragma unroll
+            for (int cb = 0; cb < SIM_NCB; cb++) {
+                const int c0 = 16 * cb + 4 * kq;
+                if (c0 + 3 < C) *reinterpret_cast<f32x4*>(dst + c0) = acc[pb][cb];
+                else
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        if (c0 + r < C) dst[c0 + r] = acc[pb][cb][r];
+            }
+        }
+    }
+}
+
 }  // namespace
 
 int codebook_loss_waves() { return 256 * 8; }  // persistent: 8 waves per CU (2 per SIMD at ~230 VGPRs)
@@ -427,6 +569,18 @@ int launch_codebook_rows(const float* sim, const float* inv_gnorm, const float* 
 }  // namespace goi
 
 namespace goi {
+size_t codebook_sim_workspace_bytes() { return (size_t)2 * SIM_NC * SIM_K * sizeof(uint16_t); }
+// sim [HW][C] and inv_gnorm [HW] from g [256][HW] (channel-major) and l1 [C][256]; workspace: codebook_sim_workspace_bytes().
+// Returns -1 when the shape is not the kernel's (D = 256, C <= 304, C % 4 = 0): the caller then uses the library GEMM.
+int launch_codebook_sim(const float* g, const float* l1, long long HW, int C, int D, float* sim, float* inv_gnorm,
+                        void* workspace, hipStream_t s) {
+    if (D != SIM_K || C < 1 || C > SIM_NC || (C & 3) != 0 || HW < 1) return -1;
+    uint16_t* planes = static_cast<uint16_t*>(workspace);
+    codebook_split_k<<<dim3((SIM_NC * SIM_K / 2 + 255) / 256), dim3(256), 0, s>>>(l1, C, planes);
+    codebook_sim_k<<<dim3((unsigned)((HW + SIM_WG_PIX - 1) / SIM_WG_PIX)), dim3(64 * SIM_NW), 0, s>>>(g, planes, HW, C, sim,
+                                                                                                   inv_gnorm);
+    return 0;
+}
 int codebook_dlut_blocks() { return 256; }  // pixel ranges; two workgroups (column halves) per range
 // partial: [codebook_dlut_blocks()][304][256]; returns -1 when the shape is not the kernel's (C in 289..304,
 // D = 256, HW % 4 = 0): the caller then uses a library GEMM

@@ -140,6 +140,9 @@ int launch_semantic_decode(const float* sem, int S, long long HW, const float* W
 int codebook_loss_waves();
 int launch_codebook_rows(const float* sim, const float* inv_gnorm, const float* sem, const float* W, const float* bias,
                          long long HW, int C, int S, float t, float* dsim, float* dsem, float* partials, hipStream_t s);
+size_t codebook_sim_workspace_bytes();
+int launch_codebook_sim(const float* g, const float* l1, long long HW, int C, int D, float* sim, float* inv_gnorm,
+                        void* workspace, hipStream_t s);
 int codebook_dlut_blocks();
 int launch_codebook_dlut(const float* dsim, const float* g, long long HW, int C, int D, float* partial, hipStream_t s);
 int launch_adam_step(const GoiAdamGroup* groups, int n_groups, double beta1, double beta2, double eps,

@@ -170,6 +170,9 @@ def codebook_losses(sem_feature_chw: torch.Tensor, semantic_mlp: SemanticModel, 
     return loss, {"lab": lab, "sl": sl, "sl1": sl1, "recc": recc}
 
 
+_SIM_KERNEL = {"on": True}  # False: the library fp32 GEMM for sim (A/B and a fallback for other shapes)
+
+
 class _FusedCodebookLoss(torch.autograd.Function):
     """loss = lab + sl + 0.3 sl1 + recc of train.py:142-163, with all gradients produced in the forward
     (the loss is a scalar: backward only scales them)."""
@@ -189,13 +192,23 @@ class _FusedCodebookLoss(torch.autograd.Function):
         b = None if bias is None else bias.detach().contiguous().float()
         l1 = lut1.detach().contiguous().float()
         with torch.cuda.device(dev):
-            inv_gnorm = torch.linalg.vector_norm(g, dim=0).reciprocal_()            # [HW]
-            sim_raw = torch.matmul(g.t(), l1.t())                                     # [HW, C]  (matrix cores)
+            p = lambda x: None if x is None else C_.c_void_p(x.data_ptr())  # noqa: E731
+            stream = C_.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            sim_raw = inv_gnorm = None
+            if D == 256 and C <= 304 and C % 4 == 0 and _SIM_KERNEL["on"]:
+                # one pass over g: split-bf16 MFMA contraction + 1/|g| (csrc/codebook_loss.hip: codebook_sim_k)
+                sim_raw = torch.empty((HW, C), dtype=torch.float32, device=dev)
+                inv_gnorm = torch.empty((HW,), dtype=torch.float32, device=dev)
+                ws = torch.empty((int(lib.goi_codebook_sim_workspace_bytes()),), dtype=torch.uint8, device=dev)
+                if lib.goi_codebook_sim(p(g), p(l1), HW, C, D, p(sim_raw), p(inv_gnorm), p(ws), stream) < 0:
+                    raise RuntimeError(_lib.last_error())
+            else:
+                inv_gnorm = torch.linalg.vector_norm(g, dim=0).reciprocal_()        # [HW]
+                sim_raw = torch.matmul(g.t(), l1.t())                                 # [HW, C]  (library GEMM, fp32)
             dsim = torch.empty_like(sim_raw)
             dsem = torch.empty((S, HW), dtype=torch.float32, device=dev)
             rows = lib.goi_codebook_loss_partial_rows()
             partials = torch.empty((rows, C * (S + 1) + 4), dtype=torch.float32, device=dev)
-            p = lambda x: None if x is None else C_.c_void_p(x.data_ptr())  # noqa: E731
             r = lib.goi_codebook_loss_rows(p(sim_raw), p(inv_gnorm), p(sem), p(w), p(b), HW, C, S, float(t), p(dsim),
                                            p(dsem), p(partials), C_.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
             if r < 0:

@@ -237,6 +237,15 @@ int goi_codebook_loss_rows(const float* sim_raw, const float* inv_gnorm, const f
                            const float* bias, long long HW, int C, int S, float t, float* dsim, float* dsem,
                            float* partials, void* stream);
 
+/* sim_raw [HW][C] = g^T * L1^T and inv_gnorm [HW] = 1/|g_p| in one pass over g [D][HW] (the channel-major ground-truth
+ * map), L1 [C][D] the row-normalised code book: the dense code-book x feature contraction of train.py:147-149 on the bf16
+ * matrix rate with split (hi + lo) operands, fp32 accumulation (csrc/codebook_loss.hip: codebook_sim_k; products to 2^-16,
+ * sim to ~1e-6).  workspace: goi_codebook_sim_workspace_bytes() device bytes.  Supported shape: D = 256, C <= 304, C % 4 = 0;
+ * returns < 0 otherwise (use a library GEMM then). */
+size_t goi_codebook_sim_workspace_bytes(void);
+int goi_codebook_sim(const float* g, const float* lut1, long long HW, int C, int D, float* sim, float* inv_gnorm,
+                     void* workspace, void* stream);
+
 /* dL/dL1 [C][D] = dsim^T * g^T as a split-K fp32 MFMA GEMM over the pixel axis (csrc/codebook_loss.hip):
  * dsim [HW][C] (from goi_codebook_loss_rows), g [D][HW] (the channel-major ground-truth map).  Writes
  * partial [goi_codebook_dlut_partial_blocks()][304][D]; the caller sums over the first axis and keeps
