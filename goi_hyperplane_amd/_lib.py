@@ -60,6 +60,9 @@ SYMBOLS = {
                                    C.c_void_p]),
     "goi_codebook_dlut_partial_blocks": (C.c_int, []),
     "goi_codebook_dlut": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "goi_codebook_fused_workspace_bytes": (C.c_size_t, [C.c_longlong]),
+    "goi_codebook_fused_partial_rows": (C.c_int, []),
+    "goi_codebook_fused": (C.c_int, [C.c_void_p] * 5 + [C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_float] + [C.c_void_p] * 5),
     "goi_adam_step": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
     "goi_knn_workspace_bytes": (C.c_size_t, [C.c_int]),
     "goi_knn_dist2": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -689,6 +689,21 @@ int goi_codebook_dlut(const float* dsim, const float* g, long long HW, int C, in
     return 0;
 }
 
+size_t goi_codebook_fused_workspace_bytes(long long HW) { return HW < 0 ? 0 : codebook_fused_workspace_bytes(HW); }
+int goi_codebook_fused_partial_rows(void) { return codebook_fused_rows(); }
+
+int goi_codebook_fused(const float* g, const float* lut1, const float* sem, const float* W, const float* bias, long long HW,
+                       int C, int D, int S, float t, float* dsem, float* partials, float* dlut_partial, void* workspace,
+                       void* stream) {
+    if (!g || !lut1 || !sem || !W || !dsem || !partials || !dlut_partial || !workspace)
+        return fail("goi_codebook_fused: a required pointer is NULL");
+    if (launch_codebook_fused(g, lut1, sem, W, bias, HW, C, D, S, t, dsem, partials, dlut_partial, workspace,
+                              static_cast<hipStream_t>(stream)) < 0)
+        return fail("goi_codebook_fused: supported shape is D = 256, 288 < C <= 304, 1 <= S <= 16, HW % 4 = 0");
+    GOI_HIP(hipGetLastError());
+    return 0;
+}
+
 int goi_raster_sh_grad_from_views(int P, int D, int M, int V, const float* means3D, const float* campos, const float* gcol,
                            float* dL_dsh, void* stream) {
     if (P <= 0 || V <= 0) return 0;

@@ -539,6 +539,657 @@ __global__ __launch_bounds__(64 * SIM_NW) void codebook_sim_k(const float* __res
     }
 }
 
+
+// ================================================================================================================
+// The whole training half with no [HW][C] fp32 matrix in memory (train.py:142-163): four kernels,
+// each small enough to run at two waves per SIMD.
+//
+// All of them work on 16-pixel blocks in the MFMA accumulator layout with the PIXELS as rows,
+// D[pixel 4 kq + r][code 16 cb + mm]: a lane holds 4 pixels of 19 codes, a reduction over the codes of a pixel is 19 values
+// in the lane and then 4 DPP steps over the 16 lanes of a row (codebook_rows_k: full-wave reductions per PIXEL).
+//   decoder_stats_k   z = f W^T + b (K = S <= 16: one v_mfma_f32_16x16x16_bf16 per split term, the bias is the accumulator's
+//                     initial value) -> per pixel max, 1 / sum exp, sum P^2 and the first arg-maximum.
+//   codebook_simgrad_k  sim = g^T L1^T on the matrix cores (codebook_sim_k with the operands swapped), its row statistics and
+//                     dL/dsim, which leaves as bf16 hi/lo planes [16-pixel block][plane][304 codes][16 pixels]: a lane's 4
+//                     pixels are 8 bytes, a wave store is 512 contiguous bytes, and the layout is the A operand of the last
+//                     kernel.  Per pixel it records the code-book label (first arg-maximum, number of maxima; the full set
+//                     of maxima as a bit mask in the rare case of a tie).
+//   decoder_grad_k    z again, P from the recorded statistics, dz, and its two contractions:
+//                       dL/dW[c][s] = sum_p dz[p][c] f[p][s]  over pixels: the dz tile in the D layout IS the A operand
+//                                     (M = code, k = 4 kq + r = pixel) -- persistent accumulators, one partial per wave;
+//                       dL/df[p][s] = sum_c dz[p][c] W[c][s]  over codes, the lane axis of the D layout: dz goes through a
+//                                     wave-private LDS tile ([16 pixels][32 codes] bf16, 80-byte rows) to become an A
+//                                     operand (M = pixel).
+//   codebook_dlut2_k  dL/dL1[c][d] = sum_p dsim[p][c] g[d][p]: the dsim planes stream through LDS by LDS-DMA (K = pixels, 32
+//                     per chunk), g is split once by the wave that owns its 32 features, and a workgroup keeps the whole
+//                     [304][256] partial in the accumulators of its 8 waves.
+// HBM traffic: g twice (2 x 1.73 GB at 1600x1056) and the planes once each way (2 x 2.05 GB), against 11.6 GB for
+// sim kernel + row kernel + fp32 dLUT kernel.
+// (One kernel for the first three was tried first: ~400 live registers, one wave per SIMD, and the compiler spilled the
+// addresses it hoisted; every load, LDS and dependent-MFMA latency was exposed: 4.7 ms against 3.6 ms for sim + row kernels.)
+constexpr int FU_NW = 4;                      // codebook_simgrad_k: waves per workgroup (two workgroups per CU)
+constexpr int FU_WG_PIX = 32 * FU_NW;         // a wave owns two 16-pixel blocks
+constexpr int FU_TROW = 80;                   // transposition tile: row stride in bytes (64 + 16: conflict-free both ways)
+constexpr int FU_TPLANE = 16 * FU_TROW, FU_TBUF = 2 * FU_TPLANE;
+constexpr int FU_WZ_BYTES = 2 * SIM_NC * 32;  // decoder planes for z: [2][304][16] bf16
+constexpr int FU_NJ = (SIM_NCB + 1) / 2;      // 32-code K steps of the df contraction (the last one half empty)
+constexpr int FU_WT_BYTES = 2 * FU_NJ * 16 * 64;  // decoder planes for df: [2][10][16 s][32 codes] bf16
+constexpr int FU_DCHUNK = 2 * SIM_NC * 16;    // uint16 elements of one 16-pixel block of the dsim planes
+constexpr int FU_TIE_WORDS = 10;              // 304 bits
+constexpr int DG_NW = 8;                      // decoder_grad_k: waves per workgroup (one workgroup per CU, persistent)
+constexpr int DS_NW = 4;                      // decoder_stats_k
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+struct FusedArgs {
+    const float* g;          // [256][HW]   ground-truth feature map, channel-major
+    const uint16_t* planes;  // [2][304][256] bf16: the normalised code book, hi and lo
+    const uint16_t* wz;      // [2][304][16]  bf16: W[c][s] (s >= S zero, c >= C zero)
+    const uint16_t* wt;      // [2][10][16][32] bf16: W[32 j + k][s]
+    const float* bias;       // [C] or NULL
+    const float* sem;        // [S][HW]
+    uint16_t* dplanes;       // [blocks][2][304][16] bf16
+    float* dsem;             // [S][HW]
+    float* partials;         // [decoder_grad waves][C (S + 1) + 4]
+    // per-pixel records, [16 * blocks] each
+    float *r_mz, *r_rzp, *r_p2, *r_nl;
+    int *r_arga, *r_args;
+    uint32_t* r_tie;         // [16 * blocks][10]: the maxima of sim as a bit mask, written only where r_nl > 1
+    float* sums_a;           // [simgrad waves][4]: nl, m, H, sim_a sums
+    long long HW, blocks;
+    int C, S, n_sums_a;
+    float t, kappa, inv_hw, w_sl1;
+};
+
+// W [C][S] fp32 -> the two bf16 operand images of the decoder
+__global__ __launch_bounds__(256) void decoder_split_k(const float* __restrict__ W, int C, int S, uint16_t* __restrict__ wz,
+                                                       uint16_t* __restrict__ wt) {
+    const int i = blockIdx.x * 256 + threadIdx.x;  // (c, s) over [320][16]: wt's last K step is half padding
+    if (i >= FU_NJ * 32 * 16) return;
+    const int c = i >> 4, s = i & 15;
+    const float v = (c < C && s < S) ? W[(size_t)c * S + s] : 0.f;
+    uint32_t hi, lo;
+    split_pair(v, 0.f, hi, lo);
+    if (c < SIM_NC) {
+        wz[i] = (uint16_t)hi;
+        wz[SIM_NC * 16 + i] = (uint16_t)lo;
+    }
+    const int j = c >> 5, k = c & 31;
+    wt[(j * 16 + s) * 32 + k] = (uint16_t)hi;
+    wt[FU_NJ * 16 * 32 + (j * 16 + s) * 32 + k] = (uint16_t)lo;
+}
+
+#define GOI_ROWF(v, ctrl) __int_as_float(GOI_DPP(__float_as_int(v), ctrl, 0xF, 0))
+// reductions over the 16 lanes of a DPP row; every lane of the row ends up with the result
+__device__ __forceinline__ float row_sum(float v) {
+    v += GOI_ROWF(v, 0xB1);
+    v += GOI_ROWF(v, 0x4E);
+    v += GOI_ROWF(v, 0x141);
+    v += GOI_ROWF(v, 0x140);
+    return v;
+}
+__device__ __forceinline__ float row_max(float v) {
+    v = fmaxf(v, GOI_ROWF(v, 0xB1));
+    v = fmaxf(v, GOI_ROWF(v, 0x4E));
+    v = fmaxf(v, GOI_ROWF(v, 0x141));
+    v = fmaxf(v, GOI_ROWF(v, 0x140));
+    return v;
+}
+__device__ __forceinline__ int row_min(int v) {
+    v = min(v, GOI_DPP(v, 0xB1, 0xF, 0));
+    v = min(v, GOI_DPP(v, 0x4E, 0xF, 0));
+    v = min(v, GOI_DPP(v, 0x141, 0xF, 0));
+    v = min(v, GOI_DPP(v, 0x140, 0xF, 0));
+    return v;
+}
+
+// z tiles of one 16-pixel block: A = f [pixel mm][s = 4 kq + i] (fv: this lane's four values), B = W [code mm][s = 4 kq + i]
+// from the LDS image (wz_l = image + 32 mm + 8 kq), C = bias (bias_l = s_bias + mm).  The three products of a tile are issued
+// term by term over groups of four tiles: no MFMA waits for the one before it.  decoder_stats_k and decoder_grad_k both call
+// this: the same instructions in the same order, the same z to the last bit.
+__device__ __forceinline__ void decoder_logits(f32x4 (&z)[SIM_NCB], const float (&fv)[4], const char* wz_l, const float* bias_l,
+                                               bool vlast) {
+    uint32_t fh[2], fl[2];
+    split_pair(fv[0], fv[1], fh[0], fl[0]);
+    split_pair(fv[2], fv[3], fh[1], fl[1]);
+    const s16x4 fAh = __builtin_bit_cast(s16x4, uint2{fh[0], fh[1]}), fAl = __builtin_bit_cast(s16x4, uint2{fl[0], fl[1]});
+    constexpr int G = 4;
+#pragma unroll
+    for (int g0 = 0; g0 < SIM_NCB; g0 += G) {
+        s16x4 Bh[G], Bl[G];
+#pragma unroll
+        for (int i = 0; i < G; i++)
+            if (g0 + i < SIM_NCB) {
+                const float b = bias_l[16 * (g0 + i)];
+                Bh[i] = *reinterpret_cast<const s16x4*>(wz_l + 512 * (g0 + i));
+                Bl[i] = *reinterpret_cast<const s16x4*>(wz_l + 512 * (g0 + i) + FU_WZ_BYTES / 2);
+                z[g0 + i] = f32x4{b, b, b, b};
+            }
+#pragma unroll
+        for (int i = 0; i < G; i++)
+            if (g0 + i < SIM_NCB) z[g0 + i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(fAl, Bh[i], z[g0 + i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < G; i++)
+            if (g0 + i < SIM_NCB) z[g0 + i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(fAh, Bl[i], z[g0 + i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < G; i++)
+            if (g0 + i < SIM_NCB) z[g0 + i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(fAh, Bh[i], z[g0 + i], 0, 0, 0);
+    }
+    const float NEG_INF = -__builtin_inff();
+    if (!vlast) z[SIM_NCB - 1] = f32x4{NEG_INF, NEG_INF, NEG_INF, NEG_INF};  // padding codes: P = 0, no gradient
+}
+
+// ---- decoder statistics: one 16-pixel block per wave and iteration
+__global__ __launch_bounds__(64 * DS_NW, 2) void decoder_stats_k(const FusedArgs a) {
+    __shared__ __attribute__((aligned(16))) char s_wz[FU_WZ_BYTES];
+    __shared__ float s_bias[SIM_NC];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, kq = lane >> 4, mm = lane & 15;
+    const long long HW = a.HW;
+    for (int i = tid; i < FU_WZ_BYTES / 16; i += 64 * DS_NW)
+        reinterpret_cast<uint4*>(s_wz)[i] = reinterpret_cast<const uint4*>(a.wz)[i];
+    for (int i = tid; i < SIM_NC; i += 64 * DS_NW) s_bias[i] = (a.bias && i < a.C) ? a.bias[i] : 0.f;
+    __syncthreads();
+    const bool vlast = 16 * (SIM_NCB - 1) + mm < a.C;
+    const char* const wz_l = s_wz + 32 * mm + 8 * kq;
+    const float* const bias_l = s_bias + mm;
+    for (long long blk = (long long)blockIdx.x * DS_NW + w; blk < a.blocks; blk += (long long)gridDim.x * DS_NW) {
+        const long long pbase = 16 * blk;
+        float fv[4];
+        {
+            const long long p = min(pbase + mm, HW - 1);
+#pragma unroll
+            for (int i = 0; i < 4; i++) fv[i] = (4 * kq + i < a.S) ? a.sem[(size_t)(4 * kq + i) * HW + p] : 0.f;
+        }
+        f32x4 z[SIM_NCB];
+        decoder_logits(z, fv, wz_l, bias_l, vlast);
+        f32x4 o_mz, o_rzp, o_p2;
+        int4 o_arg;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            float m = -__builtin_inff();
+#pragma unroll
+            for (int cb = 0; cb < SIM_NCB; cb++) m = fmaxf(m, z[cb][r]);
+            const float mz = row_max(m);
+            float sZ = 0.f, s2 = 0.f;
+            int ia = 0x7FFFFFFF;
+#pragma unroll
+            for (int cb = SIM_NCB - 1; cb >= 0; cb--) {  // descending: the lane's FIRST maximum wins
+                ia = z[cb][r] == mz ? 16 * cb + mm : ia;
+                const float e = __expf(z[cb][r] - mz);
+                sZ += e;
+                s2 = fmaf(e, e, s2);
+            }
+            const float rZ = 1.f / row_sum(sZ);
+            o_mz[r] = mz;
+            o_rzp[r] = rZ;
+            o_p2[r] = row_sum(s2) * rZ * rZ;
+            (&o_arg.x)[r] = row_min(ia);
+        }
+        if (mm == 0) {  // rows pbase + 4 kq .. + 3
+            *reinterpret_cast<f32x4*>(a.r_mz + pbase + 4 * kq) = o_mz;
+            *reinterpret_cast<f32x4*>(a.r_rzp + pbase + 4 * kq) = o_rzp;
+            *reinterpret_cast<f32x4*>(a.r_p2 + pbase + 4 * kq) = o_p2;
+            *reinterpret_cast<int4*>(a.r_arga + pbase + 4 * kq) = o_arg;
+        }
+    }
+}
+
+// ---- sim, its statistics and dL/dsim.  The K loop is codebook_sim_k's with the operands swapped (pixels are MFMA rows).
+__global__ __launch_bounds__(64 * FU_NW, 2) void codebook_simgrad_k(const FusedArgs a) {
+    __shared__ __attribute__((aligned(1024))) char s_cb[2][SIM_BUF];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, kq = lane >> 4, mm = lane & 15;
+    const long long HW = a.HW;
+    const int C = a.C;
+    const float NEG_INF = -__builtin_inff();
+    const long long p0 = (long long)blockIdx.x * FU_WG_PIX + 32 * w;  // this wave's pixel blocks p0, p0 + 16
+    f32x4 acc[2][SIM_NCB];
+#pragma unroll
+    for (int pb = 0; pb < 2; pb++)
+#pragma unroll
+        for (int cb = 0; cb < SIM_NCB; cb++) acc[pb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float nrm[2] = {0.f, 0.f};
+    // buffer loads for g: the descriptor (per chunk) and the row offset are scalar, the lane's part is one 32-bit offset per
+    // pixel block (HW < 2^25: launch_codebook_fused checks it)
+    const uint32_t row_b = (uint32_t)HW * 4u;
+    uint32_t voff[2];
+#pragma unroll
+    for (int pb = 0; pb < 2; pb++) voff[pb] = (uint32_t)(8 * kq) * row_b + 4u * (uint32_t)min(p0 + 16 * pb + mm, HW - 1);
+    constexpr int NKC = SIM_K / SIM_KC, AHEAD = 2;
+    float araw[AHEAD][2][8];
+    auto load_a = [&](int kc, float (&dst)[2][8]) {  // g[k = 32 kc + 8 kq + i][pixel p0 + 16 pb + mm]
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.g + (size_t)SIM_KC * kc * HW), 0,
+                                                          (int)(SIM_KC * row_b), 0x00020000);
+#pragma unroll
+        for (int pb = 0; pb < 2; pb++)
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                dst[pb][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff[pb], (int)(i * row_b), 0));
+    };
+    const char* planes_b = reinterpret_cast<const char*>(a.planes);
+    constexpr int NPIECE = (SIM_PIECES + FU_NW - 1) / FU_NW;
+    auto stage = [&](int kc, int buf) {
+#pragma unroll
+        for (int j = 0; j < NPIECE; j++) {
+            const int q = w + FU_NW * j;
+            const int slot = 64 * q + lane;
+            const int plane = slot / (SIM_NC * 4), rs = slot - plane * (SIM_NC * 4), r = rs >> 2, sp = rs & 3;
+            const int piece = sp ^ ((r >> 2) & 3);
+            const uint32_t so = (uint32_t)(((plane * SIM_NC + r) * SIM_K + 8 * piece + SIM_KC * kc) * 2);
+            if (q < SIM_PIECES)  // wave-uniform
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(planes_b + so),
+                                                 (__attribute__((address_space(3))) void*)(s_cb[buf] + 1024 * q), 16, 0, 0);
+        }
+    };
+    const int b_off = 64 * mm + 16 * (kq ^ ((mm >> 2) & 3));
+    stage(0, 0);
+#pragma unroll
+    for (int kc = 0; kc < AHEAD; kc++) load_a(kc, araw[kc]);
+#pragma unroll
+    for (int kc = 0; kc < NKC; kc++) {
+        // chunk kc has landed for THIS wave's pieces (and its A values: loads return in order); past the barrier it has for
+        // every wave's, and every wave is done reading the other buffer
+        if (kc + 1 < NKC) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");  // all but the newest A chunk (16 loads)
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        bf16x8 Ah[2], Al[2];
+#pragma unroll
+        for (int pb = 0; pb < 2; pb++) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) nrm[pb] = fmaf(araw[kc % AHEAD][pb][i], araw[kc % AHEAD][pb][i], nrm[pb]);
+            split_pack8(araw[kc % AHEAD][pb], Ah[pb], Al[pb]);
+        }
+        if (kc + 1 < NKC) stage(kc + 1, (kc + 1) & 1);
+        if (kc + AHEAD < NKC) load_a(kc + AHEAD, araw[kc % AHEAD]);
+        const char* buf = s_cb[kc & 1] + b_off;
+#pragma unroll
+        for (int cb = 0; cb < SIM_NCB; cb++) {
+            const bf16x8 Bh = *reinterpret_cast<const bf16x8*>(buf + 1024 * cb);
+            const bf16x8 Bl = *reinterpret_cast<const bf16x8*>(buf + 1024 * cb + SIM_PLANE_U);
+            acc[0][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al[0], Bh, acc[0][cb], 0, 0, 0);
+            acc[1][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al[1], Bh, acc[1][cb], 0, 0, 0);
+            acc[0][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[0], Bl, acc[0][cb], 0, 0, 0);
+            acc[1][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[1], Bl, acc[1][cb], 0, 0, 0);
+            acc[0][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[0], Bh, acc[0][cb], 0, 0, 0);
+            acc[1][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[1], Bh, acc[1][cb], 0, 0, 0);
+        }
+    }
+    const bool vlast = 16 * (SIM_NCB - 1) + mm < C;  // 288 < C <= 304: only the last code block has padding
+    const float g_ent = a.w_sl1 * a.t * a.inv_hw;
+    const float first = mm == 0 ? 1.f : 0.f;  // a row's scalars are replicated over its 16 lanes: count them once
+    float acc_nl = 0.f, acc_m = 0.f, acc_H = 0.f, acc_sa = 0.f;
+#pragma unroll
+    for (int pb = 0; pb < 2; pb++) {
+        const long long pbase = p0 + 16 * pb;  // this lane's D rows are pixels pbase + 4 kq + r
+        f32x4(&sx)[SIM_NCB] = acc[pb];
+        float invl;
+        {  // 1 / |g|: this lane summed k = 8 kq .. + 7 of every chunk for pixel mm
+            float n2 = nrm[pb];
+            n2 += __shfl_xor(n2, 16, 64);
+            n2 += __shfl_xor(n2, 32, 64);
+            invl = 1.0f / sqrtf(n2);
+        }
+        const int4 arga4 = *reinterpret_cast<const int4*>(a.r_arga + pbase + 4 * kq);
+        f32x4 o_nl;
+        int4 o_args;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float inv = __shfl(invl, 4 * kq + r, 64);
+            const bool valid = pbase + 4 * kq + r < HW;
+            const float vw = valid ? first : 0.f;
+            const int arg_a = (&arga4.x)[r];
+            float m = NEG_INF;
+#pragma unroll
+            for (int cb = 0; cb < SIM_NCB; cb++) {
+                sx[cb][r] *= inv;
+                if (cb == SIM_NCB - 1) sx[cb][r] = vlast ? sx[cb][r] : NEG_INF;
+                m = fmaxf(m, sx[cb][r]);
+            }
+            const float ms = row_max(m);
+            float sZ = 0.f, sA = 0.f, sN = 0.f, sS = 0.f;
+            int is = 0x7FFFFFFF;
+#pragma unroll
+            for (int cb = SIM_NCB - 1; cb >= 0; cb--) {  // descending: the lane's FIRST maximum wins
+                const float x = sx[cb][r];
+                const bool top = x == ms;
+                is = top ? 16 * cb + mm : is;
+                sN += top ? 1.f : 0.f;
+                sS += (16 * cb + mm == arg_a) ? x : 0.f;
+                float lx = a.t * (x - ms);  // <= 0
+                const float q = __expf(lx);
+                sZ += q;
+                lx = fmaxf(lx, -FLT_MAX);  // keep 0 * lx finite for padding
+                sA = fmaf(q, lx, sA);
+            }
+            const float Zq = row_sum(sZ), Aq = row_sum(sA), nl = row_sum(sN), sim_a = row_sum(sS);
+            const int arg_s = row_min(is);
+            const float rZq = 1.f / Zq, logZq = __logf(Zq);
+            const float Hq = logZq - Aq * rZq;
+            acc_nl += vw * nl;
+            acc_m += vw * ms;
+            acc_H += vw * Hq;
+            acc_sa += vw * sim_a;
+            o_nl[r] = nl;
+            (&o_args.x)[r] = arg_s;
+            // A tie (several codes share the maximum of sim: duplicate code-book rows) is the one case in which
+            // decoder_grad_k cannot rebuild the label from (arg_s, nl): the set of maxima goes out as a bit mask, bit c of the
+            // pixel's 304.  (dL/dsim itself follows the FIRST maximum, as the row kernel and torch.max do.)
+            if (__builtin_expect(__any(nl > 1.f), 0)) {
+                uint32_t* wd = a.r_tie + (size_t)(pbase + 4 * kq + r) * FU_TIE_WORDS;
+                uint32_t word = 0;
+#pragma unroll
+                for (int cb = 0; cb < SIM_NCB; cb++) {
+                    const unsigned long long bal = __ballot(sx[cb][r] == ms);  // bit 16 kq + mm
+                    const uint32_t bits = (uint32_t)(bal >> (16 * kq)) & 0xFFFFu;
+                    word = (cb & 1) ? (word | (bits << 16)) : bits;
+                    if (((cb & 1) || cb == SIM_NCB - 1) && nl > 1.f && mm == 0) wd[cb >> 1] = word;
+                }
+            }
+            const float invr = valid ? inv : 0.f;  // a pixel beyond the map has no gradient
+            // exp(t (x - ms)) is computed a second time ON PURPOSE: kept from the statistics pass it would be 76 more live
+            // registers; the opaque copy of ms stops the compiler from "saving" the work
+            float msr = ms;
+            asm volatile("" : "+v"(msr));
+#pragma unroll
+            for (int cb = 0; cb < SIM_NCB; cb++) {
+                const int c = 16 * cb + mm;
+                const float x = sx[cb][r];
+                float lx = a.t * (x - msr);
+                const float qk = __expf(lx) * rZq;
+                lx = fmaxf(lx, -FLT_MAX);
+                float d = -g_ent * qk * ((lx - logZq) + Hq);  // d(0.3 mean H)/dsim
+                d -= c == arg_s ? a.inv_hw : 0.f;             // d(1 - mean m)/dsim
+                d -= c == arg_a ? a.inv_hw : 0.f;             // d(1 - mean sim_a)/dsim
+                sx[cb][r] = d * invr;                         // dL/dsim_raw
+            }
+        }
+        if (mm == 0) {
+            *reinterpret_cast<f32x4*>(a.r_nl + pbase + 4 * kq) = o_nl;
+            *reinterpret_cast<int4*>(a.r_args + pbase + 4 * kq) = o_args;
+        }
+        // ---- dsim planes of this block: [plane][code][16 pixels]
+        {
+            uint16_t* dst = a.dplanes + (size_t)(pbase >> 4) * FU_DCHUNK + (size_t)mm * 16 + 4 * kq;
+#pragma unroll
+            for (int cb = 0; cb < SIM_NCB; cb++) {
+                uint32_t h0, l0, h1, l1;
+                split_pair(sx[cb][0], sx[cb][1], h0, l0);
+                split_pair(sx[cb][2], sx[cb][3], h1, l1);
+                *reinterpret_cast<uint2*>(dst + 256 * cb) = uint2{h0, h1};
+                *reinterpret_cast<uint2*>(dst + 256 * cb + SIM_NC * 16) = uint2{l0, l1};
+            }
+        }
+    }
+    const float t0 = wave_sum_u(acc_nl), t1 = wave_sum_u(acc_m), t2 = wave_sum_u(acc_H), t3 = wave_sum_u(acc_sa);
+    if (lane == 0) *reinterpret_cast<f32x4*>(a.sums_a + 4 * ((size_t)blockIdx.x * FU_NW + w)) = f32x4{t0, t1, t2, t3};
+}
+
+// ---- decoder gradients: persistent, one 16-pixel block per wave and iteration
+__global__ __launch_bounds__(64 * DG_NW, 1) void decoder_grad_k(const FusedArgs a) {
+    __shared__ __attribute__((aligned(16))) char s_wz[FU_WZ_BYTES];
+    __shared__ __attribute__((aligned(16))) char s_wt[FU_WT_BYTES];
+    __shared__ __attribute__((aligned(16))) char s_tr[DG_NW][2][FU_TBUF];
+    __shared__ float s_bias[SIM_NC];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, kq = lane >> 4, mm = lane & 15;
+    const long long HW = a.HW;
+    const int C = a.C, S = a.S;
+    for (int i = tid; i < FU_WZ_BYTES / 16; i += 64 * DG_NW)
+        reinterpret_cast<uint4*>(s_wz)[i] = reinterpret_cast<const uint4*>(a.wz)[i];
+    for (int i = tid; i < FU_WT_BYTES / 16; i += 64 * DG_NW)
+        reinterpret_cast<uint4*>(s_wt)[i] = reinterpret_cast<const uint4*>(a.wt)[i];
+    for (int i = tid; i < SIM_NC; i += 64 * DG_NW) s_bias[i] = (a.bias && i < a.C) ? a.bias[i] : 0.f;
+    __syncthreads();
+    const bool vlast = 16 * (SIM_NCB - 1) + mm < C;
+    const char* const wz_l = s_wz + 32 * mm + 8 * kq;
+    const float* const bias_l = s_bias + mm;
+    const char* const wt_l = s_wt + 64 * mm + 16 * kq;
+    char* const tw_l = s_tr[w][0] + 2 * mm + FU_TROW * 4 * kq;     // tile writes: this lane's code column, its 4 pixel rows
+    const char* const tr_l = s_tr[w][0] + FU_TROW * mm + 16 * kq;  // tile reads: pixel row mm, codes 8 kq ..
+
+    f32x4 dWacc[SIM_NCB];  // D[code 16 cb + 4 kq + r][s = mm]
+    float dbr[SIM_NCB];    // lane (kq, mm): sum of dz[pixel rows 4 kq + r][code 16 cb + mm]
+#pragma unroll
+    for (int cb = 0; cb < SIM_NCB; cb++) {
+        dWacc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dbr[cb] = 0.f;
+    }
+    float acc_lab = 0.f;
+    const float first = mm == 0 ? 1.f : 0.f;
+    const long long wave = (long long)blockIdx.x * DG_NW + w, n_waves = (long long)gridDim.x * DG_NW;
+    for (long long blk = wave; blk < a.blocks; blk += n_waves) {
+        const long long pbase = 16 * blk;
+        // the decoder's two views of the feature: f[s = 4 kq + i][pixel mm], f[s = mm][pixel 4 kq + i]
+        float fvz[4], fvw[4];
+        {
+            const long long pz = min(pbase + mm, HW - 1);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                fvz[i] = (4 * kq + i < S) ? a.sem[(size_t)(4 * kq + i) * HW + pz] : 0.f;
+                fvw[i] = mm < S ? a.sem[(size_t)mm * HW + min(pbase + 4 * kq + i, HW - 1)] : 0.f;
+            }
+        }
+        const f32x4 mz4 = *reinterpret_cast<const f32x4*>(a.r_mz + pbase + 4 * kq);
+        const f32x4 rzp4 = *reinterpret_cast<const f32x4*>(a.r_rzp + pbase + 4 * kq);
+        const f32x4 p24 = *reinterpret_cast<const f32x4*>(a.r_p2 + pbase + 4 * kq);
+        const f32x4 nl4 = *reinterpret_cast<const f32x4*>(a.r_nl + pbase + 4 * kq);
+        const int4 args4 = *reinterpret_cast<const int4*>(a.r_args + pbase + 4 * kq);
+        f32x4 z[SIM_NCB];
+        decoder_logits(z, fvz, wz_l, bias_l, vlast);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const bool valid = pbase + 4 * kq + r < HW;
+            const float mz = mz4[r], rZ = rzp4[r], P2 = p24[r], nl = nl4[r];
+            const int arg_s = (&args4.x)[r];
+            // P, and P at the labelled codes
+            float sP = 0.f;
+            uint32_t labm = 0;  // bit cb: this lane's code of block cb is a maximum of sim
+            if (__builtin_expect(__any(nl > 1.f), 0)) {
+                const uint32_t* wd = a.r_tie + (size_t)(pbase + 4 * kq + r) * FU_TIE_WORDS;
+#pragma unroll
+                for (int cb = 0; cb < SIM_NCB; cb++) {
+                    const bool lab = nl > 1.f ? ((wd[cb >> 1] >> (16 * (cb & 1) + mm)) & 1u) != 0 : (16 * cb + mm == arg_s);
+                    labm |= lab ? (1u << cb) : 0u;
+                }
+            } else {
+#pragma unroll
+                for (int cb = 0; cb < SIM_NCB; cb++) labm |= (16 * cb + mm == arg_s) ? (1u << cb) : 0u;
+            }
+#pragma unroll
+            for (int cb = 0; cb < SIM_NCB; cb++) {
+                z[cb][r] = __expf(z[cb][r] - mz) * rZ;  // P
+                sP += (labm >> cb) & 1u ? z[cb][r] : 0.f;
+            }
+            const float Pl = row_sum(sP);
+            acc_lab += (valid ? first : 0.f) * ((P2 - 2.f * Pl) + nl);
+            const float kap = valid ? a.kappa : 0.f;  // a pixel beyond the map has no gradient
+            const float Dsum = kap * (P2 - Pl);
+#pragma unroll
+            for (int cb = 0; cb < SIM_NCB; cb++) {
+                const float P = z[cb][r], lab = (labm >> cb) & 1u ? 1.f : 0.f;
+                z[cb][r] = P * (kap * (P - lab) - Dsum);  // dz
+            }
+        }
+        uint32_t dzh[SIM_NCB][2], dzl[SIM_NCB][2];  // dz as an A operand: 4 pixels (k) per plane, packed
+#pragma unroll
+        for (int cb = 0; cb < SIM_NCB; cb++) {
+            split_pair(z[cb][0], z[cb][1], dzh[cb][0], dzl[cb][0]);
+            split_pair(z[cb][2], z[cb][3], dzh[cb][1], dzl[cb][1]);
+            dbr[cb] += (z[cb][0] + z[cb][1]) + (z[cb][2] + z[cb][3]);
+        }
+        // ---- dL/dW += dz^T f: A = dz [code mm][k = pixel 4 kq + r], B = f [k = pixel 4 kq + i][s = mm]
+        {
+            uint32_t bh[2], bl[2];
+            split_pair(fvw[0], fvw[1], bh[0], bl[0]);
+            split_pair(fvw[2], fvw[3], bh[1], bl[1]);
+            const s16x4 Bh = __builtin_bit_cast(s16x4, uint2{bh[0], bh[1]}), Bl = __builtin_bit_cast(s16x4, uint2{bl[0], bl[1]});
+#pragma unroll
+            for (int cb = 0; cb < SIM_NCB; cb++)
+                dWacc[cb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, uint2{dzl[cb][0], dzl[cb][1]}), Bh,
+                                                                      dWacc[cb], 0, 0, 0);
+#pragma unroll
+            for (int cb = 0; cb < SIM_NCB; cb++)
+                dWacc[cb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, uint2{dzh[cb][0], dzh[cb][1]}), Bl,
+                                                                      dWacc[cb], 0, 0, 0);
+#pragma unroll
+            for (int cb = 0; cb < SIM_NCB; cb++)
+                dWacc[cb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, uint2{dzh[cb][0], dzh[cb][1]}), Bh,
+                                                                      dWacc[cb], 0, 0, 0);
+        }
+        // ---- dL/df = dz W: dz through the wave's LDS tile to become A [pixel mm][k = code 8 kq + i]; tile j + 1 is written
+        // before tile j is read, and the three products keep separate accumulators (no dependent MFMA chain)
+        {
+            f32x4 df0 = f32x4{0.f, 0.f, 0.f, 0.f}, df1 = df0, df2 = df0;
+            auto put = [&](int j) {
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int cb = 2 * j + h;
+                    char* col = tw_l + FU_TBUF * (j & 1) + 32 * h;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const uint32_t hw_ = cb < SIM_NCB ? dzh[cb < SIM_NCB ? cb : 0][r >> 1] : 0u;
+                        const uint32_t lw_ = cb < SIM_NCB ? dzl[cb < SIM_NCB ? cb : 0][r >> 1] : 0u;
+                        *reinterpret_cast<uint16_t*>(col + FU_TROW * r) = (uint16_t)((r & 1) ? hw_ >> 16 : hw_);
+                        *reinterpret_cast<uint16_t*>(col + FU_TROW * r + FU_TPLANE) = (uint16_t)((r & 1) ? lw_ >> 16 : lw_);
+                    }
+                }
+            };
+            put(0);
+#pragma unroll
+            for (int j = 0; j < FU_NJ; j++) {
+                if (j + 1 < FU_NJ) put(j + 1);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const bf16x8 Ah = *reinterpret_cast<const bf16x8*>(tr_l + FU_TBUF * (j & 1));
+                const bf16x8 Al = *reinterpret_cast<const bf16x8*>(tr_l + FU_TBUF * (j & 1) + FU_TPLANE);
+                const bf16x8 Bh = *reinterpret_cast<const bf16x8*>(wt_l + 1024 * j);
+                const bf16x8 Bl = *reinterpret_cast<const bf16x8*>(wt_l + 1024 * j + FU_WT_BYTES / 2);
+                df0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bh, df0, 0, 0, 0);
+                df1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bl, df1, 0, 0, 0);
+                df2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh, df2, 0, 0, 0);
+            }
+            // D[pixel 4 kq + r][s = mm]
+            if (mm < S) {
+                float* dst = a.dsem + (size_t)mm * HW + pbase + 4 * kq;
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    if (pbase + 4 * kq + r < HW) dst[r] = (df0[r] + df1[r]) + df2[r];
+            }
+        }
+    }
+    // ---- this wave's partial sums
+    float* out = a.partials + (size_t)wave * ((size_t)C * (S + 1) + 4);
+#pragma unroll
+    for (int cb = 0; cb < SIM_NCB; cb++) {
+        if (mm < S) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int c = 16 * cb + 4 * kq + r;
+                if (c < C) out[(size_t)c * (S + 1) + mm] = dWacc[cb][r];
+            }
+        }
+        float d = dbr[cb];
+        d += __shfl_xor(d, 16, 64);
+        d += __shfl_xor(d, 32, 64);
+        if (kq == 0 && 16 * cb + mm < C) out[(size_t)(16 * cb + mm) * (S + 1) + S] = d;
+    }
+    // the loss sums: this kernel's part (sum P^2 - 2 sum_label P + number of labels) and, folded in in a fixed order,
+    // codebook_simgrad_k's per-wave sums (rows wave, wave + n_waves, ...)
+    float t0 = wave_sum_u(acc_lab);
+    if (lane == 0) {
+        float t1 = 0.f, t2 = 0.f, t3 = 0.f;
+        for (long long i = wave; i < a.n_sums_a; i += n_waves) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(a.sums_a + 4 * i);
+            t1 += v[1];
+            t2 += v[2];
+            t3 += v[3];
+        }
+        float* lo = out + (size_t)C * (S + 1);
+        lo[0] = t0;
+        lo[1] = t1;
+        lo[2] = t2;
+        lo[3] = t3;
+    }
+}
+
+// ---- dL/dL1 from the dsim planes: partial[wg][304][256]
+constexpr int DL2_NW = 8;
+__global__ __launch_bounds__(64 * DL2_NW, 1) void codebook_dlut2_k(const uint16_t* __restrict__ dplanes, const float* __restrict__ g,
+                                                                  long long HW, float* __restrict__ partial) {
+    __shared__ __attribute__((aligned(1024))) char s_a[2][SIM_BUF];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, kq = lane >> 4, mm = lane & 15;
+    const long long n_chunks = (HW + 31) / 32;  // 32 pixels = two blocks of the planes
+    const long long per = (n_chunks + gridDim.x - 1) / gridDim.x;
+    const long long c0 = (long long)blockIdx.x * per, c1 = min(c0 + per, n_chunks);
+    f32x4 acc[SIM_NCB][2];
+#pragma unroll
+    for (int cb = 0; cb < SIM_NCB; cb++) acc[cb][0] = acc[cb][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // LDS image of a chunk: [plane][code][32 pixels], 64-byte rows, 16-byte pieces swizzled as in codebook_sim_k; piece sp of
+    // a row is pixels 8 sp .. 8 sp + 7 = half (sp & 1) of the row in 16-pixel block (sp >> 1)
+    auto stage = [&](long long ch, int buf) {
+        for (int q = w; q < SIM_PIECES; q += DL2_NW) {
+            const int slot = 64 * q + lane;
+            const int plane = slot / (SIM_NC * 4), rs = slot - plane * (SIM_NC * 4), r = rs >> 2, sp = rs & 3;
+            const int piece = sp ^ ((r >> 2) & 3);
+            const uint16_t* src = dplanes + (size_t)(2 * ch + (piece >> 1)) * FU_DCHUNK + ((size_t)plane * SIM_NC + r) * 16 + 8 * (piece & 1);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(s_a[buf] + 1024 * q), 16, 0, 0);
+        }
+    };
+    f32x4 braw[2][2];
+    auto load_b = [&](long long ch) {  // g[d = 32 w + 16 j + mm][pixels 32 ch + 8 kq .. + 7]   (HW % 4 == 0)
+        const long long p = 32 * ch + 8 * kq;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const float* row = g + (size_t)(32 * w + 16 * j + mm) * HW;
+            braw[j][0] = *reinterpret_cast<const f32x4*>(row + min(p, HW - 4));
+            braw[j][1] = *reinterpret_cast<const f32x4*>(row + min(p + 4, HW - 4));
+        }
+    };
+    const int a_off = 64 * mm + 16 * (kq ^ ((mm >> 2) & 3));
+    if (c0 < c1) {
+        stage(c0, 0);
+        load_b(c0);
+    }
+    for (long long ch = c0; ch < c1; ch++) {
+        const int cur = (int)((ch - c0) & 1);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        bf16x8 Bh[2], Bl[2];
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const float y[8] = {braw[j][0][0], braw[j][0][1], braw[j][0][2], braw[j][0][3],
+                                braw[j][1][0], braw[j][1][1], braw[j][1][2], braw[j][1][3]};
+            split_pack8(y, Bh[j], Bl[j]);
+        }
+        if (ch + 1 < c1) {
+            stage(ch + 1, cur ^ 1);
+            load_b(ch + 1);
+        }
+        const char* buf = s_a[cur] + a_off;
+#pragma unroll
+        for (int cb = 0; cb < SIM_NCB; cb++) {
+            const bf16x8 Ah = *reinterpret_cast<const bf16x8*>(buf + 1024 * cb);
+            const bf16x8 Al = *reinterpret_cast<const bf16x8*>(buf + 1024 * cb + SIM_PLANE_U);
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                acc[cb][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bh[j], acc[cb][j], 0, 0, 0);
+                acc[cb][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bl[j], acc[cb][j], 0, 0, 0);
+                acc[cb][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh[j], acc[cb][j], 0, 0, 0);
+            }
+        }
+    }
+    // D[code 16 cb + 4 kq + r][d = 32 w + 16 j + mm]
+    float* out = partial + (size_t)blockIdx.x * SIM_NC * 256;
+#pragma unroll
+    for (int cb = 0; cb < SIM_NCB; cb++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) out[(size_t)(16 * cb + 4 * kq + r) * 256 + 32 * w + 16 * j + mm] = acc[cb][j][r];
+}
+
 }  // namespace
 
 int codebook_loss_waves() { return 256 * 8; }  // persistent: 8 waves per CU (2 per SIMD at ~230 VGPRs)
@@ -566,6 +1217,7 @@ int launch_codebook_rows(const float* sim, const float* inv_gnorm, const float* 
     return 0;
 }
 
+
 }  // namespace goi
 
 namespace goi {
@@ -591,6 +1243,60 @@ int launch_codebook_dlut(const float* dsim, const float* g, long long HW, int C,
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(codebook_dlut_k<NCB>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     codebook_dlut_k<NCB><<<dim3(2 * codebook_dlut_blocks()), dim3(DL_THREADS), lds, s>>>(dsim, g, HW, C, partial);
+    return 0;
+}
+
+// ---- the training half in one call.  workspace: code-book planes | decoder images | per-pixel records | simgrad wave sums |
+// dsim planes (the only large part: 2 x 2 B per (pixel, code))
+static size_t fu_align(size_t x) { return (x + 255) & ~(size_t)255; }
+static long long fu_blocks(long long HW) { return (HW + FU_WG_PIX - 1) / FU_WG_PIX * (FU_WG_PIX / 16); }
+static long long fu_simgrad_wgs(long long HW) { return (HW + FU_WG_PIX - 1) / FU_WG_PIX; }
+size_t codebook_fused_workspace_bytes(long long HW) {
+    const size_t npad = (size_t)16 * fu_blocks(HW);
+    return fu_align((size_t)2 * SIM_NC * SIM_K * 2) + fu_align(FU_WZ_BYTES) + fu_align(FU_WT_BYTES) + 6 * fu_align(npad * 4) +
+           fu_align(npad * FU_TIE_WORDS * 4) + fu_align((size_t)fu_simgrad_wgs(HW) * FU_NW * 16) +
+           (size_t)fu_blocks(HW) * FU_DCHUNK * 2;
+}
+int codebook_fused_rows() { return 256 * DG_NW; }
+// returns -1 when the shape is not the kernels' (D = 256, C in 289..304, S <= 16, HW % 4 = 0, HW < 2^25)
+int launch_codebook_fused(const float* g, const float* l1, const float* sem, const float* W, const float* bias, long long HW,
+                          int C, int D, int S, float t, float* dsem, float* partials, float* dl1_partial, void* workspace,
+                          hipStream_t s) {
+    if (D != SIM_K || C > SIM_NC || C <= SIM_NC - 16 || S < 1 || S > 16 || HW < 4 || (HW & 3) != 0 || HW >= (1ll << 25)) return -1;
+    const long long blocks = fu_blocks(HW);
+    const size_t npad = (size_t)16 * blocks;
+    char* ws = static_cast<char*>(workspace);
+    auto take = [&](size_t bytes) {
+        char* p = ws;
+        ws += fu_align(bytes);
+        return p;
+    };
+    FusedArgs a;
+    uint16_t* planes = reinterpret_cast<uint16_t*>(take((size_t)2 * SIM_NC * SIM_K * 2));
+    uint16_t* wz = reinterpret_cast<uint16_t*>(take(FU_WZ_BYTES));
+    uint16_t* wt = reinterpret_cast<uint16_t*>(take(FU_WT_BYTES));
+    a.r_mz = reinterpret_cast<float*>(take(npad * 4));
+    a.r_rzp = reinterpret_cast<float*>(take(npad * 4));
+    a.r_p2 = reinterpret_cast<float*>(take(npad * 4));
+    a.r_nl = reinterpret_cast<float*>(take(npad * 4));
+    a.r_arga = reinterpret_cast<int*>(take(npad * 4));
+    a.r_args = reinterpret_cast<int*>(take(npad * 4));
+    a.r_tie = reinterpret_cast<uint32_t*>(take(npad * FU_TIE_WORDS * 4));
+    a.n_sums_a = (int)(fu_simgrad_wgs(HW) * FU_NW);
+    a.sums_a = reinterpret_cast<float*>(take((size_t)a.n_sums_a * 16));
+    uint16_t* dplanes = reinterpret_cast<uint16_t*>(ws);
+    codebook_split_k<<<dim3((SIM_NC * SIM_K / 2 + 255) / 256), dim3(256), 0, s>>>(l1, C, planes);
+    decoder_split_k<<<dim3((FU_NJ * 32 * 16 + 255) / 256), dim3(256), 0, s>>>(W, C, S, wz, wt);
+    a.g = g; a.planes = planes; a.wz = wz; a.wt = wt; a.bias = bias; a.sem = sem; a.dplanes = dplanes; a.dsem = dsem;
+    a.partials = partials; a.HW = HW; a.blocks = blocks; a.C = C; a.S = S; a.t = t;
+    a.kappa = (float)(2.0 * 50.0 / ((double)HW * (double)C));
+    a.inv_hw = (float)(1.0 / (double)HW);
+    a.w_sl1 = 0.3f;
+    const long long stat_wgs = (blocks + DS_NW - 1) / DS_NW;
+    decoder_stats_k<<<dim3((unsigned)(stat_wgs < 2048 ? stat_wgs : 2048)), dim3(64 * DS_NW), 0, s>>>(a);
+    codebook_simgrad_k<<<dim3((unsigned)fu_simgrad_wgs(HW)), dim3(64 * FU_NW), 0, s>>>(a);
+    decoder_grad_k<<<dim3(codebook_fused_rows() / DG_NW), dim3(64 * DG_NW), 0, s>>>(a);
+    codebook_dlut2_k<<<dim3(codebook_dlut_blocks()), dim3(64 * DL2_NW), 0, s>>>(dplanes, g, HW, dl1_partial);
     return 0;
 }
 }  // namespace goi

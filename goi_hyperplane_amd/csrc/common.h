@@ -144,6 +144,11 @@ size_t codebook_sim_workspace_bytes();
 int launch_codebook_sim(const float* g, const float* l1, long long HW, int C, int D, float* sim, float* inv_gnorm,
                         void* workspace, hipStream_t s);
 int codebook_dlut_blocks();
+size_t codebook_fused_workspace_bytes(long long HW);
+int codebook_fused_rows();
+int launch_codebook_fused(const float* g, const float* l1, const float* sem, const float* W, const float* bias, long long HW,
+                          int C, int D, int S, float t, float* dsem, float* partials, float* dl1_partial, void* workspace,
+                          hipStream_t s);
 int launch_codebook_dlut(const float* dsim, const float* g, long long HW, int C, int D, float* partial, hipStream_t s);
 int launch_adam_step(const GoiAdamGroup* groups, int n_groups, double beta1, double beta2, double eps,
                      const uint8_t* nograd_mask, hipStream_t s);

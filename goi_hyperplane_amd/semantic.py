@@ -171,6 +171,7 @@ def codebook_losses(sem_feature_chw: torch.Tensor, semantic_mlp: SemanticModel, 
 
 
 _SIM_KERNEL = {"on": True}  # False: the library fp32 GEMM for sim (A/B and a fallback for other shapes)
+_FUSED_KERNELS = {"on": True}  # False: the three-kernel path (sim, rows, dLUT) -- kept for other shapes and as a cross-check
 
 
 class _FusedCodebookLoss(torch.autograd.Function):
@@ -194,6 +195,17 @@ class _FusedCodebookLoss(torch.autograd.Function):
         with torch.cuda.device(dev):
             p = lambda x: None if x is None else C_.c_void_p(x.data_ptr())  # noqa: E731
             stream = C_.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            if _FUSED_KERNELS["on"] and D == 256 and 288 < C <= 304 and S <= 16 and HW % 4 == 0:
+                # sim -> losses -> gradients in two kernels, no [HW, C] fp32 matrix (csrc/codebook_loss.hip: codebook_fused_k)
+                dsem = torch.empty((S, HW), dtype=torch.float32, device=dev)
+                partials = torch.empty((lib.goi_codebook_fused_partial_rows(), C * (S + 1) + 4), dtype=torch.float32, device=dev)
+                part = torch.empty((lib.goi_codebook_dlut_partial_blocks(), 304, D), dtype=torch.float32, device=dev)
+                ws = torch.empty((int(lib.goi_codebook_fused_workspace_bytes(HW)),), dtype=torch.uint8, device=dev)
+                if lib.goi_codebook_fused(p(g), p(l1), p(sem), p(w), p(b), HW, C, D, S, float(t), p(dsem), p(partials), p(part),
+                                          p(ws), stream) < 0:
+                    raise RuntimeError(_lib.last_error())
+                del ws
+                return _FusedCodebookLoss._finish(ctx, sem_chw, bias, partials, dsem, part.sum(dim=0)[:C].contiguous(), HW, C, S)
             sim_raw = inv_gnorm = None
             if D == 256 and C <= 304 and C % 4 == 0 and _SIM_KERNEL["on"]:
                 # one pass over g: split-bf16 MFMA contraction + 1/|g| (csrc/codebook_loss.hip: codebook_sim_k)
@@ -214,13 +226,6 @@ class _FusedCodebookLoss(torch.autograd.Function):
             if r < 0:
                 raise RuntimeError(_lib.last_error())
             del sim_raw
-            tot = partials.sum(dim=0)                                                 # fixed order: reproducible
-            dWb = tot[: C * (S + 1)].view(C, S + 1)
-            sums = tot[C * (S + 1):]
-            lab = sums[0] * (50.0 / (HW * C))
-            sl = 1.0 - sums[1] / HW
-            sl1 = sums[2] / HW
-            recc = 1.0 - sums[3] / HW
             if D == 256 and 288 < C <= 304 and HW % 4 == 0:
                 # split-K MFMA GEMM over the pixel axis with a persistent [304, 256] accumulator per CU
                 blocks = lib.goi_codebook_dlut_partial_blocks()
@@ -231,6 +236,17 @@ class _FusedCodebookLoss(torch.autograd.Function):
                 dl1 = part.sum(dim=0)[:C].contiguous()
             else:
                 dl1 = torch.matmul(dsim.t(), g.t())                                   # [C, D]   (library GEMM)
+        return _FusedCodebookLoss._finish(ctx, sem_chw, bias, partials, dsem, dl1, HW, C, S)
+
+    @staticmethod
+    def _finish(ctx, sem_chw, bias, partials, dsem, dl1, HW, C, S):
+        tot = partials.sum(dim=0)                                                     # fixed order: reproducible
+        dWb = tot[: C * (S + 1)].view(C, S + 1)
+        sums = tot[C * (S + 1):]
+        lab = sums[0] * (50.0 / (HW * C))
+        sl = 1.0 - sums[1] / HW
+        sl1 = sums[2] / HW
+        recc = 1.0 - sums[3] / HW
         ctx.save_for_backward(dsem.view_as(sem_chw), dWb[:, :S].contiguous(), dWb[:, S].contiguous(), dl1)
         ctx.has_bias = bias is not None
         terms = torch.stack([lab, sl, sl1, recc])

@@ -82,3 +82,75 @@ def test_headline_resolution_runs_and_agrees_on_the_loss():
         l0, t0 = codebook_losses(sem.detach(), mlp, lut.detach(), gtl, 10)
     assert abs(float(l0 - l1)) <= 2e-5 * abs(float(l0))
     assert torch.isfinite(g1["sem"]).all() and torch.isfinite(g1["lut"]).all()
+
+
+@pytest.mark.parametrize("HW,C", [(1, 4), (127, 300), (128, 304), (5000, 300), (33 * 47, 64), (1600 * 1056, 300)])
+def test_similarity_kernel_against_fp64(HW, C):
+    """goi_codebook_sim (split-bf16 MFMA, three partial products) against an fp64 product on the same inputs: the result
+    must be as good as an fp32 GEMM's (2^-16-relative operand error squared is below fp32 rounding of a 256-term sum), so
+    the bound is a few fp32 ulps of the scale.  Ragged pixel counts exercise the clamped tail block; C = 304 the full tile."""
+    import ctypes as C_
+
+    from goi_hyperplane_amd import _lib
+    lib = _lib.load()
+    D = 256
+    g_ = torch.Generator(device="cuda").manual_seed(HW % 1000 + C)
+    lut = torch.rand(C, D, device="cuda", generator=g_) * 0.03
+    l1 = (lut / lut.norm(dim=1, keepdim=True)).contiguous()
+    idx = torch.randint(0, C, (HW,), device="cuda", generator=g_)
+    g = (lut[idx] * 30 + 0.3 * torch.randn(HW, D, device="cuda", generator=g_)).t().contiguous()  # [D, HW]
+    sim = torch.full((HW, C), float("nan"), device="cuda")
+    inv = torch.full((HW,), float("nan"), device="cuda")
+    ws = torch.empty((int(lib.goi_codebook_sim_workspace_bytes()),), dtype=torch.uint8, device="cuda")
+    p = lambda t: C_.c_void_p(t.data_ptr())  # noqa: E731
+    rc = lib.goi_codebook_sim(p(g), p(l1), HW, C, D, p(sim), p(inv), p(ws),
+                              C_.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, _lib.last_error()
+    n = min(HW, 100_000)
+    ref = g.double().t()[:n] @ l1.double().t()
+    scale = float(ref.abs().max())
+    assert torch.isfinite(sim).all() and torch.isfinite(inv).all()
+    assert float((sim[:n].double() - ref).abs().max()) <= 4e-6 * scale
+    if HW > n:  # the rest against the library's fp32 product
+        assert float((sim - g.t() @ l1.t()).abs().max()) <= 6e-6 * scale
+    inv_ref = g.double().norm(dim=0).reciprocal()
+    assert float(((inv.double() - inv_ref) / inv_ref).abs().max()) <= 2e-6
+
+
+def test_similarity_kernel_rejects_shapes_it_does_not_cover():
+    import ctypes as C_
+
+    from goi_hyperplane_amd import _lib
+    lib = _lib.load()
+    t = torch.zeros(1024, device="cuda")
+    p = C_.c_void_p(t.data_ptr())
+    for HW, C, D in [(4, 300, 128), (4, 308, 256), (4, 302, 256), (0, 300, 256)]:
+        assert lib.goi_codebook_sim(p, p, HW, C, D, p, p, p, None) != 0, (HW, C, D)
+
+
+@pytest.mark.parametrize("H,W,S,C,it,bias", [(40, 56, 16, 300, 10, True), (36, 37, 16, 304, 2000, True),
+                                             (12, 9, 7, 289, 10, False), (64, 128, 16, 300, 1500, True)])
+def test_two_kernel_path_against_three_kernel_path(H, W, S, C, it, bias):
+    """codebook_fused_k + codebook_dlut2_k (no [HW, C] matrix in memory) against sim kernel + row kernel + fp32 dLUT kernel on
+    the same inputs: the loss terms to 1e-5 relative, gradients to 1e-3 of their scale away from near-ties (both paths
+    evaluate sim with split-bf16 products, in different summation orders).  36x37 and 12x9 end inside a 16-pixel block."""
+    from goi_hyperplane_amd import semantic
+    sem, mlp, lut, gtl = setup(H, W, S=S, C=C, bias=bias)
+    assert (H * W) % 4 == 0
+    try:
+        semantic._FUSED_KERNELS["on"] = False
+        l0, t0, g0 = grads(fused_codebook_losses, sem, mlp, lut, gtl, it)
+    finally:
+        semantic._FUSED_KERNELS["on"] = True
+    l1, t1, g1 = grads(fused_codebook_losses, sem, mlp, lut, gtl, it)
+    assert abs(float(l0 - l1)) <= 1e-5 * abs(float(l0))
+    for k in t0:
+        assert abs(float(t0[k] - t1[k])) <= 1e-5 * max(abs(float(t0[k])), 1e-3), k
+    for k in ("sem", "W", "b", "lut"):
+        if g0[k] is None:
+            assert g1[k] is None
+            continue
+        scale = float(g0[k].abs().max())
+        bad = (g0[k] - g1[k]).abs() > 1e-3 * scale
+        # a pixel whose best two codes tie to the last bit may label differently: allow a handful
+        assert int(bad.sum()) <= (4 * S if k == "sem" else 0), (k, int(bad.sum()), float((g0[k] - g1[k]).abs().max()) / scale)
