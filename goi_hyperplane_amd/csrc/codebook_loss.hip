@@ -426,6 +426,9 @@ __global__ __launch_bounds__(256) void codebook_split_k(const float* __restrict_
     reinterpret_cast<uint32_t*>(planes + (size_t)SIM_NC * SIM_K)[i] = lo;
 }
 
+#ifndef GOI_SIM_EXP
+#define GOI_SIM_EXP 0  // timing experiments (tools/build/exp_sim_parts.sh): 1 no code-book staging, 2 no g loads, 4 no products
+#endif
 #ifndef GOI_SIM_PB
 #define GOI_SIM_PB 2
 #endif
@@ -499,10 +502,19 @@ __global__ __launch_bounds__(64 * SIM_NW) void codebook_sim_k(const float* __res
             split_pack8(braw[pb], Bh[pb], Bl[pb]);
         }
         if (kc + 1 < SIM_K / SIM_KC) {  // the next chunk's traffic flies under this chunk's MFMAs
+#if !(GOI_SIM_EXP & 1)
             stage(kc + 1, (kc + 1) & 1);
+#endif
+#if !(GOI_SIM_EXP & 2)
             load_b(kc + 1);
+#endif
         }
+#if GOI_SIM_EXP & 4
+        const char* buf = s_a[0] + a_off;
+        if (kc > 0) continue;   // no products after the first chunk
+#else
         const char* buf = s_a[kc & 1] + a_off;
+#endif
 #pragma unroll
         for (int cb = 0; cb < SIM_NCB; cb++) {
             const bf16x8 Ah = *reinterpret_cast<const bf16x8*>(buf + 1024 * cb);
@@ -578,6 +590,7 @@ constexpr int FU_DCHUNK = 2 * SIM_NC * 16;    // uint16 elements of one 16-pixel
 constexpr int FU_TIE_WORDS = 10;              // 304 bits
 constexpr int DG_NW = 8;                      // decoder_grad_k: waves per workgroup (one workgroup per CU, persistent)
 constexpr int DS_NW = 4;                      // decoder_stats_k
+constexpr int DF_NW = 12;                     // decoder_df_k: three waves per SIMD, one workgroup per CU
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
@@ -674,13 +687,14 @@ __device__ __forceinline__ void decoder_logits(f32x4 (&z)[SIM_NCB], const float 
 #pragma unroll
         for (int i = 0; i < G; i++)
             if (g0 + i < SIM_NCB) z[g0 + i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(fAh, Bh[i], z[g0 + i], 0, 0, 0);
+        asm volatile("" ::: "memory");  // one group's operands in flight at a time: all 19 at once cost 100 registers
     }
     const float NEG_INF = -__builtin_inff();
     if (!vlast) z[SIM_NCB - 1] = f32x4{NEG_INF, NEG_INF, NEG_INF, NEG_INF};  // padding codes: P = 0, no gradient
 }
 
 // ---- decoder statistics: one 16-pixel block per wave and iteration
-__global__ __launch_bounds__(64 * DS_NW, 2) void decoder_stats_k(const FusedArgs a) {
+__global__ __launch_bounds__(64 * DS_NW, 3) void decoder_stats_k(const FusedArgs a) {
     __shared__ __attribute__((aligned(16))) char s_wz[FU_WZ_BYTES];
     __shared__ float s_bias[SIM_NC];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, kq = lane >> 4, mm = lane & 15;
@@ -692,14 +706,18 @@ __global__ __launch_bounds__(64 * DS_NW, 2) void decoder_stats_k(const FusedArgs
     const bool vlast = 16 * (SIM_NCB - 1) + mm < a.C;
     const char* const wz_l = s_wz + 32 * mm + 8 * kq;
     const float* const bias_l = s_bias + mm;
-    for (long long blk = (long long)blockIdx.x * DS_NW + w; blk < a.blocks; blk += (long long)gridDim.x * DS_NW) {
-        const long long pbase = 16 * blk;
-        float fv[4];
-        {
-            const long long p = min(pbase + mm, HW - 1);
+    auto fetch = [&](long long blk, float (&fv)[4]) {  // one block ahead: see decoder_grad_k
+        const long long p = min(16 * min(blk, a.blocks - 1) + mm, HW - 1);
 #pragma unroll
-            for (int i = 0; i < 4; i++) fv[i] = (4 * kq + i < a.S) ? a.sem[(size_t)(4 * kq + i) * HW + p] : 0.f;
-        }
+        for (int i = 0; i < 4; i++) fv[i] = (4 * kq + i < a.S) ? a.sem[(size_t)(4 * kq + i) * HW + p] : 0.f;
+    };
+    const long long stride = (long long)gridDim.x * DS_NW;
+    float fvn[4];
+    fetch((long long)blockIdx.x * DS_NW + w, fvn);
+    for (long long blk = (long long)blockIdx.x * DS_NW + w; blk < a.blocks; blk += stride) {
+        const long long pbase = 16 * blk;
+        const float fv[4] = {fvn[0], fvn[1], fvn[2], fvn[3]};
+        fetch(blk + stride, fvn);
         f32x4 z[SIM_NCB];
         decoder_logits(z, fv, wz_l, bias_l, vlast);
         f32x4 o_mz, o_rzp, o_p2;
@@ -742,6 +760,9 @@ __global__ __launch_bounds__(64 * FU_NW, 2) void codebook_simgrad_k(const FusedA
     const int C = a.C;
     const float NEG_INF = -__builtin_inff();
     const long long p0 = (long long)blockIdx.x * FU_WG_PIX + 32 * w;  // this wave's pixel blocks p0, p0 + 16
+#ifdef GOI_FU_PROF
+    const long long tk0 = __builtin_readcyclecounter();
+#endif
     f32x4 acc[2][SIM_NCB];
 #pragma unroll
     for (int pb = 0; pb < 2; pb++)
@@ -814,6 +835,11 @@ __global__ __launch_bounds__(64 * FU_NW, 2) void codebook_simgrad_k(const FusedA
             acc[1][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[1], Bh, acc[1][cb], 0, 0, 0);
         }
     }
+#ifdef GOI_FU_PROF  // experiment builds: phase clocks of this wave instead of its loss sums
+    __builtin_amdgcn_sched_barrier(0);
+    const long long tk1 = __builtin_readcyclecounter();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     const bool vlast = 16 * (SIM_NCB - 1) + mm < C;  // 288 < C <= 304: only the last code block has padding
     const float g_ent = a.w_sl1 * a.t * a.inv_hw;
     const float first = mm == 0 ? 1.f : 0.f;  // a row's scalars are replicated over its 16 lanes: count them once
@@ -832,39 +858,45 @@ __global__ __launch_bounds__(64 * FU_NW, 2) void codebook_simgrad_k(const FusedA
         const int4 arga4 = *reinterpret_cast<const int4*>(a.r_arga + pbase + 4 * kq);
         f32x4 o_nl;
         int4 o_args;
+        // The per-element work below is the kernel's VALU bill (152 elements per lane): everything that is constant over a row
+        // is folded into row scalars first -- exp(t (x - ms)) as exp2(x tl + nb), the entropy sums in log2 units, the gradient
+        // as (c1 q)(e2 + k2) -- and the two one-element terms of the gradient enter through a per-lane multiplicity word.
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const float inv = __shfl(invl, 4 * kq + r, 64);
             const bool valid = pbase + 4 * kq + r < HW;
             const float vw = valid ? first : 0.f;
             const int arg_a = (&arga4.x)[r];
+            const int cba = (arg_a & 15) == mm ? arg_a >> 4 : -1;  // the code block in which THIS lane holds code arg_a
             float m = NEG_INF;
 #pragma unroll
             for (int cb = 0; cb < SIM_NCB; cb++) {
-                sx[cb][r] *= inv;
-                if (cb == SIM_NCB - 1) sx[cb][r] = vlast ? sx[cb][r] : NEG_INF;
-                m = fmaxf(m, sx[cb][r]);
+                float x = sx[cb][r] * inv;
+                if (cb == SIM_NCB - 1) x = vlast ? x : NEG_INF;
+                sx[cb][r] = x;
+                m = fmaxf(m, x);
             }
             const float ms = row_max(m);
-            float sZ = 0.f, sA = 0.f, sN = 0.f, sS = 0.f;
-            int is = 0x7FFFFFFF;
+            const float tl = a.t * 1.44269504088896341f, nb = -ms * tl;  // t (x - ms) in log2 units: e2 = x tl + nb <= 0
+            float sZ = 0.f, sA = 0.f, sel = 0.f;
+            int is = 0x7FFFFFFF, cnt = 0;
 #pragma unroll
             for (int cb = SIM_NCB - 1; cb >= 0; cb--) {  // descending: the lane's FIRST maximum wins
                 const float x = sx[cb][r];
                 const bool top = x == ms;
                 is = top ? 16 * cb + mm : is;
-                sN += top ? 1.f : 0.f;
-                sS += (16 * cb + mm == arg_a) ? x : 0.f;
-                float lx = a.t * (x - ms);  // <= 0
-                const float q = __expf(lx);
+                cnt += top ? 1 : 0;
+                sel = cb == cba ? x : sel;
+                float e2 = fmaf(x, tl, nb);
+                const float q = __builtin_amdgcn_exp2f(e2);
                 sZ += q;
-                lx = fmaxf(lx, -FLT_MAX);  // keep 0 * lx finite for padding
-                sA = fmaf(q, lx, sA);
+                if (cb == SIM_NCB - 1) e2 = fmaxf(e2, -FLT_MAX);  // padding: keep 0 * e2 finite
+                sA = fmaf(q, e2, sA);
             }
-            const float Zq = row_sum(sZ), Aq = row_sum(sA), nl = row_sum(sN), sim_a = row_sum(sS);
+            const float Zq = row_sum(sZ), A2 = row_sum(sA), nl = row_sum((float)cnt), sim_a = row_sum(sel);
             const int arg_s = row_min(is);
-            const float rZq = 1.f / Zq, logZq = __logf(Zq);
-            const float Hq = logZq - Aq * rZq;
+            const float rZq = 1.f / Zq, k2 = -A2 * rZq;                        // k2 = (H - log Zq) / ln 2
+            const float Hq = 0.69314718055994531f * (__builtin_amdgcn_logf(Zq) + k2);  // v_log_f32 is log2
             acc_nl += vw * nl;
             acc_m += vw * ms;
             acc_H += vw * Hq;
@@ -885,22 +917,24 @@ __global__ __launch_bounds__(64 * FU_NW, 2) void codebook_simgrad_k(const FusedA
                     if (((cb & 1) || cb == SIM_NCB - 1) && nl > 1.f && mm == 0) wd[cb >> 1] = word;
                 }
             }
+            // dL/dsim_raw = inv ( -g_ent q / Zq (ln q - log Zq + H)  -  [c = arg_s] / HW  -  [c = arg_a] / HW ),  ln q = e2 ln 2
             const float invr = valid ? inv : 0.f;  // a pixel beyond the map has no gradient
-            // exp(t (x - ms)) is computed a second time ON PURPOSE: kept from the statistics pass it would be 76 more live
-            // registers; the opaque copy of ms stops the compiler from "saving" the work
-            float msr = ms;
-            asm volatile("" : "+v"(msr));
+            const float c1 = -g_ent * 0.69314718055994531f * rZq * invr, wone = -a.inv_hw * invr;
+            // multiplicity (0, 1, 2) of the one-element terms at this lane's code of block cb: two bits per block
+            const int cbs = (arg_s & 15) == mm ? arg_s >> 4 : -1;
+            unsigned long long mult = (cbs >= 0 ? 1ull << (2 * cbs) : 0ull) + (cba >= 0 ? 1ull << (2 * cba) : 0ull);
+            const uint32_t mult_lo = (uint32_t)mult, mult_hi = (uint32_t)(mult >> 32);
+            // exp2 is evaluated a second time ON PURPOSE: kept from the statistics pass q would be 76 more live registers;
+            // the opaque copy of nb stops the compiler from "saving" the work
+            float nbr = nb;
+            asm volatile("" : "+v"(nbr));
 #pragma unroll
             for (int cb = 0; cb < SIM_NCB; cb++) {
-                const int c = 16 * cb + mm;
-                const float x = sx[cb][r];
-                float lx = a.t * (x - msr);
-                const float qk = __expf(lx) * rZq;
-                lx = fmaxf(lx, -FLT_MAX);
-                float d = -g_ent * qk * ((lx - logZq) + Hq);  // d(0.3 mean H)/dsim
-                d -= c == arg_s ? a.inv_hw : 0.f;             // d(1 - mean m)/dsim
-                d -= c == arg_a ? a.inv_hw : 0.f;             // d(1 - mean sim_a)/dsim
-                sx[cb][r] = d * invr;                         // dL/dsim_raw
+                float e2 = fmaf(sx[cb][r], tl, nbr);
+                const float q = __builtin_amdgcn_exp2f(e2);
+                if (cb == SIM_NCB - 1) e2 = fmaxf(e2, -FLT_MAX);
+                const uint32_t mu = cb < 16 ? (mult_lo >> (2 * cb)) & 3u : (mult_hi >> (2 * (cb - 16))) & 3u;
+                sx[cb][r] = fmaf(wone, (float)mu, (c1 * q) * (e2 + k2));
             }
         }
         if (mm == 0) {
@@ -920,32 +954,80 @@ __global__ __launch_bounds__(64 * FU_NW, 2) void codebook_simgrad_k(const FusedA
             }
         }
     }
-    const float t0 = wave_sum_u(acc_nl), t1 = wave_sum_u(acc_m), t2 = wave_sum_u(acc_H), t3 = wave_sum_u(acc_sa);
+    float t0 = wave_sum_u(acc_nl), t1 = wave_sum_u(acc_m), t2 = wave_sum_u(acc_H), t3 = wave_sum_u(acc_sa);
+#ifdef GOI_FU_PROF
+    __builtin_amdgcn_sched_barrier(0);
+    t0 = (float)(tk1 - tk0);
+    t1 = (float)(__builtin_readcyclecounter() - tk1);
+#endif
     if (lane == 0) *reinterpret_cast<f32x4*>(a.sums_a + 4 * ((size_t)blockIdx.x * FU_NW + w)) = f32x4{t0, t1, t2, t3};
 }
 
-// ---- decoder gradients: persistent, one 16-pixel block per wave and iteration
+// dz of one 16-pixel block in place of its logits z: P from the recorded statistics, the label from (arg_s, nl) or, for a tie,
+// from the recorded bit mask.  Returns this lane's share of the lab loss sum (counted once per pixel row: lanes mm = 0).
+struct DecIn {
+    f32x4 mz, rzp, p2, nl;
+    int4 args;
+};
+__device__ __forceinline__ float decoder_dz(f32x4 (&z)[SIM_NCB], const DecIn& in, const FusedArgs& a, long long pbase, int kq, int mm) {
+    float lab_sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const bool valid = pbase + 4 * kq + r < a.HW;
+        const float mz = in.mz[r], rZ = in.rzp[r], P2 = in.p2[r], nl = in.nl[r];
+        const int arg_s = (&in.args.x)[r];
+        float sP = 0.f;
+        uint32_t labm = 0;  // bit cb: this lane's code of block cb is a maximum of sim
+        if (__builtin_expect(__any(nl > 1.f), 0)) {
+            const uint32_t* wd = a.r_tie + (size_t)(pbase + 4 * kq + r) * FU_TIE_WORDS;
+#pragma unroll
+            for (int cb = 0; cb < SIM_NCB; cb++) {
+                const bool lab = nl > 1.f ? ((wd[cb >> 1] >> (16 * (cb & 1) + mm)) & 1u) != 0 : (16 * cb + mm == arg_s);
+                labm |= lab ? (1u << cb) : 0u;
+            }
+        } else {
+            labm = (arg_s & 15) == mm ? 1u << (arg_s >> 4) : 0u;
+        }
+#pragma unroll
+        for (int cb = 0; cb < SIM_NCB; cb++) {
+            z[cb][r] = __expf(z[cb][r] - mz) * rZ;  // P
+            sP += (labm >> cb) & 1u ? z[cb][r] : 0.f;
+        }
+        const float Pl = row_sum(sP);
+        lab_sum += (valid && mm == 0) ? (P2 - 2.f * Pl) + nl : 0.f;
+        const float kap = valid ? a.kappa : 0.f;  // a pixel beyond the map has no gradient
+        const float Dsum = kap * (P2 - Pl);
+#pragma unroll
+        for (int cb = 0; cb < SIM_NCB; cb++) {
+            const float P = z[cb][r], lab = (labm >> cb) & 1u ? 1.f : 0.f;
+            z[cb][r] = P * (kap * (P - lab) - Dsum);  // dz
+        }
+    }
+    return lab_sum;
+}
+__device__ __forceinline__ void decoder_fetch(DecIn& in, const FusedArgs& a, long long pbase, int kq) {
+    in.mz = *reinterpret_cast<const f32x4*>(a.r_mz + pbase + 4 * kq);
+    in.rzp = *reinterpret_cast<const f32x4*>(a.r_rzp + pbase + 4 * kq);
+    in.p2 = *reinterpret_cast<const f32x4*>(a.r_p2 + pbase + 4 * kq);
+    in.nl = *reinterpret_cast<const f32x4*>(a.r_nl + pbase + 4 * kq);
+    in.args = *reinterpret_cast<const int4*>(a.r_args + pbase + 4 * kq);
+}
+
+// ---- dL/dW, dL/db: persistent, one 16-pixel block per wave and iteration.
+//   dL/dW[c][s] += sum_p dz[p][c] f[p][s]: A = dz [code mm][k = pixel 4 kq + r] (the D layout as it is), B = f [k = pixel 4 kq + i][s = mm]
 __global__ __launch_bounds__(64 * DG_NW, 1) void decoder_grad_k(const FusedArgs a) {
     __shared__ __attribute__((aligned(16))) char s_wz[FU_WZ_BYTES];
-    __shared__ __attribute__((aligned(16))) char s_wt[FU_WT_BYTES];
-    __shared__ __attribute__((aligned(16))) char s_tr[DG_NW][2][FU_TBUF];
     __shared__ float s_bias[SIM_NC];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, kq = lane >> 4, mm = lane & 15;
     const long long HW = a.HW;
     const int C = a.C, S = a.S;
     for (int i = tid; i < FU_WZ_BYTES / 16; i += 64 * DG_NW)
         reinterpret_cast<uint4*>(s_wz)[i] = reinterpret_cast<const uint4*>(a.wz)[i];
-    for (int i = tid; i < FU_WT_BYTES / 16; i += 64 * DG_NW)
-        reinterpret_cast<uint4*>(s_wt)[i] = reinterpret_cast<const uint4*>(a.wt)[i];
     for (int i = tid; i < SIM_NC; i += 64 * DG_NW) s_bias[i] = (a.bias && i < a.C) ? a.bias[i] : 0.f;
     __syncthreads();
     const bool vlast = 16 * (SIM_NCB - 1) + mm < C;
     const char* const wz_l = s_wz + 32 * mm + 8 * kq;
     const float* const bias_l = s_bias + mm;
-    const char* const wt_l = s_wt + 64 * mm + 16 * kq;
-    char* const tw_l = s_tr[w][0] + 2 * mm + FU_TROW * 4 * kq;     // tile writes: this lane's code column, its 4 pixel rows
-    const char* const tr_l = s_tr[w][0] + FU_TROW * mm + 16 * kq;  // tile reads: pixel row mm, codes 8 kq ..
-
     f32x4 dWacc[SIM_NCB];  // D[code 16 cb + 4 kq + r][s = mm]
     float dbr[SIM_NCB];    // lane (kq, mm): sum of dz[pixel rows 4 kq + r][code 16 cb + mm]
 #pragma unroll
@@ -954,127 +1036,42 @@ __global__ __launch_bounds__(64 * DG_NW, 1) void decoder_grad_k(const FusedArgs 
         dbr[cb] = 0.f;
     }
     float acc_lab = 0.f;
-    const float first = mm == 0 ? 1.f : 0.f;
     const long long wave = (long long)blockIdx.x * DG_NW + w, n_waves = (long long)gridDim.x * DG_NW;
+    // A block's inputs are requested a block ahead: the loop is short and only two waves share a SIMD, so a load issued where
+    // it is used costs its whole latency.
+    float fvz[4], fvw[4];  // the decoder's two views of the feature: f[s = 4 kq + i][pixel mm], f[s = mm][pixel 4 kq + i]
+    DecIn in;
+    auto fetch = [&](long long blk) {
+        const long long pbase = 16 * min(blk, a.blocks - 1);
+        const long long pz = min(pbase + mm, HW - 1);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            fvz[i] = (4 * kq + i < S) ? a.sem[(size_t)(4 * kq + i) * HW + pz] : 0.f;
+            fvw[i] = mm < S ? a.sem[(size_t)mm * HW + min(pbase + 4 * kq + i, HW - 1)] : 0.f;
+        }
+        decoder_fetch(in, a, pbase, kq);
+    };
+    fetch(wave);
     for (long long blk = wave; blk < a.blocks; blk += n_waves) {
         const long long pbase = 16 * blk;
-        // the decoder's two views of the feature: f[s = 4 kq + i][pixel mm], f[s = mm][pixel 4 kq + i]
-        float fvz[4], fvw[4];
-        {
-            const long long pz = min(pbase + mm, HW - 1);
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                fvz[i] = (4 * kq + i < S) ? a.sem[(size_t)(4 * kq + i) * HW + pz] : 0.f;
-                fvw[i] = mm < S ? a.sem[(size_t)mm * HW + min(pbase + 4 * kq + i, HW - 1)] : 0.f;
-            }
-        }
-        const f32x4 mz4 = *reinterpret_cast<const f32x4*>(a.r_mz + pbase + 4 * kq);
-        const f32x4 rzp4 = *reinterpret_cast<const f32x4*>(a.r_rzp + pbase + 4 * kq);
-        const f32x4 p24 = *reinterpret_cast<const f32x4*>(a.r_p2 + pbase + 4 * kq);
-        const f32x4 nl4 = *reinterpret_cast<const f32x4*>(a.r_nl + pbase + 4 * kq);
-        const int4 args4 = *reinterpret_cast<const int4*>(a.r_args + pbase + 4 * kq);
         f32x4 z[SIM_NCB];
         decoder_logits(z, fvz, wz_l, bias_l, vlast);
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const bool valid = pbase + 4 * kq + r < HW;
-            const float mz = mz4[r], rZ = rzp4[r], P2 = p24[r], nl = nl4[r];
-            const int arg_s = (&args4.x)[r];
-            // P, and P at the labelled codes
-            float sP = 0.f;
-            uint32_t labm = 0;  // bit cb: this lane's code of block cb is a maximum of sim
-            if (__builtin_expect(__any(nl > 1.f), 0)) {
-                const uint32_t* wd = a.r_tie + (size_t)(pbase + 4 * kq + r) * FU_TIE_WORDS;
-#pragma unroll
-                for (int cb = 0; cb < SIM_NCB; cb++) {
-                    const bool lab = nl > 1.f ? ((wd[cb >> 1] >> (16 * (cb & 1) + mm)) & 1u) != 0 : (16 * cb + mm == arg_s);
-                    labm |= lab ? (1u << cb) : 0u;
-                }
-            } else {
-#pragma unroll
-                for (int cb = 0; cb < SIM_NCB; cb++) labm |= (16 * cb + mm == arg_s) ? (1u << cb) : 0u;
-            }
-#pragma unroll
-            for (int cb = 0; cb < SIM_NCB; cb++) {
-                z[cb][r] = __expf(z[cb][r] - mz) * rZ;  // P
-                sP += (labm >> cb) & 1u ? z[cb][r] : 0.f;
-            }
-            const float Pl = row_sum(sP);
-            acc_lab += (valid ? first : 0.f) * ((P2 - 2.f * Pl) + nl);
-            const float kap = valid ? a.kappa : 0.f;  // a pixel beyond the map has no gradient
-            const float Dsum = kap * (P2 - Pl);
-#pragma unroll
-            for (int cb = 0; cb < SIM_NCB; cb++) {
-                const float P = z[cb][r], lab = (labm >> cb) & 1u ? 1.f : 0.f;
-                z[cb][r] = P * (kap * (P - lab) - Dsum);  // dz
-            }
-        }
-        uint32_t dzh[SIM_NCB][2], dzl[SIM_NCB][2];  // dz as an A operand: 4 pixels (k) per plane, packed
+        acc_lab += decoder_dz(z, in, a, pbase, kq, mm);
+        uint32_t bh[2], bl[2];
+        split_pair(fvw[0], fvw[1], bh[0], bl[0]);
+        split_pair(fvw[2], fvw[3], bh[1], bl[1]);
+        const s16x4 fBh = __builtin_bit_cast(s16x4, uint2{bh[0], bh[1]}), fBl = __builtin_bit_cast(s16x4, uint2{bl[0], bl[1]});
+        fetch(blk + n_waves);  // the next block's inputs (this block's are consumed): they land under the products below
 #pragma unroll
         for (int cb = 0; cb < SIM_NCB; cb++) {
-            split_pair(z[cb][0], z[cb][1], dzh[cb][0], dzl[cb][0]);
-            split_pair(z[cb][2], z[cb][3], dzh[cb][1], dzl[cb][1]);
+            uint32_t dh[2], dl[2];
+            split_pair(z[cb][0], z[cb][1], dh[0], dl[0]);
+            split_pair(z[cb][2], z[cb][3], dh[1], dl[1]);
             dbr[cb] += (z[cb][0] + z[cb][1]) + (z[cb][2] + z[cb][3]);
-        }
-        // ---- dL/dW += dz^T f: A = dz [code mm][k = pixel 4 kq + r], B = f [k = pixel 4 kq + i][s = mm]
-        {
-            uint32_t bh[2], bl[2];
-            split_pair(fvw[0], fvw[1], bh[0], bl[0]);
-            split_pair(fvw[2], fvw[3], bh[1], bl[1]);
-            const s16x4 Bh = __builtin_bit_cast(s16x4, uint2{bh[0], bh[1]}), Bl = __builtin_bit_cast(s16x4, uint2{bl[0], bl[1]});
-#pragma unroll
-            for (int cb = 0; cb < SIM_NCB; cb++)
-                dWacc[cb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, uint2{dzl[cb][0], dzl[cb][1]}), Bh,
-                                                                      dWacc[cb], 0, 0, 0);
-#pragma unroll
-            for (int cb = 0; cb < SIM_NCB; cb++)
-                dWacc[cb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, uint2{dzh[cb][0], dzh[cb][1]}), Bl,
-                                                                      dWacc[cb], 0, 0, 0);
-#pragma unroll
-            for (int cb = 0; cb < SIM_NCB; cb++)
-                dWacc[cb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, uint2{dzh[cb][0], dzh[cb][1]}), Bh,
-                                                                      dWacc[cb], 0, 0, 0);
-        }
-        // ---- dL/df = dz W: dz through the wave's LDS tile to become A [pixel mm][k = code 8 kq + i]; tile j + 1 is written
-        // before tile j is read, and the three products keep separate accumulators (no dependent MFMA chain)
-        {
-            f32x4 df0 = f32x4{0.f, 0.f, 0.f, 0.f}, df1 = df0, df2 = df0;
-            auto put = [&](int j) {
-#pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    const int cb = 2 * j + h;
-                    char* col = tw_l + FU_TBUF * (j & 1) + 32 * h;
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const uint32_t hw_ = cb < SIM_NCB ? dzh[cb < SIM_NCB ? cb : 0][r >> 1] : 0u;
-                        const uint32_t lw_ = cb < SIM_NCB ? dzl[cb < SIM_NCB ? cb : 0][r >> 1] : 0u;
-                        *reinterpret_cast<uint16_t*>(col + FU_TROW * r) = (uint16_t)((r & 1) ? hw_ >> 16 : hw_);
-                        *reinterpret_cast<uint16_t*>(col + FU_TROW * r + FU_TPLANE) = (uint16_t)((r & 1) ? lw_ >> 16 : lw_);
-                    }
-                }
-            };
-            put(0);
-#pragma unroll
-            for (int j = 0; j < FU_NJ; j++) {
-                if (j + 1 < FU_NJ) put(j + 1);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const bf16x8 Ah = *reinterpret_cast<const bf16x8*>(tr_l + FU_TBUF * (j & 1));
-                const bf16x8 Al = *reinterpret_cast<const bf16x8*>(tr_l + FU_TBUF * (j & 1) + FU_TPLANE);
-                const bf16x8 Bh = *reinterpret_cast<const bf16x8*>(wt_l + 1024 * j);
-                const bf16x8 Bl = *reinterpret_cast<const bf16x8*>(wt_l + 1024 * j + FU_WT_BYTES / 2);
-                df0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bh, df0, 0, 0, 0);
-                df1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bl, df1, 0, 0, 0);
-                df2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh, df2, 0, 0, 0);
-            }
-            // D[pixel 4 kq + r][s = mm]
-            if (mm < S) {
-                float* dst = a.dsem + (size_t)mm * HW + pbase + 4 * kq;
-#pragma unroll
-                for (int r = 0; r < 4; r++)
-                    if (pbase + 4 * kq + r < HW) dst[r] = (df0[r] + df1[r]) + df2[r];
-            }
+            const s16x4 Ah = __builtin_bit_cast(s16x4, uint2{dh[0], dh[1]}), Al = __builtin_bit_cast(s16x4, uint2{dl[0], dl[1]});
+            dWacc[cb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(Al, fBh, dWacc[cb], 0, 0, 0);
+            dWacc[cb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(Ah, fBl, dWacc[cb], 0, 0, 0);
+            dWacc[cb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(Ah, fBh, dWacc[cb], 0, 0, 0);
         }
     }
     // ---- this wave's partial sums
@@ -1109,6 +1106,93 @@ __global__ __launch_bounds__(64 * DG_NW, 1) void decoder_grad_k(const FusedArgs 
         lo[1] = t1;
         lo[2] = t2;
         lo[3] = t3;
+    }
+}
+
+// ---- dL/df[p][s] = sum_c dz[p][c] W[c][s]: the contraction runs over the codes, the LANE axis of the D layout, so dz goes
+// through a wave-private LDS tile ([16 pixels][32 codes] bf16 hi and lo, 80-byte rows) to become the A operand
+// [pixel mm][k = code 8 kq + i]; tile j + 1 is written before tile j is read, and the three products keep separate
+// accumulators (no dependent MFMA chain).  One 16-pixel block per wave and iteration; z and dz are recomputed here rather than
+// shared with decoder_grad_k: together the two kernels need more registers than two waves per SIMD have.
+__global__ __launch_bounds__(64 * DF_NW, 1) void decoder_df_k(const FusedArgs a) {
+    __shared__ __attribute__((aligned(16))) char s_wz[FU_WZ_BYTES];
+    __shared__ __attribute__((aligned(16))) char s_wt[FU_WT_BYTES];
+    __shared__ __attribute__((aligned(16))) char s_tr[DF_NW][2][FU_TBUF];
+    __shared__ float s_bias[SIM_NC];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, kq = lane >> 4, mm = lane & 15;
+    const long long HW = a.HW;
+    const int C = a.C, S = a.S;
+    for (int i = tid; i < FU_WZ_BYTES / 16; i += 64 * DF_NW)
+        reinterpret_cast<uint4*>(s_wz)[i] = reinterpret_cast<const uint4*>(a.wz)[i];
+    for (int i = tid; i < FU_WT_BYTES / 16; i += 64 * DF_NW)
+        reinterpret_cast<uint4*>(s_wt)[i] = reinterpret_cast<const uint4*>(a.wt)[i];
+    for (int i = tid; i < SIM_NC; i += 64 * DF_NW) s_bias[i] = (a.bias && i < a.C) ? a.bias[i] : 0.f;
+    __syncthreads();
+    const bool vlast = 16 * (SIM_NCB - 1) + mm < C;
+    const char* const wz_l = s_wz + 32 * mm + 8 * kq;
+    const float* const bias_l = s_bias + mm;
+    const char* const wt_l = s_wt + 64 * mm + 16 * kq;
+    char* const tw_l = s_tr[w][0] + 2 * mm + FU_TROW * 4 * kq;     // tile writes: this lane's code column, its 4 pixel rows
+    const char* const tr_l = s_tr[w][0] + FU_TROW * mm + 16 * kq;  // tile reads: pixel row mm, codes 8 kq ..
+    const long long wave = (long long)blockIdx.x * DF_NW + w, n_waves = (long long)gridDim.x * DF_NW;
+    float fvz[4];
+    DecIn in;
+    auto fetch = [&](long long blk) {
+        const long long pbase = 16 * min(blk, a.blocks - 1);
+        const long long pz = min(pbase + mm, HW - 1);
+#pragma unroll
+        for (int i = 0; i < 4; i++) fvz[i] = (4 * kq + i < S) ? a.sem[(size_t)(4 * kq + i) * HW + pz] : 0.f;
+        decoder_fetch(in, a, pbase, kq);
+    };
+    fetch(wave);
+    for (long long blk = wave; blk < a.blocks; blk += n_waves) {
+        const long long pbase = 16 * blk;
+        f32x4 z[SIM_NCB];
+        decoder_logits(z, fvz, wz_l, bias_l, vlast);
+        (void)decoder_dz(z, in, a, pbase, kq, mm);
+        fetch(blk + n_waves);
+        f32x4 df0 = f32x4{0.f, 0.f, 0.f, 0.f}, df1 = df0, df2 = df0;
+        auto put = [&](int j) {  // dz of code blocks 2 j, 2 j + 1 -> tile j & 1
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int cb = 2 * j + h;
+                char* col = tw_l + FU_TBUF * (j & 1) + 32 * h;
+                uint32_t dh[2] = {0u, 0u}, dl[2] = {0u, 0u};
+                if (cb < SIM_NCB) {
+                    const f32x4 d = z[cb < SIM_NCB ? cb : 0];
+                    split_pair(d[0], d[1], dh[0], dl[0]);
+                    split_pair(d[2], d[3], dh[1], dl[1]);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    *reinterpret_cast<uint16_t*>(col + FU_TROW * r) = (uint16_t)((r & 1) ? dh[r >> 1] >> 16 : dh[r >> 1]);
+                    *reinterpret_cast<uint16_t*>(col + FU_TROW * r + FU_TPLANE) = (uint16_t)((r & 1) ? dl[r >> 1] >> 16 : dl[r >> 1]);
+                }
+            }
+        };
+        put(0);
+#pragma unroll
+        for (int j = 0; j < FU_NJ; j++) {
+            if (j + 1 < FU_NJ) put(j + 1);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const bf16x8 Ah = *reinterpret_cast<const bf16x8*>(tr_l + FU_TBUF * (j & 1));
+            const bf16x8 Al = *reinterpret_cast<const bf16x8*>(tr_l + FU_TBUF * (j & 1) + FU_TPLANE);
+            const bf16x8 Bh = *reinterpret_cast<const bf16x8*>(wt_l + 1024 * j);
+            const bf16x8 Bl = *reinterpret_cast<const bf16x8*>(wt_l + 1024 * j + FU_WT_BYTES / 2);
+            df0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bh, df0, 0, 0, 0);
+            df1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bl, df1, 0, 0, 0);
+            df2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh, df2, 0, 0, 0);
+            asm volatile("" ::: "memory");  // or all ten K steps' decoder operands are read up front: 80 registers
+        }
+        // D[pixel 4 kq + r][s = mm]
+        if (mm < S) {
+            float* dst = a.dsem + (size_t)mm * HW + pbase + 4 * kq;
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                if (pbase + 4 * kq + r < HW) dst[r] = (df0[r] + df1[r]) + df2[r];
+        }
     }
 }
 
@@ -1296,6 +1380,8 @@ int launch_codebook_fused(const float* g, const float* l1, const float* sem, con
     decoder_stats_k<<<dim3((unsigned)(stat_wgs < 2048 ? stat_wgs : 2048)), dim3(64 * DS_NW), 0, s>>>(a);
     codebook_simgrad_k<<<dim3((unsigned)fu_simgrad_wgs(HW)), dim3(64 * FU_NW), 0, s>>>(a);
     decoder_grad_k<<<dim3(codebook_fused_rows() / DG_NW), dim3(64 * DG_NW), 0, s>>>(a);
+    const long long df_wgs = (blocks + DF_NW - 1) / DF_NW;
+    decoder_df_k<<<dim3((unsigned)(df_wgs < 1024 ? df_wgs : 1024)), dim3(64 * DF_NW), 0, s>>>(a);
     codebook_dlut2_k<<<dim3(codebook_dlut_blocks()), dim3(64 * DL2_NW), 0, s>>>(dplanes, g, HW, dl1_partial);
     return 0;
 }

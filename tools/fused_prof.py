@@ -32,10 +32,11 @@ for _ in range(3):
     assert lib.goi_codebook_fused(p(g), p(l1), p(sem), p(Wd), p(b), HW, Cn, D, S, 1.0, p(dsem), p(partials), p(part), p(ws),
                                   stream) == 0, _lib.last_error()
 torch.cuda.synchronize()
-pr = partials[:, :6].double()
-tot = pr.sum(dim=1)
-names = ["K loop", "1/|g| + logits", "statistics", "gradients", "plane stores + dW", "df"]
-print("per wave: total %.0f cycles (min %.0f, max %.0f); clock ticks are s_memtime (100 MHz) or shader clocks -- compare shares"
-      % (tot.mean(), tot.min(), tot.max()))
-for i, n in enumerate(names):
-    print("  %-20s %5.1f %%   %.0f" % (n, 100 * float(pr[:, i].sum() / tot.sum()), float(pr[:, i].mean())))
+# codebook_simgrad_k's per-wave record sits in the workspace after: planes | wz | wt | 6 records | tie masks
+al = lambda x: (x + 255) & ~255  # noqa: E731
+blocks = (HW + 127) // 128 * 8
+npad = 16 * blocks
+off = al(2 * 304 * 256 * 2) + al(2 * 304 * 32) + al(2 * 10 * 16 * 64) + 6 * al(npad * 4) + al(npad * 10 * 4)
+n_a = (HW + 127) // 128 * 4
+rec = ws[off: off + n_a * 16].view(torch.float32).view(n_a, 4).double()
+print("codebook_simgrad_k per wave: K loop %.0f clocks, statistics + gradients + stores %.0f clocks" % (rec[:, 0].mean(), rec[:, 1].mean()))
