@@ -699,7 +699,7 @@ int goi_codebook_fused(const float* g, const float* lut1, const float* sem, cons
         return fail("goi_codebook_fused: a required pointer is NULL");
     if (launch_codebook_fused(g, lut1, sem, W, bias, HW, C, D, S, t, dsem, partials, dlut_partial, workspace,
                               static_cast<hipStream_t>(stream)) < 0)
-        return fail("goi_codebook_fused: supported shape is D = 256, 288 < C <= 304, 1 <= S <= 16, HW % 4 = 0");
+        return fail("goi_codebook_fused: supported shape is D = 256, 288 < C <= 304, 1 <= S <= 16, HW % 4 = 0, HW < 2^25");
     GOI_HIP(hipGetLastError());
     return 0;
 }

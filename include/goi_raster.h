@@ -254,13 +254,13 @@ int goi_codebook_sim(const float* g, const float* lut1, long long HW, int C, int
 int goi_codebook_dlut_partial_blocks(void);
 int goi_codebook_dlut(const float* dsim, const float* g, long long HW, int C, int D, float* partial, void* stream);
 
-/* The three steps above as one call with no [HW][C] fp32 matrix in memory (csrc/codebook_loss.hip: codebook_fused_k,
- * codebook_dlut2_k): g [D][HW], lut1 [C][D] (rows normalised), sem [S][HW], W [C][S], bias [C] or NULL, t as in
+/* The three steps above as one call with no [HW][C] fp32 matrix in memory (csrc/codebook_loss.hip: decoder_stats_k,
+ * codebook_simgrad_k, decoder_grad_k, decoder_df_k, codebook_dlut2_k): g [D][HW], lut1 [C][D] (rows normalised), sem [S][HW], W [C][S], bias [C] or NULL, t as in
  * goi_codebook_loss_rows.  Writes dsem [S][HW], partials [goi_codebook_fused_partial_rows()][C*(S+1)+4] (same row format
  * as goi_codebook_loss_rows) and dlut_partial [goi_codebook_dlut_partial_blocks()][304][D]; the caller sums both over the
  * first axis.  workspace: goi_codebook_fused_workspace_bytes(HW) device bytes (dL/dsim as two bf16 planes: 4 bytes per
- * (pixel, code)).  Supported shape: D = 256, 288 < C <= 304, 1 <= S <= 16, HW % 4 = 0; anything else returns -1 and the
- * caller uses the three separate entry points.  Reference: train.py:142-163. */
+ * (pixel, code), plus 64 B of records per pixel).  Supported shape: D = 256, 288 < C <= 304, 1 <= S <= 16, HW % 4 = 0,
+ * HW < 2^25; anything else returns -1 and the caller uses the three separate entry points.  Reference: train.py:142-163. */
 size_t goi_codebook_fused_workspace_bytes(long long HW);
 int goi_codebook_fused_partial_rows(void);
 int goi_codebook_fused(const float* g, const float* lut1, const float* sem, const float* W, const float* bias, long long HW,

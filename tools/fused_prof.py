@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Phase clocks of codebook_fused_k (a library built with -DGOI_FU_PROF: tools/build/exp_fu_prof.sh) at 1600x1056."""
+"""Phase clocks of codebook_simgrad_k at 1600x1056: K loop vs statistics + gradients + plane stores, per wave, from a library
+built with -DGOI_FU_PROF (tools/build/exp_fu_prof.sh; that build writes the clocks where the product writes loss sums)."""
 import ctypes as C
 import os
 import sys
