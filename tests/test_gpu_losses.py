@@ -154,3 +154,40 @@ def test_two_kernel_path_against_three_kernel_path(H, W, S, C, it, bias):
         bad = (g0[k] - g1[k]).abs() > 1e-3 * scale
         # a pixel whose best two codes tie to the last bit may label differently: allow a handful
         assert int(bad.sum()) <= (4 * S if k == "sem" else 0), (k, int(bad.sum()), float((g0[k] - g1[k]).abs().max()) / scale)
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_duplicate_codebook_rows_label_every_maximum(fused):
+    """train.py:151 labels EVERY code whose similarity equals the row maximum (`sim == sim.max(...)`).  With duplicate
+    code-book rows (k-means can return them, train.py:78-84) whole groups of codes tie on every pixel they win: the label has
+    several ones, the lab loss and dL/dz see all of them.  The five-kernel path carries that set as a 304-bit mask from
+    codebook_simgrad_k to the decoder kernels -- this is the only test that reaches that branch."""
+    from goi_hyperplane_amd import semantic
+    H, W, S, C = 24, 40, 16, 300
+    sem, mlp, lut, gtl = setup(H, W, S=S, C=C, bias=True)
+    with torch.no_grad():
+        lut[200] = lut[5]
+        lut[18] = lut[17]
+        lut[250] = lut[17]
+        idx = torch.randint(0, C, (H * W,), device="cuda")
+        idx[::3] = 5       # a third of the pixels are won by the pair, a fifth by the triple
+        idx[1::5] = 17
+        gtl.copy_((lut.detach()[idx] * 30 + 0.3 * torch.randn(H * W, 256, device="cuda")).t().reshape(256, H, W))
+    l0, t0, g0 = grads(codebook_losses, sem, mlp, lut, gtl, 10)
+    try:
+        semantic._FUSED_KERNELS["on"] = fused
+        l1, t1, g1 = grads(fused_codebook_losses, sem, mlp, lut, gtl, 10)
+    finally:
+        semantic._FUSED_KERNELS["on"] = True
+    with torch.no_grad():  # the premise: many pixels really have 2 or 3 maxima
+        gn = gtl.reshape(256, -1).t()
+        sim = (gn / gn.norm(dim=1, keepdim=True)) @ (lut / lut.norm(dim=1, keepdim=True)).t()
+        n_max = (sim == sim.max(dim=1, keepdim=True)[0]).sum(dim=1)
+        assert int((n_max == 2).sum()) > 100 and int((n_max == 3).sum()) > 50
+    assert abs(float(l0 - l1)) <= 1e-5 * abs(float(l0))
+    for k in t0:
+        assert abs(float(t0[k] - t1[k])) <= 1e-5 * max(abs(float(t0[k])), 1e-3), k
+    for k in ("sem", "W", "b", "lut"):
+        scale = float(g0[k].abs().max())
+        bad = (g0[k] - g1[k]).abs() > 1e-3 * scale
+        assert int(bad.sum()) <= (4 * S if k == "sem" else 0), (k, int(bad.sum()), float((g0[k] - g1[k]).abs().max()) / scale)
