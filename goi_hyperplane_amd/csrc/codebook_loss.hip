@@ -579,8 +579,7 @@ __global__ __launch_bounds__(64 * SIM_NW) void codebook_sim_k(const float* __res
 // sim kernel + row kernel + fp32 dLUT kernel.
 // (One kernel for the first three was tried first: ~400 live registers, one wave per SIMD, and the compiler spilled the
 // addresses it hoisted; every load, LDS and dependent-MFMA latency was exposed: 4.7 ms against 3.6 ms for sim + row kernels.)
-constexpr int FU_NW = 4;                      // codebook_simgrad_k: waves per workgroup (two workgroups per CU)
-constexpr int FU_WG_PIX = 32 * FU_NW;         // a wave owns two 16-pixel blocks
+constexpr int FU_WG_PIX = 128;                // pixels of one codebook_simgrad_k workgroup: 8 waves x one 16-pixel block
 constexpr int FU_TROW = 80;                   // transposition tile: row stride in bytes (64 + 16: conflict-free both ways)
 constexpr int FU_TPLANE = 16 * FU_TROW, FU_TBUF = 2 * FU_TPLANE;
 constexpr int FU_WZ_BYTES = 2 * SIM_NC * 32;  // decoder planes for z: [2][304][16] bf16
@@ -752,87 +751,124 @@ __global__ __launch_bounds__(64 * DS_NW, 3) void decoder_stats_k(const FusedArgs
     }
 }
 
-// ---- sim, its statistics and dL/dsim.  The K loop is codebook_sim_k's with the operands swapped (pixels are MFMA rows).
-__global__ __launch_bounds__(64 * FU_NW, 2) void codebook_simgrad_k(const FusedArgs a) {
-    __shared__ __attribute__((aligned(1024))) char s_cb[2][SIM_BUF];
+// ---- sim, its statistics and dL/dsim.  Pixels are MFMA rows; one 16-pixel block per wave, 8 waves per workgroup.
+// BOTH operands reach LDS by LDS-DMA: the code book's chunk (shared, 3 buffers, requested two iterations ahead) and the
+// wave's own g tile ([32 k][16 pixels] fp32, 2 buffers, requested two iterations ahead and re-filled right after it is read).
+// An ordinary load in this loop would make hipcc drain the vector-memory counter at its use, LDS-DMA included, and the loop
+// would run at the latency of one chunk's trip through L2 (that is what bounds codebook_sim_k); with nothing but LDS-DMA in
+// flight the only waits are the counted ones below.  All LDS is ONE array: a second __shared__ object costs a vmcnt(0)
+// before the first ds_read of every iteration.
+#ifndef GOI_SG_EXP
+#define GOI_SG_EXP 0  // timing experiments (tools/build/exp_sg_parts.sh): 1 no code-book staging, 2 no products, 4 no g staging
+#endif
+constexpr int SG_NW = 8, SG_NBUF = 3;
+constexpr int SG_A_BYTES = SIM_KC * 16 * 4;                         // one wave's g tile of one chunk
+constexpr int SG_LDS = SG_NBUF * SIM_BUF + SG_NW * 2 * SG_A_BYTES;  // 146 KiB: one workgroup per CU
+__global__ __launch_bounds__(64 * SG_NW, 1) void codebook_simgrad_k(const FusedArgs a) {
+    __shared__ __attribute__((aligned(1024))) char smem[SG_LDS];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, kq = lane >> 4, mm = lane & 15;
     const long long HW = a.HW;
     const int C = a.C;
     const float NEG_INF = -__builtin_inff();
-    const long long p0 = (long long)blockIdx.x * FU_WG_PIX + 32 * w;  // this wave's pixel blocks p0, p0 + 16
+    const long long pbase = (long long)blockIdx.x * FU_WG_PIX + 16 * w;  // this lane's D rows are pixels pbase + 4 kq + r
 #ifdef GOI_FU_PROF
     const long long tk0 = __builtin_readcyclecounter();
 #endif
-    f32x4 acc[2][SIM_NCB];
+    char* const s_cb = smem;                                           // [SG_NBUF][SIM_BUF]
+    char* const s_aw = smem + SG_NBUF * SIM_BUF + w * 2 * SG_A_BYTES;  // this wave's [2][32 k][16 pixels] floats
+    f32x4 sx[SIM_NCB];
 #pragma unroll
-    for (int pb = 0; pb < 2; pb++)
+    for (int cb = 0; cb < SIM_NCB; cb++) sx[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float nrm = 0.f;
+    constexpr int NKC = SIM_K / SIM_KC;
+    // g tile of chunk kc: two wave instructions; lane l of instruction j moves 4 consecutive pixels of row k = 16 j + (l >> 2)
+    // (a pixel group lies wholly inside or wholly outside the map: HW % 4 = 0; outside, the last group is read instead)
+    const float* const a_src = a.g + (size_t)(lane >> 2) * HW + min(pbase + 4 * (lane & 3), HW - 4);
+    auto stage_a = [&](int kc) {
 #pragma unroll
-        for (int cb = 0; cb < SIM_NCB; cb++) acc[pb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float nrm[2] = {0.f, 0.f};
-    // buffer loads for g: the descriptor (per chunk) and the row offset are scalar, the lane's part is one 32-bit offset per
-    // pixel block (HW < 2^25: launch_codebook_fused checks it)
-    const uint32_t row_b = (uint32_t)HW * 4u;
-    uint32_t voff[2];
-#pragma unroll
-    for (int pb = 0; pb < 2; pb++) voff[pb] = (uint32_t)(8 * kq) * row_b + 4u * (uint32_t)min(p0 + 16 * pb + mm, HW - 1);
-    constexpr int NKC = SIM_K / SIM_KC, AHEAD = 2;
-    float araw[AHEAD][2][8];
-    auto load_a = [&](int kc, float (&dst)[2][8]) {  // g[k = 32 kc + 8 kq + i][pixel p0 + 16 pb + mm]
-        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.g + (size_t)SIM_KC * kc * HW), 0,
-                                                          (int)(SIM_KC * row_b), 0x00020000);
-#pragma unroll
-        for (int pb = 0; pb < 2; pb++)
-#pragma unroll
-            for (int i = 0; i < 8; i++)
-                dst[pb][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff[pb], (int)(i * row_b), 0));
+        for (int j = 0; j < 2; j++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src + (size_t)(SIM_KC * kc + 16 * j) * HW),
+                                             (__attribute__((address_space(3))) void*)(s_aw + SG_A_BYTES * (kc & 1) + 1024 * j), 16, 0, 0);
     };
+    // code-book chunk: every wave moves the same number of 1 KiB pieces (the waits count them): 38 pieces over 8 waves are 5
+    // each, the two surplus slots repeat piece 37 (the same bytes to the same place)
     const char* planes_b = reinterpret_cast<const char*>(a.planes);
-    constexpr int NPIECE = (SIM_PIECES + FU_NW - 1) / FU_NW;
-    auto stage = [&](int kc, int buf) {
+    constexpr int NPIECE = (SIM_PIECES + SG_NW - 1) / SG_NW;
+    auto stage = [&](int kc) {
 #pragma unroll
         for (int j = 0; j < NPIECE; j++) {
-            const int q = w + FU_NW * j;
+            const int q = min(w + SG_NW * j, SIM_PIECES - 1);
             const int slot = 64 * q + lane;
             const int plane = slot / (SIM_NC * 4), rs = slot - plane * (SIM_NC * 4), r = rs >> 2, sp = rs & 3;
             const int piece = sp ^ ((r >> 2) & 3);
             const uint32_t so = (uint32_t)(((plane * SIM_NC + r) * SIM_K + 8 * piece + SIM_KC * kc) * 2);
-            if (q < SIM_PIECES)  // wave-uniform
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(planes_b + so),
-                                                 (__attribute__((address_space(3))) void*)(s_cb[buf] + 1024 * q), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(planes_b + so),
+                                             (__attribute__((address_space(3))) void*)(s_cb + SIM_BUF * (kc % SG_NBUF) + 1024 * q), 16, 0, 0);
         }
     };
+    static_assert(NPIECE == 5 && SG_NBUF == 3, "the s_waitcnt immediates below are written for 5 + 2 operations per chunk, two chunks ahead");
     const int b_off = 64 * mm + 16 * (kq ^ ((mm >> 2) & 3));
-    stage(0, 0);
-#pragma unroll
-    for (int kc = 0; kc < AHEAD; kc++) load_a(kc, araw[kc]);
+    const char* const a_rd = s_aw + 4 * (16 * 8 * kq + mm);  // A[k = 8 kq + i][pixel mm]: + 64 i
+    stage(0);
+    stage_a(0);
+    stage(1);
+    stage_a(1);
 #pragma unroll
     for (int kc = 0; kc < NKC; kc++) {
-        // chunk kc has landed for THIS wave's pieces (and its A values: loads return in order); past the barrier it has for
-        // every wave's, and every wave is done reading the other buffer
-        if (kc + 1 < NKC) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");  // all but the newest A chunk (16 loads)
+        // issue order: chunk kc + 2's seven operations in iteration kc.  Needed now: chunk kc (issued two iterations ago); the
+        // seven of chunk kc + 1 may stay in flight.  Past the barrier chunk kc has landed for every wave, and every wave is
+        // done reading the buffer chunk kc + 2 goes to.
+        if (kc + 1 < NKC) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        bf16x8 Ah[2], Al[2];
+        float araw[8];
 #pragma unroll
-        for (int pb = 0; pb < 2; pb++) {
+        for (int i = 0; i < 8; i++) araw[i] = *reinterpret_cast<const float*>(a_rd + SG_A_BYTES * (kc & 1) + 64 * i);
+        bf16x8 Ah, Al;
 #pragma unroll
-            for (int i = 0; i < 8; i++) nrm[pb] = fmaf(araw[kc % AHEAD][pb][i], araw[kc % AHEAD][pb][i], nrm[pb]);
-            split_pack8(araw[kc % AHEAD][pb], Ah[pb], Al[pb]);
+        for (int i = 0; i < 8; i++) nrm = fmaf(araw[i], araw[i], nrm);
+        split_pack8(araw, Ah, Al);
+        if (kc + 2 < NKC) {
+#if !(GOI_SG_EXP & 1)
+            stage(kc + 2);
+#endif
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the tile is in registers before its buffer is re-filled
+#if !(GOI_SG_EXP & 4)
+            stage_a(kc + 2);
+#endif
         }
-        if (kc + 1 < NKC) stage(kc + 1, (kc + 1) & 1);
-        if (kc + AHEAD < NKC) load_a(kc + AHEAD, araw[kc % AHEAD]);
-        const char* buf = s_cb[kc & 1] + b_off;
+#if GOI_SG_EXP & 2
+        if (kc > 0) continue;
+#endif
+        const char* buf = s_cb + SIM_BUF * (kc % SG_NBUF) + b_off;
+        // Three products per code block on one accumulator.  Issued block by block they form a chain (a dependent 16x16x32
+        // issues every ~36 clocks, an independent one every 16) behind the block's own LDS reads: 19 x (LDS latency + chain)
+        // per chunk.  Issued term by term over GROUPS of four blocks, with the next group's operands requested first, neither
+        // latency is on the path.
+        constexpr int G = 4, NG = (SIM_NCB + G - 1) / G;
+        bf16x8 Bh[2][G], Bl[2][G];
+        auto fetch_b = [&](int g, int slot) {
 #pragma unroll
-        for (int cb = 0; cb < SIM_NCB; cb++) {
-            const bf16x8 Bh = *reinterpret_cast<const bf16x8*>(buf + 1024 * cb);
-            const bf16x8 Bl = *reinterpret_cast<const bf16x8*>(buf + 1024 * cb + SIM_PLANE_U);
-            acc[0][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al[0], Bh, acc[0][cb], 0, 0, 0);
-            acc[1][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al[1], Bh, acc[1][cb], 0, 0, 0);
-            acc[0][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[0], Bl, acc[0][cb], 0, 0, 0);
-            acc[1][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[1], Bl, acc[1][cb], 0, 0, 0);
-            acc[0][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[0], Bh, acc[0][cb], 0, 0, 0);
-            acc[1][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[1], Bh, acc[1][cb], 0, 0, 0);
+            for (int i = 0; i < G; i++)
+                if (G * g + i < SIM_NCB) {
+                    Bh[slot][i] = *reinterpret_cast<const bf16x8*>(buf + 1024 * (G * g + i));
+                    Bl[slot][i] = *reinterpret_cast<const bf16x8*>(buf + 1024 * (G * g + i) + SIM_PLANE_U);
+                }
+        };
+        fetch_b(0, 0);
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+            if (g + 1 < NG) fetch_b(g + 1, (g + 1) & 1);
+#pragma unroll
+            for (int i = 0; i < G; i++)
+                if (G * g + i < SIM_NCB) sx[G * g + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bh[g & 1][i], sx[G * g + i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < G; i++)
+                if (G * g + i < SIM_NCB) sx[G * g + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bl[g & 1][i], sx[G * g + i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < G; i++)
+                if (G * g + i < SIM_NCB) sx[G * g + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh[g & 1][i], sx[G * g + i], 0, 0, 0);
         }
     }
 #ifdef GOI_FU_PROF  // experiment builds: phase clocks of this wave instead of its loss sums
@@ -844,13 +880,10 @@ __global__ __launch_bounds__(64 * FU_NW, 2) void codebook_simgrad_k(const FusedA
     const float g_ent = a.w_sl1 * a.t * a.inv_hw;
     const float first = mm == 0 ? 1.f : 0.f;  // a row's scalars are replicated over its 16 lanes: count them once
     float acc_nl = 0.f, acc_m = 0.f, acc_H = 0.f, acc_sa = 0.f;
-#pragma unroll
-    for (int pb = 0; pb < 2; pb++) {
-        const long long pbase = p0 + 16 * pb;  // this lane's D rows are pixels pbase + 4 kq + r
-        f32x4(&sx)[SIM_NCB] = acc[pb];
+    {
         float invl;
         {  // 1 / |g|: this lane summed k = 8 kq .. + 7 of every chunk for pixel mm
-            float n2 = nrm[pb];
+            float n2 = nrm;
             n2 += __shfl_xor(n2, 16, 64);
             n2 += __shfl_xor(n2, 32, 64);
             invl = 1.0f / sqrtf(n2);
@@ -868,22 +901,20 @@ __global__ __launch_bounds__(64 * FU_NW, 2) void codebook_simgrad_k(const FusedA
             const float vw = valid ? first : 0.f;
             const int arg_a = (&arga4.x)[r];
             const int cba = (arg_a & 15) == mm ? arg_a >> 4 : -1;  // the code block in which THIS lane holds code arg_a
+            // sx holds the RAW products <g, L1_c>; sim = raw / |g| never exists per element: 1 / |g| > 0 goes into the row
+            // constants (maxima and ties are those of the raw row)
             float m = NEG_INF;
+            if (!vlast) sx[SIM_NCB - 1][r] = NEG_INF;
 #pragma unroll
-            for (int cb = 0; cb < SIM_NCB; cb++) {
-                float x = sx[cb][r] * inv;
-                if (cb == SIM_NCB - 1) x = vlast ? x : NEG_INF;
-                sx[cb][r] = x;
-                m = fmaxf(m, x);
-            }
-            const float ms = row_max(m);
-            const float tl = a.t * 1.44269504088896341f, nb = -ms * tl;  // t (x - ms) in log2 units: e2 = x tl + nb <= 0
+            for (int cb = 0; cb < SIM_NCB; cb++) m = fmaxf(m, sx[cb][r]);
+            const float mraw = row_max(m), ms = mraw * inv;
+            const float tl = a.t * 1.44269504088896341f * inv, nb = -mraw * tl;  // t (sim - ms) in log2 units: e2 = raw tl + nb <= 0
             float sZ = 0.f, sA = 0.f, sel = 0.f;
             int is = 0x7FFFFFFF, cnt = 0;
 #pragma unroll
             for (int cb = SIM_NCB - 1; cb >= 0; cb--) {  // descending: the lane's FIRST maximum wins
                 const float x = sx[cb][r];
-                const bool top = x == ms;
+                const bool top = x == mraw;
                 is = top ? 16 * cb + mm : is;
                 cnt += top ? 1 : 0;
                 sel = cb == cba ? x : sel;
@@ -893,7 +924,7 @@ __global__ __launch_bounds__(64 * FU_NW, 2) void codebook_simgrad_k(const FusedA
                 if (cb == SIM_NCB - 1) e2 = fmaxf(e2, -FLT_MAX);  // padding: keep 0 * e2 finite
                 sA = fmaf(q, e2, sA);
             }
-            const float Zq = row_sum(sZ), A2 = row_sum(sA), nl = row_sum((float)cnt), sim_a = row_sum(sel);
+            const float Zq = row_sum(sZ), A2 = row_sum(sA), nl = row_sum((float)cnt), sim_a = row_sum(sel) * inv;
             const int arg_s = row_min(is);
             const float rZq = 1.f / Zq, k2 = -A2 * rZq;                        // k2 = (H - log Zq) / ln 2
             const float Hq = 0.69314718055994531f * (__builtin_amdgcn_logf(Zq) + k2);  // v_log_f32 is log2
@@ -911,7 +942,7 @@ __global__ __launch_bounds__(64 * FU_NW, 2) void codebook_simgrad_k(const FusedA
                 uint32_t word = 0;
 #pragma unroll
                 for (int cb = 0; cb < SIM_NCB; cb++) {
-                    const unsigned long long bal = __ballot(sx[cb][r] == ms);  // bit 16 kq + mm
+                    const unsigned long long bal = __ballot(sx[cb][r] == mraw);  // bit 16 kq + mm
                     const uint32_t bits = (uint32_t)(bal >> (16 * kq)) & 0xFFFFu;
                     word = (cb & 1) ? (word | (bits << 16)) : bits;
                     if (((cb & 1) || cb == SIM_NCB - 1) && nl > 1.f && mm == 0) wd[cb >> 1] = word;
@@ -960,7 +991,7 @@ __global__ __launch_bounds__(64 * FU_NW, 2) void codebook_simgrad_k(const FusedA
     t0 = (float)(tk1 - tk0);
     t1 = (float)(__builtin_readcyclecounter() - tk1);
 #endif
-    if (lane == 0) *reinterpret_cast<f32x4*>(a.sums_a + 4 * ((size_t)blockIdx.x * FU_NW + w)) = f32x4{t0, t1, t2, t3};
+    if (lane == 0) *reinterpret_cast<f32x4*>(a.sums_a + 4 * ((size_t)blockIdx.x * SG_NW + w)) = f32x4{t0, t1, t2, t3};
 }
 
 // dz of one 16-pixel block in place of its logits z: P from the recorded statistics, the label from (arg_s, nl) or, for a tie,
@@ -1093,14 +1124,17 @@ __global__ __launch_bounds__(64 * DG_NW, 1) void decoder_grad_k(const FusedArgs 
     // the loss sums: this kernel's part (sum P^2 - 2 sum_label P + number of labels) and, folded in in a fixed order,
     // codebook_simgrad_k's per-wave sums (rows wave, wave + n_waves, ...)
     float t0 = wave_sum_u(acc_lab);
+    float t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    for (long long i = wave + n_waves * lane; i < a.n_sums_a; i += 64 * n_waves) {  // lane partials, then the fixed DPP order
+        const f32x4 v = *reinterpret_cast<const f32x4*>(a.sums_a + 4 * i);
+        t1 += v[1];
+        t2 += v[2];
+        t3 += v[3];
+    }
+    t1 = wave_sum_u(t1);
+    t2 = wave_sum_u(t2);
+    t3 = wave_sum_u(t3);
     if (lane == 0) {
-        float t1 = 0.f, t2 = 0.f, t3 = 0.f;
-        for (long long i = wave; i < a.n_sums_a; i += n_waves) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(a.sums_a + 4 * i);
-            t1 += v[1];
-            t2 += v[2];
-            t3 += v[3];
-        }
         float* lo = out + (size_t)C * (S + 1);
         lo[0] = t0;
         lo[1] = t1;
@@ -1338,7 +1372,7 @@ static long long fu_simgrad_wgs(long long HW) { return (HW + FU_WG_PIX - 1) / FU
 size_t codebook_fused_workspace_bytes(long long HW) {
     const size_t npad = (size_t)16 * fu_blocks(HW);
     return fu_align((size_t)2 * SIM_NC * SIM_K * 2) + fu_align(FU_WZ_BYTES) + fu_align(FU_WT_BYTES) + 6 * fu_align(npad * 4) +
-           fu_align(npad * FU_TIE_WORDS * 4) + fu_align((size_t)fu_simgrad_wgs(HW) * FU_NW * 16) +
+           fu_align(npad * FU_TIE_WORDS * 4) + fu_align((size_t)fu_simgrad_wgs(HW) * SG_NW * 16) +
            (size_t)fu_blocks(HW) * FU_DCHUNK * 2;
 }
 int codebook_fused_rows() { return 256 * DG_NW; }
@@ -1366,7 +1400,7 @@ int launch_codebook_fused(const float* g, const float* l1, const float* sem, con
     a.r_arga = reinterpret_cast<int*>(take(npad * 4));
     a.r_args = reinterpret_cast<int*>(take(npad * 4));
     a.r_tie = reinterpret_cast<uint32_t*>(take(npad * FU_TIE_WORDS * 4));
-    a.n_sums_a = (int)(fu_simgrad_wgs(HW) * FU_NW);
+    a.n_sums_a = (int)(fu_simgrad_wgs(HW) * SG_NW);
     a.sums_a = reinterpret_cast<float*>(take((size_t)a.n_sums_a * 16));
     uint16_t* dplanes = reinterpret_cast<uint16_t*>(ws);
     codebook_split_k<<<dim3((SIM_NC * SIM_K / 2 + 255) / 256), dim3(256), 0, s>>>(l1, C, planes);
@@ -1378,7 +1412,7 @@ int launch_codebook_fused(const float* g, const float* l1, const float* sem, con
     a.w_sl1 = 0.3f;
     const long long stat_wgs = (blocks + DS_NW - 1) / DS_NW;
     decoder_stats_k<<<dim3((unsigned)(stat_wgs < 2048 ? stat_wgs : 2048)), dim3(64 * DS_NW), 0, s>>>(a);
-    codebook_simgrad_k<<<dim3((unsigned)fu_simgrad_wgs(HW)), dim3(64 * FU_NW), 0, s>>>(a);
+    codebook_simgrad_k<<<dim3((unsigned)fu_simgrad_wgs(HW)), dim3(64 * SG_NW), 0, s>>>(a);
     decoder_grad_k<<<dim3(codebook_fused_rows() / DG_NW), dim3(64 * DG_NW), 0, s>>>(a);
     const long long df_wgs = (blocks + DF_NW - 1) / DF_NW;
     decoder_df_k<<<dim3((unsigned)(df_wgs < 1024 ? df_wgs : 1024)), dim3(64 * DF_NW), 0, s>>>(a);

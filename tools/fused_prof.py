@@ -38,6 +38,6 @@ al = lambda x: (x + 255) & ~255  # noqa: E731
 blocks = (HW + 127) // 128 * 8
 npad = 16 * blocks
 off = al(2 * 304 * 256 * 2) + al(2 * 304 * 32) + al(2 * 10 * 16 * 64) + 6 * al(npad * 4) + al(npad * 10 * 4)
-n_a = (HW + 127) // 128 * 4
+n_a = (HW + 127) // 128 * 8
 rec = ws[off: off + n_a * 16].view(torch.float32).view(n_a, 4).double()
 print("codebook_simgrad_k per wave: K loop %.0f clocks, statistics + gradients + stores %.0f clocks" % (rec[:, 0].mean(), rec[:, 1].mean()))
