@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The training half of the semantic head at 1600x1056, 300 codes, D = 256, S = 16: fused_codebook_losses forward + backward
-with the two-kernel path (codebook_fused_k + codebook_dlut2_k) and with the three-kernel path (sim, rows, fp32 dLUT),
+with goi_codebook_fused (five kernels, no [HW, C] matrix) and with the three-kernel path (sim, rows, fp32 dLUT),
 ms per call from events on the stream, and the agreement of the two."""
 import os
 import sys
@@ -42,6 +42,6 @@ semantic._FUSED_KERNELS["on"] = True
 t2, o2 = run()
 semantic._FUSED_KERNELS["on"] = False
 t3, o3 = run()
-print("two-kernel path %.3f ms   three-kernel path %.3f ms" % (t2, t3))
+print("goi_codebook_fused (five kernels) %.3f ms   three-kernel path %.3f ms" % (t2, t3))
 print("loss %.7f vs %.7f; max |d| / scale: dsem %.2e  dlut %.2e  dW %.2e" % (
     float(o2[0]), float(o3[0]), *[float((a - b).abs().max() / b.abs().max()) for a, b in zip(o2[1:], o3[1:])]))
