@@ -191,3 +191,47 @@ def test_duplicate_codebook_rows_label_every_maximum(fused):
         scale = float(g0[k].abs().max())
         bad = (g0[k] - g1[k]).abs() > 1e-3 * scale
         assert int(bad.sum()) <= (4 * S if k == "sem" else 0), (k, int(bad.sum()), float((g0[k] - g1[k]).abs().max()) / scale)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fused_path_fuzz(seed):
+    """Random shapes inside goi_codebook_fused's domain (tab_len 289..304, semantic_dim 1..16, any H x W with HW % 4 = 0, with and
+    without bias, both anneal stages) against the PyTorch restatement: every loss term to 1e-5, every gradient to 1e-3 of its
+    scale away from near-ties."""
+    import random
+
+    from goi_hyperplane_amd import _lib, semantic
+    rng = random.Random(1234 + seed)
+    C = rng.randint(289, 304)
+    S = rng.randint(1, 16)
+    H = rng.randint(3, 70)
+    W = 4 * rng.randint(1, 24)
+    bias = rng.random() < 0.7
+    it = rng.choice([10, 1500])
+    sem, mlp, lut, gtl = setup(H, W, S=S, C=C, bias=bias, seed=seed)
+    calls = {"n": 0}
+    lib = _lib.load()
+    real = lib.goi_codebook_fused
+
+    class Spy:  # the fused entry point must be the one that runs for these shapes
+        def __call__(self, *a):
+            calls["n"] += 1
+            return real(*a)
+    try:
+        lib.goi_codebook_fused = Spy()
+        l1, t1, g1 = grads(fused_codebook_losses, sem, mlp, lut, gtl, it)
+    finally:
+        lib.goi_codebook_fused = real
+    assert calls["n"] == 1, (C, S, H, W)
+    l0, t0, g0 = grads(codebook_losses, sem, mlp, lut, gtl, it)
+    assert abs(float(l0 - l1)) <= 1e-5 * abs(float(l0)), (C, S, H, W)
+    for k in t0:
+        assert abs(float(t0[k] - t1[k])) <= 1e-5 * max(abs(float(t0[k])), 1e-3), (k, C, S, H, W)
+    for k in ("sem", "W", "b", "lut"):
+        if g0[k] is None:
+            assert g1[k] is None
+            continue
+        scale = float(g0[k].abs().max())
+        bad = (g0[k] - g1[k]).abs() > 1e-3 * scale
+        assert int(bad.sum()) <= (4 * S if k == "sem" else 0), (k, C, S, H, W, int(bad.sum()),
+                                                               float((g0[k] - g1[k]).abs().max()) / scale)
