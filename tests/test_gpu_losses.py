@@ -235,3 +235,24 @@ def test_fused_path_fuzz(seed):
         bad = (g0[k] - g1[k]).abs() > 1e-3 * scale
         assert int(bad.sum()) <= (4 * S if k == "sem" else 0), (k, C, S, H, W, int(bad.sum()),
                                                                float((g0[k] - g1[k]).abs().max()) / scale)
+
+
+def test_fused_entry_rejects_shapes_it_does_not_cover_and_the_wrapper_falls_back():
+    """goi_codebook_fused covers tab_len 289..304, ape_dim 256, semantic_dim <= 16, HW % 4 = 0; anything else must come back as
+    an error from the C ABI (nothing launched) and go through the three-step path in the Python wrapper."""
+    import ctypes as C_
+
+    from goi_hyperplane_amd import _lib
+    lib = _lib.load()
+    t = torch.zeros(4096, device="cuda")
+    p = C_.c_void_p(t.data_ptr())
+    for HW, C, D, S in [(64, 300, 128, 16), (64, 288, 256, 16), (64, 305, 256, 16), (64, 300, 256, 17), (66, 300, 256, 16),
+                        (0, 300, 256, 16)]:
+        assert lib.goi_codebook_fused(p, p, p, p, None, HW, C, D, S, 1.0, p, p, p, p, None) != 0, (HW, C, D, S)
+        assert "goi_codebook_fused" in _lib.last_error()
+    # 33 x 47 = 1551 pixels (not a multiple of 4) and 40 codes: the wrapper must still produce the reference's losses
+    for H, W, C in [(33, 47, 300), (24, 40, 40)]:
+        sem, mlp, lut, gtl = setup(H, W, S=10, C=C, bias=True)
+        l0, t0, g0 = grads(codebook_losses, sem, mlp, lut, gtl, 10)
+        l1, t1, g1 = grads(fused_codebook_losses, sem, mlp, lut, gtl, 10)
+        assert abs(float(l0 - l1)) <= 1e-5 * abs(float(l0))
