@@ -135,6 +135,7 @@ def main():
     ap.add_argument("--forward", choices=["speculative", "exact"], default=None,
                     help="forward mode (default: the package default, speculative = no host round trip)")
     ap.add_argument("--no-fp32-flush", action="store_true", help="skip the secondary exact-fp32-flush figure")
+    ap.add_argument("--no-two-streams", action="store_true", help="skip the secondary two-views-in-flight figure")
     ap.add_argument("--no-overlap", action="store_true",
                     help="--gpus > 1: wait for each step's gradient exchange inside the step instead of letting it run "
                          "behind the next step's render + backward")
@@ -492,6 +493,37 @@ def main():
                       "what": "bwd_variant 2: per-Gaussian sums of the backward on v_mfma_f32_16x16x4_f32 (exact fp32 "
                               "products) instead of split-bf16 operands"}
 
+    # Secondary figure: TWO independent views in flight on two HIP streams of this GPU (a micro-batch of views whose
+    # gradients are accumulated, as in a multi-view batch).  Every view does the same forward + backward as in the timed
+    # region; what overlaps is one view's latency-bound small kernels (sorts, scans) and kernel tails with the other
+    # view's work.  train.py's own loop (one view, optimizer step, next view) cannot do this, so `value` stays the
+    # one-view-at-a-time figure.
+    two_streams = None
+    if world == 1 and not args.no_two_streams:
+        pcs = [pc, GaussianSet.from_scene(sc, dev) if sc is not None else GaussianSet.from_ply(args.ply, dev, sh_degree=3)]
+        streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+
+        def step2(i):
+            k = i & 1
+            with torch.cuda.stream(streams[k]):
+                for p_ in pcs[k].parameters():
+                    p_.grad = None
+                o = render(cams[i % len(cams)], pcs[k], pipe, bg)
+                torch.autograd.backward((o["render"], o["semantics"]), (g_color, g_sem))
+        torch.cuda.synchronize(dev)
+        for i in range(10):  # each stream's allocator pool and the second parameter set's first frames
+            step2(i)
+        torch.cuda.synchronize(dev)
+        s0 = time.perf_counter()
+        n2 = max(10, min(args.steps, 60))
+        for i in range(n2):
+            step2(args.warmup + i)
+        torch.cuda.synchronize(dev)
+        s_elapsed = time.perf_counter() - s0
+        two_streams = {"views_per_s": n2 / s_elapsed, "ms_per_view": s_elapsed / n2 * 1e3, "views": n2, "streams": 2,
+                       "what": "two independent views in flight on two HIP streams of one GPU (same work per view)"}
+        del pcs, streams
+
     if rank == 0:
         sb = stage_bytes(args.P, V, N, T, HW, args.S)
         b_fwd, b_bwd = survey_bytes(args.P, V, N, T, HW, args.S)
@@ -553,6 +585,8 @@ def main():
             "step_enqueue_ms": step_enqueue_ms,  # host-side, informational (stall detector; not used for value)
             "semantic_finetune": sem_only,
             "value_fp32_flush": None if fp32_flush is None else fp32_flush["views_per_s"],
+            "value_two_views_in_flight": None if two_streams is None else two_streams["views_per_s"],
+            "two_views_in_flight": two_streams,
             "fp32_flush": fp32_flush,
             # forward mode of the timed region and what the speculation did in it (exact_frames / waits / overflows
             # should all be 0: nothing in the timed steps waited for the device)
