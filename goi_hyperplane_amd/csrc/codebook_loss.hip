@@ -575,8 +575,8 @@ __global__ __launch_bounds__(64 * SIM_NW) void codebook_sim_k(const float* __res
 //   codebook_dlut2_k  dL/dL1[c][d] = sum_p dsim[p][c] g[d][p]: the dsim planes stream through LDS by LDS-DMA (K = pixels, 32
 //                     per chunk), g is split once by the wave that owns its 32 features, and a workgroup keeps the whole
 //                     [304][256] partial in the accumulators of its 8 waves.
-// HBM traffic: g twice (2 x 1.73 GB at 1600x1056) and the planes once each way (2 x 2.05 GB), against 11.6 GB for
-// sim kernel + row kernel + fp32 dLUT kernel.
+// HBM traffic at 1600x1056 (FETCH_SIZE / WRITE_SIZE counters): 8.6 GB -- g twice (2 x 1.73 GB), the planes once each way
+// (2 x 2.05 GB), 0.8 GB in the decoder kernels -- against 14.4 GB for sim kernel + row kernel + fp32 dLUT kernel.
 // (One kernel for the first three was tried first: ~400 live registers, one wave per SIMD, and the compiler spilled the
 // addresses it hoisted; every load, LDS and dependent-MFMA latency was exposed: 4.7 ms against 3.6 ms for sim + row kernels.)
 constexpr int FU_WG_PIX = 128;                // pixels of one codebook_simgrad_k workgroup: 8 waves x one 16-pixel block
