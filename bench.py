@@ -461,6 +461,31 @@ def main():
         sem_only = {"views_per_s": nss * world / sem_elapsed, "ms_per_step": sem_elapsed / nss * 1e3, "steps": nss,
                     "what": "only the semantic features trainable (the reference's default): forward + "
                             "feature-gradient-only backward" + (" + RCCL all-reduce of dL/dsemantics" if world > 1 else "")}
+        # ... and with the opt-in geometry cache: the cameras repeat (as the training views of an epoch do) and nothing but
+        # the semantic features changes, so after the first pass over the cameras every frame is the blend alone
+        rasterizer.set_geometry_cache(64 << 30)
+        try:
+            for i in range(len(cams) + 2):
+                sem_step(i)
+            barrier()
+            c0 = rasterizer.geometry_cache_stats()
+            s0 = time.perf_counter()
+            for i in range(nss):
+                sem_step(i)
+            barrier()
+            c_elapsed = time.perf_counter() - s0
+            c1 = rasterizer.geometry_cache_stats()
+        finally:
+            rasterizer.set_geometry_cache(0)
+        if dist is not None:
+            tt = torch.tensor([c_elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            c_elapsed = float(tt.item())
+        sem_only["geometry_cache"] = {"views_per_s": nss * world / c_elapsed, "ms_per_step": c_elapsed / nss * 1e3,
+                                      "hits": c1["hits"] - c0["hits"], "misses": c1["misses"] - c0["misses"],
+                                      "bytes_per_camera": c1["bytes"] // max(1, c1["entries"]),
+                                      "what": "the same with rasterizer.set_geometry_cache on (opt-in): cameras seen before "
+                                              "render with the blend alone"}
         rasterizer.set_backward_mode(semantics_only="auto")
         for p in params:
             p.requires_grad_(True)

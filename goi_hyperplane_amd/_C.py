@@ -201,7 +201,7 @@ _FWD = {"mode": _env_forward_mode(), "inference": _env_inference_mode(),
         "max_ahead": int(os.environ.get("GOI_MAX_AHEAD", "64"))}
 _SPEC = {}  # device index -> {"high_water": int, "P": int, "pending": deque of LazyCount}
 _SPEC_LOCK = threading.RLock()
-SPECULATION_STATS = {"exact_frames": 0, "speculative_frames": 0, "overflows": 0, "redone": 0, "waits": 0}
+SPECULATION_STATS = {"exact_frames": 0, "speculative_frames": 0, "overflows": 0, "redone": 0, "waits": 0, "cached_frames": 0}
 _MIN_CAPACITY = 1 << 16
 _KEEP_WORKSPACES = 2  # pending frames per device whose workspaces stay alive for a possible redo
 
@@ -428,11 +428,128 @@ def _scene(P, S, H, W, bg, means3D, sh, colors, semantics, opacity, scales, rota
         int(bool(debug)))
 
 
+# ---- opt-in geometry cache ---------------------------------------------------------------------------
+# The reference's semantic stage trains ONLY the semantic features (arguments/__init__.py:85-90): positions, covariances,
+# opacities and SH colours are frozen, so for a camera that was rendered before, everything in front of the blend
+# (preprocess, depth sort, scan, emit, tile sort: 0.35 of the 0.63 ms forward at the headline size) reproduces what is still
+# sitting in that frame's workspaces.  With the cache on, such a frame runs goi_raster_forward_reblend alone.  It is OPT-IN
+# because the premise cannot be verified here: the activated tensors the rasterizer is handed (exp(scaling), sigmoid(opacity),
+# ...) are new objects on every call.  A frame is eligible only if no geometry input requires a gradient; the key holds the
+# camera tensors' and the positions' identity and version (an optimizer step, a densification or a new camera object miss).
+_GEOM_CACHE = {"max_bytes": int(float(os.environ.get("GOI_GEOMETRY_CACHE_GB", "0")) * (1 << 30)), "bytes": 0,
+               "entries": collections.OrderedDict(), "hits": 0, "misses": 0, "evictions": 0}
+_GEOM_LOCK = threading.RLock()
+
+
+def set_geometry_cache(max_bytes) -> None:
+    """Enables (max_bytes > 0), resizes or disables and empties (0 / None) the per-camera geometry cache.  About
+    goi_raster_geom_bytes(P) + goi_raster_binning_bytes(capacity) per cached camera (~270 MB at 1 M Gaussians, 1600x1056)."""
+    with _GEOM_LOCK:
+        _GEOM_CACHE["max_bytes"] = int(max_bytes or 0)
+        _geom_evict()
+
+
+def geometry_cache_stats() -> dict:
+    with _GEOM_LOCK:
+        return {k: (len(v) if k == "entries" else v) for k, v in _GEOM_CACHE.items()}
+
+
+def _geom_evict():
+    c = _GEOM_CACHE
+    while c["entries"] and c["bytes"] > c["max_bytes"]:
+        _k, e = c["entries"].popitem(last=False)  # least recently used
+        c["bytes"] -= e["bytes"]
+        c["evictions"] += 1
+
+
+def _ident(t):
+    return None if (t is None or not isinstance(t, torch.Tensor) or t.numel() == 0) else (t.data_ptr(), t._version, tuple(t.shape))
+
+
+def _geom_key(dev, P, H, W, means3D, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, degree, campos, prefiltered):
+    return (dev.index, P, H, W, float(scale_modifier), float(tan_fovx), float(tan_fovy), int(degree), bool(prefiltered),
+            _ident(means3D), _ident(viewmatrix), _ident(projmatrix), _ident(campos), tuple(sorted(_lib.OPTIONS.items())))
+
+
 def rasterize_gaussians(background, means3D, colors, semantics, opacity, scales, rotations, scale_modifier,
                         cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh,
                         degree, campos, prefiltered, debug):
     """-> (num_rendered, color[3,H,W], semantic[S,H,W], depth[1,H,W], alpha[1,H,W], radii[P] i32,
     geomBuffer u8, binningBuffer u8, imgBuffer u8)"""
+    args = (background, means3D, colors, semantics, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+            projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered, debug)
+    P = int(means3D.size(0)) if isinstance(means3D, torch.Tensor) and means3D.ndimension() == 2 else 0
+    if not (_GEOM_CACHE["max_bytes"] > 0 and getattr(_CALL, "geometry_frozen", False) and P > 0 and not debug
+            and isinstance(semantics, torch.Tensor) and semantics.ndimension() == 2 and semantics.size(0) == P):
+        return _rasterize_gaussians_frame(*args)
+    dev = _check_device(means3D)
+    H, W = int(image_height), int(image_width)
+    key = _geom_key(dev, P, H, W, means3D, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, degree, campos,
+                    prefiltered)
+    with _GEOM_LOCK:
+        e = _GEOM_CACHE["entries"].get(key)
+        if e is not None:
+            R = e["R"]
+            if isinstance(R, LazyCount):
+                if not R.resolved:
+                    R._resolve(wait=False, lazy=True)
+                usable = R.resolved and R._error is None
+            else:
+                usable = True
+            if usable:
+                _GEOM_CACHE["entries"].move_to_end(key)
+                _GEOM_CACHE["hits"] += 1
+            else:
+                e = None
+    if e is not None:
+        return _reblend(e, background, semantics, P, H, W, dev)
+    res = _rasterize_gaussians_frame(*args)
+    R, _c, _s, _d, _a, radii, geom, binning, img = res
+    with _GEOM_LOCK:
+        _GEOM_CACHE["misses"] += 1
+        nbytes = geom.numel() + img.numel() + radii.numel() * 4 + (binning.numel() if isinstance(binning, torch.Tensor) else 0)
+        old = _GEOM_CACHE["entries"].pop(key, None)
+        if old is not None:
+            _GEOM_CACHE["bytes"] -= old["bytes"]
+        if nbytes <= _GEOM_CACHE["max_bytes"]:
+            _GEOM_CACHE["entries"][key] = dict(R=R, radii=radii, geom=geom, binning=binning, img=img, bytes=nbytes,
+                                               stream=torch.cuda.current_stream(dev))
+            _GEOM_CACHE["bytes"] += nbytes
+            _geom_evict()
+    return res
+
+
+def _reblend(e, background, semantics, P, H, W, dev):
+    """A cached camera: the blend alone, over the cached frame's workspaces (goi_raster_forward_reblend)."""
+    lib = _lib.load()
+    S = int(semantics.size(1))
+    R = e["R"]
+    layout, bin_override = _layout_of(R)
+    binning = bin_override if bin_override is not None else e["binning"]
+    f32 = dict(dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        cur = torch.cuda.current_stream(dev)
+        if e["stream"] != cur:
+            cur.wait_stream(e["stream"])  # the frame that filled the workspaces ran on another stream
+        out_color = torch.empty((3, H, W), **f32)
+        out_sem = torch.empty((S, H, W), **f32)
+        out_depth = torch.empty((1, H, W), **f32)
+        out_alpha = torch.empty((1, H, W), **f32)
+        img = torch.empty_like(e["img"])
+        bg_c, sem_c = _prep(background, "background", dev), _prep(semantics, "semantics", dev)
+        sc = _scene(P, S, H, W, bg_c, None, None, None, sem_c, None, None, None, 1.0, None, None, None, 0.0, 0.0, 0, None,
+                    False, False)
+        r = lib.goi_raster_forward_reblend(C.byref(sc), int(layout), _ptr(e["geom"]), _ptr(binning), _ptr(e["img"]), _ptr(img),
+                                           _ptr(out_color), _ptr(out_sem), _ptr(out_depth), _ptr(out_alpha), _stream(dev))
+    if r < 0:
+        raise RuntimeError(_lib.last_error())
+    SPECULATION_STATS["cached_frames"] += 1
+    return R, out_color, out_sem, out_depth, out_alpha, e["radii"], e["geom"], binning, img
+
+
+def _rasterize_gaussians_frame(background, means3D, colors, semantics, opacity, scales, rotations, scale_modifier,
+                               cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh,
+                               degree, campos, prefiltered, debug):
     lib = _lib.load()
     dev = _check_device(means3D)
     P, H, W = int(means3D.size(0)), int(image_height), int(image_width)

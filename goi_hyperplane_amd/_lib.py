@@ -47,6 +47,7 @@ SYMBOLS = {
     "goi_raster_ticket_result": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "goi_raster_forward_redo": (C.c_int, [C.POINTER(GoiRasterScene), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
                                 + [C.c_void_p] * 5 + [C.c_void_p]),
+    "goi_raster_forward_reblend": (C.c_int, [C.POINTER(GoiRasterScene), C.c_int] + [C.c_void_p] * 9),
     "goi_raster_backward": (C.c_int, [C.POINTER(GoiRasterScene), C.c_int] + [C.c_void_p] * 3 + [C.c_void_p] * 6
                             + [C.c_void_p] * 11 + [C.c_void_p, C.c_void_p]),
     "goi_raster_backward_semantics": (C.c_int, [C.POINTER(GoiRasterScene), C.c_int] + [C.c_void_p] * 9),

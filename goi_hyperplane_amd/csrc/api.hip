@@ -507,6 +507,40 @@ int goi_raster_forward_redo(const GoiRasterScene* scene, int num_rendered, void*
     return 0;
 }
 
+int goi_raster_forward_reblend(const GoiRasterScene* scene, int R, const void* geom_buffer, const void* binning_buffer,
+                               const void* cached_image_buffer, void* image_buffer, float* out_color, float* out_semantic,
+                               float* out_depth, float* out_alpha, void* stream) {
+    // (only the blend runs: it reads P, S, W, H, the semantic rows and the background from the scene; the Gaussian records,
+    // the tile lists and the tile ranges are those of the frame that filled the workspaces)
+    if (!scene) return fail("scene is NULL");
+    const GoiRasterScene& sc = *scene;
+    if (sc.P <= 0 || sc.W <= 0 || sc.H <= 0 || sc.S < 1 || sc.S > 32) return fail("goi_raster_forward_reblend: bad P/W/H/S");
+    if (!sc.semantics || !sc.bg) return fail("goi_raster_forward_reblend: semantics and bg are required");
+    if (R < 0) return fail("goi_raster_forward_reblend: bad R");
+    if (!geom_buffer || !cached_image_buffer || !image_buffer || (R > 0 && !binning_buffer))
+        return fail("workspace pointer is NULL");
+    if (!out_color || !out_semantic || !out_depth || !out_alpha) return fail("output pointer is NULL");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    GeomView g;
+    ImageView im_old, im;
+    BinView bv;
+    geom_layout(sc.P, static_cast<char*>(const_cast<void*>(geom_buffer)), &g);
+    image_layout(sc.W, sc.H, static_cast<char*>(const_cast<void*>(cached_image_buffer)), &im_old);
+    image_layout(sc.W, sc.H, static_cast<char*>(image_buffer), &im);
+    binning_layout(R, static_cast<char*>(const_cast<void*>(binning_buffer)), &bv);
+    const int gx = (sc.W + TILE - 1) / TILE, gy = (sc.H + TILE - 1) / TILE;
+    // the new frame gets its own image state (n_contrib is written by the blend and read by ITS backward); the tile ranges
+    // are the cached frame's
+    GOI_HIP(hipMemcpyAsync(im.ranges, im_old.ranges, sizeof(uint2) * (size_t)gx * gy, hipMemcpyDeviceToDevice, s));
+    const uint32_t* plist = bv.vals[tile_sort_result_index(sc.W, sc.H, R)];
+    {
+        StageTimer t(GOI_STAGE_BLEND_FWD, s);
+        launch_render_fwd(sc, g, im, plist, out_color, out_semantic, out_depth, out_alpha, s);
+    }
+    GOI_HIP(hipGetLastError());
+    return 0;
+}
+
 int goi_raster_trace(const GoiRasterScene* scene, const float* img_sem, void* geom_buffer, void* image_buffer,
                      goi_alloc_fn binning_alloc, void* alloc_user, float* out_color, float* gau_sem, int* num_gsem,
                      int* radii, void* stream) {

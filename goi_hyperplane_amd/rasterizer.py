@@ -227,11 +227,27 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, semantics, opaciti
     tensors = (means3D, sh, colors_precomp, semantics, opacities, scales, rotations, cov3Ds_precomp)
     _C._CALL.inference = not (torch.is_grad_enabled()
                               and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors))
+    # eligible for the opt-in geometry cache: no input but the semantic features (and the sink) can receive a gradient
+    _C._CALL.geometry_frozen = not any(isinstance(t, torch.Tensor) and t.requires_grad
+                                       for t in (means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp))
     try:
         return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, semantics, opacities, scales, rotations,
                                          cov3Ds_precomp, raster_settings)
     finally:
         _C._CALL.inference = False
+        _C._CALL.geometry_frozen = False
+
+
+def set_geometry_cache(max_bytes) -> None:
+    """Opt-in cache of per-camera geometry and tile lists for runs in which ONLY the semantic features are trained (the
+    reference's semantic stage): a camera seen before renders with the blend alone.  max_bytes of device memory (~270 MB per
+    camera at 1 M Gaussians, 1600x1056); 0 / None disables and empties it.  The caller vouches that positions, covariances,
+    opacities and colours do not change while the cache is on; env GOI_GEOMETRY_CACHE_GB sets it at import."""
+    _C.set_geometry_cache(max_bytes)
+
+
+def geometry_cache_stats() -> dict:
+    return _C.geometry_cache_stats()
 
 
 def trace_gaussians(means3D, means2D, sh, colors_precomp, img_sem, opacities, scales, rotations, cov3Ds_precomp,

@@ -122,6 +122,19 @@ int goi_raster_forward_redo(const GoiRasterScene* scene, int num_rendered, void*
                             void* binning_buffer, float* out_color, float* out_semantic, float* out_depth,
                             float* out_alpha, const int* radii, void* stream);
 
+/* The blend of a frame whose geometry and tile lists are already in workspaces filled by an earlier goi_raster_forward /
+ * _async / _redo of the SAME camera over the SAME Gaussian geometry (positions, covariances, opacities, colours): only the
+ * semantic rows and the background may have changed.  Runs the forward blend alone (no preprocess, sort or emit), writes the
+ * four outputs and a fresh image workspace (`image_buffer`, goi_raster_image_bytes; the tile ranges are copied from
+ * `cached_image_buffer`), and leaves geometry and binning workspaces untouched, so the result is what goi_raster_forward
+ * would produce for the current semantics, bit for bit, and goi_raster_backward* can follow with (geom, binning, the NEW
+ * image workspace, R).  R as for goi_raster_backward.  Reads only P, S, W, H, semantics and bg from `scene`.  What it cannot
+ * check is the premise: the caller vouches that nothing but the semantics changed (goi_hyperplane_amd: opt-in geometry cache,
+ * DESIGN.md 7c).  No counterpart in the reference, which redoes the whole frame (CR/rasterizer_impl.cu:198-344). */
+int goi_raster_forward_reblend(const GoiRasterScene* scene, int R, const void* geom_buffer, const void* binning_buffer,
+                               const void* cached_image_buffer, void* image_buffer, float* out_color, float* out_semantic,
+                               float* out_depth, float* out_alpha, void* stream);
+
 /* Backward of the forward that filled the three workspaces.  R = the instance count the binning workspace was laid out
  * for: goi_raster_forward's return value, or the `capacity` of a goi_raster_forward_async frame (the kernels read the
  * true count from the geometry workspace), or num_rendered after goi_raster_forward_redo.

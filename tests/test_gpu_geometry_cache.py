@@ -1,0 +1,130 @@
+"""Opt-in geometry cache (goi_raster_forward_reblend): with only the semantic features trainable, a camera that
+was rendered before must render from the cached geometry state with the blend alone -- outputs and dL/dsemantics bit for bit
+what the full forward gives for the current semantics -- and anything the key can see (an in-place update of the positions, a new
+camera, an option switch) must miss."""
+import pytest
+import torch
+
+from goi_hyperplane_amd import _C, _lib, rasterizer
+from goi_hyperplane_amd.render import GaussianSet, PipelineParams, TorchCamera, render
+from goi_hyperplane_amd.scene import make_camera, make_scene
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def cache():
+    rasterizer.set_geometry_cache(4 << 30)
+    base = rasterizer.geometry_cache_stats()
+    yield base
+    rasterizer.set_geometry_cache(0)
+    assert rasterizer.geometry_cache_stats()["entries"] == 0
+
+
+def _model(P=30000, S=16, seed=2):
+    dev = torch.device("cuda", 0)
+    sc = make_scene(P, S=S, sh_degree=3, seed=seed, extent=(2.0, 1.5, 1.0), log_scale_mean=-3.2)
+    pc = GaussianSet.from_scene(sc, dev)
+    for p in pc.parameters():  # the reference's semantic stage: arguments/__init__.py:85-90
+        p.requires_grad_(False)
+    pc._semantics.requires_grad_(True)
+    return dev, pc
+
+
+def _frame(cam, pc, g_sem, g_col):
+    pc._semantics.grad = None
+    out = render(cam, pc, PipelineParams(), torch.zeros(3, device=g_sem.device))
+    ((out["semantics"] * g_sem).sum() + (out["render"] * g_col).sum()).backward()
+    return {k: out[k].detach().clone() for k in ("render", "semantics", "depth", "alpha", "radii")}, pc._semantics.grad.clone()
+
+
+@pytest.mark.parametrize("speculative", [True, False])
+def test_cached_frames_are_bit_identical_and_hit(cache, speculative):
+    dev, pc = _model()
+    W, H = 400, 304
+    cams = [TorchCamera(make_camera(W, H, fovx=1.0, yaw=0.04 * i), dev) for i in range(3)]
+    gen = torch.Generator(device=dev).manual_seed(9)
+    g_sem = torch.randn((16, H, W), device=dev, generator=gen)
+    g_col = torch.randn((3, H, W), device=dev, generator=gen)
+    rasterizer.set_forward_mode(speculative=speculative)
+    try:
+        s0 = rasterizer.geometry_cache_stats()
+        first = [_frame(c, pc, g_sem, g_col) for c in cams]  # misses: fill the cache
+        torch.cuda.synchronize()
+        _C.poll_counts(dev, wait=True)
+        s1 = rasterizer.geometry_cache_stats()
+        assert s1["misses"] - s0["misses"] == 3 and s1["entries"] == 3
+        with torch.no_grad():  # "training": the semantic features move, nothing else does
+            pc._semantics.add_(0.05 * torch.randn(pc._semantics.shape, device=dev, generator=gen))
+        cached = [_frame(c, pc, g_sem, g_col) for c in cams]
+        s2 = rasterizer.geometry_cache_stats()
+        assert s2["hits"] - s1["hits"] == 3, s2
+        assert rasterizer.last_backward_kernel() == "semantics"
+        rasterizer.set_geometry_cache(0)  # the same frames by the full forward
+        full = [_frame(c, pc, g_sem, g_col) for c in cams]
+        for (oc, gc), (of, gf), (o1, _g1) in zip(cached, full, first):
+            for k in oc:
+                assert torch.equal(oc[k], of[k]), k
+            assert torch.equal(gc, gf)
+            assert not torch.equal(oc["semantics"], o1["semantics"])  # the features did change
+    finally:
+        rasterizer.set_forward_mode(speculative=True)
+
+
+def test_what_the_key_sees_misses(cache):
+    dev, pc = _model(P=8000)
+    W, H = 240, 160
+    cam = TorchCamera(make_camera(W, H, fovx=1.0, yaw=0.1), dev)
+    g_sem = torch.ones((16, H, W), device=dev)
+    g_col = torch.ones((3, H, W), device=dev)
+    _frame(cam, pc, g_sem, g_col)
+    _C.poll_counts(dev, wait=True)
+    base = rasterizer.geometry_cache_stats()
+    _frame(cam, pc, g_sem, g_col)
+    assert rasterizer.geometry_cache_stats()["hits"] == base["hits"] + 1
+    with torch.no_grad():
+        pc._xyz.add_(0.01)  # an in-place update bumps the version of the positions
+    want = rasterizer.geometry_cache_stats()["misses"] + 1
+    moved, _ = _frame(cam, pc, g_sem, g_col)
+    assert rasterizer.geometry_cache_stats()["misses"] == want
+    rasterizer.set_geometry_cache(0)
+    ref, _ = _frame(cam, pc, g_sem, g_col)
+    assert torch.equal(moved["render"], ref["render"])  # and the frame is the moved scene's
+    rasterizer.set_geometry_cache(4 << 30)
+    _frame(cam, pc, g_sem, g_col)
+    _C.poll_counts(dev, wait=True)
+    cam2 = TorchCamera(make_camera(W, H, fovx=1.0, yaw=0.1), dev)  # same pose, new tensors: a miss, by design
+    m = rasterizer.geometry_cache_stats()["misses"]
+    _frame(cam2, pc, g_sem, g_col)
+    assert rasterizer.geometry_cache_stats()["misses"] == m + 1
+    try:
+        _lib.set_option("cull_variant", 0)
+        m = rasterizer.geometry_cache_stats()["misses"]
+        _frame(cam, pc, g_sem, g_col)
+        assert rasterizer.geometry_cache_stats()["misses"] == m + 1
+    finally:
+        _lib.set_option("cull_variant", 1)
+
+
+def test_not_eligible_when_geometry_is_trainable_and_bounded_by_bytes(cache):
+    dev, pc = _model(P=8000)
+    W, H = 240, 160
+    cams = [TorchCamera(make_camera(W, H, fovx=1.0, yaw=0.05 * i), dev) for i in range(4)]
+    g_sem = torch.ones((16, H, W), device=dev)
+    g_col = torch.ones((3, H, W), device=dev)
+    pc._opacity.requires_grad_(True)
+    before = rasterizer.geometry_cache_stats()
+    _frame(cams[0], pc, g_sem, g_col)
+    _frame(cams[0], pc, g_sem, g_col)
+    after = rasterizer.geometry_cache_stats()
+    assert after["hits"] == before["hits"] and after["misses"] == before["misses"] and after["entries"] == 0
+    pc._opacity.requires_grad_(False)
+    pc._opacity.grad = None
+    _frame(cams[0], pc, g_sem, g_col)
+    one = rasterizer.geometry_cache_stats()["bytes"]
+    assert one > 0
+    rasterizer.set_geometry_cache(int(2.5 * one))  # room for two cameras
+    for c in cams:
+        _frame(c, pc, g_sem, g_col)
+    st = rasterizer.geometry_cache_stats()
+    assert st["entries"] == 2 and st["bytes"] <= int(2.5 * one) and st["evictions"] >= 2
