@@ -466,9 +466,13 @@ def _ident(t):
     return None if (t is None or not isinstance(t, torch.Tensor) or t.numel() == 0) else (t.data_ptr(), t._version, tuple(t.shape))
 
 
-def _geom_key(dev, P, H, W, means3D, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, degree, campos, prefiltered):
+def _geom_key(dev, P, H, W, means3D, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, degree, campos, prefiltered,
+              colors, cov3D):
+    # (precomputed colours / covariances are the caller's own tensors: their identity is meaningful; the SH coefficients and
+    # the activated scales / rotations / opacities are rebuilt by the reference's model on every call and cannot be keyed)
     return (dev.index, P, H, W, float(scale_modifier), float(tan_fovx), float(tan_fovy), int(degree), bool(prefiltered),
-            _ident(means3D), _ident(viewmatrix), _ident(projmatrix), _ident(campos), tuple(sorted(_lib.OPTIONS.items())))
+            _ident(means3D), _ident(viewmatrix), _ident(projmatrix), _ident(campos), _ident(colors), _ident(cov3D),
+            tuple(sorted(_lib.OPTIONS.items())))
 
 
 def rasterize_gaussians(background, means3D, colors, semantics, opacity, scales, rotations, scale_modifier,
@@ -485,7 +489,7 @@ def rasterize_gaussians(background, means3D, colors, semantics, opacity, scales,
     dev = _check_device(means3D)
     H, W = int(image_height), int(image_width)
     key = _geom_key(dev, P, H, W, means3D, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, degree, campos,
-                    prefiltered)
+                    prefiltered, colors, cov3D_precomp)
     with _GEOM_LOCK:
         e = _GEOM_CACHE["entries"].get(key)
         if e is not None:
