@@ -27,14 +27,19 @@ def test_two_ranks_on_one_gpu(exchange):
     env = dict(os.environ, GOI_BENCH_BACKEND="gloo", GOI_BENCH_SHARE_GPU="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--P", "20000", "--W", "320", "--H", "208", "--no-cpu-baseline", "--no-semantic-finetune", "--no-stage-timing",
-           "--exchange", exchange]
+           "--P", "20000", "--W", "320", "--H", "208", "--no-cpu-baseline", "--no-stage-timing", "--exchange", exchange]
+    if exchange == "factored":
+        cmd.append("--no-semantic-finetune")  # the other parametrisation runs every secondary phase of the default bench
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
     assert d["config"]["exchange"] == exchange
+    if exchange == "allreduce":  # semantics-only phase, with and without the geometry cache, across two ranks
+        sf = d["semantic_finetune"]
+        assert sf["views_per_s"] > 0 and sf["geometry_cache"]["views_per_s"] > 0 and sf["geometry_cache"]["misses"] == 0
+        assert d["value_fp32_flush"] > 0 and d["value_two_views_in_flight"] is None
     if exchange == "factored":
         assert d["config"]["exchange_note"].startswith("verified against the plain all-reduce"), d["config"]["exchange_note"]
         assert d["config"]["allgather_bytes"] == 20000 * 3 * 4 * 2
@@ -55,8 +60,9 @@ def test_single_rank_rccl_path_runs_on_hardware(exchange):
     env = dict(os.environ, GOI_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0",
                WORLD_SIZE="1", LOCAL_RANK="0")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--P", "50000",
-           "--W", "400", "--H", "304", "--no-cpu-baseline", "--no-semantic-finetune", "--no-fp32-flush", "--exchange",
-           exchange]
+           "--W", "400", "--H", "304", "--no-cpu-baseline", "--exchange", exchange]
+    if exchange == "factored":
+        cmd += ["--no-semantic-finetune", "--no-fp32-flush"]  # "allreduce" runs the default bench's secondary phases too
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
