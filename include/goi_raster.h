@@ -45,7 +45,8 @@
 extern "C" {
 #endif
 
-#define GOI_RASTER_ABI_VERSION 2
+/* 3: + goi_raster_forward_reblend, goi_codebook_sim, goi_codebook_fused (additions only; 2: + the asynchronous forward) */
+#define GOI_RASTER_ABI_VERSION 3
 
 typedef struct GoiRasterScene {
     int P;                       /* number of Gaussians */
