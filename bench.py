@@ -536,8 +536,8 @@ def main():
                 o = render(cams[i % len(cams)], pcs[k], pipe, bg)
                 torch.autograd.backward((o["render"], o["semantics"]), (g_color, g_sem))
         torch.cuda.synchronize(dev)
-        for i in range(10):  # each stream's allocator pool and the second parameter set's first frames
-            step2(i)
+        for i in range(24):  # each stream's allocator pool (its own backward scratch: 4 x capacity x 129 bytes, 31 GB at 3 M
+            step2(i)         # Gaussians) must have stopped growing: ten views were not enough at that size
         torch.cuda.synchronize(dev)
         s0 = time.perf_counter()
         n2 = max(10, min(args.steps, 60))

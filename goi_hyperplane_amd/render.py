@@ -176,9 +176,10 @@ def render_views(cameras, pc, pipe, bg_color, loss_fn=None, streams=2, **render_
     """A batch of INDEPENDENT views of one model on `streams` HIP streams of its device: view i runs on stream
     i % streams -- forward and, when `loss_fn(i, out) -> scalar` is given, `loss.backward()` right behind it, so the gradients of
     the batch accumulate in the model's leaves exactly as a loop over the views would leave them.  One view's small, latency-bound
-    kernels and kernel tails overlap with another view's work: +12 % (two streams) to +18 % (four) on the headline scene, +10 %
-    at 6 M Gaussians / 512x512 -- but -38 % at 3 M Gaussians / 1600x1056, where every kernel fills the chip and two views evict
-    each other's tile lists from L2: measure on the scene at hand (bench.py reports `value_two_views_in_flight`).
+    kernels and kernel tails overlap with another view's work: +12 % (two streams) to +18 % (four) on the headline scene, +13 %
+    at 3 M Gaussians, +11 % at 6 M / 512x512 (bench.py reports `value_two_views_in_flight`).  Every stream in flight owns its
+    workspaces -- above all the backward's row scratch, 4 x capacity x 129 bytes (31 GB per stream at 3 M Gaussians) -- and the
+    gain only shows once the streams' allocator pools have stopped growing (a couple of dozen views).
     Returns the list of render() dictionaries (every tensor safe to use on the caller's current stream).
     Not for the reference's own loop (one view, optimizer step, next view: train.py:112-199) -- there the views are not
     independent."""

@@ -16,7 +16,8 @@ from goi_hyperplane_amd.scene import HEADLINE, make_camera, make_scene  # noqa: 
 dev = torch.device("cuda", 0)
 _lib.load()
 W, H, S = HEADLINE["W"], HEADLINE["H"], HEADLINE["S"]
-sc = make_scene(HEADLINE["P"], S=S, sh_degree=3, seed=0, extent=HEADLINE["extent"], log_scale_mean=HEADLINE["log_scale_mean"],
+P_ = int(sys.argv[1]) if len(sys.argv) > 1 else HEADLINE["P"]
+sc = make_scene(P_, S=S, sh_degree=3, seed=0, extent=HEADLINE["extent"], log_scale_mean=HEADLINE["log_scale_mean"],
                 log_scale_std=HEADLINE["log_scale_std"])
 cams = [TorchCamera(make_camera(W, H, fovx=HEADLINE["fovx"], yaw=0.02 * (i - 8), pitch=0.01 * ((i * 7) % 5 - 2)), dev) for i in range(16)]
 bg = torch.zeros(3, device=dev)
@@ -51,6 +52,6 @@ def run(K, steps=60, warmup=6):
     return steps / dt, dt / steps * 1e3, chk
 
 
-for K in (1, 2, 3, 4, 6):
-    v, ms, chk = run(K)
+for K in ((1, 2, 3, 4, 6) if len(sys.argv) <= 2 else tuple(int(x) for x in sys.argv[2].split(","))):
+    v, ms, chk = run(K, warmup=int(sys.argv[3]) if len(sys.argv) > 3 else 6)
     print("streams %d: %.1f views/s  (%.3f ms per view)   grad checksum of stream 0's last view %.6e" % (K, v, ms, chk))
