@@ -136,6 +136,7 @@ def main():
                     help="forward mode (default: the package default, speculative = no host round trip)")
     ap.add_argument("--no-fp32-flush", action="store_true", help="skip the secondary exact-fp32-flush figure")
     ap.add_argument("--no-two-streams", action="store_true", help="skip the secondary two-views-in-flight figure")
+    ap.add_argument("--no-train-iteration", action="store_true", help="skip the secondary semantic-stage iteration figure")
     ap.add_argument("--no-overlap", action="store_true",
                     help="--gpus > 1: wait for each step's gradient exchange inside the step instead of letting it run "
                          "behind the next step's render + backward")
@@ -518,6 +519,45 @@ def main():
                       "what": "bwd_variant 2: per-Gaussian sums of the backward on v_mfma_f32_16x16x4_f32 (exact fp32 "
                               "products) instead of split-bf16 operands"}
 
+    # Secondary figure: one iteration of the reference's semantic stage (train.py:112-199) with this build's pieces at the
+    # workload's size: render -> code-book losses (goi_codebook_fused) -> backward -> three fused Adam steps; only the semantic
+    # features, the decoder and the code book train (the reference's default).  tools/train_iter_bench.py also times the
+    # PyTorch pieces around the same rasterizer.
+    train_iter = None
+    if world == 1 and not args.no_train_iteration and sc is not None and args.S <= 16:
+        from goi_hyperplane_amd.optim import FusedAdam
+        from goi_hyperplane_amd.semantic import SemanticModel, fused_codebook_losses
+        tpc = GaussianSet.from_scene(sc, dev)
+        for p_ in tpc.parameters():
+            p_.requires_grad_(False)
+        tpc._semantics.requires_grad_(True)
+        mlp = SemanticModel(dim_in=args.S, dim_out=300, num_layer=1, use_bias=True, device=dev)
+        lut = torch.nn.Parameter(torch.rand(300, 256, device=dev) * 0.03)
+        gtl = torch.randn(256, args.H, args.W, device=dev)
+        opts = [FusedAdam([{"params": [tpc._semantics], "lr": 5e-3, "name": "semantics"}], lr=0.0, eps=1e-15),
+                FusedAdam(mlp.parameters(), lr=0.003), FusedAdam([lut], lr=0.001)]
+
+        def train_it(i):
+            o = render(cams[i % len(cams)], tpc, pipe, bg)
+            loss, _terms = fused_codebook_losses(o["semantics"], mlp, lut, gtl, 10 + i)
+            loss.backward()
+            for o_ in opts:
+                o_.step()
+                o_.zero_grad(set_to_none=True)
+        for i in range(4):
+            train_it(i)
+        torch.cuda.synchronize(dev)
+        t0_ = time.perf_counter()
+        nti = 12
+        for i in range(nti):
+            train_it(i)
+        torch.cuda.synchronize(dev)
+        train_iter = {"ms_per_iteration": (time.perf_counter() - t0_) / nti * 1e3, "iterations": nti,
+                      "what": "render -> fused code-book losses (300 codes, 256-d ground truth) -> backward -> 3 fused Adam "
+                              "steps; semantic features, decoder and code book trainable (train.py:112-199)"}
+        del tpc, mlp, lut, gtl, opts
+        torch.cuda.empty_cache()
+
     # Secondary figure: TWO independent views in flight on two HIP streams of this GPU (a micro-batch of views whose
     # gradients are accumulated, as in a multi-view batch).  Every view does the same forward + backward as in the timed
     # region; what overlaps is one view's latency-bound small kernels (sorts, scans) and kernel tails with the other
@@ -610,6 +650,7 @@ def main():
             "step_enqueue_ms": step_enqueue_ms,  # host-side, informational (stall detector; not used for value)
             "semantic_finetune": sem_only,
             "value_fp32_flush": None if fp32_flush is None else fp32_flush["views_per_s"],
+            "semantic_train_iteration": train_iter,
             "value_two_views_in_flight": None if two_streams is None else two_streams["views_per_s"],
             "two_views_in_flight": two_streams,
             "fp32_flush": fp32_flush,

@@ -13,7 +13,7 @@ for set in \
   "WRITE_SIZE TCC_ATOMIC_sum" \
   "TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE" ; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/p$i -o p$i -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-stage-timing --no-fp32-flush --no-two-streams "$@" > $OUT/p$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/p$i -o p$i -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-stage-timing --no-fp32-flush --no-two-streams --no-train-iteration "$@" > $OUT/p$i.log 2>&1
   rm -f $OUT/p$i/*kernel_trace.csv $OUT/p$i/*.db
 done
 python $GRAFT_REPO_ROOT/tools/pmc_summary.py $OUT > $OUT/summary.txt 2>&1
