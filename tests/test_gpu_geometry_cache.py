@@ -128,3 +128,39 @@ def test_not_eligible_when_geometry_is_trainable_and_bounded_by_bytes(cache):
         _frame(c, pc, g_sem, g_col)
     st = rasterizer.geometry_cache_stats()
     assert st["entries"] == 2 and st["bytes"] <= int(2.5 * one) and st["evictions"] >= 2
+
+
+def test_hits_from_other_streams_than_the_one_that_filled_the_cache(cache):
+    """render_views puts view i on stream i % streams: with three cameras on two streams, the second pass renders camera 1 on the
+    stream that rendered it before but cameras 0 and 2 swap streams relative to a one-stream fill -- a hit must wait for the
+    stream that filled the workspaces."""
+    from goi_hyperplane_amd.render import render_views
+    dev, pc = _model(P=20000)
+    W, H = 320, 208
+    cams = [TorchCamera(make_camera(W, H, fovx=1.0, yaw=0.05 * i), dev) for i in range(3)]
+    bg = torch.zeros(3, device=dev)
+    gen = torch.Generator(device=dev).manual_seed(3)
+    g_sem = torch.randn((16, H, W), device=dev, generator=gen)
+    loss = lambda i, o: (o["semantics"] * g_sem).sum()  # noqa: E731
+    for c in cams:  # fill on the caller's stream
+        render(c, pc, PipelineParams(), bg)
+    _C.poll_counts(dev, wait=True)
+    with torch.no_grad():
+        pc._semantics.mul_(1.01)
+    h0 = rasterizer.geometry_cache_stats()["hits"]
+    pc._semantics.grad = None
+    outs = render_views(cams, pc, PipelineParams(), bg, loss_fn=loss, streams=2)
+    torch.cuda.synchronize()
+    assert rasterizer.geometry_cache_stats()["hits"] == h0 + 3
+    g_cached = pc._semantics.grad.clone()
+    rasterizer.set_geometry_cache(0)
+    pc._semantics.grad = None
+    ref = []
+    for i, c in enumerate(cams):
+        o = render(c, pc, PipelineParams(), bg)
+        loss(i, o).backward()
+        ref.append(o["semantics"].detach().clone())
+    for r, o in zip(ref, outs):
+        assert torch.equal(r, o["semantics"].detach())
+    scale = float(pc._semantics.grad.abs().max())
+    assert float((pc._semantics.grad - g_cached).abs().max()) <= 2e-6 * scale  # three views: the order of the additions may differ
