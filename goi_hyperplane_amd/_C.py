@@ -40,8 +40,11 @@ def _ext():
             spec = importlib.util.spec_from_file_location("_goi_C", path)
             mod = importlib.util.module_from_spec(spec)
             spec.loader.exec_module(mod)
-            if mod.abi_version() != _lib.ABI_VERSION:
-                raise ImportError(f"{path}: built against ABI {mod.abi_version()}, expected {_lib.ABI_VERSION}; rebuild")
+            # abi_version(): the header the binding was COMPILED against; library_abi_version(): what the library it is
+            # linked with reports -- a stale _goi_C.so next to a newer libgoi_raster.so fails the first test
+            if mod.abi_version() != _lib.ABI_VERSION or mod.library_abi_version() != _lib.ABI_VERSION:
+                raise ImportError(f"{path}: built against ABI {mod.abi_version()} (library: {mod.library_abi_version()}), "
+                                  f"expected {_lib.ABI_VERSION}; rebuild (python -m goi_hyperplane_amd.build)")
             _EXT["mod"] = mod
     return _EXT["mod"]
 
@@ -160,9 +163,12 @@ def release_scratch(device=None) -> int:
 #   * a frame whose count fits its capacity is bit-identical to the exact path's (outputs, lists, gradients);
 #   * OVERFLOW (count > capacity): the frame was rendered from a truncated instance list.  Whoever reads the count
 #     (int(num_rendered), .resolve()) BEFORE consuming the outputs gets the frame redone in place -- bit-identical to the
-#     exact path.  If nobody asks, the overflow is found by the poll at a later forward: the frame cannot be repaired
-#     any more (its consumers are already enqueued), a RasterOverflowWarning is issued (GOI_OVERFLOW=raise: a
-#     RasterOverflowError), and the capacity is raised.  Its backward stays consistent with what was rendered.
+#     exact path.  If nobody asks, the DEVICE still knows: emit sets the frame's "truncated" word and every backward
+#     kernel of such a frame writes ZERO gradients (csrc/common.h COUNTER_OVF), so the view trains nothing -- a skipped
+#     view, not a wrong one -- and FusedAdam.step(skip_if=truncated_flag()) leaves parameters and moments untouched.
+#     The host finds out at a later poll: a RasterOverflowWarning (GOI_OVERFLOW=raise: a RasterOverflowError) names
+#     the skipped view and the capacity is raised.
+#   * the first `min_history` frames of a scene on a device are exact (they teach the capacity policy);
 #   * at most `max_ahead` frames stay unresolved per device; the oldest is waited for beyond that (flow control: the
 #     host may run that far ahead of the GPU, which is what absorbs a host stall).  A pending frame pins no device
 #     memory: the LazyCount refers to the frame's tensors weakly (a frame whose outputs have died has no consumer
@@ -198,16 +204,18 @@ _CALL = threading.local()
 _FWD = {"mode": _env_forward_mode(), "inference": _env_inference_mode(),
         "headroom": float(os.environ.get("GOI_BINNING_HEADROOM", "2.0")),
         "capacity": None, "on_overflow": os.environ.get("GOI_OVERFLOW", "warn").strip().lower(),
-        "max_ahead": int(os.environ.get("GOI_MAX_AHEAD", "64"))}
+        "max_ahead": int(os.environ.get("GOI_MAX_AHEAD", "64")),
+        "min_history": int(os.environ.get("GOI_SPECULATE_AFTER", "3"))}
 _SPEC = {}  # device index -> {"high_water": int, "P": int, "pending": deque of LazyCount}
 _SPEC_LOCK = threading.RLock()
-SPECULATION_STATS = {"exact_frames": 0, "speculative_frames": 0, "overflows": 0, "redone": 0, "waits": 0, "cached_frames": 0}
+SPECULATION_STATS = {"exact_frames": 0, "speculative_frames": 0, "overflows": 0, "redone": 0, "waits": 0, "cached_frames": 0,
+                     "skipped_views": 0}
 _MIN_CAPACITY = 1 << 16
 _KEEP_WORKSPACES = 2  # pending frames per device whose workspaces stay alive for a possible redo
 
 
 def set_forward_mode(speculative=None, headroom=None, capacity="keep", on_overflow=None, max_ahead=None,
-                     inference_speculative=None):
+                     inference_speculative=None, min_history=None):
     """speculative: True / False (exact, the reference's synchronous forward) for frames a backward may follow.
     inference_speculative: the same for frames rendered without autograd (default False: exact).  headroom: capacity = headroom x the
     largest num_rendered seen on the device.  capacity: an int forces that capacity for every frame (tests), None returns
@@ -229,12 +237,14 @@ def set_forward_mode(speculative=None, headroom=None, capacity="keep", on_overfl
         _FWD["on_overflow"] = on_overflow
     if max_ahead is not None:
         _FWD["max_ahead"] = max(1, int(max_ahead))
+    if min_history is not None:  # counts seen on a device (for the current scene) before frames are speculative
+        _FWD["min_history"] = max(1, int(min_history))
 
 
 def _spec_state(dev):
     st = _SPEC.get(dev.index)
     if st is None:
-        st = _SPEC[dev.index] = {"high_water": 0, "P": 0, "pending": collections.deque()}
+        st = _SPEC[dev.index] = {"high_water": 0, "P": 0, "seen": 0, "pending": collections.deque()}
     return st
 
 
@@ -242,8 +252,10 @@ def _note_count(dev, P, n):
     st = _spec_state(dev)
     if P > 2 * st["P"] or 2 * P < st["P"]:  # another scene: forget what the previous one needed
         st["high_water"] = 0
+        st["seen"] = 0
     st["P"] = P
     st["high_water"] = max(st["high_water"], int(n))
+    st["seen"] = st.get("seen", 0) + 1
 
 
 def _pick_capacity(dev, P, debug, prefiltered):
@@ -257,8 +269,8 @@ def _pick_capacity(dev, P, debug, prefiltered):
     if _FWD["capacity"] is not None:
         return _FWD["capacity"]
     st = _spec_state(dev)
-    if st["high_water"] <= 0 or P > 2 * st["P"] or 2 * P < st["P"]:
-        return None  # nothing to go by yet: this frame is exact and teaches the policy
+    if st["high_water"] <= 0 or P > 2 * st["P"] or 2 * P < st["P"] or st.get("seen", 0) < _FWD["min_history"]:
+        return None  # nothing (or too little) to go by yet: this frame is exact and teaches the policy
     return max(_MIN_CAPACITY, int(_FWD["headroom"] * st["high_water"]) + 4096)
 
 
@@ -334,12 +346,15 @@ class LazyCount:
             self.overflowed = True
             SPECULATION_STATS["overflows"] += 1
             if lazy:
-                # found after the fact: whatever consumed the outputs is already enqueued, nothing to repair
+                # found after the fact: whatever consumed the outputs is already enqueued.  Nothing was trained on the
+                # truncated frame: its backward wrote zero gradients on the device (COUNTER_OVF) -- a skipped view.
                 self._redo = self._hold = None
+                SPECULATION_STATS["skipped_views"] += 1
                 msg = (f"goi_hyperplane_amd: a speculative forward overflowed its binning capacity (num_rendered = "
-                       f"{self._n} > {self.capacity}); that frame was rendered from a truncated instance list and "
-                       f"nobody read num_rendered before using it. The capacity has been raised; use "
-                       f"GOI_BINNING_HEADROOM / set_forward_mode(headroom=...) or GOI_FORWARD=exact to avoid this.")
+                       f"{self._n} > {self.capacity}) and nobody read num_rendered before using the frame: its image "
+                       f"was that of a truncated instance list and its backward produced ZERO gradients (the view was "
+                       f"skipped, nothing was trained on it). The capacity has been raised; use GOI_BINNING_HEADROOM / "
+                       f"set_forward_mode(headroom=...) or GOI_FORWARD=exact to avoid skipped views.")
                 if _FWD["on_overflow"] == "raise":
                     raise RasterOverflowError(msg)
                 warnings.warn(msg, RasterOverflowWarning, stacklevel=3)
@@ -408,6 +423,27 @@ class LazyCount:
     __format__ = lambda self, spec: format(self.resolve(), spec)
 
 
+def _note_frame(geom, P):
+    """Remembers the geometry workspace of this thread's most recent frame (truncated_flag)."""
+    _CALL.last_frame = (geom, int(P))
+
+
+def truncated_flag():
+    """int32[1] device tensor: the "truncated" word of this thread's most recent forward (a view into its geometry
+    workspace), non-zero iff that frame's instance list did not fit the capacity of a speculative forward -- in which case
+    its backward writes zero gradients on the device.  FusedAdam.step(skip_if=truncated_flag()) then leaves parameters and
+    moments untouched for that view: nothing on the host ever waits.  None if there was no frame (or P == 0)."""
+    last = getattr(_CALL, "last_frame", None)
+    if last is None or last[1] <= 0 or last[0] is None or last[0].numel() == 0:
+        return None
+    geom, P = last
+    ptr = _lib.load().goi_raster_truncated_flag(C.c_void_p(geom.data_ptr()), P)
+    if not ptr:
+        return None
+    off = int(ptr) - int(geom.data_ptr())
+    return geom[off:off + 4].view(torch.int32)
+
+
 def _layout_of(R):
     """(instances the binning buffer of this frame was laid out for, that buffer or None) for the R a caller hands to
     the backward: a plain int (exact frame) or the LazyCount of a speculative one -- which is NOT resolved here."""
@@ -435,7 +471,8 @@ def _scene(P, S, H, W, bg, means3D, sh, colors, semantics, opacity, scales, rota
 # sitting in that frame's workspaces.  With the cache on, such a frame runs goi_raster_forward_reblend alone.  It is OPT-IN
 # because the premise cannot be verified here: the activated tensors the rasterizer is handed (exp(scaling), sigmoid(opacity),
 # ...) are new objects on every call.  A frame is eligible only if no geometry input requires a gradient; the key holds the
-# camera tensors' and the positions' identity and version (an optimizer step, a densification or a new camera object miss).
+# camera tensors' and the positions' identity and version (an optimizer step, a densification or a new camera object miss),
+# and the entry keeps those tensors alive so that their addresses cannot be recycled under the key.
 _GEOM_CACHE = {"max_bytes": int(float(os.environ.get("GOI_GEOMETRY_CACHE_GB", "0")) * (1 << 30)), "bytes": 0,
                "entries": collections.OrderedDict(), "hits": 0, "misses": 0, "evictions": 0}
 _GEOM_LOCK = threading.RLock()
@@ -494,16 +531,27 @@ def rasterize_gaussians(background, means3D, colors, semantics, opacity, scales,
         e = _GEOM_CACHE["entries"].get(key)
         if e is not None:
             R = e["R"]
+            drop = False
             if isinstance(R, LazyCount):
                 if not R.resolved:
                     R._resolve(wait=False, lazy=True)
                 usable = R.resolved and R._error is None
+                if usable and R.overflowed and not R.redone:
+                    # the cached frame was TRUNCATED and never repaired (the overflow was only found lazily): its binning
+                    # workspace holds a cut-off tile list.  Never reblend over it: drop the entry and render the frame again
+                    # (the capacity policy has been raised by the resolve above)
+                    usable, drop = False, True
+                elif R.resolved and R._error is not None:
+                    drop = True
             else:
                 usable = True
             if usable:
                 _GEOM_CACHE["entries"].move_to_end(key)
                 _GEOM_CACHE["hits"] += 1
             else:
+                if drop:
+                    _GEOM_CACHE["bytes"] -= e["bytes"]
+                    del _GEOM_CACHE["entries"][key]
                 e = None
     if e is not None:
         return _reblend(e, background, semantics, P, H, W, dev)
@@ -511,13 +559,19 @@ def rasterize_gaussians(background, means3D, colors, semantics, opacity, scales,
     R, _c, _s, _d, _a, radii, geom, binning, img = res
     with _GEOM_LOCK:
         _GEOM_CACHE["misses"] += 1
-        nbytes = geom.numel() + img.numel() + radii.numel() * 4 + (binning.numel() if isinstance(binning, torch.Tensor) else 0)
+        # The key identifies tensors by (address, version, shape): that is only sound while the tensors are ALIVE -- a freed
+        # camera matrix or `xyz[mask]` temporary hands its address (version 0 again) to the next frame's tensors.  The entry
+        # therefore holds strong references to every keyed tensor for as long as it lives (and accounts for their bytes).
+        keyed = tuple(t for t in (means3D, viewmatrix, projmatrix, campos, colors, cov3D_precomp)
+                      if isinstance(t, torch.Tensor) and t.numel() > 0)
+        nbytes = (geom.numel() + img.numel() + radii.numel() * 4 + (binning.numel() if isinstance(binning, torch.Tensor) else 0)
+                  + sum(t.numel() * t.element_size() for t in keyed))
         old = _GEOM_CACHE["entries"].pop(key, None)
         if old is not None:
             _GEOM_CACHE["bytes"] -= old["bytes"]
         if nbytes <= _GEOM_CACHE["max_bytes"]:
             _GEOM_CACHE["entries"][key] = dict(R=R, radii=radii, geom=geom, binning=binning, img=img, bytes=nbytes,
-                                               stream=torch.cuda.current_stream(dev))
+                                               stream=torch.cuda.current_stream(dev), keyed=keyed)
             _GEOM_CACHE["bytes"] += nbytes
             _geom_evict()
     return res
@@ -547,6 +601,7 @@ def _reblend(e, background, semantics, P, H, W, dev):
                                            _ptr(out_color), _ptr(out_sem), _ptr(out_depth), _ptr(out_alpha), _stream(dev))
     if r < 0:
         raise RuntimeError(_lib.last_error())
+    _note_frame(e["geom"], P)
     SPECULATION_STATS["cached_frames"] += 1
     return R, out_color, out_sem, out_depth, out_alpha, e["radii"], e["geom"], binning, img
 
@@ -577,11 +632,13 @@ def _rasterize_gaussians_frame(background, means3D, colors, semantics, opacity, 
         cap = _pick_capacity(dev, P, debug, prefiltered)
         if cap is None:
             res = ext.rasterize_gaussians(*args)
+            _note_frame(res[6], P)
             if P > 0:
                 SPECULATION_STATS["exact_frames"] += 1
                 _note_count(dev, P, res[0])
             return res
         ticket, out_color, out_sem, out_depth, out_alpha, radii, geom, binning, img = ext.rasterize_gaussians_async(*args, cap)
+        _note_frame(geom, P)
         SPECULATION_STATS["speculative_frames"] += 1
         refs = [weakref.ref(t) for t in (geom, img, radii, out_color, out_sem, out_depth, out_alpha)]
 
@@ -607,6 +664,7 @@ def _rasterize_gaussians_frame(background, means3D, colors, semantics, opacity, 
                    projmatrix=_prep(projmatrix, "projmatrix", dev), campos=_prep(campos, "campos", dev))
         geom = torch.empty(lib.goi_raster_geom_bytes(P) if P > 0 else 0, dtype=torch.uint8, device=dev)
         img = torch.empty(lib.goi_raster_image_bytes(W, H) if P > 0 else 0, dtype=torch.uint8, device=dev)
+        _note_frame(geom, P)
         sc = _scene(P, S, H, W, ten["bg"], ten["means3D"], ten["sh"], ten["colors"], ten["semantics"], ten["opacity"],
                     ten["scales"], ten["rotations"], scale_modifier, ten["cov3D"], ten["viewmatrix"],
                     ten["projmatrix"], tan_fovx, tan_fovy, degree, ten["campos"], prefiltered, debug)

@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libgoi_raster.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 STAGES = ("preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges", "blend_fwd", "blend_bwd",
           "preprocess_bwd")
@@ -65,6 +65,9 @@ SYMBOLS = {
     "goi_codebook_fused_partial_rows": (C.c_int, []),
     "goi_codebook_fused": (C.c_int, [C.c_void_p] * 5 + [C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_float] + [C.c_void_p] * 5),
     "goi_adam_step": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
+    "goi_adam_step_guarded": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p,
+                                        C.c_void_p]),
+    "goi_raster_truncated_flag": (C.c_void_p, [C.c_void_p, C.c_int]),
     "goi_knn_workspace_bytes": (C.c_size_t, [C.c_int]),
     "goi_knn_dist2": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "goi_raster_sh_grad_from_views": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -39,7 +39,12 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
     p = p + step_size_neg * (m / den);
 }
 
-__global__ __launch_bounds__(ADAM_THREADS) void adam_step_k(const AdamTable t, const uint8_t* __restrict__ nograd_mask) {
+// skip_flag (device word, may be NULL): a non-zero value makes the whole launch a no-op -- parameters and moments stay
+// as they are.  The rasterizer sets such a word for a view whose speculative forward was truncated (goi_raster_truncated_flag):
+// that view is skipped on the device, with no host round trip.
+__global__ __launch_bounds__(ADAM_THREADS) void adam_step_k(const AdamTable t, const uint8_t* __restrict__ nograd_mask,
+                                                            const uint32_t* __restrict__ skip_flag) {
+    if (skip_flag && *skip_flag) return;
     int gi = 0;
 #pragma unroll
     for (int i = 0; i < GOI_ADAM_MAX_GROUPS - 1; i++)
@@ -82,7 +87,7 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_step_k(const AdamTable t, c
 }  // namespace
 
 int launch_adam_step(const GoiAdamGroup* groups, int n_groups, double beta1, double beta2, double eps,
-                     const uint8_t* nograd_mask, hipStream_t s) {
+                     const uint8_t* nograd_mask, const uint32_t* skip_flag, hipStream_t s) {
     AdamTable t;
     unsigned int blocks = 0;
     t.n = 0;
@@ -103,7 +108,7 @@ int launch_adam_step(const GoiAdamGroup* groups, int n_groups, double beta1, dou
     t.beta2 = (float)beta2;
     t.one_minus_beta2 = (float)(1.0 - beta2);
     t.eps = (float)eps;
-    adam_step_k<<<dim3(blocks), dim3(ADAM_THREADS), 0, s>>>(t, nograd_mask);
+    adam_step_k<<<dim3(blocks), dim3(ADAM_THREADS), 0, s>>>(t, nograd_mask, skip_flag);
     return 0;
 }
 

@@ -750,6 +750,18 @@ int goi_raster_sh_grad_from_views(int P, int D, int M, int V, const float* means
 
 int goi_adam_step(const GoiAdamGroup* groups, int n_groups, double beta1, double beta2, double eps,
                   const unsigned char* nograd_mask, void* stream) {
+    return goi_adam_step_guarded(groups, n_groups, beta1, beta2, eps, nograd_mask, nullptr, stream);
+}
+
+const uint32_t* goi_raster_truncated_flag(const void* geom_buffer, int P) {
+    if (!geom_buffer || P <= 0) return nullptr;
+    GeomView g;
+    geom_layout(P, const_cast<char*>(static_cast<const char*>(geom_buffer)), &g);
+    return g.counters + COUNTER_OVF;
+}
+
+int goi_adam_step_guarded(const GoiAdamGroup* groups, int n_groups, double beta1, double beta2, double eps,
+                          const unsigned char* nograd_mask, const uint32_t* skip_flag, void* stream) {
     if (n_groups < 0 || n_groups > GOI_ADAM_MAX_GROUPS) return fail("goi_adam_step: n_groups must be 0..8");
     if (n_groups && !groups) return fail("goi_adam_step: groups is NULL");
     for (int i = 0; i < n_groups; i++) {
@@ -761,7 +773,7 @@ int goi_adam_step(const GoiAdamGroup* groups, int n_groups, double beta1, double
              reinterpret_cast<uintptr_t>(g.exp_avg) | reinterpret_cast<uintptr_t>(g.exp_avg_sq)) & 15)
             return fail("goi_adam_step: tensors must be 16-byte aligned");
     }
-    launch_adam_step(groups, n_groups, beta1, beta2, eps, nograd_mask, static_cast<hipStream_t>(stream));
+    launch_adam_step(groups, n_groups, beta1, beta2, eps, nograd_mask, skip_flag, static_cast<hipStream_t>(stream));
     GOI_HIP(hipGetLastError());
     return 0;
 }

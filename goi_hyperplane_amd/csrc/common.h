@@ -151,7 +151,7 @@ int launch_codebook_fused(const float* g, const float* l1, const float* sem, con
                           hipStream_t s);
 int launch_codebook_dlut(const float* dsim, const float* g, long long HW, int C, int D, float* partial, hipStream_t s);
 int launch_adam_step(const GoiAdamGroup* groups, int n_groups, double beta1, double beta2, double eps,
-                     const uint8_t* nograd_mask, hipStream_t s);
+                     const uint8_t* nograd_mask, const uint32_t* skip_flag, hipStream_t s);
 size_t knn_workspace_bytes(int P);
 int launch_knn(int P, const float* points, float* mean_dist2, void* workspace, hipStream_t s);
 void launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
@@ -198,6 +198,10 @@ constexpr int COUNTER_WORDS = NR_BASE + NR_STRIPES * NR_STRIDE;
 constexpr int COUNTER_CULL = 2;  // GeomView::counters[COUNTER_CULL]: the forward's cull_variant, read by emit / backward
 constexpr int COUNTER_N = 3;     // num_rendered as ONE device word (the scan's total): what the tile sort, the ranges pass and
                                  // the backward's row reduction read when the host sized the frame from a capacity
+constexpr int COUNTER_OVF = 4;   // 1: this frame's instance list was TRUNCATED (num_rendered > the binning capacity of a
+                                 // speculative forward).  Written by emit; every backward kernel reads it and, if set, produces
+                                 // ZERO gradients: a truncated frame must never reach the optimiser (the reference sizes its
+                                 // buffers from the true count, CR/rasterizer_impl.cu:283-289, and cannot truncate)
 
 // The depth sort runs ceil(32/8) = 4 ping-pong passes from buffer 0, so its result is in buffer 0.
 inline int depth_sort_result_index() { return ((32 + 7) / 8) & 1; }

@@ -250,6 +250,7 @@ struct BwdArgs {
 // dL_dcolor instead: dL/dSH[k] = basis_k(view direction) * g is then formed elsewhere (goi_raster_sh_grad_from_views).
 template <bool WITH_DSH>
 __global__ __launch_bounds__(256) void preprocess_bwd_k(const BwdArgs args, const int* __restrict__ radii,
+                                                        const uint32_t* __restrict__ counters,
                                                         const uint8_t* __restrict__ clamped,
                                                         const float* __restrict__ dL_dmean2D,
                                                         const float* __restrict__ dL_dconic,
@@ -277,7 +278,8 @@ __global__ __launch_bounds__(256) void preprocess_bwd_k(const BwdArgs args, cons
     float gcov[6] = {0, 0, 0, 0, 0, 0};
     V3 gscale = {0, 0, 0};
     float4 grot = make_float4(0, 0, 0, 0);
-    const bool visible = radii[idx] > 0;
+    // (a truncated frame -- COUNTER_OVF -- is treated as if nothing were visible: all gradients zero)
+    const bool visible = radii[idx] > 0 && counters[COUNTER_OVF] == 0;
     V3* dsh = WITH_DSH ? reinterpret_cast<V3*>(s_dsh + (size_t)threadIdx.x * (3 * a.M + 1)) : nullptr;
     auto put = [&](int k, const V3& v) {
         if constexpr (WITH_DSH) dsh[k] = v;
@@ -610,7 +612,8 @@ __global__ __launch_bounds__(256) void reduce_rows_k(int P, int S, int nch, uint
     // N_cap: the slot capacity the scratch was laid out for; n_dev: the forward's instance count on the device (the
     // exact forward passes N_cap = num_rendered; the speculative one a capacity, and an overflowed frame stored only
     // the first N_cap instances)
-    const uint32_t N = min(N_cap, *n_dev);
+    // a TRUNCATED frame (COUNTER_OVF, set by emit) has no valid rows: every Gaussian gets zeros
+    const uint32_t N = n_dev[COUNTER_OVF - COUNTER_N] ? 0u : min(N_cap, *n_dev);
     const int lane = threadIdx.x & 63, quarter = lane >> 4, e = lane & 15;
     const uint32_t* flags32 = reinterpret_cast<const uint32_t*>(flags);
     const int nsem = nch - 4;
@@ -740,12 +743,14 @@ __global__ __launch_bounds__(256) void emit_k(int P, int gx, int gy, const Gauss
                                               const int* __restrict__ radii, const uint32_t* __restrict__ order,
                                               const uint32_t* __restrict__ offsets, uint32_t* __restrict__ goff,
                                               uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                              uint32_t* __restrict__ tile_count, const uint32_t* __restrict__ counters,
+                                              uint32_t* __restrict__ tile_count, uint32_t* __restrict__ counters,
                                               uint32_t* __restrict__ clear, uint32_t clear_words, uint32_t cap) {
     // cap: number of instances keys[] / vals[] can hold.  The exact forward sizes them for num_rendered, so the
     // guard below never fires; the speculative forward sizes them from a guess, and a frame that overflows must
     // stay memory-safe and self-consistent (the tile counts only count what was stored) until the host notices.
     const bool cull = counters[COUNTER_CULL] != 0;
+    // the frame's "truncated" flag (COUNTER_OVF): emit is the first kernel that knows both the count and the capacity
+    if (blockIdx.x == 0 && threadIdx.x == 0) counters[COUNTER_OVF] = counters[COUNTER_N] > cap ? 1u : 0u;
     // COUNT: the blocks also zero the control words of the tile sort that follows (its own memset launch otherwise)
     if (COUNT)
         for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < clear_words; i += gridDim.x * 256u) clear[i] = 0u;
@@ -926,10 +931,10 @@ void launch_preprocess_bwd(const GoiRasterScene& sc, const GeomView& g, const in
     const size_t lds = with_sh ? (size_t)256 * (3 * sc.M + 1) * sizeof(float) : 0;  // 50 KB at M = 16
     if (with_sh)
         preprocess_bwd_k<true><<<dim3((sc.P + 255) / 256), dim3(256), lds, s>>>(
-            a, radii, g.clamped, dL_dmean2D, dL_dconic, dL_dcolor, dL_ddepth, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+            a, radii, g.counters, g.clamped, dL_dmean2D, dL_dconic, dL_dcolor, dL_ddepth, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
     else
         preprocess_bwd_k<false><<<dim3((sc.P + 255) / 256), dim3(256), 0, s>>>(
-            a, radii, g.clamped, dL_dmean2D, dL_dconic, dL_dcolor, dL_ddepth, dL_dmean3D, dL_dcov3D, nullptr, dL_dscale, dL_drot);
+            a, radii, g.counters, g.clamped, dL_dmean2D, dL_dconic, dL_dcolor, dL_ddepth, dL_dmean3D, dL_dcov3D, nullptr, dL_dscale, dL_drot);
 }
 
 void launch_sh_grad_from_views(int P, int D, int M, int V, const float* means3D, const float* campos, const float* gcol,

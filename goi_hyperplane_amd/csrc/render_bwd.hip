@@ -110,6 +110,7 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
     const int exp_flags = EXP ? exp_flags_rt : 0;
     const QuadGeom t = quad_geom(W, H, gx, n_quads);
     if (t.tile < 0) return;
+    if (counters[COUNTER_OVF]) return;  // truncated frame: no rows (reduce_rows_k writes zero gradients)
     const int lane = t.lane;
     const uint2 range = ranges[t.tile];
     const size_t HW = (size_t)W * H;

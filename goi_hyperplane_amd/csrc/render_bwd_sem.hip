@@ -46,6 +46,7 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
 
     const QuadGeom t = quad_geom(W, H, gx, n_quads);
     if (t.tile < 0) return;
+    if (counters[COUNTER_OVF]) return;  // truncated frame: no rows (the row reduction writes zero gradients)
     const int lane = t.lane;
     const uint2 range = ranges[t.tile];
     const float QCX = t.QX0 + 3.5f, QCY = t.QY0 + 3.5f;  // quadrant centre

@@ -49,7 +49,9 @@ __global__ __launch_bounds__(256) void render_bwd_tile_k(
     const float* __restrict__ out_alpha, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
     const float* __restrict__ dL_dpixsem, const float* __restrict__ dL_dpixdepth, const float* __restrict__ dL_dalphas,
     float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
-    float* __restrict__ dL_dcolor, float* __restrict__ dL_dsemantic, float* __restrict__ dL_ddepths) {
+    float* __restrict__ dL_dcolor, float* __restrict__ dL_dsemantic, float* __restrict__ dL_ddepths,
+    const uint32_t* __restrict__ counters) {
+    if (counters[COUNTER_OVF]) return;  // truncated frame: the accumulators stay at the zeros they were cleared to
     using Cfg = BwdTileCfg<S4>;
     constexpr int NF4 = Cfg::NF4, NCH = Cfg::NCH, NB = Cfg::NB, NQ = Cfg::NQ;
     __shared__ float4 s_geo[BATCH];            // x, y, conic a, b
@@ -331,7 +333,7 @@ void launch_bwd_tile_s4(const GoiRasterScene& sc, const GeomView& g, const Image
     render_bwd_tile_k<S4><<<dim3(gx * gy), dim3(256), 0, s>>>(im.ranges, point_list, sc.W, sc.H, gx, sc.S, g.rec, sc.semantics,
                                                        sc.bg, out_alpha, im.n_contrib, dL_dpix, dL_dsem, dL_ddepth,
                                                        dL_dalpha, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor,
-                                                       dL_dsemantic, dL_ddepths);
+                                                       dL_dsemantic, dL_ddepths, g.counters);
 }
 
 }  // namespace

@@ -380,5 +380,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("backward_ex", &backward_ex);
     m.def("backward_semantics", &backward_semantics);
     m.def("release_scratch", &release_scratch);
-    m.def("abi_version", []() { return goi_raster_abi_version(); });
+    // the header this binding was COMPILED against (a stale _goi_C.so next to a newer library must be detectable) ...
+    m.def("abi_version", []() { return (int)GOI_RASTER_ABI_VERSION; });
+    // ... and what the library it is linked with reports at run time
+    m.def("library_abi_version", []() { return goi_raster_abi_version(); });
 }

@@ -194,7 +194,9 @@ def allreduce_gradients_async(params, dist) -> PendingExchange:
 
 def allreduce_gradients_sh_factored_async(params, sh_leaves, means3D, factor, dist, reconstruct=None) -> PendingExchange:
     """allreduce_gradients_sh_factored with the collectives left in flight; wait() rebuilds dL/dSH from the gathered
-    factors and assigns / accumulates it into the SH leaves."""
+    factors and ASSIGNS each SH leaf's part to `leaf.grad` (as the blocking variant does; in sh_factored mode autograd
+    gives the SH leaves no gradient of its own, so there is nothing to accumulate into).  The same tensors are also left
+    in `handle.sh_grads[id(leaf)]` for callers whose leaves have moved on to the next step's gradients by then."""
     if factor is None:
         raise RuntimeError("no SH factor: run the backward with rasterizer.set_backward_mode(sh_factored=True)")
     if reconstruct is None:
@@ -225,6 +227,7 @@ def allreduce_gradients_sh_factored_async(params, sh_leaves, means3D, factor, di
             n = int(leaf.shape[1])
             part = dsh[:, k:k + n, :].contiguous() if (k or n != dsh.shape[1]) else dsh
             result[id(leaf)] = part
+            leaf.grad = part
             k += n
         if k != dsh.shape[1]:
             raise ValueError(f"sh_leaves hold {k} coefficients, the rasterizer was given {dsh.shape[1]}")

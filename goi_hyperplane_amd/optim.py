@@ -31,15 +31,21 @@ class FusedAdam(torch.optim.Optimizer):
         super().__init__(params, defaults)
 
     @torch.no_grad()
-    def step(self, closure=None, nograd_mask: torch.Tensor | None = None):
+    def step(self, closure=None, nograd_mask: torch.Tensor | None = None, skip_if: torch.Tensor | None = None):
         """One Adam update of every parameter that has a gradient.  nograd_mask: optional [P] bool/uint8
-        tensor; Gaussians with a non-zero entry are updated as if their gradient rows were zero."""
+        tensor; Gaussians with a non-zero entry are updated as if their gradient rows were zero.
+        skip_if: optional int32[1] DEVICE tensor read by the kernel: non-zero makes this step a no-op on the device
+        (parameters and both moments untouched; only the host-side step count advances).  Pass
+        rasterizer.truncated_flag() to skip the view of a truncated speculative forward without any host round trip."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
         if nograd_mask is not None and nograd_mask.dim() != 1:
             raise ValueError("nograd_mask must be a 1-D [P] tensor")
+        if skip_if is not None and (not skip_if.is_cuda or skip_if.dtype not in (torch.int32, torch.uint32)
+                                    or skip_if.numel() != 1):
+            raise ValueError("skip_if must be a 1-element int32 tensor on the GPU")
         lib = _lib.load()
         launches = {}  # (beta1, beta2, eps, device) -> list of GoiAdamGroup
         keep = []
@@ -84,6 +90,11 @@ class FusedAdam(torch.optim.Optimizer):
                     chunk = groups[i:i + _lib.ADAM_MAX_GROUPS]
                     arr = (_lib.GoiAdamGroup * len(chunk))(*chunk)
                     mp = C.c_void_p(mask.data_ptr()) if mask is not None else None
-                    if lib.goi_adam_step(arr, len(chunk), beta1, beta2, eps, mp, stream) < 0:
+                    sp = None
+                    if skip_if is not None:
+                        if skip_if.device != dev:
+                            raise ValueError("skip_if lives on another device than the parameters")
+                        sp = C.c_void_p(skip_if.data_ptr())
+                    if lib.goi_adam_step_guarded(arr, len(chunk), beta1, beta2, eps, mp, sp, stream) < 0:
                         raise RuntimeError(_lib.last_error())
         return loss

@@ -109,12 +109,19 @@ def set_backward_mode(semantics_only=None, sh_factored: bool = None) -> None:
 
 
 def set_forward_mode(speculative=None, headroom=None, capacity="keep", on_overflow=None, max_ahead=None,
-                     inference_speculative=None) -> None:
+                     inference_speculative=None, min_history=None) -> None:
     """Forward without the host round trip (default for frames a backward may follow) or the reference's synchronous
     forward (default for frames rendered without autograd: their image is the product): see _C.set_forward_mode and
     include/goi_raster.h (goi_raster_forward_async).  GOI_FORWARD=exact|speculative, GOI_FORWARD_INFERENCE=exact|speculative,
     GOI_BINNING_HEADROOM, GOI_OVERFLOW=warn|raise set the process defaults."""
-    _C.set_forward_mode(speculative, headroom, capacity, on_overflow, max_ahead, inference_speculative)
+    _C.set_forward_mode(speculative, headroom, capacity, on_overflow, max_ahead, inference_speculative, min_history)
+
+
+def truncated_flag():
+    """int32[1] device tensor (or None): non-zero iff the most recent forward of this thread was a speculative frame
+    whose instance list did not fit its capacity.  Such a frame back-propagates ZERO gradients on the device;
+    `FusedAdam.step(skip_if=truncated_flag())` skips its optimiser step on the device as well (see _C.truncated_flag)."""
+    return _C.truncated_flag()
 
 
 def speculation_stats() -> dict:

@@ -195,7 +195,10 @@ class _FusedCodebookLoss(torch.autograd.Function):
         with torch.cuda.device(dev):
             p = lambda x: None if x is None else C_.c_void_p(x.data_ptr())  # noqa: E731
             stream = C_.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-            if _FUSED_KERNELS["on"] and D == 256 and 288 < C <= 304 and S <= 16 and HW % 4 == 0:
+            # (the full shape predicate of launch_codebook_fused, csrc/codebook_loss.hip: anything else takes the
+            # three-kernel path below instead of raising)
+            if (_FUSED_KERNELS["on"] and D == 256 and 288 < C <= 304 and 1 <= S <= 16 and HW % 4 == 0
+                    and 4 <= HW < (1 << 25)):
                 # sim -> losses -> gradients in two kernels, no [HW, C] fp32 matrix (csrc/codebook_loss.hip: codebook_fused_k)
                 dsem = torch.empty((S, HW), dtype=torch.float32, device=dev)
                 partials = torch.empty((lib.goi_codebook_fused_partial_rows(), C * (S + 1) + 4), dtype=torch.float32, device=dev)

@@ -45,8 +45,9 @@
 extern "C" {
 #endif
 
-/* 3: + goi_raster_forward_reblend, goi_codebook_sim, goi_codebook_fused (additions only; 2: + the asynchronous forward) */
-#define GOI_RASTER_ABI_VERSION 3
+/* 4: + goi_raster_truncated_flag, goi_adam_step_guarded; a truncated speculative frame back-propagates ZERO gradients
+ * (3: + goi_raster_forward_reblend, goi_codebook_sim, goi_codebook_fused; 2: + the asynchronous forward; additions only) */
+#define GOI_RASTER_ABI_VERSION 4
 
 typedef struct GoiRasterScene {
     int P;                       /* number of Gaussians */
@@ -107,7 +108,11 @@ int goi_raster_forward(const GoiRasterScene* scene, void* geom_buffer, void* ima
  *   n <= capacity : the frame is exactly what goi_raster_forward would have produced (bit-identical outputs; the
  *       tile lists are identical, only the workspace is larger).  Pass R = capacity to goi_raster_backward.
  *   n >  capacity : OVERFLOW.  The frame was rendered from the first `capacity` instances in emit (depth) order --
- *       memory-safe and self-consistent with a backward called with R = capacity, but not the right image.
+ *       memory-safe, but not the right image.  The device knows (emit sets the frame's "truncated" word in the
+ *       geometry workspace, goi_raster_truncated_flag): goi_raster_backward / _backward_semantics on such a frame write
+ *       ZERO into every gradient, so a truncated frame never trains anything even if the host has not looked at the
+ *       count yet (the reference sizes its buffers from the true count and cannot truncate, CR/rasterizer_impl.cu:283-289);
+ *       goi_adam_step_guarded can skip the optimiser step of that view on the device as well.
  *       goi_raster_forward_redo re-runs emit -> tile sort -> blend from the geometry state that is still in the
  *       workspace, into a binning buffer of goi_raster_binning_bytes(n) bytes: afterwards outputs and workspaces are
  *       bit-identical to goi_raster_forward's, and R = n.
@@ -119,6 +124,11 @@ int goi_raster_forward_async(const GoiRasterScene* scene, void* geom_buffer, voi
                              int capacity, float* out_color, float* out_semantic, float* out_depth, float* out_alpha,
                              int* radii, void* stream);
 int goi_raster_ticket_result(int ticket, int wait, int* num_rendered);
+/* Device pointer (inside the geometry workspace of a frame over P Gaussians) of the frame's "truncated" word: non-zero
+ * iff the frame's instance list did not fit its binning capacity.  Written by every forward (0 for goi_raster_forward
+ * and after goi_raster_forward_redo); read on the device by the backward kernels and, if handed over, by
+ * goi_adam_step_guarded.  NULL for P <= 0. */
+const uint32_t* goi_raster_truncated_flag(const void* geom_buffer, int P);
 int goi_raster_forward_redo(const GoiRasterScene* scene, int num_rendered, void* geom_buffer, void* image_buffer,
                             void* binning_buffer, float* out_color, float* out_semantic, float* out_depth,
                             float* out_alpha, const int* radii, void* stream);
@@ -300,6 +310,11 @@ typedef struct GoiAdamGroup {
 } GoiAdamGroup;
 int goi_adam_step(const GoiAdamGroup* groups, int n_groups, double beta1, double beta2, double eps,
                   const unsigned char* nograd_mask /*[P] or NULL*/, void* stream);
+/* The same with a device-side guard: if *skip_flag (a device word, e.g. goi_raster_truncated_flag of the view the
+ * gradients came from) is non-zero when the kernel runs, nothing is updated -- parameters and both moments keep their
+ * values (the host-side step count of the caller is the caller's business).  skip_flag == NULL: goi_adam_step. */
+int goi_adam_step_guarded(const GoiAdamGroup* groups, int n_groups, double beta1, double beta2, double eps,
+                          const unsigned char* nograd_mask /*[P] or NULL*/, const uint32_t* skip_flag, void* stream);
 
 /* Inspection of the opaque workspaces (tests only): copies device -> caller DEVICE buffers.
  * Any pointer may be NULL.  point_list is in final sorted order. */

@@ -164,3 +164,63 @@ def test_hits_from_other_streams_than_the_one_that_filled_the_cache(cache):
         assert torch.equal(r, o["semantics"].detach())
     scale = float(pc._semantics.grad.abs().max())
     assert float((pc._semantics.grad - g_cached).abs().max()) <= 2e-6 * scale  # three views: the order of the additions may differ
+
+
+def test_a_truncated_cached_frame_is_never_reblended(cache):
+    """a speculative frame that overflowed and whose overflow was only found lazily (nobody read the
+    count) holds a cut-off tile list in its binning workspace.  The cache must not serve it: the next frame of that camera
+    drops the entry and renders in full, bit-identical to the uncached frame."""
+    import warnings
+    dev, pc = _model(P=8000)
+    W, H = 240, 160
+    cam = TorchCamera(make_camera(W, H, fovx=1.0, yaw=0.07), dev)
+    g_sem = torch.ones((16, H, W), device=dev)
+    g_col = torch.ones((3, H, W), device=dev)
+    rasterizer.set_geometry_cache(0)
+    ref, gref = _frame(cam, pc, g_sem, g_col)
+    rasterizer.set_geometry_cache(4 << 30)
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", _C.RasterOverflowWarning)
+            rasterizer.set_forward_mode(speculative=True, capacity=3000)  # far below the ~60 k instances of this view
+            bad, gbad = _frame(cam, pc, g_sem, g_col)                     # truncated, never read, cached as pending
+            torch.cuda.synchronize()
+            assert not torch.equal(bad["render"], ref["render"]) and float(gbad.abs().max()) == 0.0
+            rasterizer.set_forward_mode(capacity=None)
+            s0 = rasterizer.geometry_cache_stats()
+            again, gagain = _frame(cam, pc, g_sem, g_col)  # must NOT be a hit on the truncated lists
+            s1 = rasterizer.geometry_cache_stats()
+        assert s1["hits"] == s0["hits"] and s1["misses"] == s0["misses"] + 1
+        for k in ref:
+            assert torch.equal(again[k], ref[k]), k
+        assert torch.equal(gagain, gref)
+        _C.poll_counts(dev, wait=True)
+        hit, ghit = _frame(cam, pc, g_sem, g_col)  # and the repaired entry is a hit with the right bits
+        assert rasterizer.geometry_cache_stats()["hits"] == s1["hits"] + 1
+        assert torch.equal(hit["render"], ref["render"]) and torch.equal(ghit, gref)
+    finally:
+        rasterizer.set_forward_mode(speculative=True, capacity=None)
+
+
+def test_recycled_addresses_of_freed_camera_tensors_do_not_alias(cache):
+    """the key identifies tensors by (address, version, shape).  A viewer builds its camera tensors per
+    frame (gui/gs_renderer.py MiniCam) and frees them after the call; the caching allocator then hands the next camera's
+    tensors the SAME addresses with version 0.  The entry keeps the keyed tensors alive, so a different camera can never
+    inherit a stale entry's identity."""
+    dev, pc = _model(P=8000)
+    W, H = 240, 160
+    g_sem = torch.ones((16, H, W), device=dev)
+    g_col = torch.ones((3, H, W), device=dev)
+    outs = []
+    for i in range(6):  # every camera is a temporary: dropped right after its frame
+        cam = TorchCamera(make_camera(W, H, fovx=1.0, yaw=0.15 * i - 0.4), dev)
+        o, _g = _frame(cam, pc, g_sem, g_col)
+        outs.append(o["render"])
+        del cam
+    st = rasterizer.geometry_cache_stats()
+    assert st["hits"] == cache["hits"], "a new camera hit a stale entry"
+    rasterizer.set_geometry_cache(0)
+    for i in range(6):
+        cam = TorchCamera(make_camera(W, H, fovx=1.0, yaw=0.15 * i - 0.4), dev)
+        o, _g = _frame(cam, pc, g_sem, g_col)
+        assert torch.equal(o["render"], outs[i]), i

@@ -284,8 +284,8 @@ def test_api_errors(dev):
 
 
 def test_full_size_properties(dev):
-    """BASELINE.json's full size (1M Gaussians, 1600x1056, S=16) -- too big for the oracle, so the
-    checks are size-independent properties of the operator:
+    """BASELINE.json's full size (1M Gaussians, 1600x1056, S=16): size-independent properties of the operator, next
+    to the oracle comparison at this size (test_metric_configuration_matches_oracle):
       * forward and backward are bit-reproducible (the backward has no atomics);
       * semantics enter linearly: render(s1 + s2) == render(s1) + render(s2), colour/alpha unchanged;
       * with loss = sum of semantic channel c, dL/dsemantics[g][c'] = delta(c,c') * sum_pix w[pix,g],
@@ -342,6 +342,65 @@ def test_full_size_properties(dev):
     assert other == 0.0
     o4, g4 = fwd_bwd(lambda o: o["semantics"][11].sum())
     assert (g4["_semantics"][:, 11] - g3["_semantics"][:, 3]).abs().max().item() <= 1e-6 * g3["_semantics"][:, 3].abs().max().item() + 1e-9
+
+
+@pytest.mark.parametrize("P,yaw", [(1_000_000, 0.0), (3_000_000, -0.05)])
+def test_metric_configuration_matches_oracle(oracle_mod, dev, P, yaw):
+    """BASELINE.json's own metric configuration -- 1 M Gaussians, 1600x1056, S = 16, SH degree 3 (and the 3 M size of
+    configs 2 / 3 with a non-zero dL/dcolour) -- through the DEFAULT HIP path (culled tile lists, speculative forward,
+    split-bf16 flush) against the CPU oracle on all host threads (CR/forward.cu:261-386, CR/backward.cu:415-625), with a
+    dense random upstream gradient on colour, semantics, depth AND alpha: forward 1e-4 outside the fragile mask, every
+    gradient tensor 1e-3 of its scale, element-wise statistics recorded (gpurun_out/parity_stats.json)."""
+    from goi_hyperplane_amd import _C, rasterizer
+    from goi_hyperplane_amd.render import GaussianSet, PipelineParams, TorchCamera, render
+    from goi_hyperplane_amd.scene import HEADLINE
+    from oracle import compare
+    h = HEADLINE
+    W, H, S = h["W"], h["H"], h["S"]
+    sc = make_scene(P, S=S, sh_degree=3, seed=0 if P == h["P"] else 1, extent=h["extent"],
+                    log_scale_mean=h["log_scale_mean"], log_scale_std=h["log_scale_std"])
+    cam = make_camera(W, H, fovx=h["fovx"], yaw=yaw)
+    bg = np.array([0.05, 0.1, 0.2], np.float32)
+    gc, gs, gd, ga = upstream_grads(S, H, W, seed=11)
+    scale = 1.0 / (W * H)
+    gc, gs, gd, ga = gc * scale, gs * scale, gd * scale, ga * scale
+
+    pc = GaussianSet.from_scene(sc, dev)
+    tcam = TorchCamera(cam, dev)
+    tbg = torch.tensor(bg, device=dev)
+    pipe = PipelineParams()
+    for _ in range(3):
+        render(tcam, pc, pipe, tbg)  # the first frames of a scene are exact and teach the capacity policy ...
+    out = render(tcam, pc, pipe, tbg)  # ... this one takes the default forward
+    n_lazy = rasterizer.last_num_rendered()
+    if _C._FWD["mode"] == "speculative":
+        assert isinstance(n_lazy, _C.LazyCount), "the metric configuration must be checked on the default forward"
+    loss = ((out["render"] * torch.tensor(gc, device=dev)).sum() + (out["semantics"] * torch.tensor(gs, device=dev)).sum()
+            + (out["depth"] * torch.tensor(gd, device=dev)).sum() + (out["alpha"] * torch.tensor(ga, device=dev)).sum())
+    loss.backward()
+    res = {k: out[k].detach().cpu().numpy() for k in ("render", "semantics", "depth", "alpha", "radii")}
+    g_hip = dict(means3D=pc._xyz.grad, opacity=pc._opacity.grad, semantics=pc._semantics.grad, sh=pc._features.grad,
+                 scales=pc._scaling.grad, rotations=pc._rotation.grad, means2D=out["viewspace_points"].grad)
+    g_hip = {k: v.detach().cpu().numpy() for k, v in g_hip.items()}
+    n_hip = int(n_lazy)
+    del out, pc, loss
+    torch.cuda.empty_cache()
+
+    o = oracle_mod.from_scene(sc, cam, bg=bg, threads=os.cpu_count() or 1)
+    f = o.forward()
+    g_orc = o.backward(gc, gs, gd, ga)
+    tag = f"metric_config_P{P}_{W}x{H}_S{S}"
+    assert 0 < n_hip <= f.num_rendered  # (culled lists: never more instances than the reference's rectangles)
+    fw = compare.forward_stats(res, f)
+    bw = compare.backward_stats(g_hip, g_orc)
+    PARITY_STATS[tag] = dict(bw, forward=fw, num_rendered_oracle=int(f.num_rendered), num_rendered_listed=n_hip)
+    assert fw["radii_equal"], f"{tag}: radii differ"
+    assert fw["fragile_frac"] < 0.02, fw["fragile_frac"]
+    for k in ("render", "semantics", "depth", "alpha"):
+        assert fw[k]["max"] < FWD_TOL, f"{tag}: {k} {fw[k]}"
+    for k, st in bw.items():
+        assert st["finite"] and st["max"] < BWD_TOL, f"{tag}: grad {k} {st}"
+    assert set(bw) == {"means3D", "opacity", "semantics", "sh", "scales", "rotations", "means2D"}
 
 
 def test_fused_semantic_decode_matches_unfused_reference(dev):

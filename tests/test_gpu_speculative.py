@@ -5,8 +5,9 @@ returns `num_rendered` lazily; these tests pin down that it changes no result:
   * capacity >= count (any capacity): outputs, sorted lists, ranges and every gradient are BIT-identical to the exact,
     synchronous path;
   * capacity < count (forced): reading the count before the outputs redoes the frame in place -> bit-identical again,
-    forward and backward; not reading it leaves a truncated-but-consistent frame that is reported at the next forward;
-  * the default policy: first frame exact, later frames speculative, nothing waits."""
+    forward and backward; not reading it leaves a truncated IMAGE but a backward that writes ZERO gradients on the device
+    (a skipped view; FusedAdam.step(skip_if=...) leaves the parameters untouched), reported at the next forward;
+  * the default policy: the first three frames of a scene exact, later frames speculative, nothing waits."""
 import warnings
 
 import numpy as np
@@ -32,7 +33,7 @@ def _restore_mode():
     yield
     _C.poll_counts(wait=True)
     _C.set_forward_mode(speculative=True, headroom=2.0, capacity=None, on_overflow="warn", max_ahead=64,
-                        inference_speculative=False)
+                        inference_speculative=False, min_history=3)
 
 
 def _args(sc, cam, dev, bg):
@@ -138,7 +139,70 @@ def test_overflow_through_autograd_read_before_use_gives_exact_gradients(dev):
     assert torch.equal(v0, v2)
 
 
-def test_unread_overflow_is_reported_at_a_later_forward_and_stays_consistent(dev):
+@pytest.mark.parametrize("path", ["rows", "rows_fp32", "atomic", "semantics_only"])
+def test_unread_overflow_never_trains_anything(dev, path):
+    """VERDICT r02 item 2 / ADVICE r02: a truncated frame must never reach the optimiser unnoticed.  Overflow is forced
+    and the count is NEVER read: every gradient the backward produces is exactly zero (decided on the device: emit's
+    COUNTER_OVF word), the fused Adam step guarded by rasterizer.truncated_flag() leaves parameters and moments bit for
+    bit where they were, and an unguarded torch.optim.Adam sees a zero gradient.  The same frame with room to spare
+    trains normally.  All three backward paths (atomic-free rows with either flush, float-atomic per tile,
+    feature-gradient-only)."""
+    from goi_hyperplane_amd import _C, _lib, rasterizer
+    from goi_hyperplane_amd.optim import FusedAdam
+    from goi_hyperplane_amd.render import GaussianSet, PipelineParams, TorchCamera, render
+    sc = make_scene(4000, S=16, seed=5, log_scale_mean=-2.7)
+    cam = TorchCamera(make_camera(160, 128), dev)
+    pc = GaussianSet.from_scene(sc, dev)
+    bg = torch.zeros(3, device=dev)
+    sem_only = path == "semantics_only"
+    _lib.set_option("bwd_variant", {"rows": 0, "rows_fp32": 2, "atomic": 1, "semantics_only": 0}[path])
+    rasterizer.set_backward_mode(semantics_only=sem_only)
+    if sem_only:
+        for p in pc.parameters():
+            p.requires_grad_(False)
+        pc._semantics.requires_grad_(True)
+    trainable = [p for p in pc.parameters() if p.requires_grad]
+    opt = FusedAdam([{"params": trainable, "lr": 1e-2}], lr=1e-2)
+    try:
+        def step(capacity, guarded=True):
+            _C.set_forward_mode(speculative=True, capacity=capacity)
+            opt.zero_grad(set_to_none=True)
+            out = render(cam, pc, PipelineParams(), bg)
+            flag = rasterizer.truncated_flag()
+            loss = out["semantics"].sum() if sem_only else out["render"].sum() + out["semantics"].sum() + out["depth"].sum()
+            loss.backward()
+            grads = [p.grad.clone() for p in trainable]
+            opt.step(skip_if=flag if guarded else None)
+            return flag, grads, out["viewspace_points"].grad
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", _C.RasterOverflowWarning)
+            flag, grads, _ = step(capacity=1 << 20)  # fits: a normal training step (also creates the Adam state)
+            torch.cuda.synchronize()
+            assert int(flag.item()) == 0 and any(float(g.abs().max()) > 0 for g in grads)
+            before = [p.detach().clone() for p in trainable]
+            moments = [(opt.state[p]["exp_avg"].clone(), opt.state[p]["exp_avg_sq"].clone()) for p in trainable]
+            flag, grads, vs = step(capacity=2000)  # TRUNCATED, never read
+            torch.cuda.synchronize()
+            assert int(flag.item()) == 1
+            for g in grads:
+                assert float(g.abs().max()) == 0.0, "a truncated frame produced a non-zero gradient"
+            assert vs is None or float(vs.abs().max()) == 0.0
+            for p, b, (m, v) in zip(trainable, before, moments):
+                assert torch.equal(p.detach(), b), "the guarded optimiser step moved a parameter"
+                assert torch.equal(opt.state[p]["exp_avg"], m) and torch.equal(opt.state[p]["exp_avg_sq"], v)
+            # the same view with room: trains again, and the flag is back to zero
+            flag, grads, _ = step(capacity=1 << 20)
+            torch.cuda.synchronize()
+            assert int(flag.item()) == 0 and any(float(g.abs().max()) > 0 for g in grads)
+            assert any(not torch.equal(p.detach(), b) for p, b in zip(trainable, before))
+        assert _C.SPECULATION_STATS["skipped_views"] >= 1
+    finally:
+        _lib.set_option("bwd_variant", 0)
+        rasterizer.set_backward_mode(semantics_only="auto")
+
+
+def test_unread_overflow_is_reported_at_a_later_forward_as_a_skipped_view(dev):
     from goi_hyperplane_amd import _C
     from goi_hyperplane_amd.render import GaussianSet, PipelineParams, TorchCamera, render
     sc = make_scene(4000, S=16, seed=5, log_scale_mean=-2.7)
@@ -146,11 +210,11 @@ def test_unread_overflow_is_reported_at_a_later_forward_and_stays_consistent(dev
     pc = GaussianSet.from_scene(sc, dev)
     bg = torch.zeros(3, device=dev)
     _C.set_forward_mode(speculative=True, capacity=2000)
-    with pytest.warns(_C.RasterOverflowWarning, match="overflowed its binning capacity"):
+    with pytest.warns(_C.RasterOverflowWarning, match="ZERO gradients"):
         out = render(cam, pc, PipelineParams(), bg)
-        (out["render"].sum() + out["semantics"].sum()).backward()  # backward of the truncated frame: consistent, finite
+        (out["render"].sum() + out["semantics"].sum()).backward()  # backward of the truncated frame: zeros
         torch.cuda.synchronize()
-        assert all(torch.isfinite(p.grad).all() for p in pc.parameters())
+        assert all(float(p.grad.abs().max()) == 0.0 for p in pc.parameters())
         _C.set_forward_mode(capacity=None)
         # found by whichever looks first without waiting: the backward's free look, or the poll of the next forward
         render(cam, pc, PipelineParams(), bg)
@@ -173,7 +237,7 @@ def test_unread_overflow_is_reported_at_a_later_forward_and_stays_consistent(dev
         render(cam, pc, PipelineParams(), bg)
 
 
-def test_default_policy_first_frame_exact_then_nothing_waits(dev):
+def test_default_policy_first_frames_exact_then_nothing_waits(dev):
     from goi_hyperplane_amd import _C
     from goi_hyperplane_amd.render import GaussianSet, PipelineParams, TorchCamera, render
     _C._SPEC.clear()  # a fresh process
@@ -190,8 +254,8 @@ def test_default_policy_first_frame_exact_then_nothing_waits(dev):
     torch.cuda.synchronize()
     _C.poll_counts(wait=True)
     s1 = _C.SPECULATION_STATS
-    assert s1["exact_frames"] - s0["exact_frames"] == 1
-    assert s1["speculative_frames"] - s0["speculative_frames"] == 23
+    assert s1["exact_frames"] - s0["exact_frames"] == 3  # (min_history: three counts teach the capacity policy)
+    assert s1["speculative_frames"] - s0["speculative_frames"] == 21
     assert s1["overflows"] == s0["overflows"]
     assert len(_C._SPEC[dev.index]["pending"]) == 0
 
