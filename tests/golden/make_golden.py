@@ -94,17 +94,79 @@ def ref_python_pins():
     print("wrote ref_python_pins.npz", {k: v.shape for k, v in out.items()})
 
 
+def _ref_ast(relpath):
+    import ast
+    return ast.parse(open(os.path.join(REF, relpath)).read())
+
+
+def _exec_stmts(stmts, ns, label):
+    """Executes the reference's OWN statements (AST nodes sliced out of its source, nothing re-typed) in `ns`."""
+    import ast
+    mod = ast.Module(body=list(stmts), type_ignores=[])
+    ast.fix_missing_locations(mod)
+    exec(compile(mod, label, "exec"), ns)
+    return ns
+
+
+def _method(tree, cls, name):
+    import ast
+    c = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == cls)
+    return next(n for n in c.body if isinstance(n, ast.FunctionDef) and n.name == name)
+
+
+class _cuda_is_cpu:
+    """The reference hard-codes .cuda() / .to("cuda") / device="cuda"; for the duration of a call those land on the CPU
+    (same device redirection as the torch.zeros one in ref_python_pins; no reference code is modified or copied)."""
+
+    def __enter__(self):
+        self.saved = (torch.Tensor.cuda, torch.Tensor.to, torch.tensor, torch.zeros)
+        real_to, real_tensor, real_zeros = torch.Tensor.to, torch.tensor, torch.zeros
+
+        def to(t, *a, **k):
+            a = tuple(x for x in a if not (isinstance(x, str) and x.startswith("cuda")))
+            if isinstance(k.get("device"), str) and k["device"].startswith("cuda"):
+                k.pop("device")
+            return real_to(t, *a, **k) if (a or k) else t
+
+        def strip(fn):
+            def f(*a, **k):
+                if isinstance(k.get("device"), str) and k["device"].startswith("cuda"):
+                    k.pop("device")
+                return fn(*a, **k)
+            return f
+        torch.Tensor.cuda = lambda t, *a, **k: t
+        torch.Tensor.to = to
+        torch.tensor = strip(real_tensor)
+        torch.zeros = strip(real_zeros)
+        return self
+
+    def __exit__(self, *exc):
+        torch.Tensor.cuda, torch.Tensor.to, torch.tensor, torch.zeros = self.saved
+        return False
+
+
 def semantic_pins():
-    """Semantic head: outputs of the REFERENCE's SemanticModel class
-    (scene/semantic_model.py, loaded by file path because the `scene` package imports clip) and a
-    checkpoint written by its own save(); the gui/main.py:364-386 decode and the train.py:142-163
-    losses are evaluated here with that model (those two files cannot be imported: dearpygui / cv2)."""
+    """Semantic head, pinned to the reference's OWN statements -- nothing below re-types a line of it:
+
+      * the model is the reference's SemanticModel class (scene/semantic_model.py, loaded by file path because the
+        `scene` package imports clip) and the checkpoint is written by its own save();
+      * the GUI decode is GUI.compute_similarity (gui/main.py:362-384) -- the method's AST node, compiled as it stands and
+        called with a stand-in `self` that only carries the attributes the method reads (renderer.MLP, renderer.LUT,
+        res_finetuned, resMLP = the reference's own LinearSVM class from networks.py:12-59, also taken by AST because the
+        module imports cv2-dependent helpers);
+      * the training losses are the statements of training()'s loop body from `sem_feature = sem_feature.permute(...)` to
+        `sem_loss = lab + sl + 0.3 * sl1 + recc` (train.py:141-163), sliced out of the function's AST and executed on
+        seeded inputs; the gradients are autograd's through those statements.
+    gui/main.py and train.py cannot be imported here (dearpygui / cv2 / the CUDA extensions)."""
+    import ast
     import importlib.util
+    import types
     spec = importlib.util.spec_from_file_location("ref_semantic_model", os.path.join(REF, "scene", "semantic_model.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     torch.manual_seed(7)
-    S, TAB, APE, HW = 10, 300, 256, 24 * 16
+    S, TAB, APE, H, W = 10, 300, 256, 24, 16
+    HW = H * W
     mlp = mod.SemanticModel(dim_in=S, dim_out=TAB, num_layer=1, use_bias=True, device="cpu")
     with torch.no_grad():
         mlp.layers[0].bias.normal_(0, 0.1)
@@ -113,39 +175,126 @@ def semantic_pins():
     lut = torch.rand(TAB, APE) * 0.03 + 0.01 * torch.randn(TAB, APE)
     svm_w = torch.randn(1, APE) * 0.5
     svm_b = torch.tensor([0.3])
+
+    # ---- decode: the reference's GUI.compute_similarity and LinearSVM, as they stand
+    net = _ref_ast("networks.py")
+    net_ns = {"torch": torch, "nn": torch.nn, "optim": torch.optim, "F": torch.nn.functional}
+    _exec_stmts([n for n in net.body if isinstance(n, ast.FunctionDef) and n.name == "inverse_sigmoid"]
+                + [n for n in net.body if isinstance(n, ast.ClassDef) and n.name == "LinearSVM"], net_ns, "networks.py")
+    svm = net_ns["LinearSVM"]()
+    svm.weight_set(svm_w)
+    with torch.no_grad():
+        svm.linear.bias.copy_(svm_b)
+    gui_ns = _exec_stmts([_method(_ref_ast("gui/main.py"), "GUI", "compute_similarity")], {"torch": torch},
+                         "gui/main.py:GUI.compute_similarity")
+    gui_self = types.SimpleNamespace(renderer=types.SimpleNamespace(MLP=mlp, LUT=lut), res_finetuned=True, resMLP=svm,
+                                     vlm=None, clip_feature_thresh=0.5)
+    bg = torch.zeros(HW, dtype=torch.bool)
+    with _cuda_is_cpu():
+        sim_out = gui_ns["compute_similarity"](gui_self, feats, bg)
     with torch.no_grad():
         dec = mlp(feats)
-        sem_logit = torch.softmax(dec * 10, dim=-1).argmax(dim=-1)            # gui/main.py:366
-        sem_feature = lut[sem_logit]                                          # :367
-        normed = sem_feature / sem_feature.norm(dim=-1, keepdim=True)         # :370
-        logit = torch.nn.functional.linear(normed / 0.3438, svm_w, svm_b).squeeze()  # networks.py:56-57
-        sim = logit.sigmoid()                                                 # :374
-        bg = sim < 0.5                                                        # :379
-        sim_out = sim.clone()
-        sim_out[bg] = 0                                                       # :382
-    # training losses, train.py:142-163, iteration < 1000
+        sem_logit = torch.softmax(dec * 10, dim=-1).argmax(dim=-1)  # (only stored for the tests' index comparison)
+
+    # ---- training losses: train.py's own loop-body statements
+    tr = _ref_ast("train.py")
+    fn = next(n for n in tr.body if isinstance(n, ast.FunctionDef) and n.name == "training")
+    loop = next(n for n in ast.walk(fn) if isinstance(n, ast.For) and getattr(n.target, "id", "") == "iteration")
+
+    def assigns(node, name):
+        return isinstance(node, ast.Assign) and any(getattr(t, "id", None) == name for t in node.targets)
+    first = next(i for i, n in enumerate(loop.body) if assigns(n, "sem_feature") and "permute" in ast.unparse(n))
+    last = next(i for i, n in enumerate(loop.body) if assigns(n, "sem_loss"))
+    stmts = loop.body[first:last + 1]
+    lines = (stmts[0].lineno, stmts[-1].end_lineno)
     gtl = torch.randn(HW, APE)
     lutp = lut.clone().requires_grad_(True)
     f = feats.clone().requires_grad_(True)
-    sem_label = torch.softmax(mlp(f), dim=-1)
-    g = gtl / gtl.norm(dim=1, keepdim=True)
-    lut1 = lutp / lutp.norm(dim=1, keepdim=True)
-    simm = g @ lut1.T
-    sim_val = simm.max(dim=1, keepdim=True)[0]
-    label = (simm == sim_val).float().detach()
-    lab = torch.nn.MSELoss()(sem_label, label) * 50
-    sl = (1 - sim_val.mean())
-    recc = 1 - torch.nn.functional.cosine_similarity(lutp[sem_label.argmax(-1)], g, dim=-1).mean()
-    b = torch.softmax(simm * 1, dim=1) * torch.log_softmax(simm * 1, dim=1)
-    sl1 = -1.0 * b.sum(dim=-1).mean()
-    loss = lab + sl + 0.3 * sl1 + recc
-    loss.backward()
+    out = {}
+    for tag, iteration in (("", 10), ("_t2", 1500)):  # t = 1 below iteration 1000, 2 afterwards (train.py:156)
+        lutp.grad = f.grad = None
+        ns = {"torch": torch, "softmax": torch.nn.functional.softmax, "log_softmax": torch.nn.functional.log_softmax,
+              "cosine_similarity": torch.nn.functional.cosine_similarity, "iteration": iteration, "semantic_MLP": mlp,
+              "lut": lutp, "dataset": types.SimpleNamespace(sem_dim=S, ape_dim=APE),
+              "sem_feature": f.T.reshape(S, H, W),  # the rasterizer's [S,H,W] map: permute(1,2,0).reshape gives `f` back
+              "viewpoint_cam": types.SimpleNamespace(semantic={"ape": gtl.T.reshape(APE, H, W).clone()})}
+        with _cuda_is_cpu():
+            _exec_stmts(stmts, ns, f"train.py:{lines[0]}-{lines[1]}")
+        ns["sem_loss"].backward()
+        out["loss" + tag] = ns["sem_loss"].item()
+        out["terms" + tag] = np.array([ns[k].item() for k in ("lab", "sl", "sl1", "recc")])
+        out["grad_feats" + tag] = f.grad.numpy().copy()
+        out["grad_lut" + tag] = lutp.grad.numpy().copy()
     np.savez_compressed(os.path.join(HERE, "ref_semantic_pins.npz"), feats=feats.numpy(), lut=lut.numpy(),
                         svm_w=svm_w.numpy(), svm_b=svm_b.numpy(), dec=dec.numpy(), idx=sem_logit.numpy(),
-                        sim=sim_out.numpy(), bg=bg.numpy(), gtl=gtl.numpy(), loss=loss.item(),
-                        terms=np.array([lab.item(), sl.item(), sl1.item(), recc.item()]),
-                        grad_feats=f.grad.numpy(), grad_lut=lutp.grad.numpy())
-    print("wrote ref_semantic_pins.npz, ref_semantic_mlp.pt; loss", loss.item())
+                        sim=sim_out.numpy(), bg=bg.numpy(), gtl=gtl.numpy(),
+                        ref_lines=np.array(lines), **out)
+    print("wrote ref_semantic_pins.npz, ref_semantic_mlp.pt; loss", out["loss"], out["loss_t2"], "train.py lines", lines)
+
+
+def format_pins():
+    """On-disk formats, pinned to the reference's OWN statements of scene/gaussian_model.py (its
+    module cannot be imported: plyfile, simple_knn): construct_list_of_attributes (:255-269) as it stands; save_ply
+    (:271-289) up to the numpy structured array `elements` it hands to plyfile (the mkdir and the two plyfile lines are
+    left out: plyfile is not in this image); load_ply (:307-352) from behind PlyData.read on an object that exposes that
+    very `elements` array the way plyfile does (elements[0][name], elements[0].properties[i].name); capture (:53-68)."""
+    import types
+    tree = _ref_ast("scene/gaussian_model.py")
+    g = torch.Generator().manual_seed(3)
+    P, S = 7, 10
+    r = lambda *s: torch.randn(*s, generator=g)  # noqa: E731
+    raw = dict(xyz=r(P, 3), features_dc=r(P, 1, 3), features_rest=r(P, 15, 3), semantics=r(P, S), opacity=r(P, 1),
+               scaling=r(P, 3), rotation=r(P, 4))
+
+    class Stub:
+        max_sh_degree = 3
+        semantic_dim = S
+        get_xyz = property(lambda self: self._xyz)
+    me = Stub()
+    me._xyz, me._features_dc, me._features_rest = raw["xyz"], raw["features_dc"], raw["features_rest"]
+    me._semantics, me._opacity, me._scaling, me._rotation = raw["semantics"], raw["opacity"], raw["scaling"], raw["rotation"]
+    ns = _exec_stmts([_method(tree, "GaussianModel", "construct_list_of_attributes")], {}, "gaussian_model.py:construct_list")
+    Stub.construct_list_of_attributes = ns["construct_list_of_attributes"]
+    names = me.construct_list_of_attributes()
+    sp = _method(tree, "GaussianModel", "save_ply")
+    body = sp.body[1:-2]  # without mkdir_p(...) and the two plyfile lines
+    import ast
+    assert "mkdir_p" in ast.unparse(sp.body[0]) and "PlyElement" in ast.unparse(sp.body[-2]) and "write" in ast.unparse(sp.body[-1])
+    ns = _exec_stmts(body, {"np": np, "torch": torch, "self": me, "path": "unused"}, "gaussian_model.py:save_ply")
+    elements = ns["elements"]
+    assert list(elements.dtype.names) == names and elements.dtype.itemsize == 4 * len(names)
+    out = {"names": np.array(names), "elements_bytes": np.frombuffer(elements.tobytes(), np.uint8), "P": P}
+    out.update({"in_" + k: v.numpy() for k, v in raw.items()})
+
+    lp = _method(tree, "GaussianModel", "load_ply")
+    assert "PlyData.read" in ast.unparse(lp.body[0])
+
+    class El:
+        def __init__(self, arr):
+            self.arr = arr
+            self.properties = [types.SimpleNamespace(name=n) for n in arr.dtype.names]
+
+        def __getitem__(self, k):
+            return self.arr[k]
+    for tag, sem_dim in (("", S), ("_mismatch", 16)):
+        you = Stub()
+        you.semantic_dim = sem_dim
+        with _cuda_is_cpu():
+            _exec_stmts(lp.body[1:], {"np": np, "torch": torch, "nn": torch.nn, "self": you,
+                                      "plydata": types.SimpleNamespace(elements=[El(elements)])}, "gaussian_model.py:load_ply")
+        for k in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation", "_semantics"):
+            out["load" + tag + k] = getattr(you, k).detach().numpy()
+        assert you.active_sh_degree == 3
+
+    cap = Stub()
+    for k in ("active_sh_degree", "_xyz", "_features_dc", "_features_rest", "_semantics", "_scaling", "_rotation", "_opacity",
+              "max_radii2D", "xyz_gradient_accum", "denom", "spatial_lr_scale"):
+        setattr(cap, k, k.lstrip("_"))
+    cap.optimizer = types.SimpleNamespace(state_dict=lambda: "optimizer_state")
+    ns = _exec_stmts([_method(tree, "GaussianModel", "capture")], {}, "gaussian_model.py:capture")
+    out["capture_order"] = np.array(ns["capture"](cap))
+    np.savez_compressed(os.path.join(HERE, "ref_format_pins.npz"), **out)
+    print("wrote ref_format_pins.npz:", len(names), "attributes,", elements.nbytes, "payload bytes; capture:", list(out["capture_order"]))
 
 
 ORACLE_CASES = {
@@ -231,4 +380,5 @@ if __name__ == "__main__":
     kmeans_pins()
     ref_python_pins()
     semantic_pins()
+    format_pins()
     oracle_goldens()

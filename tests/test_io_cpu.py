@@ -110,3 +110,52 @@ def test_checkpoint_tuple_round_trip(tmp_path):
     assert torch.equal(tup[4], params["semantics"]) and tup[11]["param_groups"][0]["name"] == "semantics"
     back, it2 = gio.load_checkpoint(path)
     assert it2 == 30000 and torch.equal(back["rotation"], params["rotation"])
+
+
+def _format_pins():
+    return np.load(os.path.join(GOLD, "ref_format_pins.npz"))
+
+
+def test_ply_writer_emits_the_reference_writers_own_records(tmp_path):
+    """tests/golden/ref_format_pins.npz holds what the REFERENCE's statements produce (make_golden.py:format_pins, AST-exec
+    of scene/gaussian_model.py): construct_list_of_attributes' list and the structured array `elements` save_ply builds and
+    hands to plyfile.  This module's writer must put exactly those records behind a header that declares exactly those
+    properties (plyfile writes a float32 structured array as its raw little-endian records)."""
+    z = _format_pins()
+    names = [str(n) for n in z["names"]]
+    m = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in_")}
+    assert gio.ply_attribute_names(3, 45, m["semantics"].shape[1]) == names
+    path = tmp_path / "pc.ply"
+    gio.save_ply(str(path), **m)
+    head, payload = path.read_bytes().split(b"end_header\n", 1)
+    lines = head.decode().splitlines()
+    assert lines[:3] == ["ply", "format binary_little_endian 1.0", f"element vertex {int(z['P'])}"]
+    assert [ln.split() for ln in lines[3:]] == [["property", "float", n] for n in names]
+    assert payload == z["elements_bytes"].tobytes()
+
+
+@pytest.mark.parametrize("tag,sem_dim", [("", 10), ("_mismatch", 16)])
+def test_ply_reader_returns_what_the_reference_reader_builds(tmp_path, tag, sem_dim):
+    """... and reading that file back gives the parameter tensors the reference's load_ply statements build from the same
+    records (feature layouts after its transposes; its rule for a semantic width that differs from the file's: zeros of
+    the FILE's width)."""
+    z = _format_pins()
+    path = tmp_path / "pc.ply"
+    path.write_bytes(("ply\nformat binary_little_endian 1.0\nelement vertex %d\n" % int(z["P"])
+                      + "".join(f"property float {n}\n" for n in z["names"]) + "end_header\n").encode()
+                     + z["elements_bytes"].tobytes())
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", UserWarning)
+        got = gio.load_ply(str(path), max_sh_degree=3, semantic_dim=sem_dim)
+    for ours, theirs in (("xyz", "_xyz"), ("features_dc", "_features_dc"), ("features_rest", "_features_rest"),
+                         ("opacity", "_opacity"), ("scaling", "_scaling"), ("rotation", "_rotation"),
+                         ("semantics", "_semantics")):
+        ref = z["load" + tag + theirs]
+        assert got[ours].shape == ref.shape and np.array_equal(got[ours], ref), (ours, got[ours].shape, ref.shape)
+    if tag:
+        assert not got["semantics"].any()
+
+
+def test_checkpoint_field_order_is_the_reference_capture_order():
+    assert list(gio.CHECKPOINT_FIELDS) == [str(n) for n in _format_pins()["capture_order"]]

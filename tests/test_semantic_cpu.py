@@ -1,5 +1,7 @@
-"""CPU pins of the semantic head against vectors produced by the REFERENCE's own
-SemanticModel class and its checkpoint format (tests/golden/make_golden.py:semantic_pins)."""
+"""CPU pins of the semantic head against vectors produced by the REFERENCE's own code: its
+SemanticModel class and checkpoint format, its GUI.compute_similarity method (gui/main.py:362-384) with its own LinearSVM
+(networks.py:12-59), and the loss statements of its training loop (train.py:142-163) -- all executed from the reference's
+AST by tests/golden/make_golden.py:semantic_pins, nothing re-typed."""
 import os
 
 import numpy as np
@@ -43,16 +45,22 @@ def test_decode_restatement_matches_reference_lines():
     np.testing.assert_allclose(sim.numpy(), pins["sim"], rtol=1e-5, atol=1e-6)
 
 
-def test_training_losses_match_reference_lines():
+import pytest
+
+
+@pytest.mark.parametrize("tag,iteration", [("", 10), ("_t2", 1500)])  # anneal factor t = 1 / 2 (train.py:156)
+def test_training_losses_match_reference_lines(tag, iteration):
     pins, mlp = _load()
+    assert tuple(pins["ref_lines"]) == (142, 163)  # the statements the vectors were produced by
     S, H, W = 10, 24, 16
     f = torch.tensor(pins["feats"]).T.reshape(S, H, W).clone().requires_grad_(True)
     lut = torch.tensor(pins["lut"]).clone().requires_grad_(True)
     gtl = torch.tensor(pins["gtl"]).T.reshape(256, H, W)
-    loss, terms = codebook_losses(f, mlp, lut, gtl, iteration=1)
+    loss, terms = codebook_losses(f, mlp, lut, gtl, iteration=iteration)
     loss.backward()
-    assert abs(loss.item() - float(pins["loss"])) < 1e-5
-    np.testing.assert_allclose([terms[k].item() for k in ("lab", "sl", "sl1", "recc")], pins["terms"], rtol=1e-5, atol=1e-6)
+    assert abs(loss.item() - float(pins["loss" + tag])) < 1e-5
+    np.testing.assert_allclose([terms[k].item() for k in ("lab", "sl", "sl1", "recc")], pins["terms" + tag], rtol=1e-5,
+                               atol=1e-6)
     gf = f.grad.reshape(S, -1).T.numpy()
-    np.testing.assert_allclose(gf, pins["grad_feats"], rtol=1e-4, atol=1e-8)
-    np.testing.assert_allclose(lut.grad.numpy(), pins["grad_lut"], rtol=1e-4, atol=1e-8)
+    np.testing.assert_allclose(gf, pins["grad_feats" + tag], rtol=1e-4, atol=1e-8)
+    np.testing.assert_allclose(lut.grad.numpy(), pins["grad_lut" + tag], rtol=1e-4, atol=1e-8)
