@@ -225,16 +225,24 @@ int enqueue_front(const GoiRasterScene& sc, GeomView& g, ImageView& im, int* rad
     }
     if (check_stage(sc, s, "preprocess")) return -1;
     if (ticket >= 0 && enqueue_readback(g, ticket, s)) return -1;
+    // Only the V LISTED Gaussians (tiles_touched > 0; half of the headline scene is culled) are depth-sorted: one small
+    // pass compacts their (depth key, id) in id order -- the sort must stay stable -- and, reading the keys anyway, forms
+    // the sort's digit histograms (its prologue kernel is skipped).  V lives on the device: grids cover P, the kernels stop
+    // at counters[COUNTER_V]; the prefix sum over the depth order and emit walk the V listed Gaussians only.
+    const bool onesweep = g_options.sort_variant == 1;
+    const uint32_t* v_dev = g.counters + COUNTER_V;
     int order_idx;
     {
         StageTimer t(GOI_STAGE_DEPTH_SORT, s);
-        order_idx = radix_sort_pairs(g.sort_keys, g.sort_vals, (size_t)P, 0, 32, g.scratch, s, /*cleared=*/true);
+        launch_compact_listed(P, g, onesweep ? radix_sort_ghist(g.scratch, (size_t)P, 0, 32) : nullptr, /*pad=*/!onesweep, s);
+        order_idx = radix_sort_pairs(g.sort_keys, g.sort_vals, (size_t)P, 0, 32, g.scratch, s, /*cleared=*/true,
+                                     /*ghist_ready=*/onesweep, onesweep ? v_dev : nullptr);
     }
     if (check_stage(sc, s, "depth sort")) return -1;
     *order_out = g.sort_vals[order_idx];
     {
         StageTimer t(GOI_STAGE_SCAN, s);
-        exclusive_scan_u32(g.tiles_touched, *order_out, g.offsets, (size_t)P, g.counters + COUNTER_N, g.scratch, s);
+        exclusive_scan_u32(g.tiles_touched, *order_out, g.offsets, (size_t)P, nullptr, g.scratch, s, v_dev);
     }
     return 0;
 }
@@ -313,7 +321,13 @@ int geometry_and_binning(const GoiRasterScene& sc, GeomView& g, ImageView& im, g
 
 }  // namespace
 
-Options g_options;
+thread_local Options g_options;
+static Options g_shared_options;
+static std::mutex g_options_mu;
+void refresh_options() {
+    std::lock_guard<std::mutex> lk(g_options_mu);
+    g_options = g_shared_options;
+}
 
 // Which ping-pong buffer holds the tile-sorted list: a pure function of the pass count, so the
 // backward can recompute it instead of storing it.
@@ -339,6 +353,7 @@ size_t geom_layout(int P, char* base, GeomView* v) {
     carve(p, g.sort_vals[1], n);
     carve(p, g.offsets, n);
     carve(p, g.goff, n);
+    carve(p, g.blk_agg, (n + PRE_BLOCK - 1) / PRE_BLOCK);
     carve(p, g.counters, COUNTER_WORDS);  // directly in front of the sort scratch: one memset clears both
     g.scratch_words = sort_scratch_words(n) + scan_scratch_words(n);
     carve(p, g.scratch, g.scratch_words);
@@ -352,6 +367,8 @@ size_t image_layout(int W, int H, char* base, ImageView* v) {
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     carve(p, im.n_contrib, (size_t)W * H);
     carve(p, im.ranges, (size_t)gx * gy);
+    carve(p, im.qcost, (size_t)gx * gy * 4);
+    carve(p, im.qorder, (size_t)gx * gy * 4 + 8);
     return (size_t)(p - base) + 256;
 }
 
@@ -398,6 +415,7 @@ size_t goi_raster_backward_scratch_bytes(int N, int S) { return bwd_scratch_layo
 int goi_raster_forward(const GoiRasterScene* scene, void* geom_buffer, void* image_buffer, goi_alloc_fn binning_alloc,
                        void* alloc_user, float* out_color, float* out_semantic, float* out_depth, float* out_alpha,
                        int* radii, void* stream) {
+    refresh_options();
     if (validate(scene, true)) return -1;
     const GoiRasterScene& sc = *scene;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -429,6 +447,7 @@ int goi_raster_forward(const GoiRasterScene* scene, void* geom_buffer, void* ima
 int goi_raster_forward_async(const GoiRasterScene* scene, void* geom_buffer, void* image_buffer, void* binning_buffer,
                              int capacity, float* out_color, float* out_semantic, float* out_depth, float* out_alpha,
                              int* radii, void* stream) {
+    refresh_options();
     if (validate(scene, true)) return -1;
     const GoiRasterScene& sc = *scene;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -477,6 +496,7 @@ int goi_raster_ticket_result(int ticket, int wait, int* num_rendered) {
 int goi_raster_forward_redo(const GoiRasterScene* scene, int num_rendered, void* geom_buffer, void* image_buffer,
                             void* binning_buffer, float* out_color, float* out_semantic, float* out_depth,
                             float* out_alpha, const int* radii, void* stream) {
+    refresh_options();
     // (the back half of a frame reads P, S, W, H, the semantic rows and the background from the scene; everything else
     // comes from the geometry workspace of the first attempt, so only those fields are checked)
     if (!scene) return fail("scene is NULL");
@@ -510,6 +530,7 @@ int goi_raster_forward_redo(const GoiRasterScene* scene, int num_rendered, void*
 int goi_raster_forward_reblend(const GoiRasterScene* scene, int R, const void* geom_buffer, const void* binning_buffer,
                                const void* cached_image_buffer, void* image_buffer, float* out_color, float* out_semantic,
                                float* out_depth, float* out_alpha, void* stream) {
+    refresh_options();
     // (only the blend runs: it reads P, S, W, H, the semantic rows and the background from the scene; the Gaussian records,
     // the tile lists and the tile ranges are those of the frame that filled the workspaces)
     if (!scene) return fail("scene is NULL");
@@ -544,6 +565,7 @@ int goi_raster_forward_reblend(const GoiRasterScene* scene, int R, const void* g
 int goi_raster_trace(const GoiRasterScene* scene, const float* img_sem, void* geom_buffer, void* image_buffer,
                      goi_alloc_fn binning_alloc, void* alloc_user, float* out_color, float* gau_sem, int* num_gsem,
                      int* radii, void* stream) {
+    refresh_options();
     if (validate(scene, false)) return -1;
     const GoiRasterScene& sc = *scene;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -573,6 +595,7 @@ int goi_raster_backward(const GoiRasterScene* scene, int R, const void* geom_buf
                         float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dsemantic,
                         float* dL_ddepth, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
                         float* dL_drot, void* scratch, void* stream) {
+    refresh_options();
     if (validate(scene, true, false)) return -1;  // opacity lives in the forward's records
     const GoiRasterScene& sc = *scene;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -595,6 +618,7 @@ int goi_raster_backward(const GoiRasterScene* scene, int R, const void* geom_buf
             StageTimer t(GOI_STAGE_BLEND_BWD, s);
             if (R > 0) {
                 GOI_HIP(hipMemsetAsync(scr.flags, 0, round_up_256((size_t)R * 4), s));  // (the layout ends with 256 spare bytes)
+                launch_quad_order(sc, im, s);
                 launch_render_bwd_rows(sc, g, im, bv.vals[fin], radii, out_alpha, dL_dout_color, dL_dout_semantic,
                                        dL_dout_depth, dL_dout_alpha, scr, s);
             }
@@ -631,6 +655,7 @@ int goi_raster_backward(const GoiRasterScene* scene, int R, const void* geom_buf
 int goi_raster_backward_semantics(const GoiRasterScene* scene, int R, const void* geom_buffer, const void* binning_buffer,
                                   const void* image_buffer, const int* radii, const float* out_alpha,
                                   const float* dL_dout_semantic, float* dL_dsemantic, void* scratch, void* stream) {
+    refresh_options();
     if (validate(scene, true, false)) return -1;
     const GoiRasterScene& sc = *scene;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -652,6 +677,7 @@ int goi_raster_backward_semantics(const GoiRasterScene* scene, int R, const void
         StageTimer t(GOI_STAGE_BLEND_BWD, s);
         if (R > 0) {
             GOI_HIP(hipMemsetAsync(scr.flags, 0, round_up_256((size_t)R * 4), s));  // (the layout ends with 256 spare bytes)
+            launch_quad_order(sc, im, s);
             launch_render_bwd_sem(sc, g, im, bv.vals[fin], radii, out_alpha, dL_dout_semantic, scr.rows, scr.flags,
                                   row_floats, s);
         }
@@ -677,6 +703,7 @@ int goi_raster_mark_visible(int P, const float* means3D, const float* viewmatrix
 int goi_semantic_decode(const float* sem, int S, long long HW, const float* W, const float* bias, int n_codes,
                         const float* code_score, float thresh, float* sim_out, int* idx_out, uint8_t* bg_mask_out,
                         void* stream) {
+    refresh_options();
     if (!sem || !W || !bias) return fail("goi_semantic_decode: NULL input");
     if (S < 1 || S > 32 || n_codes < 1 || HW < 0) return fail("goi_semantic_decode: need 1 <= S <= 32, n_codes >= 1");
     if (HW == 0) return 0;
@@ -796,16 +823,16 @@ void goi_raster_profile_stages(unsigned stage_mask) { g_profile_mask.store(stage
 
 int goi_raster_set_option(const char* name, int value) {
     if (!name) return fail("option name is NULL");
+    std::lock_guard<std::mutex> lk(g_options_mu);
+    Options& g_options = g_shared_options;  // (calls already running keep their own snapshot)
     if (!strcmp(name, "fwd_variant")) g_options.fwd_variant = value;
     else if (!strcmp(name, "bwd_variant")) {
-        // bits 4..15 are timing experiments (skip parts of the backward / pad LDS): results are NOT valid
-        // gradients, so they are only honoured when GOI_EXPERIMENTS=1 is set in the environment
-        if ((value & ~0xF) && !(getenv("GOI_EXPERIMENTS") && !strcmp(getenv("GOI_EXPERIMENTS"), "1")))
-            return fail("bwd_variant: experiment bits need GOI_EXPERIMENTS=1 (they produce invalid gradients)");
+        if (value < 0 || value > 2) return fail("bwd_variant must be 0, 1 or 2");
         g_options.bwd_variant = value;
     }
     else if (!strcmp(name, "sort_variant")) g_options.sort_variant = value;
     else if (!strcmp(name, "cull_variant")) g_options.cull_variant = value;
+    else if (!strcmp(name, "bwd_order")) g_options.bwd_order = value;
     else if (!strcmp(name, "decode_variant")) g_options.decode_variant = value;
     else return fail(std::string("unknown option ") + name);
     return 0;

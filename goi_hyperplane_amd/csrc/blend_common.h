@@ -255,12 +255,15 @@ struct QuadGeom {
     bool inside;
     float pxf, pyf, QX0, QY0;
 };
-__device__ __forceinline__ QuadGeom quad_geom(int W, int H, int gx, int n_quads) {
-    QuadGeom t;
+// launch slot of this workgroup in band-major order: slot = (XCD the hardware deals it to) * per + position in the band
+__device__ __forceinline__ int quad_slot() {
     const int per = (int)(gridDim.x >> 3);
-    const int tq = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    return (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+}
+__device__ __forceinline__ QuadGeom quad_geom_of(int tq, int W, int H, int gx, int n_quads) {
+    QuadGeom t;
     t.lane = threadIdx.x & 63;
-    if (tq >= n_quads) {
+    if (tq < 0 || tq >= n_quads) {
         t.tile = -1;
         return t;
     }
@@ -277,6 +280,9 @@ __device__ __forceinline__ QuadGeom quad_geom(int W, int H, int gx, int n_quads)
     t.QX0 = (float)qx0;
     t.QY0 = (float)qy0;
     return t;
+}
+__device__ __forceinline__ QuadGeom quad_geom(int W, int H, int gx, int n_quads) {
+    return quad_geom_of(quad_slot(), W, H, gx, n_quads);
 }
 inline int quad_grid(int n_quads) { return 8 * ((n_quads + 7) / 8); }
 

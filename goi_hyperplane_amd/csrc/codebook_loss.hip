@@ -426,9 +426,6 @@ __global__ __launch_bounds__(256) void codebook_split_k(const float* __restrict_
     reinterpret_cast<uint32_t*>(planes + (size_t)SIM_NC * SIM_K)[i] = lo;
 }
 
-#ifndef GOI_SIM_EXP
-#define GOI_SIM_EXP 0  // timing experiments (tools/build/exp_sim_parts.sh): 1 no code-book staging, 2 no g loads, 4 no products
-#endif
 #ifndef GOI_SIM_PB
 #define GOI_SIM_PB 2
 #endif
@@ -502,19 +499,10 @@ __global__ __launch_bounds__(64 * SIM_NW) void codebook_sim_k(const float* __res
             split_pack8(braw[pb], Bh[pb], Bl[pb]);
         }
         if (kc + 1 < SIM_K / SIM_KC) {  // the next chunk's traffic flies under this chunk's MFMAs
-#if !(GOI_SIM_EXP & 1)
             stage(kc + 1, (kc + 1) & 1);
-#endif
-#if !(GOI_SIM_EXP & 2)
             load_b(kc + 1);
-#endif
         }
-#if GOI_SIM_EXP & 4
-        const char* buf = s_a[0] + a_off;
-        if (kc > 0) continue;   // no products after the first chunk
-#else
         const char* buf = s_a[kc & 1] + a_off;
-#endif
 #pragma unroll
         for (int cb = 0; cb < SIM_NCB; cb++) {
             const bf16x8 Ah = *reinterpret_cast<const bf16x8*>(buf + 1024 * cb);
@@ -758,9 +746,6 @@ __global__ __launch_bounds__(64 * DS_NW, 3) void decoder_stats_k(const FusedArgs
 // would run at the latency of one chunk's trip through L2 (that is what bounds codebook_sim_k); with nothing but LDS-DMA in
 // flight the only waits are the counted ones below.  All LDS is ONE array: a second __shared__ object costs a vmcnt(0)
 // before the first ds_read of every iteration.
-#ifndef GOI_SG_EXP
-#define GOI_SG_EXP 0  // timing experiments (tools/build/exp_sg_parts.sh): 1 no code-book staging, 2 no products, 4 no g staging
-#endif
 constexpr int SG_NW = 8, SG_NBUF = 3;
 constexpr int SG_A_BYTES = SIM_KC * 16 * 4;                         // one wave's g tile of one chunk
 constexpr int SG_LDS = SG_NBUF * SIM_BUF + SG_NW * 2 * SG_A_BYTES;  // 146 KiB: one workgroup per CU
@@ -771,9 +756,6 @@ __global__ __launch_bounds__(64 * SG_NW, 1) void codebook_simgrad_k(const FusedA
     const int C = a.C;
     const float NEG_INF = -__builtin_inff();
     const long long pbase = (long long)blockIdx.x * FU_WG_PIX + 16 * w;  // this lane's D rows are pixels pbase + 4 kq + r
-#ifdef GOI_FU_PROF
-    const long long tk0 = __builtin_readcyclecounter();
-#endif
     char* const s_cb = smem;                                           // [SG_NBUF][SIM_BUF]
     char* const s_aw = smem + SG_NBUF * SIM_BUF + w * 2 * SG_A_BYTES;  // this wave's [2][32 k][16 pixels] floats
     f32x4 sx[SIM_NCB];
@@ -830,17 +812,10 @@ __global__ __launch_bounds__(64 * SG_NW, 1) void codebook_simgrad_k(const FusedA
         for (int i = 0; i < 8; i++) nrm = fmaf(araw[i], araw[i], nrm);
         split_pack8(araw, Ah, Al);
         if (kc + 2 < NKC) {
-#if !(GOI_SG_EXP & 1)
             stage(kc + 2);
-#endif
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the tile is in registers before its buffer is re-filled
-#if !(GOI_SG_EXP & 4)
             stage_a(kc + 2);
-#endif
         }
-#if GOI_SG_EXP & 2
-        if (kc > 0) continue;
-#endif
         const char* buf = s_cb + SIM_BUF * (kc % SG_NBUF) + b_off;
         // Three products per code block on one accumulator.  Issued block by block they form a chain (a dependent 16x16x32
         // issues every ~36 clocks, an independent one every 16) behind the block's own LDS reads: 19 x (LDS latency + chain)
@@ -871,11 +846,6 @@ __global__ __launch_bounds__(64 * SG_NW, 1) void codebook_simgrad_k(const FusedA
                 if (G * g + i < SIM_NCB) sx[G * g + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh[g & 1][i], sx[G * g + i], 0, 0, 0);
         }
     }
-#ifdef GOI_FU_PROF  // experiment builds: phase clocks of this wave instead of its loss sums
-    __builtin_amdgcn_sched_barrier(0);
-    const long long tk1 = __builtin_readcyclecounter();
-    __builtin_amdgcn_sched_barrier(0);
-#endif
     const bool vlast = 16 * (SIM_NCB - 1) + mm < C;  // 288 < C <= 304: only the last code block has padding
     const float g_ent = a.w_sl1 * a.t * a.inv_hw;
     const float first = mm == 0 ? 1.f : 0.f;  // a row's scalars are replicated over its 16 lanes: count them once
@@ -985,12 +955,7 @@ __global__ __launch_bounds__(64 * SG_NW, 1) void codebook_simgrad_k(const FusedA
             }
         }
     }
-    float t0 = wave_sum_u(acc_nl), t1 = wave_sum_u(acc_m), t2 = wave_sum_u(acc_H), t3 = wave_sum_u(acc_sa);
-#ifdef GOI_FU_PROF
-    __builtin_amdgcn_sched_barrier(0);
-    t0 = (float)(tk1 - tk0);
-    t1 = (float)(__builtin_readcyclecounter() - tk1);
-#endif
+    const float t0 = wave_sum_u(acc_nl), t1 = wave_sum_u(acc_m), t2 = wave_sum_u(acc_H), t3 = wave_sum_u(acc_sa);
     if (lane == 0) *reinterpret_cast<f32x4*>(a.sums_a + 4 * ((size_t)blockIdx.x * SG_NW + w)) = f32x4{t0, t1, t2, t3};
 }
 

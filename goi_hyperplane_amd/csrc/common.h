@@ -28,10 +28,11 @@ struct GeomView {
     float* cov3D;             // [6P] (only when computed from scale/rotation)
     uint32_t* tiles_touched;  // [P]
     uint8_t* clamped;         // [P] bit0..2 = r,g,b clamped at 0
-    uint32_t* sort_keys[2];   // [P] depth bits (ping-pong)
-    uint32_t* sort_vals[2];   // [P] Gaussian ids (ping-pong); [final] = depth order
-    uint32_t* offsets;        // [P] exclusive prefix of tiles_touched in depth order
-    uint32_t* goff;           // [P] the same prefix indexed by Gaussian id = first emit-order instance of g
+    uint32_t* sort_keys[2];   // [P] depth bits (ping-pong); preprocess leaves the RAW keys (by Gaussian id) in [1]
+    uint32_t* sort_vals[2];   // [P] Gaussian ids (ping-pong); [final][0 .. V) = depth order of the V listed Gaussians
+    uint32_t* offsets;        // [V] exclusive prefix of tiles_touched in DEPTH order: where emit puts a Gaussian's instances
+    uint32_t* goff;           // [P] the same prefix by Gaussian id (listed Gaussians only) = its first row slot in the backward
+    uint2* blk_agg;           // [ceil(P/256)] per preprocess block: (listed Gaussians, tiles touched)
     uint32_t* scratch;        // scan partials + radix histograms
     uint32_t* counters;       // [COUNTER_WORDS]: 1 = error flag, 2 = cull_variant of this forward, NR_BASE.. = num_rendered stripes
     size_t scratch_words;
@@ -39,6 +40,8 @@ struct GeomView {
 struct ImageView {
     uint32_t* n_contrib;  // [HW]
     uint2* ranges;        // [T]
+    uint32_t* qcost;      // [4T] per 8x8 quadrant: list positions its wave has to walk in the backward (max n_contrib)
+    uint32_t* qorder;     // [quad_grid(4T)] launch slot -> quadrant, heaviest first inside each XCD's band (backward)
 };
 // Backward scratch (goi_raster_backward_scratch_bytes): one 128-byte partial-gradient row per
 // (emit-order instance, quadrant) and one validity byte per row.
@@ -65,21 +68,27 @@ size_t binning_layout(int N, char* base, BinView* v);
 struct Options {
     int fwd_variant = 1;  // 0: one candidate per loop trip, 1: two candidates per trip (default)
     int bwd_variant = 0;  // low 4 bits: 0 atomic-free wave-per-quadrant backward (needs scratch) with the split-bf16
-                          // MFMA flush, 2 the same with the exact-fp32 flush, 1 workgroup-per-tile + atomics;
-                          // bits 4..15: timing experiments (GOI_EXPERIMENTS=1 only, invalid gradients)
+                          // MFMA flush, 2 the same with the exact-fp32 flush, 1 workgroup-per-tile + atomics
     int sort_variant = 1;  // 0: histogram / scan / scatter per pass, 1: onesweep (decoupled look-back, default)
     int decode_variant = 1;  // semantic decode, S <= 16: 1 split-bf16 MFMA contraction, 2 pixel blocks per operand fetch (2: 4 blocks, 3: 1 block; bit-identical), 0 fp32 MFMA
     int cull_variant = 1;  // 0: a Gaussian is listed in every tile of its 3-sigma rectangle (the reference's lists),
                            // 1: only in the tiles its exact contribution box touches (same images and gradients)
+    int bwd_order = 1;     // backward blend: 1 the quadrants of each XCD's band are launched longest-first (their cost is
+                           // known from the forward's n_contrib), 0 in tile order.  Same rows, same gradients.
 };
-extern Options g_options;
+// The switches an entry point works with are a per-THREAD snapshot taken when the call starts (refresh_options):
+// goi_raster_set_option changes the process-wide set under a mutex, and a call that is already running on another host
+// thread keeps the values it started with -- every stage of one forward or backward sees one consistent set.
+extern thread_local Options g_options;
+void refresh_options();
 
 // ---- device-wide primitives (scan_sort.hip) ----------------------------------------------------
 size_t scan_scratch_words(size_t n);
 size_t sort_scratch_words(size_t n);
 // out[i] = sum_{j<i} f(j), f(j) = gather ? in[gather[j]] : in[j]; *total (device, may be NULL) = sum.
+// n_dev (may be NULL): the count lives on the device, `n` is a capacity (grids cover n; min(*n_dev, n) elements are scanned).
 void exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, size_t n, uint32_t* total,
-                        uint32_t* scratch, hipStream_t s);
+                        uint32_t* scratch, hipStream_t s, const uint32_t* n_dev = nullptr);
 // Stable LSD radix sort of (key,val) pairs on key bits [lo, hi).  Data start in keys[0]/vals[0];
 // returns the index (0/1) of the buffers holding the sorted result.
 // Onesweep control words (status, global digit histograms, tickets, error) sit at the start of `scratch`:
@@ -97,6 +106,12 @@ uint32_t* radix_sort_ghist(uint32_t* scratch, size_t n, int lo, int hi);
 // ---- stages ---------------------------------------------------------------------------------------
 void launch_preprocess_fwd(const GoiRasterScene& sc, const GeomView& g, int* radii, uint2* ranges, int n_tiles,
                            hipStream_t s);
+// Listed Gaussians (tiles_touched > 0) compacted in id order into sort_keys[0] / sort_vals[0] (the depth sort's input),
+// counters[COUNTER_V / COUNTER_N], and -- ghist != NULL -- the four digit histograms of the compacted keys (the onesweep
+// sort's prologue).  pad: entries [V, P) get key 0xFFFFFFFF (a sort
+// that cannot take its count from the device sorts all P).
+void launch_compact_listed(int P, const GeomView& g, uint32_t* ghist, bool pad, hipStream_t s);
+constexpr int PRE_BLOCK = 256;  // Gaussians per workgroup of preprocess_fwd_k = granularity of blk_agg / blk_pre
 // cap: instances keys[] / vals[] can hold (instances past it are dropped: only an overflowed speculative frame has any)
 void launch_emit(int P, int W, int H, const GeomView& g, const uint32_t* order, const int* radii, uint32_t* keys,
                  uint32_t* vals, uint32_t cap, hipStream_t s);
@@ -109,6 +124,9 @@ void launch_render_fwd(const GoiRasterScene& sc, const GeomView& g, const ImageV
                        float* out_color, float* out_sem, float* out_depth, float* out_alpha, hipStream_t s);
 void launch_trace_fwd(const GoiRasterScene& sc, const float* img_sem, const GeomView& g, const ImageView& im,
                       const uint32_t* point_list, float* out_color, float* gau_sem, int* num_gsem, hipStream_t s);
+// launch order of the backward's quadrant waves (render_bwd.hip): im.qcost -> im.qorder
+bool quad_order_enabled(int W, int H);
+void launch_quad_order(const GoiRasterScene& sc, const ImageView& im, hipStream_t s);
 // atomic-free backward blend: partial rows + flags into the scratch (render_bwd.hip)
 void launch_render_bwd_rows(const GoiRasterScene& sc, const GeomView& g, const ImageView& im,
                             const uint32_t* point_list, const int* radii, const float* out_alpha, const float* dL_dpix,
@@ -198,6 +216,7 @@ constexpr int COUNTER_WORDS = NR_BASE + NR_STRIPES * NR_STRIDE;
 constexpr int COUNTER_CULL = 2;  // GeomView::counters[COUNTER_CULL]: the forward's cull_variant, read by emit / backward
 constexpr int COUNTER_N = 3;     // num_rendered as ONE device word (the scan's total): what the tile sort, the ranges pass and
                                  // the backward's row reduction read when the host sized the frame from a capacity
+constexpr int COUNTER_V = 5;     // number of LISTED Gaussians (tiles_touched > 0): the depth sort, its prefix sum and emit work on these only
 constexpr int COUNTER_OVF = 4;   // 1: this frame's instance list was TRUNCATED (num_rendered > the binning capacity of a
                                  // speculative forward).  Written by emit; every backward kernel reads it and, if set, produces
                                  // ZERO gradients: a truncated frame must never reach the optimiser (the reference sizes its

@@ -84,8 +84,8 @@ __device__ __forceinline__ Camera load_camera(const float* __restrict__ v, const
 __global__ __launch_bounds__(256) void preprocess_fwd_k(const PreArgs args, GaussRec* __restrict__ rec,
                                                         float* __restrict__ cov3D_out,
                                                         uint32_t* __restrict__ tiles_touched,
-                                                        uint8_t* __restrict__ clamped, uint32_t* __restrict__ sort_key,
-                                                        uint32_t* __restrict__ sort_val, int* __restrict__ radii,
+                                                        uint8_t* __restrict__ clamped, uint32_t* __restrict__ raw_key,
+                                                        uint2* __restrict__ blk_agg, int* __restrict__ radii,
                                                         uint32_t* __restrict__ counters, uint2* __restrict__ ranges,
                                                         int n_tiles) {
     const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -215,20 +215,124 @@ __global__ __launch_bounds__(256) void preprocess_fwd_k(const PreArgs args, Gaus
         radii[idx] = my_radius_i;
         tiles_touched[idx] = touched;
         clamped[idx] = clamp_bits;
-        sort_key[idx] = key;
-        sort_val[idx] = (uint32_t)idx;
+        raw_key[idx] = key;  // depth bits by Gaussian id; compact_listed_k keeps the listed ones for the depth sort
     }
     // num_rendered = sum of tiles_touched: order-independent, so it is formed HERE (one integer atomic per wave)
     // instead of falling out of the prefix sum after the depth sort -- the host can read it while the sort runs
-    __shared__ uint32_t s_wsum[4];
+    __shared__ uint32_t s_wsum[4], s_wvis[4];
     uint32_t wsum = live ? touched : 0u;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) wsum += (uint32_t)__shfl_xor((int)wsum, d, 64);
-    if ((threadIdx.x & 63) == 0) s_wsum[threadIdx.x >> 6] = wsum;
+    const uint32_t wvis = (uint32_t)__popcll(__ballot(live && touched > 0));  // LISTED Gaussians of this wave
+    if ((threadIdx.x & 63) == 0) {
+        s_wsum[threadIdx.x >> 6] = wsum;
+        s_wvis[threadIdx.x >> 6] = wvis;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t bsum = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
         if (bsum) atomicAdd(&counters[NR_BASE + NR_STRIDE * (blockIdx.x % NR_STRIPES)], bsum);
+        // the block's aggregate: compact_listed_k ranks the listed Gaussians with it
+        blk_agg[blockIdx.x] = make_uint2(s_wvis[0] + s_wvis[1] + s_wvis[2] + s_wvis[3], bsum);
+    }
+}
+
+// Compaction of the LISTED Gaussians (tiles_touched > 0) for the depth sort.  A workgroup covers COMPACT_ROUNDS
+// consecutive blocks of preprocess_fwd_k (2048 Gaussians).  Its base rank is the sum of the per-block aggregates
+// preprocess left behind for the blocks in front of it -- every workgroup adds them up itself (at most 3907 pairs at
+// 1 M Gaussians, out of L2: cheaper than a scan kernel of its own plus the launch) -- and workgroup 0 also leaves the
+// totals in counters[COUNTER_V] (listed Gaussians) and counters[COUNTER_N] (tiles touched = num_rendered).  A listed
+// Gaussian puts (depth key, id) at its rank among the listed ones, i.e. in id order: the sort is stable, so ties keep
+// ascending id as in the reference.  Reading the keys anyway, the workgroup counts their four digits for the onesweep
+// sort (which then skips its own histogram pass); 2048 keys per workgroup keep the global atomics of that flush at the
+// level of sweep_hist_k (one flush per 256 keys cost 2.3 M same-line atomics: +45 us).
+// pad (a sort that cannot take its count from the device): the unlisted Gaussians follow with key 0xFFFFFFFF.
+constexpr int COMPACT_ROUNDS = 8;
+__global__ __launch_bounds__(PRE_BLOCK) void compact_listed_k(int P, const uint32_t* __restrict__ tiles_touched,
+                                                              const uint32_t* __restrict__ raw_key,
+                                                              const uint2* __restrict__ blk_agg,
+                                                              uint32_t* __restrict__ counters,
+                                                              uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                              uint32_t* __restrict__ ghist, int pad) {
+    __shared__ uint32_t s_h[4][256];
+    __shared__ uint32_t s_wv[COMPACT_ROUNDS][4];
+    __shared__ uint32_t s_red[3][4];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int nblk = (P + PRE_BLOCK - 1) / PRE_BLOCK;
+    const int blk0 = blockIdx.x * COMPACT_ROUNDS;
+    // ---- all of this workgroup's Gaussians are requested before anything is waited for
+    uint32_t t[COMPACT_ROUNDS], key[COMPACT_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < COMPACT_ROUNDS; r++) {
+        const int i = (blk0 + r) * PRE_BLOCK + tid;
+        const bool live = i < P;
+        t[r] = live ? tiles_touched[i] : 0u;
+        key[r] = live ? raw_key[i] : 0xFFFFFFFFu;
+    }
+    // ---- base rank (blocks in front) and totals
+    uint32_t before = 0, all_v = 0, all_t = 0;
+    for (int i = tid; i < nblk; i += PRE_BLOCK) {
+        const uint2 a = blk_agg[i];
+        before += i < blk0 ? a.x : 0u;
+        all_v += a.x;
+        all_t += a.y;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        before += (uint32_t)__shfl_xor((int)before, d, 64);
+        all_v += (uint32_t)__shfl_xor((int)all_v, d, 64);
+        all_t += (uint32_t)__shfl_xor((int)all_t, d, 64);
+    }
+    if (lane == 0) {
+        s_red[0][w] = before;
+        s_red[1][w] = all_v;
+        s_red[2][w] = all_t;
+    }
+    if (ghist) {
+#pragma unroll
+        for (int p = 0; p < 4; p++) s_h[p][tid] = 0;
+    }
+    unsigned long long bal[COMPACT_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < COMPACT_ROUNDS; r++) {
+        bal[r] = __ballot(t[r] > 0);
+        if (lane == 0) s_wv[r][w] = (uint32_t)__popcll(bal[r]);
+    }
+    __syncthreads();
+    uint32_t base = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+    const uint32_t V = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
+    if (blockIdx.x == 0 && tid == 0) {
+        counters[COUNTER_V] = V;
+        counters[COUNTER_N] = s_red[2][0] + s_red[2][1] + s_red[2][2] + s_red[2][3];
+    }
+#pragma unroll
+    for (int r = 0; r < COMPACT_ROUNDS; r++) {
+        const int i = (blk0 + r) * PRE_BLOCK + tid;
+        uint32_t v_ex = base + (uint32_t)__popcll(bal[r] & ((1ull << lane) - 1ull));
+        for (int k = 0; k < w; k++) v_ex += s_wv[r][k];
+        base += s_wv[r][0] + s_wv[r][1] + s_wv[r][2] + s_wv[r][3];
+        if (i < P) {
+            if (t[r] > 0) {
+                keys[v_ex] = key[r];
+                vals[v_ex] = (uint32_t)i;
+                if (ghist) {
+#pragma unroll
+                    for (int p = 0; p < 4; p++) atomicAdd(&s_h[p][(key[r] >> (8 * p)) & 255u], 1u);
+                }
+            } else if (pad) {
+                const uint32_t pos = V + ((uint32_t)i - v_ex);  // unlisted Gaussians before i
+                keys[pos] = 0xFFFFFFFFu;
+                vals[pos] = (uint32_t)i;
+            }
+        }
+    }
+    if (ghist) {
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const uint32_t c = s_h[p][tid];
+            if (c) atomicAdd(&ghist[p * 256 + tid], c);
+        }
     }
 }
 
@@ -603,6 +707,7 @@ template <int K, int GPQ>  // K = row_floats / 16; GPQ = Gaussians per quarter w
 __global__ __launch_bounds__(256) void reduce_rows_k(int P, int S, int nch, uint32_t N_cap, const uint32_t* __restrict__ n_dev,
                                                      const uint32_t* __restrict__ order,
                                                      const uint32_t* __restrict__ offsets,
+                                                     const uint32_t* __restrict__ tiles_touched,
                                                      const float* __restrict__ rows, const uint8_t* __restrict__ flags,
                                                      float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic,
                                                      float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor,
@@ -613,26 +718,55 @@ __global__ __launch_bounds__(256) void reduce_rows_k(int P, int S, int nch, uint
     // exact forward passes N_cap = num_rendered; the speculative one a capacity, and an overflowed frame stored only
     // the first N_cap instances)
     // a TRUNCATED frame (COUNTER_OVF, set by emit) has no valid rows: every Gaussian gets zeros
-    const uint32_t N = n_dev[COUNTER_OVF - COUNTER_N] ? 0u : min(N_cap, *n_dev);
+    const bool truncated = n_dev[COUNTER_OVF - COUNTER_N] != 0;
+    const uint32_t N = truncated ? 0u : min(N_cap, *n_dev);
+    const int V = truncated ? 0 : (int)n_dev[COUNTER_V - COUNTER_N];  // listed Gaussians: the only ones that own rows
     const int lane = threadIdx.x & 63, quarter = lane >> 4, e = lane & 15;
     const uint32_t* flags32 = reinterpret_cast<const uint32_t*>(flags);
     const int nsem = nch - 4;
-    // Gaussians are visited in DEPTH order: that is the order of the slot space, so consecutive quarter
-    // waves stream through rows[] and flags[] front to back (DRAM-page and TLB friendly); only the
-    // per-Gaussian outputs are scattered.  Step k of the block covers 16 consecutive Gaussians.
+    // ---- phase 0 (the first ceil(P/256) workgroups): zeros for the Gaussians that are NOT listed (culled, or a culled
+    // rectangle without tiles; all of them for a truncated frame) -- one Gaussian per lane.  The listed ones are written
+    // by phase 1 below, so every element of the six arrays is written exactly once.
+    {
+        const int i = blockIdx.x * 256 + threadIdx.x;
+        if (i < P && (truncated || tiles_touched[i] == 0)) {
+            if ((S & 3) == 0) {
+                float4* d4 = reinterpret_cast<float4*>(dL_dsemantic + (size_t)i * S);
+                for (int ch = 0; ch < S / 4; ch++) d4[ch] = make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                for (int ch = 0; ch < S; ch++) dL_dsemantic[(size_t)i * S + ch] = 0.f;
+            }
+            if (dL_dopacity) {  // (NULL in the feature-gradient-only reduction)
+                dL_dopacity[i] = 0.f;
+                dL_ddepth[i] = 0.f;
+#pragma unroll
+                for (int k = 0; k < 3; k++) dL_dcolor[(size_t)i * 3 + k] = dL_dmean2D[(size_t)i * 3 + k] = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; k++) dL_dconic[(size_t)i * 4 + k] = 0.f;
+            }
+        }
+    }
+    // ---- phase 1: the V LISTED Gaussians in DEPTH order.  That is the order of the slot space (emit order), so
+    // consecutive quarter waves stream through rows[] and flags[] front to back -- and it is the order in which the valid
+    // rows are DENSE: near Gaussians contribute in most of their tiles, far ones are behind the saturation front and own
+    // hardly any row, so the rows that exist sit close together at the front of the slot space (DRAM pages, TLB).  A
+    // slot space in id order (tried: the outputs then leave as neighbouring lines instead of six scattered partial
+    // stores per Gaussian) spreads the same rows evenly over 2.6 GB and costs more than the scatter saves (0.235 ->
+    // 0.32 ms).  Step k of the block covers 16 consecutive listed Gaussians.
     const int i0 = blockIdx.x * (16 * GPQ) + (threadIdx.x >> 4);
+    if (blockIdx.x * (16 * GPQ) >= V) return;  // (block-uniform)
     struct Meta {
         uint32_t g, off0, off1;
     };
-    // slots of the i-th Gaussian in depth order: [offsets[i], offsets[i+1]) -- straight from the prefix sum; the
+    // slots of the i-th listed Gaussian in depth order: [offsets[i], offsets[i+1]) -- straight from the prefix sum; the
     // Gaussian's id is only needed for the final store
     auto load_meta = [&](int k) {
         const int i = i0 + 16 * k;
         Meta m{0u, 0u, 0u};
-        if (k < GPQ && i < P) {
+        if (k < GPQ && i < V) {
             m.g = order[i];
             m.off0 = min(offsets[i], N);
-            m.off1 = i + 1 < P ? min(offsets[i + 1], N) : N;
+            m.off1 = i + 1 < V ? min(offsets[i + 1], N) : N;
         }
         return m;
     };
@@ -643,10 +777,10 @@ __global__ __launch_bounds__(256) void reduce_rows_k(int P, int S, int nch, uint
     uint32_t w_cur = load_flags(cur, 0);
 #pragma unroll 1
     for (int k = 0; k < GPQ; k++) {
-        if (i0 + 16 * k - (int)(threadIdx.x >> 4) >= P) break;  // (block-uniform: nothing left for any quarter wave)
+        if (i0 + 16 * k - (int)(threadIdx.x >> 4) >= V) break;  // (block-uniform: nothing left for any quarter wave)
         const Meta nn = load_meta(k + 2);        // two Gaussians ahead: slot range
         const uint32_t w_nxt = load_flags(nxt, 0);  // one ahead: validity bytes of its first 16 instances
-        const bool live = i0 + 16 * k < P;
+        const bool live = i0 + 16 * k < V;
         const uint32_t cnt = cur.off1 - cur.off0;
         const size_t inst0 = cur.off0;
         float sum[K];
@@ -665,10 +799,6 @@ __global__ __launch_bounds__(256) void reduce_rows_k(int P, int S, int nch, uint
                 m |= ((bal >> (16 * quarter)) & 0xFFFFull) << (16 * q);
             }
             const float* chunk = rows + (inst0 + c) * 4 * RF;
-#ifdef GOI_EXP_DENSE2
-            int dense_j = 0;  // TIMING EXPERIMENT (wrong results): the j-th valid row of a Gaussian is read from a compact,
-                              // contiguous position -- what a densely packed row store would look like to this kernel
-#endif
             while (m) {
                 float v[INFLIGHT][K];
 #pragma unroll
@@ -676,11 +806,7 @@ __global__ __launch_bounds__(256) void reduce_rows_k(int P, int S, int nch, uint
                     const bool have = m != 0;
                     const int bit = have ? __builtin_ctzll(m) : 0;
                     if (have) m &= m - 1;
-#ifdef GOI_EXP_DENSE2
-                    const float* r = rows + ((inst0 + c) * 4 / 5 + (size_t)(dense_j++)) * RF;
-#else
                     const float* r = chunk + (size_t)((bit & 15) * 4 + (bit >> 4)) * RF;
-#endif
                     if (K == 2) {  // one 8-byte load per lane: the quarter wave reads the 128-byte row in one request
                         const float2 t = have ? reinterpret_cast<const float2*>(r)[e] : make_float2(0.f, 0.f);
                         v[i][0] = t.x;
@@ -749,11 +875,14 @@ __global__ __launch_bounds__(256) void emit_k(int P, int gx, int gy, const Gauss
     // guard below never fires; the speculative forward sizes them from a guess, and a frame that overflows must
     // stay memory-safe and self-consistent (the tile counts only count what was stored) until the host notices.
     const bool cull = counters[COUNTER_CULL] != 0;
+    P = min(P, (int)counters[COUNTER_V]);  // order[] / offsets[] hold the LISTED Gaussians only (front of the depth order)
     // the frame's "truncated" flag (COUNTER_OVF): emit is the first kernel that knows both the count and the capacity
     if (blockIdx.x == 0 && threadIdx.x == 0) counters[COUNTER_OVF] = counters[COUNTER_N] > cap ? 1u : 0u;
     // COUNT: the blocks also zero the control words of the tile sort that follows (its own memset launch otherwise)
     if (COUNT)
         for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < clear_words; i += gridDim.x * 256u) clear[i] = 0u;
+    constexpr int ROUNDS_PER_BLOCK = COUNT ? EMIT_ROUNDS : 1;
+    if ((int)blockIdx.x * ROUNDS_PER_BLOCK * 256 >= P) return;  // (block-uniform) nothing listed left for this block
     extern __shared__ uint32_t s_cnt[];  // [gx * gy] when COUNT
     __shared__ int s_incl[4][64];    // per wave: inclusive scan of the rectangles' tile counts
     __shared__ uint4 s_info[4][64];  // (x0 | y0 << 16, exclusive count, offsets[] - exclusive count, Gaussian id)
@@ -774,7 +903,7 @@ __global__ __launch_bounds__(256) void emit_k(int P, int gx, int gy, const Gauss
         if (i < P) {
             g = order[i];
             off = offsets[i];
-            goff[g] = off;
+            goff[g] = off;  // the Gaussian's first row slot in the backward (slot space = emit order = depth order)
             const int r = radii[g];
             if (r > 0) {
                 const float4 q0 = rec[g].q0;
@@ -834,43 +963,50 @@ __global__ __launch_bounds__(256) void emit_k(int P, int gx, int gy, const Gauss
 }
 
 // One workgroup: per-tile counts (in ranges[t].y) -> ranges[t] = [start, end) ((0,0) for an empty tile, as
-// the reference leaves it) and the global digit histograms of the tile sort's passes.
+// the reference leaves it) and the global digit histograms of the tile sort's passes.  A thread owns IT = ceil(T / 1024)
+// consecutive tiles (IT <= 12: emit only counts grids of at most 12288 tiles), so the prefix sum is ONE block scan
+// (chunks of 1024 tiles with three barriers each took 14 us at 6600 tiles: pure latency).
+constexpr int TRH_MAX_IT = 12;
 __global__ __launch_bounds__(1024) void tile_ranges_hist_k(int T, uint2* __restrict__ ranges, int passes, int shift0,
                                                            int nbits0, int shift1, int nbits1,
                                                            uint32_t* __restrict__ ghist) {
     __shared__ uint32_t s_h[2][256];
     __shared__ uint32_t s_wave[16];
-    __shared__ uint32_t s_carry;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (tid < 512) (&s_h[0][0])[tid] = 0;
-    if (tid == 0) s_carry = 0;
-    __syncthreads();
-    for (int base = 0; base < T; base += 1024) {
-        const int t = base + tid;
-        const uint32_t c = t < T ? ranges[t].y : 0u;
-        // inclusive scan of the 1024 counts of this chunk
-        uint32_t v = c;
+    const int IT = (T + 1023) / 1024;
+    const int t0 = tid * IT;
+    uint32_t c[TRH_MAX_IT];
+    uint32_t sum = 0;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = __shfl_up(v, d, 64);
-            if (lane >= d) v += o;
-        }
-        if (lane == 63) s_wave[w] = v;
-        __syncthreads();
-        uint32_t pre = s_carry;
-        for (int k = 0; k < w; k++) pre += s_wave[k];
-        const uint32_t end = pre + v;
-        if (t < T) {
-            ranges[t] = c ? make_uint2(end - c, end) : make_uint2(0u, 0u);
-            if (c) {
-                atomicAdd(&s_h[0][((uint32_t)t >> shift0) & ((1u << nbits0) - 1u)], c);
-                if (passes > 1) atomicAdd(&s_h[1][((uint32_t)t >> shift1) & ((1u << nbits1) - 1u)], c);
-            }
-        }
-        __syncthreads();
-        if (tid == 1023) s_carry = end;
-        __syncthreads();
+    for (int k = 0; k < TRH_MAX_IT; k++) {
+        c[k] = (k < IT && t0 + k < T) ? ranges[t0 + k].y : 0u;
+        sum += c[k];
     }
+    uint32_t v = sum;  // inclusive scan of the 1024 per-thread sums
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    if (lane == 63) s_wave[w] = v;
+    __syncthreads();  // (also orders the zeroing of s_h before the atomics below)
+    uint32_t run = v - sum;
+    for (int k = 0; k < w; k++) run += s_wave[k];
+#pragma unroll
+    for (int k = 0; k < TRH_MAX_IT; k++) {
+        const int t = t0 + k;
+        if (k < IT && t < T) {
+            const uint32_t ck = c[k];
+            ranges[t] = ck ? make_uint2(run, run + ck) : make_uint2(0u, 0u);
+            if (ck) {
+                atomicAdd(&s_h[0][((uint32_t)t >> shift0) & ((1u << nbits0) - 1u)], ck);
+                if (passes > 1) atomicAdd(&s_h[1][((uint32_t)t >> shift1) & ((1u << nbits1) - 1u)], ck);
+            }
+            run += ck;
+        }
+    }
+    __syncthreads();
     if (tid < 256) {
         ghist[tid] = s_h[0][tid];
         ghist[256 + tid] = s_h[1][tid];
@@ -912,8 +1048,15 @@ void launch_preprocess_fwd(const GoiRasterScene& sc, const GeomView& g, int* rad
     a.focal_y = sc.H / (2.0f * sc.tan_fovy);
     a.focal_x = sc.W / (2.0f * sc.tan_fovx);
     a.view_p = sc.viewmatrix; a.proj_p = sc.projmatrix; a.campos_p = sc.campos;
-    preprocess_fwd_k<<<dim3((sc.P + 255) / 256), dim3(256), 0, s>>>(a, g.rec, g.cov3D, g.tiles_touched, g.clamped,
-                                                                   g.sort_keys[0], g.sort_vals[0], radii, g.counters, ranges, n_tiles);
+    static_assert(PRE_BLOCK == 256, "preprocess_fwd_k is written for 256-thread workgroups");
+    preprocess_fwd_k<<<dim3((sc.P + PRE_BLOCK - 1) / PRE_BLOCK), dim3(PRE_BLOCK), 0, s>>>(
+        a, g.rec, g.cov3D, g.tiles_touched, g.clamped, g.sort_keys[1], g.blk_agg, radii, g.counters, ranges, n_tiles);
+}
+
+void launch_compact_listed(int P, const GeomView& g, uint32_t* ghist, bool pad, hipStream_t s) {
+    const int nblk = (P + PRE_BLOCK - 1) / PRE_BLOCK;
+    compact_listed_k<<<dim3((nblk + COMPACT_ROUNDS - 1) / COMPACT_ROUNDS), dim3(PRE_BLOCK), 0, s>>>(
+        P, g.tiles_touched, g.sort_keys[1], g.blk_agg, g.counters, g.sort_keys[0], g.sort_vals[0], ghist, pad ? 1 : 0);
 }
 
 void launch_preprocess_bwd(const GoiRasterScene& sc, const GeomView& g, const int* radii, const float* dL_dmean2D,
@@ -955,13 +1098,13 @@ void launch_reduce_rows(const GoiRasterScene& sc, const GeomView& g, int N, cons
     const dim3 grid((sc.P + 16 * REDUCE_GPQ - 1) / (16 * REDUCE_GPQ));
     const uint32_t* order = g.sort_vals[depth_sort_result_index()];
     if (rf == 32)
-        reduce_rows_k<2, REDUCE_GPQ><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, scr.rows, scr.flags,
+        reduce_rows_k<2, REDUCE_GPQ><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, g.tiles_touched, scr.rows, scr.flags,
                                                     dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dsemantic, dL_ddepth);
     else if (rf == 16)
-        reduce_rows_k<1, REDUCE_GPQ><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, scr.rows, scr.flags,
+        reduce_rows_k<1, REDUCE_GPQ><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, g.tiles_touched, scr.rows, scr.flags,
                                                     dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dsemantic, dL_ddepth);
     else
-        reduce_rows_k<3, REDUCE_GPQ><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, scr.rows, scr.flags,
+        reduce_rows_k<3, REDUCE_GPQ><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, g.tiles_touched, scr.rows, scr.flags,
                                                     dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dsemantic, dL_ddepth);
 }
 
@@ -972,10 +1115,10 @@ void launch_reduce_sem_rows(const GoiRasterScene& sc, const GeomView& g, int N, 
     const dim3 grid((sc.P + 16 * REDUCE_GPQ - 1) / (16 * REDUCE_GPQ));
     const uint32_t* order = g.sort_vals[depth_sort_result_index()];
     if (row_floats == 16)
-        reduce_rows_k<1, REDUCE_GPQ><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, rows, flags, nullptr,
+        reduce_rows_k<1, REDUCE_GPQ><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, g.tiles_touched, rows, flags, nullptr,
                                                     nullptr, nullptr, nullptr, dL_dsemantic, nullptr);
     else
-        reduce_rows_k<2, REDUCE_GPQ><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, rows, flags, nullptr,
+        reduce_rows_k<2, REDUCE_GPQ><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, g.tiles_touched, rows, flags, nullptr,
                                                     nullptr, nullptr, nullptr, dL_dsemantic, nullptr);
 }
 
@@ -988,7 +1131,9 @@ void launch_emit(int P, int W, int H, const GeomView& g, const uint32_t* order, 
 
 bool emit_can_count_tiles(int W, int H) {
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
-    return (size_t)gx * gy * sizeof(uint32_t) <= 48 * 1024 && tile_key_bits((uint32_t)(gx * gy)) <= 16;
+    // (tile_ranges_hist_k: at most TRH_MAX_IT x 1024 tiles; the per-tile LDS counters of emit: 48 KB)
+    return (size_t)gx * gy <= (size_t)TRH_MAX_IT * 1024 && (size_t)gx * gy * sizeof(uint32_t) <= 48 * 1024 &&
+           tile_key_bits((uint32_t)(gx * gy)) <= 16;
 }
 
 // emit + per-tile counts; ranges must be zeroed by the caller's stream order (done here)

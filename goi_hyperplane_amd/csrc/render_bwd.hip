@@ -78,8 +78,7 @@ struct BwdCfg {
     static constexpr int NB = (NSEM + 15) / 16;  // 16-column MFMA blocks of semantic channels (+ 1 mixed block)
 };
 
-// MODE 0: split-bf16 flush (default).  MODE 1: exact-fp32 flush.  MODE 2: exact-fp32 flush + timing-experiment
-// flags (bits of bwd_variant skip parts of the work; invalid gradients).  Only MODE 2 reads the flags at run time.
+// MODE 0: split-bf16 flush (default).  MODE 1: exact-fp32 flush.
 template <int S4, int MODE>
 __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int gx, int gy,
@@ -87,8 +86,8 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
     const int* __restrict__ radii, const uint32_t* __restrict__ goff, const float* __restrict__ bg,
     const float* __restrict__ out_alpha, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
     const float* __restrict__ dL_dpixsem, const float* __restrict__ dL_dpixdepth, const float* __restrict__ dL_dalphas,
-    float* __restrict__ rows, uint8_t* __restrict__ flags, int row_floats, int exp_flags_rt,
-    const uint32_t* __restrict__ counters) {
+    float* __restrict__ rows, uint8_t* __restrict__ flags, int row_floats,
+    const uint32_t* __restrict__ counters, const uint32_t* __restrict__ qorder) {
     using Cfg = BwdCfg<S4>;
     const bool cull = counters[COUNTER_CULL] != 0;  // the rectangles the forward listed
     constexpr int NF4 = Cfg::NF4, NSEM = Cfg::NSEM, NCH = Cfg::NCH, NB = Cfg::NB;
@@ -98,7 +97,7 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
     __shared__ f32x4 s_geo2[BATCH + GROUP];  // (A0, A4, lim, slot index (bits))
     __shared__ float2 s_cen[BATCH + GROUP];  // Gaussian centre - quadrant centre (the flush expands the moments around it)
     __shared__ float4 s_feat[BATCH * NF4];  // (r,g,b,depth), semantics...
-    constexpr bool SPLIT = MODE == 0, EXP = MODE == 2;
+    constexpr bool SPLIT = MODE == 0;
     // [row][pixel]: rows 0..7 = w of slot, rows 8..15 = h of slot.  fp32 flush: floats, row stride TSTRIDE.
     // Split flush: floats as well (row stride TS_SPLIT, 16-byte aligned rows); the flush splits them into bf16
     // hi / lo after reading its A operand (two dword stores per member cost the LDS half of four 16-bit ones).
@@ -107,8 +106,8 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
     __shared__ __attribute__((aligned(16))) char s_traw[T_BYTES];
     float* const s_t = reinterpret_cast<float*>(s_traw);
 
-    const int exp_flags = EXP ? exp_flags_rt : 0;
-    const QuadGeom t = quad_geom(W, H, gx, n_quads);
+    // launch slot -> quadrant: tile order, or (qorder) the band's quadrants longest-first -- see quad_order_k
+    const QuadGeom t = quad_geom_of(qorder ? (int)qorder[quad_slot()] : quad_slot(), W, H, gx, n_quads);
     if (t.tile < 0) return;
     if (counters[COUNTER_OVF]) return;  // truncated frame: no rows (reduce_rows_k writes zero gradients)
     const int lane = t.lane;
@@ -248,7 +247,6 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
 
     // flushes `cnt` filled slots: D = [w]^T dL (NB blocks) and [h]^T basis, then one row per member
     auto flush_group = [&](int cnt) {
-        if (exp_flags & 1) return;
         f32x4 acc[NB];
         f32x4 accx = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -296,7 +294,7 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
         for (int r = 0; r < 4; r++) {
             const int row = 4 * kq + r;
             if (row >= GROUP && mm >= 4 && mm < 12) s_t[(row - GROUP) * 8 + (mm - 4)] = accx[r];  // moments -> exchange area
-            if (row < cnt && !(exp_flags & 2)) {
+            if (row < cnt) {
                 const int idx = (int)((jpack >> (8 * row)) & 0xFF);
                 float* dst = rows + (size_t)__float_as_uint(s_geo2[idx].w) * row_floats;
 #pragma unroll
@@ -309,7 +307,7 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
         }
         __builtin_amdgcn_wave_barrier();
         // moments -> (mean2D.x, mean2D.y, conic a, b, c, opacity): one lane per group member
-        if (lane < cnt && !(exp_flags & 2)) {
+        if (lane < cnt) {
             const float4 m03 = *reinterpret_cast<const float4*>(&s_t[lane * 8]);
             const float2 m45 = *reinterpret_cast<const float2*>(&s_t[lane * 8 + 4]);
             const int idx = (int)((jpack >> (8 * lane)) & 0xFF);
@@ -394,21 +392,17 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
             const bool c = live && e.hit;
 
             // <feature, dL/dpixel> as packed fp32 FMAs (v_pk_fma_f32: two channels per instruction)
-            f32x2 dot2 = {0.f, 0.f};
-            if (!(exp_flags & 4)) {
-                const f32x4 f0 = s_feat4[j * NF4];  // r, g, b, depth
-                f32x2 da = f0.xy * dL2[NSEM / 2];
-                f32x2 db = f0.zw * dL2[NSEM / 2 + 1];
+            const f32x4 f0 = s_feat4[j * NF4];  // r, g, b, depth
+            f32x2 da = f0.xy * dL2[NSEM / 2];
+            f32x2 db = f0.zw * dL2[NSEM / 2 + 1];
 #pragma unroll
-                for (int i = 0; i < S4; i++) {
-                    const f32x4 f = s_feat4[j * NF4 + 1 + i];
-                    da = __builtin_elementwise_fma(f.xy, dL2[2 * i], da);
-                    db = __builtin_elementwise_fma(f.zw, dL2[2 * i + 1], db);
-                }
-                dot2 = da + db;
+            for (int i = 0; i < S4; i++) {
+                const f32x4 f = s_feat4[j * NF4 + 1 + i];
+                da = __builtin_elementwise_fma(f.xy, dL2[2 * i], da);
+                db = __builtin_elementwise_fma(f.zw, dL2[2 * i + 1], db);
             }
-            float dotv = (dot2.x + dot2.y) + dLa;
-            if (exp_flags & 4) dotv = dLa;  // experiment: no feature reads / dot product
+            const f32x2 dot2 = da + db;
+            const float dotv = (dot2.x + dot2.y) + dLa;
             const float one_m_a = 1.f - e.alpha;
             const float inv = __builtin_amdgcn_rcpf(one_m_a);
             const float Tn = T * inv;
@@ -450,22 +444,89 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
     if (nslot > 0) flush_group(nslot);
 }
 
+// Launch order of the backward's quadrant waves.  The hardware deals workgroup b to XCD b % 8 and, inside an XCD, starts
+// workgroups in index order as wave slots free up.  A quadrant's cost is known before the kernel starts -- its wave walks
+// the tile list back from the largest n_contrib of its 64 pixels (qcost[], left by the forward blend) -- and the costs
+// differ by an order of magnitude, so in tile order the kernel ends with a long tail of half-empty CUs (~15 % of its
+// wave slots idle).  One workgroup per XCD band sorts the band's quadrants by cost, longest first (LPT scheduling): a
+// STABLE counting sort on 64 cost buckets, so quadrants of similar cost keep their tile order and the four quadrants of
+// a tile, and neighbouring tiles, still run close together on the XCD whose L2 holds their Gaussians.  (A global
+// heaviest-first map had lost more in L2 locality than it gained in balance.)  Which wave computes which row does not
+// change any result.
+constexpr int QO_THREADS = 1024, QO_WAVES = QO_THREADS / 64, QO_BUCKETS = 64, QO_ROUNDS = 16;
+__global__ __launch_bounds__(QO_THREADS) void quad_order_k(const uint32_t* __restrict__ qcost, int n_quads, int per,
+                                                           uint32_t* __restrict__ qorder) {
+    __shared__ uint32_t cnt[QO_WAVES][QO_BUCKETS];
+    const int band = blockIdx.x, base = band * per;
+    const int n = max(0, min(per, n_quads - base));
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < QO_WAVES * QO_BUCKETS; i += QO_THREADS) (&cnt[0][0])[i] = 0;
+    __syncthreads();
+    // wave w owns the contiguous elements [w * chunk, (w + 1) * chunk): (wave, round, lane) order == index order
+    const int chunk = (per + QO_WAVES - 1) / QO_WAVES;  // <= 64 * QO_ROUNDS (checked by the launcher)
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t d_r[QO_ROUNDS], rank_r[QO_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < QO_ROUNDS; r++) {
+        if (r * 64 >= chunk) break;  // (uniform: 4 of the 16 rounds at 1600 x 1056)
+        const int e = w * chunk + r * 64 + lane;
+        const bool ok = r * 64 + lane < chunk && e < n;
+        // bucket 0 = heaviest: 16 list positions per bucket, everything above 1008 together
+        const uint32_t c = ok ? qcost[base + e] : 0u;
+        const uint32_t d = (uint32_t)(QO_BUCKETS - 1) - min((uint32_t)(QO_BUCKETS - 1), c >> 4);
+        unsigned long long peers = __ballot(ok);
+#pragma unroll
+        for (int b = 0; b < 6; b++) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long bal = __ballot(bit);
+            peers &= bit ? bal : ~bal;
+        }
+        const uint32_t prev = ok ? cnt[w][d] : 0u;  // (same-wave LDS accesses execute in program order)
+        const uint32_t below = (uint32_t)__popcll(peers & lt);
+        d_r[r] = d;
+        rank_r[r] = prev + below;
+        __builtin_amdgcn_wave_barrier();
+        if (ok && below == 0) cnt[w][d] = prev + (uint32_t)__popcll(peers);
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {  // exclusive prefix over (bucket, wave): one wave, lane = bucket
+        uint32_t tot = 0;
+        for (int ww = 0; ww < QO_WAVES; ww++) tot += cnt[ww][lane];
+        uint32_t incl = tot;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) {
+            const uint32_t o = __shfl_up(incl, dd, 64);
+            if (lane >= dd) incl += o;
+        }
+        uint32_t run = incl - tot;
+        for (int ww = 0; ww < QO_WAVES; ww++) {
+            const uint32_t t = cnt[ww][lane];
+            cnt[ww][lane] = run;
+            run += t;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < QO_ROUNDS; r++) {
+        const int e = w * chunk + r * 64 + lane;
+        if (r * 64 + lane < chunk && e < n) qorder[base + cnt[w][d_r[r]] + rank_r[r]] = (uint32_t)(base + e);
+    }
+    for (int i = n + threadIdx.x; i < per; i += QO_THREADS) qorder[base + i] = 0xFFFFFFFFu;  // (slots past the last quadrant)
+}
+
 template <int S4>
 void launch_bwd_rows_s4(const GoiRasterScene& sc, const GeomView& g, const ImageView& im, const uint32_t* point_list,
                         const int* radii, const float* out_alpha, const float* dL_dpix, const float* dL_dsem,
                         const float* dL_ddepth, const float* dL_dalpha, const BwdScratchView& scr, hipStream_t s) {
     const int gx = (sc.W + TILE - 1) / TILE, gy = (sc.H + TILE - 1) / TILE;
     const int n_quads = gx * gy * 4;
-    const int exp_flags = (g_options.bwd_variant >> 4) & 0xF;
-    const size_t extra_lds = (size_t)((g_options.bwd_variant >> 8) & 0xFF) * 1024;
 #define GOI_LAUNCH_ROWS(MODE)                                                                                          \
-    render_bwd_rows_k<S4, MODE><<<dim3(quad_grid(n_quads)), dim3(64), extra_lds, s>>>(                                   \
+    render_bwd_rows_k<S4, MODE><<<dim3(quad_grid(n_quads)), dim3(64), 0, s>>>(                                           \
         im.ranges, point_list, sc.W, sc.H, gx, gy, n_quads, sc.S, g.rec, sc.semantics, radii, g.goff, sc.bg, out_alpha, \
-        im.n_contrib, dL_dpix, dL_dsem, dL_ddepth, dL_dalpha, scr.rows, scr.flags, bwd_row_floats(sc.S), exp_flags,      \
-        g.counters)
-    if (exp_flags)
-        GOI_LAUNCH_ROWS(2);
-    else if ((g_options.bwd_variant & 15) == 2)
+        im.n_contrib, dL_dpix, dL_dsem, dL_ddepth, dL_dalpha, scr.rows, scr.flags, bwd_row_floats(sc.S),                 \
+        g.counters, quad_order_enabled(sc.W, sc.H) ? im.qorder : nullptr)
+    if ((g_options.bwd_variant & 15) == 2)
         GOI_LAUNCH_ROWS(1);
     else
         GOI_LAUNCH_ROWS(0);
@@ -473,6 +534,20 @@ void launch_bwd_rows_s4(const GoiRasterScene& sc, const GeomView& g, const Image
 }
 
 }  // namespace
+
+bool quad_order_enabled(int W, int H) {
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+    const int per = quad_grid(gx * gy * 4) / 8;
+    // (a band of more than 16 x 1024 quadrants -- a frame beyond ~4 K x 2.2 K pixels -- keeps tile order)
+    return g_options.bwd_order != 0 && (per + QO_WAVES - 1) / QO_WAVES <= 64 * QO_ROUNDS;
+}
+
+void launch_quad_order(const GoiRasterScene& sc, const ImageView& im, hipStream_t s) {
+    if (!quad_order_enabled(sc.W, sc.H)) return;
+    const int gx = (sc.W + TILE - 1) / TILE, gy = (sc.H + TILE - 1) / TILE;
+    const int n_quads = gx * gy * 4, per = quad_grid(n_quads) / 8;
+    quad_order_k<<<dim3(8), dim3(QO_THREADS), 0, s>>>(im.qcost, n_quads, per, im.qorder);
+}
 
 void launch_render_bwd_rows(const GoiRasterScene& sc, const GeomView& g, const ImageView& im,
                             const uint32_t* point_list, const int* radii, const float* out_alpha, const float* dL_dpix,

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
     int n_quads, int S, const GaussRec* __restrict__ rec, const int* __restrict__ radii,
     const uint32_t* __restrict__ goff, const float* __restrict__ out_alpha, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dpixsem, float* __restrict__ rows, uint8_t* __restrict__ flags, int row_floats,
-    const uint32_t* __restrict__ counters) {
+    const uint32_t* __restrict__ counters, const uint32_t* __restrict__ qorder) {
     const bool cull = counters[COUNTER_CULL] != 0;  // the rectangles the forward listed
     constexpr int NSEM = 4 * S4, NB = (NSEM + 15) / 16;
     __shared__ f32x4 s_geo[SBATCH];           // (A3, A5, A1, A2) of the quadrant-centred log2-alpha polynomial
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
     float* const s_t = reinterpret_cast<float*>(s_traw);
     __shared__ uint32_t s_slot[SGROUP];
 
-    const QuadGeom t = quad_geom(W, H, gx, n_quads);
+    const QuadGeom t = quad_geom_of(qorder ? (int)qorder[quad_slot()] : quad_slot(), W, H, gx, n_quads);  // (render_bwd.hip: quad_order_k)
     if (t.tile < 0) return;
     if (counters[COUNTER_OVF]) return;  // truncated frame: no rows (the row reduction writes zero gradients)
     const int lane = t.lane;
@@ -217,11 +217,11 @@ void launch_bwd_sem_s4(const GoiRasterScene& sc, const GeomView& g, const ImageV
     if ((g_options.bwd_variant & 15) == 2)  // exact-fp32 flush, as in the full backward
         render_bwd_sem_k<S4, false><<<dim3(quad_grid(n_quads)), dim3(64), 0, s>>>(
             im.ranges, point_list, sc.W, sc.H, gx, gy, n_quads, sc.S, g.rec, radii, g.goff, out_alpha, im.n_contrib, dL_dsem,
-            rows, flags, row_floats, g.counters);
+            rows, flags, row_floats, g.counters, quad_order_enabled(sc.W, sc.H) ? im.qorder : nullptr);
     else
         render_bwd_sem_k<S4, true><<<dim3(quad_grid(n_quads)), dim3(64), 0, s>>>(
             im.ranges, point_list, sc.W, sc.H, gx, gy, n_quads, sc.S, g.rec, radii, g.goff, out_alpha, im.n_contrib, dL_dsem,
-            rows, flags, row_floats, g.counters);
+            rows, flags, row_floats, g.counters, quad_order_enabled(sc.W, sc.H) ? im.qorder : nullptr);
 }
 
 }  // namespace

@@ -31,7 +31,8 @@ __global__ __launch_bounds__(64) void render_fwd_k(const uint2* __restrict__ ran
                                                    float* __restrict__ out_color, float* __restrict__ out_sem,
                                                    float* __restrict__ out_depth, float* __restrict__ out_alpha,
                                                    uint32_t* __restrict__ n_contrib, const float* __restrict__ img_sem,
-                                                   float* __restrict__ gau_sem, int* __restrict__ num_gsem) {
+                                                   float* __restrict__ gau_sem, int* __restrict__ num_gsem,
+                                                   uint32_t* __restrict__ qcost) {
     constexpr int NF4 = TRACE ? 1 : 1 + S4;  // float4 words staged per Gaussian: (r,g,b,depth) + semantics
     constexpr int NSEM = TRACE ? 0 : 4 * S4;
     __shared__ f32x4 s_geo[64];   // (A3, A5, A1, A2) of the quadrant-centred log2-alpha polynomial (blend_common.h)
@@ -42,6 +43,7 @@ __global__ __launch_bounds__(64) void render_fwd_k(const uint2* __restrict__ ran
 
     const QuadGeom t = quad_geom(W, H, gx, n_quads);
     if (t.tile < 0) return;
+    const int tq = quad_slot();
     const uint2 range = ranges[t.tile];
     const float QCX = t.QX0 + 3.5f, QCY = t.QY0 + 3.5f;  // quadrant centre
     const f32x2 uv = {t.pxf - QCX, t.pyf - QCY};         // this lane's pixel, quadrant-centred
@@ -187,6 +189,12 @@ __global__ __launch_bounds__(64) void render_fwd_k(const uint2* __restrict__ ran
         __builtin_amdgcn_wave_barrier();
     }
 
+    {   // how far the backward's wave of this quadrant has to walk: the largest last contributor of its 64 pixels
+        int qc = (int)last_contributor;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) qc = max(qc, __shfl_xor(qc, d, 64));
+        if (qcost && lane == 0) qcost[tq] = (uint32_t)qc;
+    }
     if (t.inside) {
         n_contrib[pix_id] = last_contributor;
         out_color[0 * HW + pix_id] = C2[0].x + T * bg[0];
@@ -211,11 +219,11 @@ void launch_fwd_s4(const GoiRasterScene& sc, const GeomView& g, const ImageView&
     if (g_options.fwd_variant == 1)
         render_fwd_k<S4, false, true><<<dim3(quad_grid(n_quads)), dim3(64), 0, s>>>(
             im.ranges, point_list, sc.W, sc.H, gx, n_quads, sc.S, g.rec, sc.semantics, sc.bg, out_color, out_sem,
-            out_depth, out_alpha, im.n_contrib, nullptr, nullptr, nullptr);
+            out_depth, out_alpha, im.n_contrib, nullptr, nullptr, nullptr, im.qcost);
     else
         render_fwd_k<S4, false, false><<<dim3(quad_grid(n_quads)), dim3(64), 0, s>>>(
             im.ranges, point_list, sc.W, sc.H, gx, n_quads, sc.S, g.rec, sc.semantics, sc.bg, out_color, out_sem,
-            out_depth, out_alpha, im.n_contrib, nullptr, nullptr, nullptr);
+            out_depth, out_alpha, im.n_contrib, nullptr, nullptr, nullptr, im.qcost);
 }
 
 }  // namespace
@@ -233,7 +241,7 @@ void launch_trace_fwd(const GoiRasterScene& sc, const float* img_sem, const Geom
     const int n_quads = gx * gy * 4;
     render_fwd_k<1, true, false><<<dim3(quad_grid(n_quads)), dim3(64), 0, s>>>(
         im.ranges, point_list, sc.W, sc.H, gx, n_quads, sc.S, g.rec, nullptr, sc.bg, out_color, nullptr, nullptr, nullptr,
-        im.n_contrib, img_sem, gau_sem, num_gsem);
+        im.n_contrib, img_sem, gau_sem, num_gsem, nullptr);
 }
 
 }  // namespace goi

@@ -67,11 +67,25 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s
     return res;
 }
 
+// n_dev (may be NULL): the element count lives on the device and `n` is a capacity (the grid covers n, the kernels
+// work on min(*n_dev, n) elements; chunks past the count contribute 0 / write nothing).
+__device__ __forceinline__ size_t scan_n(size_t n, const uint32_t* __restrict__ n_dev) {
+    if (!n_dev) return n;
+    const size_t m = (size_t)*n_dev;
+    return m < n ? m : n;
+}
+
 __global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_k(const uint32_t* __restrict__ in,
-                                                              const uint32_t* __restrict__ gather, size_t n,
+                                                              const uint32_t* __restrict__ gather, size_t n_cap,
+                                                              const uint32_t* __restrict__ n_dev,
                                                               uint32_t* __restrict__ partials) {
     __shared__ uint32_t sm[SCAN_THREADS / WAVE + 1];
+    const size_t n = scan_n(n_cap, n_dev);
     const size_t base = (size_t)blockIdx.x * SCAN_CHUNK;
+    if (base >= n) {  // (block-uniform)
+        if (threadIdx.x == 0) partials[blockIdx.x] = 0u;
+        return;
+    }
     uint32_t sum = 0;
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; k++) {
@@ -100,9 +114,12 @@ __global__ __launch_bounds__(1024) void scan_partials_k(uint32_t* __restrict__ p
 
 __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_k(const uint32_t* in,  // may alias out
                                                              const uint32_t* __restrict__ gather,
-                                                             uint32_t* out, size_t n,
+                                                             uint32_t* out, size_t n_cap,
+                                                             const uint32_t* __restrict__ n_dev,
                                                              const uint32_t* __restrict__ partials) {
     __shared__ uint32_t sm[SCAN_THREADS / WAVE + 1];
+    const size_t n = scan_n(n_cap, n_dev);
+    if ((size_t)blockIdx.x * SCAN_CHUNK >= n) return;  // (block-uniform)
     const size_t base = (size_t)blockIdx.x * SCAN_CHUNK + (size_t)threadIdx.x * SCAN_ITEMS;
     uint32_t v[SCAN_ITEMS];
     uint32_t sum = 0;
@@ -432,15 +449,15 @@ size_t sort_scratch_words(size_t n) {
 }
 
 void exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* out, size_t n, uint32_t* total,
-                        uint32_t* scratch, hipStream_t s) {
+                        uint32_t* scratch, hipStream_t s, const uint32_t* n_dev) {
     if (n == 0) {
         if (total) (void)hipMemsetAsync(total, 0, sizeof(uint32_t), s);
         return;
     }
     const size_t nb = div_up(n, SCAN_CHUNK);
-    scan_reduce_k<<<dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s>>>(in, gather, n, scratch);
+    scan_reduce_k<<<dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s>>>(in, gather, n, n_dev, scratch);
     scan_partials_k<<<dim3(1), dim3(1024), 0, s>>>(scratch, nb, total);
-    scan_apply_k<<<dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s>>>(in, gather, out, n, scratch);
+    scan_apply_k<<<dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s>>>(in, gather, out, n, n_dev, scratch);
 }
 
 // Control words of the onesweep sort, contiguous at the start of the scratch so that ONE memset clears them:

@@ -30,7 +30,8 @@
  *     has the same one, cuda_rasterizer/rasterizer_impl.cu:285); goi_raster_forward_async has none;
  *   - entry points may be called concurrently from several host threads on different streams / devices
  *     (read-back tickets are pooled per device under a mutex; last_error is per thread); the
- *     goi_raster_set_option switches and the stage profile are process-wide;
+ *     goi_raster_set_option switches are process-wide but every call works with the snapshot it took when it
+ *     started (a switch flipped by another thread never changes a call half-way); the stage profile is process-wide;
  *   - return value: >= 0 on success (forward/trace: num_rendered), < 0 on error with the message
  *     available from goi_raster_last_error() (thread-local).
  *   - supported S (semantic channels): any 1..32; fast paths are instantiated for 10 and 16.
@@ -227,7 +228,10 @@ int goi_raster_profile_collect(double* ms, int* calls);
  *   "cull_variant" 1 (default) tile lists culled by the exact contribution box, 0 the reference's 3-sigma squares
  *   "decode_variant" (goi_semantic_decode, S <= 16) 1 (default) contraction as three bf16 MFMAs on exact 3-way splits of
  *                  the fp32 operands (fp32 accuracy), two 16-pixel blocks per code-book operand fetch; 2 / 3 the same
- *                  with four / one block per fetch (bit-identical results, slower); 0 fp32 MFMA */
+ *                  with four / one block per fetch (bit-identical results, slower); 0 fp32 MFMA
+ *   "bwd_order"    1 (default) the backward's quadrant waves are launched longest-first inside each XCD's band (their
+ *                  cost is known from the forward), 0 in tile order; same gradients
+ * Thread safety: the set is changed under a mutex; an entry point snapshots it when it starts. */
 int goi_raster_set_option(const char* name, int value);
 
 /* dL/dSH [P,M,3] of V views from the factors goi_raster_backward leaves in FACTORED mode: means3D [P,3], the V camera

@@ -1,0 +1,26 @@
+"""A plain loop of training steps on the headline workload (for rocprofv3 --kernel-trace --stats via tools/kstats.sh).
+usage: python tools/step_loop.py [steps]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from goi_hyperplane_amd.render import GaussianSet, PipelineParams, TorchCamera, render
+from goi_hyperplane_amd.scene import HEADLINE, make_camera, make_scene
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+dev = torch.device("cuda:0")
+h = HEADLINE
+sc = make_scene(h["P"], S=h["S"], seed=0, extent=h["extent"], log_scale_mean=h["log_scale_mean"], log_scale_std=h["log_scale_std"])
+pc = GaussianSet.from_scene(sc, dev)
+cams = [TorchCamera(make_camera(h["W"], h["H"], fovx=h["fovx"], yaw=0.02 * (i - 8), pitch=0.01 * ((i * 7) % 5 - 2)), dev) for i in range(16)]
+bg = torch.zeros(3, device=dev)
+gen = torch.Generator(device=dev).manual_seed(1234)
+inv = 1.0 / (h["W"] * h["H"])
+gc = torch.randn((3, h["H"], h["W"]), device=dev, generator=gen) * inv
+gs = torch.randn((h["S"], h["H"], h["W"]), device=dev, generator=gen) * inv
+for i in range(n):
+    for p in pc.parameters():
+        p.grad = None
+    out = render(cams[i % 16], pc, PipelineParams(), bg)
+    torch.autograd.backward((out["render"], out["semantics"]), (gc, gs))
+torch.cuda.synchronize()
+print("done", n)
