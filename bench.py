@@ -147,9 +147,17 @@ def main():
     ap.add_argument("--views", type=int, default=16, help="distinct cameras cycled through")
     ap.add_argument("--grads", choices=["all", "semantics"], default="all",
                     help="which Gaussian gradients are all-reduced when --gpus > 1")
-    ap.add_argument("--exchange", choices=["factored", "allreduce"], default="factored",
+    ap.add_argument("--exchange", choices=["factored", "allreduce", "visible"], default="factored",
                     help="--gpus > 1, --grads all: 'factored' all-gathers the factors of dL/dSH (12 B per Gaussian "
-                         "and view) and all-reduces the other 27 gradient floats; 'allreduce' all-reduces all 75")
+                         "and view) and all-reduces the other 27 gradient floats; 'allreduce' all-reduces all 75; "
+                         "'visible' all-reduces all 75 but only for Gaussians some rank saw this step")
+    ap.add_argument("--views-per-exchange", type=int, default=1,
+                    help="--gpus > 1: every rank accumulates the gradients of this many views locally before one exchange "
+                         "(an optimiser step per K x N views); 1 = one exchange per view, train.py's step semantics")
+    ap.add_argument("--overlap", action="store_true",
+                    help="--gpus > 1: make `value` the figure with the exchange left in flight behind the next step's "
+                         "render + backward (gradients one step stale: NOT train.py's semantics); by default `value` waits "
+                         "for every exchange inside its step and the in-flight figure is reported beside it")
     ap.add_argument("--ply", default=None,
                     help="point_cloud.ply saved by the reference (sem_* columns) instead of the synthetic scene; "
                          "cameras stay synthetic (the data sets are not in this image)")
@@ -161,9 +169,7 @@ def main():
     ap.add_argument("--no-fp32-flush", action="store_true", help="skip the secondary exact-fp32-flush figure")
     ap.add_argument("--no-two-streams", action="store_true", help="skip the secondary two-views-in-flight figure")
     ap.add_argument("--no-train-iteration", action="store_true", help="skip the secondary semantic-stage iteration figure")
-    ap.add_argument("--no-overlap", action="store_true",
-                    help="--gpus > 1: wait for each step's gradient exchange inside the step instead of letting it run "
-                         "behind the next step's render + backward")
+    ap.add_argument("--no-overlap", action="store_true", help="(default since round 3; kept for older command lines)")
     ap.add_argument("--no-stage-timing", action="store_true")
     ap.add_argument("--no-semantic-finetune", action="store_true",
                     help="skip the secondary semantics-only-training figure")
@@ -198,8 +204,9 @@ def main():
     from goi_hyperplane_amd import rasterizer
     if args.forward:
         rasterizer.set_forward_mode(speculative=args.forward == "speculative")
-    from goi_hyperplane_amd.dist import (allreduce_gradients, allreduce_gradients_async,
-                                         allreduce_gradients_sh_factored, allreduce_gradients_sh_factored_async)
+    from goi_hyperplane_amd.dist import (allreduce_gradients, allreduce_gradients_async, allreduce_gradients_sh_factored,
+                                         allreduce_gradients_sh_factored_async, allreduce_gradients_visible,
+                                         exchange_model_ms)
     from goi_hyperplane_amd.render import GaussianSet, PipelineParams, TorchCamera, render
     from goi_hyperplane_amd.scene import make_camera, make_scene
     _lib.load()
@@ -229,14 +236,19 @@ def main():
     g_color = torch.randn((3, args.H, args.W), device=dev, generator=gen) * inv_hw
     g_sem = torch.randn((args.S, args.H, args.W), device=dev, generator=gen) * inv_hw
 
-    exchange = {"mode": "allreduce", "note": None}
+    exchange = {"mode": "visible" if (args.exchange == "visible" and args.grads == "all") else "allreduce", "note": None}
     non_sh_params = [pc._xyz, pc._semantics, pc._opacity, pc._scaling, pc._rotation]
 
     # Gradient exchange in flight: the collective of step k is issued after its backward and waited for after step
     # k+1's backward, so it is on the wire while the next view renders.  Every step's gradients are
     # reduced, and the last exchange is drained inside the timed region.  --no-overlap keeps it inside the step.
-    overlap_default = not args.no_overlap
+    overlap_default = bool(args.overlap) and not args.no_overlap
+    K = max(1, int(args.views_per_exchange))
+    if K > 1 and args.exchange == "factored":
+        args.exchange = "allreduce"  # (the factors are per view: K views would need K factor sets; the plain sum accumulates)
+        exchange["note"] = "factored exchange needs one view per exchange: --views-per-exchange > 1 uses the plain all-reduce"
     inflight = {"h": None}
+    seen = {"vis": None}
 
     def drain():
         if inflight["h"] is not None:
@@ -246,20 +258,30 @@ def main():
     def step(i, record=False, overlap=None):
         overlap = overlap_default if overlap is None else overlap
         cam = cams[(i * world + rank) % len(cams)]  # rank r takes views r, r+G, ... of the cycle
-        for p in params:
-            p.grad = None
+        first, last = (i % K) == 0, (i % K) == K - 1
+        if first:  # (K > 1: autograd accumulates the following views into the same .grad tensors)
+            for p in params:
+                p.grad = None
+            seen["vis"] = None
         out = render(cam, pc, pipe, bg)
         torch.autograd.backward((out["render"], out["semantics"]), (g_color, g_sem))
-        if dist is not None:
+        if dist is not None and exchange["mode"] == "visible":
+            v = out["radii"] > 0
+            seen["vis"] = v if seen["vis"] is None else (seen["vis"] | v)
+        if dist is not None and last:
             if not overlap:
                 drain()
-                if exchange["mode"] == "factored":
+                if exchange["mode"] == "visible":
+                    stats["rows_sent"] = allreduce_gradients_visible(reduce_params, seen["vis"], dist)
+                elif exchange["mode"] == "factored":
                     allreduce_gradients_sh_factored(non_sh_params, (pc._features,), pc._xyz, rasterizer.take_sh_factor(), dist)
                 else:
                     allreduce_gradients(reduce_params, dist)
             else:
                 prev = inflight["h"]
-                if exchange["mode"] == "factored":
+                if exchange["mode"] == "visible":  # (its host synchronisation makes "in flight" meaningless: plain form)
+                    inflight["h"] = allreduce_gradients_async(reduce_params, dist)
+                elif exchange["mode"] == "factored":
                     inflight["h"] = allreduce_gradients_sh_factored_async(non_sh_params, (pc._features,), pc._xyz,
                                                                           rasterizer.take_sh_factor(), dist)
                 else:
@@ -390,20 +412,29 @@ def main():
         stages[dominant] = _lib.profile_collect()[dominant]
     own_elapsed = elapsed
     elapsed = elapsed_max
-    # the same steps with the exchange waited for inside every step (what a one-view-per-optimizer-step loop pays)
-    serialized = None
-    if dist is not None and overlap_default and world > 1:
-        for i in range(2):
-            step(i, overlap=False)
+    # the same steps with the OTHER exchange semantics: `value` waits for every exchange inside its step (what train.py's
+    # one-optimiser-step-per-exchange loop pays) unless --overlap was given; the figure with the exchange left in flight
+    # behind the next step (one-step-stale gradients) is reported beside it, and vice versa
+    serialized, in_flight_fig = None, None
+    if dist is not None and world > 1:
+        other = not overlap_default
+        for i in range(2 * K):
+            step(i, overlap=other)
+        drain()
         barrier()
         z0 = time.perf_counter()
-        nz = max(5, min(args.steps, 20))
+        nz = max(5, min(args.steps, 20)) // K * K or K
         for i in range(nz):
-            step(args.warmup + i, overlap=False)
+            step(args.warmup // K * K + i, overlap=other)
+        drain()
         barrier()
         tz = torch.tensor([time.perf_counter() - z0], dtype=torch.float64, device=dev)
         dist.all_reduce(tz, op=dist.ReduceOp.MAX)
-        serialized = {"views_per_s": nz * world / float(tz.item()), "ms_per_step": float(tz.item()) / nz * 1e3, "steps": nz}
+        fig = {"views_per_s": nz * world / float(tz.item()), "ms_per_step": float(tz.item()) / nz * 1e3, "steps": nz}
+        if other:
+            in_flight_fig = fig
+        else:
+            serialized = fig
     # one line per rank, so that a scaling run explains itself: is a rank slow on the GPU, or waiting for the wire?
     per_rank = None
     if dist is not None:
@@ -625,6 +656,24 @@ def main():
                        "what": "two independent views in flight on two HIP streams of one GPU (same work per view)"}
         del pcs, streams
 
+    # bytes one exchange puts on the wire per rank, and SURVEY.md 8(e)'s link model for them
+    row_bytes = int(sum(p_.numel() // max(1, p_.shape[0]) for p_ in reduce_params) * 4)
+    if world <= 1:
+        ar_bytes, ag_bytes = 0, 0
+    elif exchange["mode"] == "factored":
+        ar_bytes, ag_bytes = int(sum(p_.numel() for p_ in non_sh_params) * 4), int(args.P * 3 * 4 * world)
+    elif exchange["mode"] == "visible":
+        ar_bytes, ag_bytes = int(stats.get("rows_sent", args.P)) * row_bytes + args.P, 0  # + the P-byte visibility mask
+    else:
+        ar_bytes, ag_bytes = int(sum(p_.numel() for p_ in reduce_params) * 4), 0
+    modelled = None
+    if world > 1:
+        m = exchange_model_ms(ar_bytes, world)
+        gather_ms = ag_bytes * (world - 1) / world / (min(7, world - 1) * 153e9) * 1e3  # every rank receives (G-1)/G of it
+        modelled = {"ring_ms": round(m["ring"] + gather_ms, 4), "direct_ms": round(m["direct"] + gather_ms, 4),
+                    "per_view_ring_ms": round((m["ring"] + gather_ms) / K, 4),
+                    "what": "SURVEY.md 8(e): 7 xGMI links x 153 GB/s per GPU; a ring all-reduce is bound by one link, a direct "
+                            "reduce-scatter + all-gather uses all of them; per exchange, and per view at --views-per-exchange"}
     if rank == 0:
         sb = stage_bytes(args.P, V, N, T, HW, args.S)
         b_fwd, b_bwd = survey_bytes(args.P, V, N, T, HW, args.S)
@@ -675,11 +724,13 @@ def main():
                        "P": args.P, "V": V, "N_per_view": N, "N_listed_per_view": stats["N_listed"] / stats["views"],
                        "tiles": T, "HW": HW, "S": args.S,
                        "views_per_step": world, "parallelism": f"views sharded x{world}",
-                       "allreduce_bytes": (0 if world <= 1 else
-                                           int(sum(p.numel() for p in non_sh_params) * 4) if exchange["mode"] == "factored"
-                                           else int(sum(p.numel() for p in reduce_params) * 4)),
-                       "allgather_bytes": int(args.P * 3 * 4 * world) if (world > 1 and exchange["mode"] == "factored") else 0,
-                       "exchange": exchange["mode"] if world > 1 else None, "exchange_note": exchange["note"]},
+                       "allreduce_bytes": ar_bytes, "allgather_bytes": ag_bytes,
+                       "rows_sent": (stats.get("rows_sent") if exchange["mode"] == "visible" else None),
+                       "exchange": exchange["mode"] if world > 1 else None, "exchange_note": exchange["note"],
+                       "exchange_semantics": (None if world <= 1 else
+                                              f"one sum all-reduce per {K} view(s) per rank, " +
+                                              ("left in flight behind the next step (stale by one step)" if overlap_default
+                                               else "consumed before the next step starts (train.py: optimiser step per exchange)"))},
             "render_ms_per_frame": render_ms,
             "render_forward_mode": render_mode,  # forward of frames rendered without autograd (package default: exact)
             "render_ms_per_frame_speculative": render_ms_spec,
@@ -694,8 +745,12 @@ def main():
             # forward mode of the timed region and what the speculation did in it (exact_frames / waits / overflows
             # should all be 0: nothing in the timed steps waited for the device)
             "exchange_overlap": (None if world <= 1 else
-                                 ("in flight behind the next step's render + backward" if overlap_default else "inside the step")),
-            "serialized_exchange": serialized,  # same steps, exchange waited for inside each step
+                                 ("in flight behind the next step's render + backward (one-step-stale gradients)"
+                                  if overlap_default else "waited for inside the step (train.py's semantics)")),
+            "serialized_exchange": serialized,  # same steps, exchange waited for inside each step (when value is in flight)
+            "exchange_in_flight": in_flight_fig,  # same steps, exchange left in flight (when value waits: the default)
+            "views_per_exchange": K,
+            "modelled_exchange_ms": modelled,
             "per_rank": per_rank,
             "binding": _C.binding(),
             "forward_mode": _C._FWD["mode"],

@@ -106,6 +106,59 @@ def allreduce_gradients(params, dist, bucket_bytes: int = 0):
             off += n
 
 
+def allreduce_gradients_visible(params, visible, dist, dense_above: float = 0.9):
+    """Sum-all-reduce `.grad` of every parameter, sending only the rows of Gaussians that were VISIBLE in at least one
+    rank's view(s) of this step.
+
+    A Gaussian culled in a view (radius 0) gets an exactly-zero gradient row in every tensor of that view's backward, so
+    a row that no rank saw is zero everywhere and its sum needs no wire.  The ranks OR their visibility masks (one
+    all-reduce(MAX) of P bytes: 1 MB at 1 M Gaussians), gather the rows of the union from every per-Gaussian gradient
+    into one [n_union, 75] buffer, all-reduce that, and scatter it back; rows outside the union keep their local zeros,
+    which IS the sum.  xGMI rings are per-link bound, so volume is what counts: at the headline scene a
+    view sees 51 % of the Gaussians; BASELINE config 5 (6 M Gaussians, a 512 x 512 close-up per rank) sees far fewer.
+
+    visible: bool / uint8 [P] of this rank -- `radii > 0` of its view, OR-ed over the views it accumulated locally.
+    Tensors whose leading dimension is not P (the decoder, the code book) are all-reduced whole.  If the union covers
+    more than `dense_above` of the Gaussians the plain all-reduce is used (the gather would only add copies).
+    Costs one host synchronisation (the union's size); use it where the exchange is waited for anyway.
+    Returns the number of rows sent (P when it fell back to the dense exchange)."""
+    P = int(visible.shape[0])
+    vis = visible.to(torch.uint8).clone()
+    dist.all_reduce(vis, op=dist.ReduceOp.MAX)
+    idx = torch.nonzero(vis, as_tuple=True)[0]
+    n = int(idx.numel())
+    with_grad = [p for p in params if p.grad is not None]
+    rows = [p for p in with_grad if p.grad.dim() >= 1 and p.grad.shape[0] == P]
+    rest = [p for p in with_grad if not (p.grad.dim() >= 1 and p.grad.shape[0] == P)]
+    if n >= dense_above * P or not rows:
+        allreduce_gradients(with_grad, dist)
+        return P
+    works = [dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True)
+             for g in coalesce_shared_storage([p.grad for p in rest])] if rest else []
+    views = [p.grad.reshape(P, -1) for p in rows]
+    widths = [int(v.shape[1]) for v in views]
+    pack = torch.cat([v.index_select(0, idx) for v in views], dim=1)
+    dist.all_reduce(pack, op=dist.ReduceOp.SUM)
+    off = 0
+    for v, w in zip(views, widths):
+        v.index_copy_(0, idx, pack[:, off:off + w])
+        off += w
+    for w in works:
+        w.wait()
+    return n
+
+
+def exchange_model_ms(nbytes: float, world: int, link_GBps: float = 153.0, links: int = 7) -> dict:
+    """SURVEY.md 8(e)'s xGMI cost model for a sum all-reduce of `nbytes` over `world` fully connected GPUs: a ring is
+    bound by ONE link (2 (G-1)/G bytes / 153 GB/s); a direct reduce-scatter + all-gather spreads 2 bytes/G over each of
+    the G-1 links it uses at once.  Milliseconds; what RCCL actually achieves lies in between and is measured."""
+    if world <= 1 or nbytes <= 0:
+        return {"ring": 0.0, "direct": 0.0}
+    ring = 2.0 * (world - 1) / world * nbytes / (link_GBps * 1e9) * 1e3
+    direct = 2.0 * (nbytes / world) * (world - 1) / (min(links, world - 1) * link_GBps * 1e9) * 1e3
+    return {"ring": ring, "direct": direct}
+
+
 def allreduce_gradients_sh_factored(params, sh_leaves, means3D, factor, dist, reconstruct=None):
     """Data-parallel gradient exchange with the SH gradient sent as its FACTORS.
 
@@ -194,9 +247,9 @@ def allreduce_gradients_async(params, dist) -> PendingExchange:
 
 def allreduce_gradients_sh_factored_async(params, sh_leaves, means3D, factor, dist, reconstruct=None) -> PendingExchange:
     """allreduce_gradients_sh_factored with the collectives left in flight; wait() rebuilds dL/dSH from the gathered
-    factors and ASSIGNS each SH leaf's part to `leaf.grad` (as the blocking variant does; in sh_factored mode autograd
-    gives the SH leaves no gradient of its own, so there is nothing to accumulate into).  The same tensors are also left
-    in `handle.sh_grads[id(leaf)]` for callers whose leaves have moved on to the next step's gradients by then."""
+    factors and hands each SH leaf its part exactly as the blocking variant does: assigned to `leaf.grad`, or added to a
+    gradient that is already there (in sh_factored mode autograd gives the SH leaves none of its own).  The same tensors
+    are also left in `handle.sh_grads[id(leaf)]` for callers whose leaves have moved on to the next step by then."""
     if factor is None:
         raise RuntimeError("no SH factor: run the backward with rasterizer.set_backward_mode(sh_factored=True)")
     if reconstruct is None:
@@ -227,7 +280,10 @@ def allreduce_gradients_sh_factored_async(params, sh_leaves, means3D, factor, di
             n = int(leaf.shape[1])
             part = dsh[:, k:k + n, :].contiguous() if (k or n != dsh.shape[1]) else dsh
             result[id(leaf)] = part
-            leaf.grad = part
+            if leaf.grad is None:  # (as the blocking variant: a gradient that is already there is accumulated into)
+                leaf.grad = part
+            else:
+                leaf.grad.add_(part)
             k += n
         if k != dsh.shape[1]:
             raise ValueError(f"sh_leaves hold {k} coefficients, the rasterizer was given {dsh.shape[1]}")

@@ -19,7 +19,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("exchange", ["factored", "allreduce"])
+@pytest.mark.parametrize("exchange", ["factored", "allreduce", "visible", "allreduce_k2"])
 def test_two_ranks_on_one_gpu(exchange):
     import torch
     if not torch.cuda.is_available():
@@ -27,15 +27,29 @@ def test_two_ranks_on_one_gpu(exchange):
     env = dict(os.environ, GOI_BENCH_BACKEND="gloo", GOI_BENCH_SHARE_GPU="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--P", "20000", "--W", "320", "--H", "208", "--no-cpu-baseline", "--no-stage-timing", "--exchange", exchange]
-    if exchange == "factored":
-        cmd.append("--no-semantic-finetune")  # the other parametrisation runs every secondary phase of the default bench
+           "--P", "20000", "--W", "320", "--H", "208", "--no-cpu-baseline", "--no-stage-timing", "--exchange",
+           exchange.split("_")[0]]
+    k = 2 if exchange.endswith("_k2") else 1
+    if k > 1:
+        cmd += ["--views-per-exchange", "2", "--steps", "4", "--warmup", "2"]
+    if exchange != "allreduce":
+        cmd.append("--no-semantic-finetune")  # the "allreduce" parametrisation runs every secondary phase of the default bench
+        cmd += ["--no-fp32-flush"] if exchange != "factored" else []
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
-    assert d["config"]["exchange"] == exchange
+    assert d["config"]["exchange"] == exchange.split("_")[0]
+    # `value` has train.py's semantics (every exchange consumed inside its step); the in-flight figure stands beside it
+    assert d["exchange_overlap"].startswith("waited for inside the step") and d["serialized_exchange"] is None
+    assert d["exchange_in_flight"]["views_per_s"] > 0 and d["views_per_exchange"] == k
+    assert "consumed before the next step" in d["config"]["exchange_semantics"]
+    m = d["modelled_exchange_ms"]
+    assert m["ring_ms"] > m["direct_ms"] > 0 and abs(m["per_view_ring_ms"] * k - m["ring_ms"]) < 1e-3
+    if exchange == "visible":
+        assert 0 < d["config"]["rows_sent"] <= 20000
+        assert d["config"]["allreduce_bytes"] == d["config"]["rows_sent"] * 75 * 4 + 20000
     if exchange == "allreduce":  # semantics-only phase, with and without the geometry cache, across two ranks
         sf = d["semantic_finetune"]
         assert sf["views_per_s"] > 0 and sf["geometry_cache"]["views_per_s"] > 0 and sf["geometry_cache"]["misses"] == 0
@@ -44,7 +58,7 @@ def test_two_ranks_on_one_gpu(exchange):
         assert d["config"]["exchange_note"].startswith("verified against the plain all-reduce"), d["config"]["exchange_note"]
         assert d["config"]["allgather_bytes"] == 20000 * 3 * 4 * 2
         assert d["config"]["allreduce_bytes"] == 20000 * 27 * 4
-    else:
+    elif exchange != "visible":
         assert d["config"]["allreduce_bytes"] == 20000 * 75 * 4
 
 
@@ -52,8 +66,8 @@ def test_two_ranks_on_one_gpu(exchange):
 def test_single_rank_rccl_path_runs_on_hardware(exchange):
     """RCCL itself (torch.distributed backend "nccl"), one rank: the process group is created on the GPU, the gradient
     exchange of every step goes through real RCCL collectives (all-reduce; all-gather + all-reduce for the factored
-    form) issued in flight behind the next step -- the code path the 8-GPU scaling run takes, on the one GPU a test box
-    has.  (GOI_BENCH_FORCE_DIST=1: bench.py's hook for exactly this.)"""
+    form), waited for inside the step for `value` and left in flight for the secondary figure -- the code path the 8-GPU
+    scaling run takes, on the one GPU a test box has.  (GOI_BENCH_FORCE_DIST=1: bench.py's hook for exactly this.)"""
     import torch
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
