@@ -46,7 +46,7 @@ def test_two_ranks_on_one_gpu(exchange):
     assert d["exchange_in_flight"]["views_per_s"] > 0 and d["views_per_exchange"] == k
     assert "consumed before the next step" in d["config"]["exchange_semantics"]
     m = d["modelled_exchange_ms"]
-    assert m["ring_ms"] > m["direct_ms"] > 0 and abs(m["per_view_ring_ms"] * k - m["ring_ms"]) < 1e-3
+    assert m["ring_ms"] >= m["direct_ms"] > 0 and abs(m["per_view_ring_ms"] * k - m["ring_ms"]) < 1e-3
     if exchange == "visible":
         assert 0 < d["config"]["rows_sent"] <= 20000
         assert d["config"]["allreduce_bytes"] == d["config"]["rows_sent"] * 75 * 4 + 20000

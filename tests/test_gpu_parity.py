@@ -398,9 +398,29 @@ def test_metric_configuration_matches_oracle(oracle_mod, dev, P, yaw):
     assert fw["fragile_frac"] < 0.02, fw["fragile_frac"]
     for k in ("render", "semantics", "depth", "alpha"):
         assert fw[k]["max"] < FWD_TOL, f"{tag}: {k} {fw[k]}"
-    for k, st in bw.items():
-        assert st["finite"] and st["max"] < BWD_TOL, f"{tag}: grad {k} {st}"
     assert set(bw) == {"means3D", "opacity", "semantics", "sh", "scales", "rotations", "means2D"}
+    failing = [k for k, st in bw.items() if not (st["finite"] and st["max"] < BWD_TOL)]
+    if failing:
+        # Millions of Gaussians always hold a few needles (the one found at 3 M: scales 0.126 : 0.0036 : 0.015, 127 px
+        # radius) whose cov2D -> cov3D -> rotation chain amplifies fp32 rounding until the oracle's OWN two builds (plain /
+        # FMA-contracted) disagree by more than 1e-3 of the tensor's scale on that element.  Same criteria as
+        # tests/test_gpu_fuzz.py, applied only to the tensors that fail the plain gate and recorded with the statistics:
+        # within 1e-3 of the FMA twin, or within three times the two builds' own disagreement (never beyond 1e-2), and in
+        # either case at most a handful of elements over the tolerance.
+        o2 = oracle_mod.from_scene(sc, cam, bg=bg, threads=os.cpu_count() or 1, variant="fma")
+        o2.forward()
+        g_twin = o2.backward(gc, gs, gd, ga)
+        tw = compare.backward_stats(g_hip, g_twin, names=failing)
+        for k in failing:
+            a, b = np.asarray(g_orc[k], np.float64), np.asarray(g_twin[k], np.float64).reshape(np.asarray(g_orc[k]).shape)
+            floor = float(np.abs(a - b).max() / (np.abs(a).max() + 1e-20))
+            st = bw[k]
+            st.update(vs_fma_twin_max=tw[k]["max"], oracle_builds_disagree_by=floor,
+                      accepted_by=("fma_twin" if tw[k]["max"] < BWD_TOL else
+                                   "noise_floor" if st["max"] < min(1e-2, 3 * floor) else None))
+            assert st["finite"] and st["accepted_by"] is not None and st["n_over"] <= 8 and st["p9999"] < 1e-4, \
+                f"{tag}: grad {k} {st}"
+        assert P > h["P"], f"{tag}: the metric configuration itself must pass the plain 1e-3 gate: {failing}"
 
 
 def test_fused_semantic_decode_matches_unfused_reference(dev):
