@@ -10,6 +10,8 @@
 //             :20-139 (SH), :278-341 (cov3D)
 // Layout is this library's own: one 48-byte GaussRec per Gaussian instead of five arrays, depth
 // keys for the per-Gaussian depth sort, 3 clamp bits in one byte.
+#include <type_traits>
+
 #include "common.h"
 #include "gmath.h"
 
@@ -190,11 +192,18 @@ __global__ __launch_bounds__(256) void preprocess_fwd_k(const PreArgs args, Gaus
         const float o = a.opacities[idx];
         float hx = -1.f, hy = -1.f;
         if (o >= 1.0f / 255.0f) {
-            const double tau = log(255.0 * (double)o) * 1.01 + 0.01;
-            const double detc = (double)con_a * (double)con_c - (double)con_b * (double)con_b;
-            if (detc > 0.0 && con_a > 0.f && con_c > 0.f) {
-                hx = (float)(sqrt(2.0 * tau * (double)con_c / detc) * 1.000001) + 1e-3f;
-                hy = (float)(sqrt(2.0 * tau * (double)con_a / detc) * 1.000001) + 1e-3f;
+            // In single precision, every rounding pushed OUTWARD (the box only has to contain the region; its size
+            // decides nothing but how many tiles and quadrants are looked at): the double-precision log / sqrt / divide
+            // this replaces were software routines of a few hundred instructions on the critical path of every visible lane.
+            //   tau = 1.01 ln(255 o) + 0.01, rounded up;  det = a c - b b by Kahan's difference of products (within
+            //   1.5 ulp even when the two products cancel: a needle), rounded down;  h = sqrt(2 tau c / det), rounded up.
+            const float tau = fmaf(1.01f, logf(255.0f * o), 0.01f) * 1.000002f + 1e-6f;
+            const float bb = con_b * con_b;
+            const float detc = (fmaf(con_a, con_c, -bb) + fmaf(-con_b, con_b, bb));
+            const float det_lo = detc - 4e-7f * fabsf(detc);
+            if (det_lo > 0.f && con_a > 0.f && con_c > 0.f) {
+                hx = sqrtf(2.0f * tau * con_c / det_lo) * 1.000002f + 1e-3f;
+                hy = sqrtf(2.0f * tau * con_a / det_lo) * 1.000002f + 1e-3f;
                 if (!(hx == hx) || !(hy == hy)) hx = hy = __builtin_inff();
             } else {
                 hx = hy = __builtin_inff();
@@ -799,10 +808,15 @@ __global__ __launch_bounds__(256) void reduce_rows_k(int P, int S, int nch, uint
                 m |= ((bal >> (16 * quarter)) & 0xFFFFull) << (16 * q);
             }
             const float* chunk = rows + (inst0 + c) * 4 * RF;
-            while (m) {
-                float v[INFLIGHT][K];
+            // NF rows requested back to back, then added in slot order (absent slots add +0: the sums do not depend on
+            // NF).  Most Gaussians own a handful of rows -- 6 on average, half of them at most 4 -- and the 16-slot trip
+            // costs ~160 vector instructions whatever it finds (the kernel issued 60 M of them: 44 % VALU-busy on top
+            // of its memory waits): when no quarter of the wave has more than 4 rows left, a 4-slot trip does.
+            auto trip = [&](auto nf_c) {
+                constexpr int NF = decltype(nf_c)::value;
+                float v[NF][K];
 #pragma unroll
-                for (int i = 0; i < INFLIGHT; i++) {
+                for (int i = 0; i < NF; i++) {
                     const bool have = m != 0;
                     const int bit = have ? __builtin_ctzll(m) : 0;
                     if (have) m &= m - 1;
@@ -817,9 +831,22 @@ __global__ __launch_bounds__(256) void reduce_rows_k(int P, int S, int nch, uint
                     }
                 }
 #pragma unroll
-                for (int i = 0; i < INFLIGHT; i++)
+                for (int i = 0; i < NF; i++)
 #pragma unroll
                     for (int kk = 0; kk < K; kk++) sum[kk] += v[i][kk];
+            };
+            int left = __popcll(m);  // rows this quarter still has to fetch; the wave's largest decides the trip
+#pragma unroll
+            for (int d = 32; d >= 16; d >>= 1) left = max(left, __shfl_xor(left, d, 64));
+            left = __builtin_amdgcn_readfirstlane(left);
+            while (left > 0) {
+                if (left <= 4) {
+                    trip(std::integral_constant<int, 4>{});
+                    left -= 4;
+                } else {
+                    trip(std::integral_constant<int, INFLIGHT>{});
+                    left -= INFLIGHT;
+                }
             }
         }
         if (live) {
@@ -884,7 +911,7 @@ __global__ __launch_bounds__(256) void emit_k(int P, int gx, int gy, const Gauss
     constexpr int ROUNDS_PER_BLOCK = COUNT ? EMIT_ROUNDS : 1;
     if ((int)blockIdx.x * ROUNDS_PER_BLOCK * 256 >= P) return;  // (block-uniform) nothing listed left for this block
     extern __shared__ uint32_t s_cnt[];  // [gx * gy] when COUNT
-    __shared__ int s_incl[4][64];    // per wave: inclusive scan of the rectangles' tile counts
+    __shared__ unsigned long long s_mark[4];  // per wave and trip: bit p = some rectangle's last instance is at position p
     __shared__ uint4 s_info[4][64];  // (x0 | y0 << 16, exclusive count, offsets[] - exclusive count, Gaussian id)
     __shared__ int s_w[4][64];       // rectangle width in tiles
     const int T = gx * gy;
@@ -895,30 +922,52 @@ __global__ __launch_bounds__(256) void emit_k(int P, int gx, int gy, const Gauss
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // the counting variant amortises zeroing and flushing its tile histogram over EMIT_ROUNDS x 256 Gaussians
     constexpr int ROUNDS = COUNT ? EMIT_ROUNDS : 1;
+    // a round's Gaussian: id -> radius, position and box are dependent gathers (two DRAM round trips); the next round's
+    // are requested before this round's instances are written, or every round would start with both exposed (emit is a
+    // small kernel: two waves per SIMD have nothing to hide them behind)
+    struct Fetched {
+        uint32_t g, off;
+        int r;
+        float4 q0, q2;
+    };
+    auto fetch = [&](int rnd) {
+        Fetched f{0u, 0u, 0, make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, -1.f, -1.f)};
+        const int i = (blockIdx.x * ROUNDS + rnd) * 256 + threadIdx.x;
+        if (rnd < ROUNDS && i < P) {
+            f.g = order[i];
+            f.off = offsets[i];
+            f.r = radii[f.g];
+            f.q0 = rec[f.g].q0;
+            f.q2 = rec[f.g].q2;
+        }
+        return f;
+    };
+    Fetched nxt = fetch(0);
 #pragma unroll 1
     for (int rnd = 0; rnd < ROUNDS; rnd++) {
         const int i = (blockIdx.x * ROUNDS + rnd) * 256 + threadIdx.x;
-        uint32_t g = 0, off = 0;
+        const Fetched cur = nxt;
+        nxt = fetch(rnd + 1);
+        const uint32_t g = cur.g, off = cur.off;
         int x0 = 0, y0 = 0, w = 1, cnt = 0;
         if (i < P) {
-            g = order[i];
-            off = offsets[i];
             goff[g] = off;  // the Gaussian's first row slot in the backward (slot space = emit order = depth order)
-            const int r = radii[g];
-            if (r > 0) {
-                const float4 q0 = rec[g].q0;
-                const float4 q2 = rec[g].q2;
+            if (cur.r > 0) {
                 int x1, y1;
-                listed_rect(q0.x, q0.y, r, q2.z, q2.w, cull, gx, gy, x0, y0, x1, y1);
+                listed_rect(cur.q0.x, cur.q0.y, cur.r, cur.q2.z, cur.q2.w, cull, gx, gy, x0, y0, x1, y1);
                 w = x1 - x0;
                 cnt = w * (y1 - y0);
             }
         }
         // Load-balanced expansion: the wave's 64 rectangles hold `total` (tile, Gaussian) instances; lane l of trip
-        // t0 produces instance t0 + l, whichever rectangle it falls into (binary search in the inclusive scan of the
-        // counts).  A rectangle has ~10 tiles on average: one rectangle per trip would leave 5/6 of the lanes idle.
-        // Consecutive instances are consecutive addresses (offsets[] is the exclusive scan of the same counts in the
-        // same order): full-line stores.
+        // t0 produces instance t0 + l, whichever rectangle it falls into.  A rectangle has ~10 tiles on average: one
+        // rectangle per trip would leave 5/6 of the lanes idle.  Consecutive instances are consecutive addresses
+        // (offsets[] is the exclusive scan of the same counts in the same order): full-line stores.
+        // Which rectangle: the non-empty rectangles are numbered in lane order (their records sit at that number in
+        // LDS); each marks the position of its LAST instance in a 64-bit word for the trip it falls into, and an
+        // instance belongs to rectangle (rectangles that ended before the trip) + (marks below its own position).  Two
+        // dependent LDS round trips per trip; the binary search in the scanned counts this replaces had seven, and with
+        // two waves per SIMD (emit is a small kernel) their latency was the kernel: 59 -> 3x us.
         int incl = cnt;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -927,15 +976,24 @@ __global__ __launch_bounds__(256) void emit_k(int P, int gx, int gy, const Gauss
         }
         const int total = __builtin_amdgcn_readlane(incl, 63);
         const int excl = incl - cnt;
-        s_incl[wv][lane] = incl;
-        s_info[wv][lane] = make_uint4((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)excl, off - (uint32_t)excl, g);
-        s_w[wv][lane] = w;
-        __builtin_amdgcn_wave_barrier();
-        for (int t = lane; t < total; t += 64) {
-            int lo = 0;  // smallest l with incl[l] > t
-#pragma unroll
-            for (int step = 32; step >= 1; step >>= 1)
-                if (s_incl[wv][lo + step - 1] <= t) lo += step;
+        const int my_rank = __popcll(__ballot(cnt > 0) & ((1ull << lane) - 1ull));
+        if (cnt > 0) {
+            s_info[wv][my_rank] = make_uint4((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)excl, off - (uint32_t)excl, g);
+            s_w[wv][my_rank] = w;
+        }
+        int ended = 0;  // non-empty rectangles that end before the current trip (wave-uniform)
+        for (int t0 = 0; t0 < total; t0 += 64) {
+            const int t = t0 + lane;
+            if (lane == 0) s_mark[wv] = 0ull;
+            const int last = incl - 1 - t0;  // position of this rectangle's last instance relative to the trip
+            if (cnt > 0 && last >= 0 && last < 64)
+                atomicOr(reinterpret_cast<unsigned int*>(&s_mark[wv]) + (last >> 5), 1u << (last & 31));
+            __builtin_amdgcn_wave_barrier();
+            const unsigned long long marks = s_mark[wv];
+            __builtin_amdgcn_wave_barrier();
+            const int lo = ended + __popcll(marks & ((1ull << lane) - 1ull));
+            ended += __popcll(marks);
+            if (t >= total) continue;
             const uint4 info = s_info[wv][lo];
             const int wl = s_w[wv][lo];
             const int k = t - (int)info.y;
