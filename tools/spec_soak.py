@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """How often does the speculative forward overflow under camera motion?  (reports only)
 
-Three frame sequences over one scene, default policy (first frame exact, capacity = 2 x the largest count seen):
+Three frame sequences over one scene, default policy (first three frames exact, capacity = 2 x the largest count seen):
   random : every frame an independent camera -- distance 2.5 .. 9 (num_rendered varies ~10x), yaw/pitch anywhere in +-0.6/0.3:
            the worst case for a high-water policy is the first few frames, before a close-up has been seen;
   path   : a smooth fly-through (what a GUI or a video render produces), zooming in from far to near;
@@ -61,7 +61,7 @@ for name, cams in seqs.items():
           f"frame-to-frame growth x{(ns[1:] / np.maximum(ns[:-1], 1)).max():.2f}")
 # an overflow, read before use: redone == exact
 _C._SPEC.clear()
-_C.set_forward_mode(speculative=True, capacity=None, inference_speculative=True)
+_C.set_forward_mode(speculative=True, capacity=None, inference_speculative=True, min_history=1)  # (speculate from frame 2)
 cam = TorchCamera(make_camera(800, 528, distance=5.0), dev)
 with torch.no_grad():
     render(cam, pc, PipelineParams(), bg, scaling_modifier=0.5)       # exact, teaches a small count
