@@ -334,7 +334,7 @@ def main():
         _C.set_forward_mode(speculative=False)
         for i in range(min(args.steps, len(cams))):
             cam = cams[((args.warmup + i) * world + rank) % len(cams)]
-            for variant in (0, 1):
+            for variant in (0, 2):  # (2 = the default lists: only the tiles a Gaussian's contribution ellipse reaches)
                 _lib.set_option("cull_variant", variant)
                 n, *_r = _C.rasterize_gaussians(bg, pc._xyz, torch.Tensor([]), pc._semantics, pc._opacity, pc._scaling,
                                                 pc._rotation, 1.0, torch.Tensor([]), cam.world_view_transform,

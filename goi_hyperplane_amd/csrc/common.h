@@ -32,6 +32,8 @@ struct GeomView {
     uint32_t* sort_vals[2];   // [P] Gaussian ids (ping-pong); [final][0 .. V) = depth order of the V listed Gaussians
     uint32_t* offsets;        // [V] exclusive prefix of tiles_touched in DEPTH order: where emit puts a Gaussian's instances
     uint32_t* goff;           // [P] the same prefix by Gaussian id (listed Gaussians only) = its first row slot in the backward
+    unsigned long long* tmask;  // [P] which tiles of the listed rectangle the Gaussian's ellipse reaches (cull_variant 2), row-major
+                                // bits; TMASK_FULL: all of them (rectangles of more than 64 tiles, cull_variant < 2)
     uint2* blk_agg;           // [ceil(P/256)] per preprocess block: (listed Gaussians, tiles touched)
     uint32_t* scratch;        // scan partials + radix histograms
     uint32_t* counters;       // [COUNTER_WORDS]: 1 = error flag, 2 = cull_variant of this forward, NR_BASE.. = num_rendered stripes
@@ -71,8 +73,9 @@ struct Options {
                           // MFMA flush, 2 the same with the exact-fp32 flush, 1 workgroup-per-tile + atomics
     int sort_variant = 1;  // 0: histogram / scan / scatter per pass, 1: onesweep (decoupled look-back, default)
     int decode_variant = 1;  // semantic decode, S <= 16: 1 split-bf16 MFMA contraction, 2 pixel blocks per operand fetch (2: 4 blocks, 3: 1 block; bit-identical), 0 fp32 MFMA
-    int cull_variant = 1;  // 0: a Gaussian is listed in every tile of its 3-sigma rectangle (the reference's lists),
-                           // 1: only in the tiles its exact contribution box touches (same images and gradients)
+    int cull_variant = 2;  // 0: a Gaussian is listed in every tile of its 3-sigma rectangle (the reference's lists),
+                           // 1: only in the tiles its exact contribution box touches, 2: only in the tiles its contribution
+                           // ELLIPSE reaches (rectangles of up to 64 tiles).  Same images and gradients, bit for bit.
     int bwd_order = 1;     // backward blend: 1 the quadrants of each XCD's band are launched longest-first (their cost is
                            // known from the forward's n_contrib), 0 in tile order.  Same rows, same gradients.
 };
@@ -208,6 +211,35 @@ __device__ __forceinline__ void listed_rect(float px, float py, int r, float hx,
     }
     x1 = max(x1, x0);
     y1 = max(y1, y0);
+}
+// Tiles of a Gaussian's listed rectangle that its contribution ellipse reaches (cull_variant 2): a 64-bit mask, bit
+// (row * width + column) of the rectangle.  The tile instance of tile (tx, ty) is then the mask's set bits below that bit.
+constexpr unsigned long long TMASK_FULL = ~0ull;
+__device__ __forceinline__ uint32_t tile_instance(unsigned long long mask, int tx, int ty, int x0, int y0, int x1) {
+    const uint32_t bit = (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
+    if (mask == TMASK_FULL) return bit;
+    return (uint32_t)__popcll(mask & ((1ull << bit) - 1ull));
+}
+// position (0-based, from bit 0) of the k-th set bit of mask (k < popcount(mask))
+__device__ __forceinline__ int select_bit(unsigned long long mask, int k) {
+    uint32_t m = (uint32_t)mask;
+    int base = 0;
+    int c = __popc(m);
+    if (k >= c) {
+        k -= c;
+        base = 32;
+        m = (uint32_t)(mask >> 32);
+    }
+#pragma unroll
+    for (int sh = 16; sh >= 1; sh >>= 1) {
+        c = __popc(m & ((1u << sh) - 1u));
+        if (k >= c) {
+            k -= c;
+            m >>= sh;
+            base += sh;
+        }
+    }
+    return base;
 }
 // num_rendered is accumulated by preprocess in NR_STRIPES partial counters, one per 128-byte line (a single hot
 // counter serialises 4 K block atomics: +130 us); word NR_BASE + NR_STRIDE * i, the host adds them up

@@ -87,6 +87,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_k(const PreArgs args, Gaus
                                                         float* __restrict__ cov3D_out,
                                                         uint32_t* __restrict__ tiles_touched,
                                                         uint8_t* __restrict__ clamped, uint32_t* __restrict__ raw_key,
+                                                        unsigned long long* __restrict__ tmask,
                                                         uint2* __restrict__ blk_agg, int* __restrict__ radii,
                                                         uint32_t* __restrict__ counters, uint2* __restrict__ ranges,
                                                         int n_tiles) {
@@ -106,6 +107,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_k(const PreArgs args, Gaus
     a.proj = cam.proj;
     a.campos = cam.campos;
     int my_radius_i = 0;
+    unsigned long long tmask_v = TMASK_FULL;
     uint32_t touched = 0, key = 0xFFFFFFFFu;
     uint8_t clamp_bits = 0;
 
@@ -217,6 +219,48 @@ __global__ __launch_bounds__(256) void preprocess_fwd_k(const PreArgs args, Gaus
         my_radius_i = (int)my_radius;
         listed_rect(pix, piy, my_radius_i, hx, hy, a.cull != 0, a.gx, a.gy, x0, y0, x1, y1);
         touched = (uint32_t)((y1 - y0) * (x1 - x0));  // may be 0 for a visible Gaussian (radius stays > 0)
+        // cull_variant 2: of that rectangle, only the tiles the contribution ELLIPSE  1/2 d^T C d <= tau  reaches (the
+        // box over-covers by 1 - pi/4 for a round Gaussian, by most of its area for an elongated diagonal one: x0.80
+        // instances on the headline scene).  Exact for a convex set, one tile row at a time: over the row's pixel-centre
+        // band y in [16 t, 16 t + 15], clipped to the ellipse's own extent, the ellipse spans x in [L, R] with
+        //     R(dy) = (-b dy + sqrt(2 a tau - det dy^2)) / a   (concave: its maximum over the band is at the band's
+        // point nearest to the ellipse's rightmost point dy = -(b/c) hx), L likewise (convex, leftmost point); the row's
+        // tiles are those whose pixel-centre range [16 t, 16 t + 15] meets [L, R].  tau carries the box's inflation (1 % +
+        // 0.01: the blend kernels' evaluation error of `power` can never move a contributing pixel outside), every
+        // rounding here is pushed outward, and a NaN keeps the whole row.  A tile that is dropped can not receive a
+        // contribution; the per-pixel sequences of contributing Gaussians, hence all outputs and gradients, are untouched.
+        if (a.cull >= 2 && touched > 0 && touched <= 64 && hx < 1e30f && hy < 1e30f) {
+            const int w = x1 - x0;
+            const float tau = (fmaf(1.01f, logf(255.0f * o), 0.01f) * 1.000002f + 1e-6f) * 1.0001f + 1e-4f;
+            const float bb = con_b * con_b;
+            const float det = fmaxf((fmaf(con_a, con_c, -bb) + fmaf(-con_b, con_b, bb)) * (1.f - 4e-7f), 0.f);
+            const float inv_a = 1.f / con_a;
+            const float dyR = -(con_b / con_c) * hx, dyL = -dyR;  // where the ellipse is rightmost / leftmost
+            unsigned long long mask = 0ull;
+            for (int ry = 0; ry < y1 - y0; ry++) {
+                const float lo = fmaxf((float)((y0 + ry) * TILE) - piy, -hy), hi = fminf((float)((y0 + ry) * TILE + TILE - 1) - piy, hy);
+                if (!(lo <= hi)) {
+                    if (lo == lo && hi == hi) continue;  // the band misses the ellipse's extent
+                }
+                const float d1 = fminf(fmaxf(dyR, lo), hi), d2 = fminf(fmaxf(dyL, lo), hi);
+                const float s1 = sqrtf(fmaxf(2.f * con_a * tau - det * d1 * d1, 0.f));
+                const float s2 = sqrtf(fmaxf(2.f * con_a * tau - det * d2 * d2, 0.f));
+                float R = (-con_b * d1 + s1) * inv_a, L = (-con_b * d2 - s2) * inv_a;
+                R += 1e-3f + 4e-6f * fabsf(R);
+                L -= 1e-3f + 4e-6f * fabsf(L);
+                // columns t with 16 t <= pix + R and 16 t + 15 >= pix + L
+                int c0 = (int)ceilf((pix + L - (float)(TILE - 1)) / TILE), c1 = (int)floorf((pix + R) / TILE) + 1;
+                if (!(R == R) || !(L == L)) {
+                    c0 = x0;
+                    c1 = x1;
+                }
+                c0 = max(c0, x0);
+                c1 = min(c1, x1);
+                if (c1 > c0) mask |= ((c1 - c0 >= 64) ? ~0ull : ((1ull << (c1 - c0)) - 1ull)) << (ry * w + (c0 - x0));
+            }
+            tmask_v = mask;
+            touched = (uint32_t)__popcll(mask);
+        }
         key = __float_as_uint(p_view.z);
     } while (false);
 
@@ -225,6 +269,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_k(const PreArgs args, Gaus
         tiles_touched[idx] = touched;
         clamped[idx] = clamp_bits;
         raw_key[idx] = key;  // depth bits by Gaussian id; compact_listed_k keeps the listed ones for the depth sort
+        tmask[idx] = tmask_v;
     }
     // num_rendered = sum of tiles_touched: order-independent, so it is formed HERE (one integer atomic per wave)
     // instead of falling out of the prefix sum after the depth sort -- the host can read it while the sort runs
@@ -895,6 +940,7 @@ template <bool COUNT>
 __global__ __launch_bounds__(256) void emit_k(int P, int gx, int gy, const GaussRec* __restrict__ rec,
                                               const int* __restrict__ radii, const uint32_t* __restrict__ order,
                                               const uint32_t* __restrict__ offsets, uint32_t* __restrict__ goff,
+                                              const unsigned long long* __restrict__ tmask,
                                               uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
                                               uint32_t* __restrict__ tile_count, uint32_t* __restrict__ counters,
                                               uint32_t* __restrict__ clear, uint32_t clear_words, uint32_t cap) {
@@ -911,6 +957,7 @@ __global__ __launch_bounds__(256) void emit_k(int P, int gx, int gy, const Gauss
     constexpr int ROUNDS_PER_BLOCK = COUNT ? EMIT_ROUNDS : 1;
     if ((int)blockIdx.x * ROUNDS_PER_BLOCK * 256 >= P) return;  // (block-uniform) nothing listed left for this block
     extern __shared__ uint32_t s_cnt[];  // [gx * gy] when COUNT
+    __shared__ unsigned long long s_mask[4][64];  // the rectangles' tile masks (cull_variant 2)
     __shared__ unsigned long long s_mark[4];  // per wave and trip: bit p = some rectangle's last instance is at position p
     __shared__ uint4 s_info[4][64];  // (x0 | y0 << 16, exclusive count, offsets[] - exclusive count, Gaussian id)
     __shared__ int s_w[4][64];       // rectangle width in tiles
@@ -929,9 +976,10 @@ __global__ __launch_bounds__(256) void emit_k(int P, int gx, int gy, const Gauss
         uint32_t g, off;
         int r;
         float4 q0, q2;
+        unsigned long long mask;
     };
     auto fetch = [&](int rnd) {
-        Fetched f{0u, 0u, 0, make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, -1.f, -1.f)};
+        Fetched f{0u, 0u, 0, make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, -1.f, -1.f), TMASK_FULL};
         const int i = (blockIdx.x * ROUNDS + rnd) * 256 + threadIdx.x;
         if (rnd < ROUNDS && i < P) {
             f.g = order[i];
@@ -939,6 +987,7 @@ __global__ __launch_bounds__(256) void emit_k(int P, int gx, int gy, const Gauss
             f.r = radii[f.g];
             f.q0 = rec[f.g].q0;
             f.q2 = rec[f.g].q2;
+            f.mask = tmask[f.g];
         }
         return f;
     };
@@ -956,7 +1005,7 @@ __global__ __launch_bounds__(256) void emit_k(int P, int gx, int gy, const Gauss
                 int x1, y1;
                 listed_rect(cur.q0.x, cur.q0.y, cur.r, cur.q2.z, cur.q2.w, cull, gx, gy, x0, y0, x1, y1);
                 w = x1 - x0;
-                cnt = w * (y1 - y0);
+                cnt = cur.mask == TMASK_FULL ? w * (y1 - y0) : __popcll(cur.mask);  // (cull_variant 2: the ellipse's tiles)
             }
         }
         // Load-balanced expansion: the wave's 64 rectangles hold `total` (tile, Gaussian) instances; lane l of trip
@@ -980,6 +1029,7 @@ __global__ __launch_bounds__(256) void emit_k(int P, int gx, int gy, const Gauss
         if (cnt > 0) {
             s_info[wv][my_rank] = make_uint4((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)excl, off - (uint32_t)excl, g);
             s_w[wv][my_rank] = w;
+            s_mask[wv][my_rank] = cur.mask;
         }
         int ended = 0;  // non-empty rectangles that end before the current trip (wave-uniform)
         for (int t0 = 0; t0 < total; t0 += 64) {
@@ -996,7 +1046,9 @@ __global__ __launch_bounds__(256) void emit_k(int P, int gx, int gy, const Gauss
             if (t >= total) continue;
             const uint4 info = s_info[wv][lo];
             const int wl = s_w[wv][lo];
-            const int k = t - (int)info.y;
+            const unsigned long long mk = s_mask[wv][lo];
+            int k = t - (int)info.y;
+            if (mk != TMASK_FULL) k = select_bit(mk, k);  // the k-th tile the ellipse reaches -> its index in the rectangle
             int row = (int)((float)k * __builtin_amdgcn_rcpf((float)wl));  // k / wl, off by at most one
             row -= (row * wl > k);
             row += ((row + 1) * wl <= k);
@@ -1108,7 +1160,7 @@ void launch_preprocess_fwd(const GoiRasterScene& sc, const GeomView& g, int* rad
     a.view_p = sc.viewmatrix; a.proj_p = sc.projmatrix; a.campos_p = sc.campos;
     static_assert(PRE_BLOCK == 256, "preprocess_fwd_k is written for 256-thread workgroups");
     preprocess_fwd_k<<<dim3((sc.P + PRE_BLOCK - 1) / PRE_BLOCK), dim3(PRE_BLOCK), 0, s>>>(
-        a, g.rec, g.cov3D, g.tiles_touched, g.clamped, g.sort_keys[1], g.blk_agg, radii, g.counters, ranges, n_tiles);
+        a, g.rec, g.cov3D, g.tiles_touched, g.clamped, g.sort_keys[1], g.tmask, g.blk_agg, radii, g.counters, ranges, n_tiles);
 }
 
 void launch_compact_listed(int P, const GeomView& g, uint32_t* ghist, bool pad, hipStream_t s) {
@@ -1183,7 +1235,7 @@ void launch_reduce_sem_rows(const GoiRasterScene& sc, const GeomView& g, int N, 
 void launch_emit(int P, int W, int H, const GeomView& g, const uint32_t* order, const int* radii, uint32_t* keys,
                  uint32_t* vals, uint32_t cap, hipStream_t s) {
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
-    emit_k<false><<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, gx, gy, g.rec, radii, order, g.offsets, g.goff, keys, vals,
+    emit_k<false><<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, gx, gy, g.rec, radii, order, g.offsets, g.goff, g.tmask, keys, vals,
                                                               nullptr, g.counters, nullptr, 0u, cap);
 }
 
@@ -1200,7 +1252,7 @@ void launch_emit_counting(int P, int W, int H, const GeomView& g, const uint32_t
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     // `ranges` was zeroed by preprocess_fwd_k
     emit_k<true><<<dim3((P + 256 * EMIT_ROUNDS - 1) / (256 * EMIT_ROUNDS)), dim3(256), (size_t)gx * gy * sizeof(uint32_t), s>>>(
-        P, gx, gy, g.rec, radii, order, g.offsets, g.goff, keys, vals, reinterpret_cast<uint32_t*>(ranges) + 1, g.counters,
+        P, gx, gy, g.rec, radii, order, g.offsets, g.goff, g.tmask, keys, vals, reinterpret_cast<uint32_t*>(ranges) + 1, g.counters,
         clear, (uint32_t)clear_words, cap);
 }
 

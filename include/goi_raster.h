@@ -225,7 +225,9 @@ int goi_raster_profile_collect(double* ms, int* calls);
  *                  (within ~1e-5 relative of exact fp32, bit-reproducible); 2 the same with exact-fp32 MFMA (an fmaf chain
  *                  per output); 1 workgroup-per-tile backward with float atomics (what scratch = NULL selects)
  *   "sort_variant" 1 (default) onesweep radix sort, 0 histogram / scan / scatter per pass
- *   "cull_variant" 1 (default) tile lists culled by the exact contribution box, 0 the reference's 3-sigma squares
+ *   "cull_variant" 2 (default) a Gaussian is listed only in the tiles its contribution ellipse (alpha >= 1/255) reaches,
+ *                  1 in the tiles its axis-aligned contribution box touches, 0 in the reference's 3-sigma squares.
+ *                  Identical images; gradients equal up to the order of one fp32 sum
  *   "decode_variant" (goi_semantic_decode, S <= 16) 1 (default) contraction as three bf16 MFMAs on exact 3-way splits of
  *                  the fp32 operands (fp32 accuracy), two 16-pixel blocks per code-book operand fetch; 2 / 3 the same
  *                  with four / one block per fetch (bit-identical results, slower); 0 fp32 MFMA

@@ -103,7 +103,7 @@ def test_what_the_key_sees_misses(cache):
         _frame(cam, pc, g_sem, g_col)
         assert rasterizer.geometry_cache_stats()["misses"] == m + 1
     finally:
-        _lib.set_option("cull_variant", 1)
+        _lib.set_option("cull_variant", 2)
 
 
 def test_not_eligible_when_geometry_is_trainable_and_bounded_by_bytes(cache):

@@ -65,7 +65,7 @@ def run_hip(sc, cam, bg, dev, grads=None, pipe=None, debug_views=False):
             res["views"] = {k: v.cpu().numpy() for k, v in _C.debug_views(sc.P, cam.image_width, cam.image_height, n,
                                                                             geom, binning, img).items()}
         finally:
-            _lib.set_option("cull_variant", 1)
+            _lib.set_option("cull_variant", 2)
     return res
 
 
@@ -612,10 +612,10 @@ def test_semantics_only_backward_is_bit_identical_to_the_full_one(dev, P, W, H, 
 
 @pytest.mark.parametrize("P,W,H,S,mu", [(4000, 200, 152, 16, -2.6), (1500, 123, 77, 10, -1.8), (300_000, 800, 528, 16, -3.8)])
 def test_culled_tile_lists_change_nothing_but_the_instance_count(dev, P, W, H, S, mu):
-    """cull_variant 1 (default) lists a Gaussian only in the tiles its exact contribution box touches;
-    cull_variant 0 in every tile of the 3-sigma rectangle, like the reference.  The per-pixel sequence of
-    contributing Gaussians is the same: every output is BIT-identical and every gradient equal up to the
-    order of one fp32 sum."""
+    """cull_variant 2 (default) lists a Gaussian only in the tiles its contribution ELLIPSE reaches, cull_variant 1 in
+    the tiles its exact contribution box touches, cull_variant 0 in every tile of the 3-sigma rectangle, like the
+    reference.  The per-pixel sequence of contributing Gaussians is the same: every output is BIT-identical and every
+    gradient equal up to the order of one fp32 sum."""
     from goi_hyperplane_amd import _C, _lib
     from goi_hyperplane_amd.render import GaussianSet, PipelineParams, TorchCamera, render
     from goi_hyperplane_amd.scene import make_camera, make_scene
@@ -627,7 +627,7 @@ def test_culled_tile_lists_change_nothing_but_the_instance_count(dev, P, W, H, S
     ups = [torch.randn(shape, device=dev, generator=g) for shape in ((3, H, W), (S, H, W), (1, H, W), (1, H, W))]
     got = {}
     try:
-        for variant in (0, 1):
+        for variant in (0, 1, 2):
             _lib.set_option("cull_variant", variant)
             for p in pc.parameters():
                 p.grad = None
@@ -641,8 +641,16 @@ def test_culled_tile_lists_change_nothing_but_the_instance_count(dev, P, W, H, S
             got[variant] = (n, {k: out[k].detach().clone() for k in ("render", "semantics", "depth", "alpha", "radii")},
                             {k: p.grad.clone() for k, p in pc.named_parameters()}, out["viewspace_points"].grad.clone())
     finally:
-        _lib.set_option("cull_variant", 1)
-    (n0, o0, g0, v0), (n1, o1, g1, v1) = got[0], got[1]
+        _lib.set_option("cull_variant", 2)
+    assert got[2][0] <= got[1][0] < got[0][0], [g_[0] for g_ in got.values()]
+    if P >= 4000:
+        assert got[2][0] < 0.95 * got[1][0]  # (the ellipse test does remove tiles the box keeps)
+    for variant in (1, 2):
+        _check_culled(got[0], got[variant])
+
+
+def _check_culled(ref, culled):
+    (n0, o0, g0, v0), (n1, o1, g1, v1) = ref, culled
     assert n1 < n0, (n0, n1)
     for k in o0:
         assert torch.equal(o0[k], o1[k]), k
@@ -685,7 +693,8 @@ def test_runs_on_a_side_stream_with_identical_results(dev):
         assert torch.equal(x, y)
 
 
-@pytest.mark.parametrize("option,value", [("bwd_variant", 1), ("bwd_variant", 2), ("fwd_variant", 0), ("sort_variant", 0), ("cull_variant", 0)])
+@pytest.mark.parametrize("option,value", [("bwd_variant", 1), ("bwd_variant", 2), ("fwd_variant", 0), ("sort_variant", 0), ("cull_variant", 0),
+                                          ("cull_variant", 1)])
 def test_alternative_kernels_stay_correct(oracle_mod, dev, option, value):
     """The non-default variants kept behind goi_raster_set_option (tile + atomics backward, one-candidate forward
     loop, the exact-fp32 MFMA flush of the backward, histogram/scan/scatter sort, the reference's un-culled lists) against the oracle on one case."""
@@ -697,7 +706,7 @@ def test_alternative_kernels_stay_correct(oracle_mod, dev, option, value):
     grads = upstream_grads(S, H, W, seed=5)
     o = oracle_mod.from_scene(sc, cam, bg=bg)
     f = o.forward()
-    default = {"bwd_variant": 0, "fwd_variant": 1, "sort_variant": 1, "cull_variant": 1}[option]
+    default = {"bwd_variant": 0, "fwd_variant": 1, "sort_variant": 1, "cull_variant": 2}[option]
     _lib.set_option(option, value)
     try:
         res = run_hip(sc, cam, bg, dev, grads=grads)
