@@ -833,7 +833,10 @@ int goi_raster_set_option(const char* name, int value) {
     }
     else if (!strcmp(name, "sort_variant")) g_options.sort_variant = value;
     else if (!strcmp(name, "cull_variant")) g_options.cull_variant = value;
-    else if (!strcmp(name, "bwd_order")) g_options.bwd_order = value;
+    else if (!strcmp(name, "bwd_order")) {
+        if (value < 0 || value > 8) return fail("bwd_order must be 0 .. 8");
+        g_options.bwd_order = value;
+    }
     else if (!strcmp(name, "decode_variant")) g_options.decode_variant = value;
     else return fail(std::string("unknown option ") + name);
     return 0;

@@ -76,8 +76,9 @@ struct Options {
     int cull_variant = 2;  // 0: a Gaussian is listed in every tile of its 3-sigma rectangle (the reference's lists),
                            // 1: only in the tiles its exact contribution box touches, 2: only in the tiles its contribution
                            // ELLIPSE reaches (rectangles of up to 64 tiles).  Same images and gradients, bit for bit.
-    int bwd_order = 1;     // backward blend: 1 the quadrants of each XCD's band are launched longest-first (their cost is
-                           // known from the forward's n_contrib), 0 in tile order.  Same rows, same gradients.
+    int bwd_order = 1;     // backward blend: v >= 1 the quadrants of each XCD's band are launched longest-first (their cost is
+                           // known from the forward's n_contrib; cost classes of 2^(3+v) list positions), 0 in tile order.
+                           // Same rows, same gradients.
 };
 // The switches an entry point works with are a per-THREAD snapshot taken when the call starts (refresh_options):
 // goi_raster_set_option changes the process-wide set under a mutex, and a call that is already running on another host

@@ -455,7 +455,7 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
 // change any result.
 constexpr int QO_THREADS = 1024, QO_WAVES = QO_THREADS / 64, QO_BUCKETS = 64, QO_ROUNDS = 16;
 __global__ __launch_bounds__(QO_THREADS) void quad_order_k(const uint32_t* __restrict__ qcost, int n_quads, int per,
-                                                           uint32_t* __restrict__ qorder) {
+                                                           uint32_t* __restrict__ qorder, int shift) {
     __shared__ uint32_t cnt[QO_WAVES][QO_BUCKETS];
     const int band = blockIdx.x, base = band * per;
     const int n = max(0, min(per, n_quads - base));
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(QO_THREADS) void quad_order_k(const uint32_t* __res
         const bool ok = r * 64 + lane < chunk && e < n;
         // bucket 0 = heaviest: 16 list positions per bucket, everything above 1008 together
         const uint32_t c = ok ? qcost[base + e] : 0u;
-        const uint32_t d = (uint32_t)(QO_BUCKETS - 1) - min((uint32_t)(QO_BUCKETS - 1), c >> 4);
+        const uint32_t d = (uint32_t)(QO_BUCKETS - 1) - min((uint32_t)(QO_BUCKETS - 1), c >> shift);
         unsigned long long peers = __ballot(ok);
 #pragma unroll
         for (int b = 0; b < 6; b++) {
@@ -546,7 +546,7 @@ void launch_quad_order(const GoiRasterScene& sc, const ImageView& im, hipStream_
     if (!quad_order_enabled(sc.W, sc.H)) return;
     const int gx = (sc.W + TILE - 1) / TILE, gy = (sc.H + TILE - 1) / TILE;
     const int n_quads = gx * gy * 4, per = quad_grid(n_quads) / 8;
-    quad_order_k<<<dim3(8), dim3(QO_THREADS), 0, s>>>(im.qcost, n_quads, per, im.qorder);
+    quad_order_k<<<dim3(8), dim3(QO_THREADS), 0, s>>>(im.qcost, n_quads, per, im.qorder, 3 + g_options.bwd_order);
 }
 
 void launch_render_bwd_rows(const GoiRasterScene& sc, const GeomView& g, const ImageView& im,

@@ -232,7 +232,8 @@ int goi_raster_profile_collect(double* ms, int* calls);
  *                  the fp32 operands (fp32 accuracy), two 16-pixel blocks per code-book operand fetch; 2 / 3 the same
  *                  with four / one block per fetch (bit-identical results, slower); 0 fp32 MFMA
  *   "bwd_order"    1 (default) the backward's quadrant waves are launched longest-first inside each XCD's band (their
- *                  cost is known from the forward), 0 in tile order; same gradients
+ *                  cost is known from the forward; cost classes of 16 list positions), 2 .. 4 the same with classes of 32 ..
+ *                  128 positions (closer to tile order: less HBM traffic, less balance), 0 in tile order; same gradients
  * Thread safety: the set is changed under a mutex; an entry point snapshots it when it starts. */
 int goi_raster_set_option(const char* name, int value);
 
