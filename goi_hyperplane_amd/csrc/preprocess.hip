@@ -767,7 +767,10 @@ __global__ __launch_bounds__(256) void reduce_rows_k(int P, int S, int nch, uint
                                                      float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor,
                                                      float* __restrict__ dL_dsemantic, float* __restrict__ dL_ddepth) {
     constexpr int RF = 16 * K;
-    constexpr int INFLIGHT = 16;
+#ifndef GOI_REDUCE_INFLIGHT
+#define GOI_REDUCE_INFLIGHT 32
+#endif
+    constexpr int INFLIGHT = GOI_REDUCE_INFLIGHT;
     // N_cap: the slot capacity the scratch was laid out for; n_dev: the forward's instance count on the device (the
     // exact forward passes N_cap = num_rendered; the speculative one a capacity, and an overflowed frame stored only
     // the first N_cap instances)
@@ -844,8 +847,10 @@ __global__ __launch_bounds__(256) void reduce_rows_k(int P, int S, int nch, uint
         uint32_t cmax = cnt;
 #pragma unroll
         for (int d = 32; d >= 16; d >>= 1) cmax = max(cmax, (uint32_t)__shfl_xor((int)cmax, d, 64));
+        uint32_t w_chunk = w_cur;
         for (uint32_t c = 0; c < cmax; c += 16) {
-            const uint32_t w = c == 0 ? w_cur : load_flags(cur, c);  // 4 quadrant bytes of instance c+e
+            const uint32_t w = w_chunk;                          // 4 quadrant bytes of instance c+e
+            if (c + 16 < cmax) w_chunk = load_flags(cur, c + 16);  // (the next chunk's, under this chunk's rows)
             unsigned long long m = 0;  // bit 16q + i: quadrant q of instance c+i is valid
 #pragma unroll
             for (int q = 0; q < 4; q++) {
@@ -888,6 +893,9 @@ __global__ __launch_bounds__(256) void reduce_rows_k(int P, int S, int nch, uint
                 if (left <= 4) {
                     trip(std::integral_constant<int, 4>{});
                     left -= 4;
+                } else if (left <= 12) {
+                    trip(std::integral_constant<int, 12>{});
+                    left -= 12;
                 } else {
                     trip(std::integral_constant<int, INFLIGHT>{});
                     left -= INFLIGHT;
