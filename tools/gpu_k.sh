@@ -1,2 +1,4 @@
 cd $GRAFT_REPO_ROOT
-python tools/band_balance.py --skew 2>&1 | tail -6
+timeout 600 python -m pytest tests/test_gpu_losses.py -m gpu -x -q 2>&1 | tail -2
+GOI_SIMGRAD=2 timeout 300 python tools/fused_loss_time.py 2>&1 | tail -2
+GOI_SIMGRAD=2 bash tools/kstats.sh tools/fused_loss_time.py 2>&1 | grep -E "simgrad"
