@@ -626,9 +626,16 @@ int goi_raster_backward(const GoiRasterScene* scene, int R, const void* geom_buf
         }
         if (check_stage(sc, s, "backward blend")) return -1;
         StageTimer t(GOI_STAGE_PREPROCESS_BWD, s);
-        launch_reduce_rows(sc, g, R, scr, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dsemantic, dL_ddepth, s);
-        launch_preprocess_bwd(sc, g, radii, dL_dmean2D, dL_dconic, dL_dcolor, dL_ddepth, dL_dmean3D, dL_dcov3D, dL_dsh,
-                              dL_dscale, dL_drot, s);
+        if (g_options.bwd_records) {
+            // the sums stay in the row scratch (one record per listed Gaussian); preprocess_bwd_k writes the per-id outputs
+            launch_reduce_rows(sc, g, R, scr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, s, true);
+            launch_preprocess_bwd(sc, g, radii, dL_dmean2D, dL_dconic, dL_dcolor, dL_ddepth, dL_dmean3D, dL_dcov3D, dL_dsh,
+                                  dL_dscale, dL_drot, s, scr.rows, dL_dopacity, dL_dsemantic);
+        } else {
+            launch_reduce_rows(sc, g, R, scr, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dsemantic, dL_ddepth, s);
+            launch_preprocess_bwd(sc, g, radii, dL_dmean2D, dL_dconic, dL_dcolor, dL_ddepth, dL_dmean3D, dL_dcov3D, dL_dsh,
+                                  dL_dscale, dL_drot, s);
+        }
     } else {
         // atomic path: the accumulated gradients start from zero
         GOI_HIP(hipMemsetAsync(dL_dmean2D, 0, 3 * P * sizeof(float), s));
@@ -838,6 +845,10 @@ int goi_raster_set_option(const char* name, int value) {
         g_options.bwd_order = value;
     }
     else if (!strcmp(name, "decode_variant")) g_options.decode_variant = value;
+    else if (!strcmp(name, "bwd_records")) {
+        if (value < 0 || value > 1) return fail("bwd_records must be 0 or 1");
+        g_options.bwd_records = value;
+    }
     else return fail(std::string("unknown option ") + name);
     return 0;
 }

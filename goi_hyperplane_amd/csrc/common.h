@@ -79,6 +79,9 @@ struct Options {
     int bwd_order = 1;     // backward blend: v >= 1 the quadrants of each XCD's band are launched longest-first (their cost is
                            // known from the forward's n_contrib; cost classes of 2^(3+v) list positions), 0 in tile order.
                            // Same rows, same gradients.
+    int bwd_records = 1;   // atomic-free backward: 1 the per-Gaussian sums stay in the row scratch as records and
+                           // preprocess_bwd_k writes every per-id output (default), 0 reduce_rows_k writes six per-id arrays
+                           // (and zeros for the unlisted Gaussians) that preprocess_bwd_k reads back.  Same gradients, bit for bit.
 };
 // The switches an entry point works with are a per-THREAD snapshot taken when the call starts (refresh_options):
 // goi_raster_set_option changes the process-wide set under a mutex, and a call that is already running on another host
@@ -142,10 +145,11 @@ void launch_render_bwd_sem(const GoiRasterScene& sc, const GeomView& g, const Im
                            int row_floats, hipStream_t s);
 void launch_reduce_sem_rows(const GoiRasterScene& sc, const GeomView& g, int N, const float* rows, const uint8_t* flags,
                             int row_floats, float* dL_dsemantic, hipStream_t s);
-// sums every Gaussian's partial rows (fixed order) into the six blend-gradient arrays; writes all P rows
+// sums every Gaussian's partial rows (fixed order) into the six blend-gradient arrays (writes all P rows) -- or, `records`,
+// into one record per listed Gaussian, left in the row scratch over the Gaussian's first slot (the arrays may be NULL then)
 void launch_reduce_rows(const GoiRasterScene& sc, const GeomView& g, int N, const BwdScratchView& scr, float* dL_dmean2D,
                         float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dsemantic, float* dL_ddepth,
-                        hipStream_t s);
+                        hipStream_t s, bool records = false);
 void launch_render_bwd_tile(const GoiRasterScene& sc, const GeomView& g, const ImageView& im,
                             const uint32_t* point_list, const float* out_alpha, const float* dL_dpix,
                             const float* dL_dsem, const float* dL_ddepth, const float* dL_dalpha, float* dL_dmean2D,
@@ -153,9 +157,12 @@ void launch_render_bwd_tile(const GoiRasterScene& sc, const GeomView& g, const I
                             float* dL_ddepths, hipStream_t s);
 void launch_sh_grad_from_views(int P, int D, int M, int V, const float* means3D, const float* campos, const float* gcol,
                                float* dL_dsh, hipStream_t s);
-void launch_preprocess_bwd(const GoiRasterScene& sc, const GeomView& g, const int* radii, const float* dL_dmean2D,
+// record_rows != NULL: the blend gradients are the per-Gaussian records reduce_rows left in the row scratch, and the kernel
+// writes dL_dmean2D, dL_dcolor, dL_dopacity and dL_dsemantic itself (dL_dconic / dL_ddepth are then neither read nor written)
+void launch_preprocess_bwd(const GoiRasterScene& sc, const GeomView& g, const int* radii, float* dL_dmean2D,
                            const float* dL_dconic, float* dL_dcolor, const float* dL_ddepth, float* dL_dmean3D,
-                           float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, hipStream_t s);
+                           float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, hipStream_t s,
+                           const float* record_rows = nullptr, float* dL_dopacity = nullptr, float* dL_dsemantic = nullptr);
 int launch_semantic_decode(const float* sem, int S, long long HW, const float* W, const float* bias, int n_codes,
                            const float* code_score, float thresh, float* sim_out, int* idx_out, uint8_t* bg_mask_out,
                            hipStream_t s);

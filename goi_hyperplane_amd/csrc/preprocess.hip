@@ -406,14 +406,27 @@ struct BwdArgs {
 // WITH_DSH: dL/dSH is formed ([P,M,3], staged through LDS).  Otherwise (the caller passed dL_dsh = NULL with SH
 // colours: "factored" mode of goi_raster_backward) the kernel writes the clamp-masked colour gradient g back to
 // dL_dcolor instead: dL/dSH[k] = basis_k(view direction) * g is then formed elsewhere (goi_raster_sh_grad_from_views).
-template <bool WITH_DSH>
+// FROM_ROWS: the blend gradients of a Gaussian come from its RECORD in the row scratch (reduce_rows_k<.., RECORD>: the summed
+// row over the Gaussian's first slot, goff[id] * 4) instead of six per-id arrays, and this kernel writes the per-id outputs
+// the reduction used to write -- dL/dmean2D, dL/dcolour, dL/dopacity, dL/dsemantics -- itself: zeros for a Gaussian that is
+// not listed, coalesced either way.  (dL_dconic / dL_ddepth are not written on that path: they were only ever this
+// kernel's inputs.)
+struct RecArgs {
+    const float* rows;              // row scratch
+    const uint32_t* goff;           // [P] first emit-order instance of a listed Gaussian
+    const uint32_t* tiles_touched;  // [P] 0: not listed (no record)
+    int row_floats, S, nch;         // nch = padded semantic channels + 4 (see render_bwd.hip: BwdCfg)
+    float* dL_dopacity;
+    float* dL_dsemantic;
+};
+template <bool WITH_DSH, bool FROM_ROWS>
 __global__ __launch_bounds__(256) void preprocess_bwd_k(const BwdArgs args, const int* __restrict__ radii,
                                                         const uint32_t* __restrict__ counters,
                                                         const uint8_t* __restrict__ clamped,
-                                                        const float* __restrict__ dL_dmean2D,
+                                                        float* dL_dmean2D,
                                                         const float* __restrict__ dL_dconic,
                                                         float* dL_dcolor,
-                                                        const float* __restrict__ dL_ddepth,
+                                                        const float* __restrict__ dL_ddepth, const RecArgs ra,
                                                         float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D,
                                                         float* __restrict__ dL_dsh, float* __restrict__ dL_dscale,
                                                         float* __restrict__ dL_drot) {
@@ -438,6 +451,72 @@ __global__ __launch_bounds__(256) void preprocess_bwd_k(const BwdArgs args, cons
     float4 grot = make_float4(0, 0, 0, 0);
     // (a truncated frame -- COUNTER_OVF -- is treated as if nothing were visible: all gradients zero)
     const bool visible = radii[idx] > 0 && counters[COUNTER_OVF] == 0;
+    // ---- the blend gradients: from the per-id arrays, or from the Gaussian's record
+    float in_conic[3] = {0.f, 0.f, 0.f}, in_m2d[2] = {0.f, 0.f}, in_depth = 0.f;
+    V3 in_col = {0.f, 0.f, 0.f};
+    if constexpr (FROM_ROWS) {
+        const bool listed = visible && ra.tiles_touched[idx] != 0;
+        const float* rec = ra.rows + (size_t)(listed ? ra.goff[idx] : 0u) * 4 * ra.row_floats;
+        const int nsem = ra.nch - 4;
+        float opa = 0.f;
+        if (listed) {
+            const float4 cd = *reinterpret_cast<const float4*>(rec + nsem);        // r, g, b, depth
+            const float4 mc = *reinterpret_cast<const float4*>(rec + ra.nch);      // mean2D x, y, conic a, b
+            const float2 co = *reinterpret_cast<const float2*>(rec + ra.nch + 4);  // conic c, opacity
+            in_col = V3{cd.x, cd.y, cd.z};
+            in_depth = cd.w;
+            in_m2d[0] = mc.x;
+            in_m2d[1] = mc.y;
+            in_conic[0] = mc.z;
+            in_conic[1] = mc.w;
+            in_conic[2] = co.x;
+            opa = co.y;
+        }
+        if (live) {
+            ra.dL_dopacity[idx] = opa;
+            dL_dmean2D[3 * idx] = in_m2d[0];
+            dL_dmean2D[3 * idx + 1] = in_m2d[1];
+            dL_dmean2D[3 * idx + 2] = 0.f;
+            dL_dcolor[3 * idx] = in_col.x;  // (factored SH mode overwrites it with the clamp-masked gradient below)
+            dL_dcolor[3 * idx + 1] = in_col.y;
+            dL_dcolor[3 * idx + 2] = in_col.z;
+        }
+        // dL/dsemantics, the widest of them (64 bytes per Gaussian at S = 16).  Per thread it is S / 4 loads and stores with a
+        // 64-byte lane stride; with 4 lanes per Gaussian (one float4 each) an instruction moves 16 Gaussians: 16 x 64-byte
+        // pieces of their records in, ONE contiguous kilobyte of the output out.
+        if ((ra.S & 3) == 0 && ra.S <= 16) {
+            const int lane = threadIdx.x & 63, sub = lane & 3, S4 = ra.S >> 2;
+            const uint32_t my = listed ? ra.goff[idx] : 0xFFFFFFFFu;
+            const int wave_first = gtid - lane;  // the Gaussian of lane 0
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int src = (lane >> 2) + 16 * k;
+                const uint32_t o = (uint32_t)__shfl((int)my, src, 64);
+                const int id2 = wave_first + src;
+                if (sub < S4 && id2 < args.P) {
+                    const float4 v = o != 0xFFFFFFFFu ? *reinterpret_cast<const float4*>(ra.rows + (size_t)o * 4 * ra.row_floats + 4 * sub)
+                                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+                    *reinterpret_cast<float4*>(ra.dL_dsemantic + (size_t)id2 * ra.S + 4 * sub) = v;
+                }
+            }
+        } else if (live) {
+            float* ds = ra.dL_dsemantic + (size_t)idx * ra.S;
+            if ((ra.S & 3) == 0) {
+                for (int ch = 0; ch < ra.S; ch += 4)
+                    *reinterpret_cast<float4*>(ds + ch) = listed ? *reinterpret_cast<const float4*>(rec + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                for (int ch = 0; ch < ra.S; ch++) ds[ch] = listed ? rec[ch] : 0.f;
+            }
+        }
+    } else if (visible) {
+        in_conic[0] = dL_dconic[4 * idx];
+        in_conic[1] = dL_dconic[4 * idx + 1];
+        in_conic[2] = dL_dconic[4 * idx + 3];
+        in_m2d[0] = dL_dmean2D[3 * idx];
+        in_m2d[1] = dL_dmean2D[3 * idx + 1];
+        in_depth = dL_ddepth[idx];
+        in_col = V3{dL_dcolor[3 * idx], dL_dcolor[3 * idx + 1], dL_dcolor[3 * idx + 2]};
+    }
     V3* dsh = WITH_DSH ? reinterpret_cast<V3*>(s_dsh + (size_t)threadIdx.x * (3 * a.M + 1)) : nullptr;
     auto put = [&](int k, const V3& v) {
         if constexpr (WITH_DSH) dsh[k] = v;
@@ -450,7 +529,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_k(const BwdArgs args, cons
             float cov3D[6];
 #pragma unroll
             for (int i = 0; i < 6; i++) cov3D[i] = a.cov3D[(size_t)6 * idx + i];
-            const float dca = dL_dconic[4 * idx], dcb = dL_dconic[4 * idx + 1], dcc = dL_dconic[4 * idx + 3];
+            const float dca = in_conic[0], dcb = in_conic[1], dcc = in_conic[2];
             Cov2D c;
             ewa_cov2d(mean, a.focal_x, a.focal_y, a.tan_fovx, a.tan_fovy, cov3D, a.view, c);
             const float x_grad_mul = (c.txtz < -c.limx || c.txtz > c.limx) ? 0.f : 1.f;
@@ -509,14 +588,14 @@ __global__ __launch_bounds__(256) void preprocess_bwd_k(const BwdArgs args, cons
             const float m_w = 1.0f / (m_hom.w + 0.0000001f);
             const float mul1 = (proj[0] * mean.x + proj[4] * mean.y + proj[8] * mean.z + proj[12]) * m_w * m_w;
             const float mul2 = (proj[1] * mean.x + proj[5] * mean.y + proj[9] * mean.z + proj[13]) * m_w * m_w;
-            const float d2x = dL_dmean2D[3 * idx], d2y = dL_dmean2D[3 * idx + 1];
+            const float d2x = in_m2d[0], d2y = in_m2d[1];
             V3 g1;
             g1.x = (proj[0] * m_w - proj[3] * mul1) * d2x + (proj[1] * m_w - proj[3] * mul2) * d2y;
             g1.y = (proj[4] * m_w - proj[7] * mul1) * d2x + (proj[5] * m_w - proj[7] * mul2) * d2y;
             g1.z = (proj[8] * m_w - proj[11] * mul1) * d2x + (proj[9] * m_w - proj[11] * mul2) * d2y;
             gmean = gmean + g1;
             const float mul3 = view[2] * mean.x + view[6] * mean.y + view[10] * mean.z + view[14];
-            const float dd = dL_ddepth[idx];
+            const float dd = in_depth;
             V3 g2;
             g2.x = (view[2] - view[3] * mul3) * dd;
             g2.y = (view[6] - view[7] * mul3) * dd;
@@ -530,7 +609,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_k(const BwdArgs args, cons
             const V3 dir = dir_orig / sqrtf(dot3(dir_orig, dir_orig));
             const V3* sh = reinterpret_cast<const V3*>(a.shs) + (size_t)idx * a.M;
             const uint8_t cl = clamped[idx];
-            V3 g = {dL_dcolor[3 * idx], dL_dcolor[3 * idx + 1], dL_dcolor[3 * idx + 2]};
+            V3 g = in_col;
             g.x *= (cl & 1) ? 0.f : 1.f;
             g.y *= (cl & 2) ? 0.f : 1.f;
             g.z *= (cl & 4) ? 0.f : 1.f;
@@ -757,12 +836,19 @@ __global__ __launch_bounds__(256) void mark_visible_k(int P, const float* __rest
 // Gaussians in a software pipeline: while the rows of Gaussian k are summed, the validity word of k+1 and the slot
 // range of k+2 are already on their way -- one exposed round trip per Gaussian instead of three, 1/GPQ of the waves.
 // The order in which a Gaussian's rows are added is unchanged (bit-identical gradients).
-template <int K, int GPQ>  // K = row_floats / 16; GPQ = Gaussians per quarter wave
+// RECORD (the full backward): the sums do not leave as six per-Gaussian arrays at all.  A Gaussian's record -- its summed
+// row, 128 bytes at S <= 16 -- goes back into the row scratch, over the first slot the Gaussian owns (every listed
+// Gaussian owns at least four; its rows have all been read by then): ONE full-line store per Gaussian instead of six
+// scattered partial ones, no zeros for the unlisted Gaussians (the old form wrote 104 bytes of them for each), and
+// preprocess_bwd_k, which runs over the ids anyway, fetches the line through goff[] and writes every per-id output itself,
+// coalesced.  Measured on the headline view before it was built (timing builds): the zero phase 21 us, the scattered
+// stores 40 us of the kernel's 213; a dense 128-byte store instead 8 us.
+template <int K, int GPQ, bool RECORD>  // K = row_floats / 16; GPQ = Gaussians per quarter wave
 __global__ __launch_bounds__(256) void reduce_rows_k(int P, int S, int nch, uint32_t N_cap, const uint32_t* __restrict__ n_dev,
                                                      const uint32_t* __restrict__ order,
                                                      const uint32_t* __restrict__ offsets,
                                                      const uint32_t* __restrict__ tiles_touched,
-                                                     const float* __restrict__ rows, const uint8_t* __restrict__ flags,
+                                                     float* rows, const uint8_t* __restrict__ flags,
                                                      float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic,
                                                      float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor,
                                                      float* __restrict__ dL_dsemantic, float* __restrict__ dL_ddepth) {
@@ -784,7 +870,7 @@ __global__ __launch_bounds__(256) void reduce_rows_k(int P, int S, int nch, uint
     // ---- phase 0 (the first ceil(P/256) workgroups): zeros for the Gaussians that are NOT listed (culled, or a culled
     // rectangle without tiles; all of them for a truncated frame) -- one Gaussian per lane.  The listed ones are written
     // by phase 1 below, so every element of the six arrays is written exactly once.
-    {
+    if constexpr (!RECORD) {
         const int i = blockIdx.x * 256 + threadIdx.x;
         if (i < P && (truncated || tiles_touched[i] == 0)) {
             if ((S & 3) == 0) {
@@ -902,7 +988,17 @@ __global__ __launch_bounds__(256) void reduce_rows_k(int P, int S, int nch, uint
                 }
             }
         }
-        if (live) {
+        if constexpr (RECORD) {
+            if (live && cnt > 0) {  // (the row elements this lane summed, back where it read them)
+                float* dst = rows + inst0 * 4 * RF;
+                if (K == 2) {
+                    reinterpret_cast<float2*>(dst)[e] = make_float2(sum[0], sum[K - 1]);
+                } else {
+#pragma unroll
+                    for (int kk = 0; kk < K; kk++) dst[e + 16 * kk] = sum[kk];
+                }
+            }
+        } else if (live) {
             const uint32_t g = cur.g;
 #pragma unroll
             for (int kk = 0; kk < K; kk++) {
@@ -1177,9 +1273,10 @@ void launch_compact_listed(int P, const GeomView& g, uint32_t* ghist, bool pad, 
         P, g.tiles_touched, g.sort_keys[1], g.blk_agg, g.counters, g.sort_keys[0], g.sort_vals[0], ghist, pad ? 1 : 0);
 }
 
-void launch_preprocess_bwd(const GoiRasterScene& sc, const GeomView& g, const int* radii, const float* dL_dmean2D,
+void launch_preprocess_bwd(const GoiRasterScene& sc, const GeomView& g, const int* radii, float* dL_dmean2D,
                            const float* dL_dconic, float* dL_dcolor, const float* dL_ddepth, float* dL_dmean3D,
-                           float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, hipStream_t s) {
+                           float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, hipStream_t s,
+                           const float* record_rows, float* dL_dopacity, float* dL_dsemantic) {
     BwdArgs a;
     a.P = sc.P; a.D = sc.D; a.M = sc.M; a.W = sc.W; a.H = sc.H;
     a.means3D = sc.means3D; a.shs = sc.shs; a.scales = sc.scales; a.rotations = sc.rotations;
@@ -1190,12 +1287,24 @@ void launch_preprocess_bwd(const GoiRasterScene& sc, const GeomView& g, const in
     a.view_p = sc.viewmatrix; a.proj_p = sc.projmatrix; a.campos_p = sc.campos;
     const bool with_sh = sc.shs && sc.M > 0 && dL_dsh;  // dL_dsh == NULL with SH colours: factored mode
     const size_t lds = with_sh ? (size_t)256 * (3 * sc.M + 1) * sizeof(float) : 0;  // 50 KB at M = 16
-    if (with_sh)
-        preprocess_bwd_k<true><<<dim3((sc.P + 255) / 256), dim3(256), lds, s>>>(
-            a, radii, g.counters, g.clamped, dL_dmean2D, dL_dconic, dL_dcolor, dL_ddepth, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+    // record_rows: the blend gradients are the records reduce_rows_k<.., RECORD> left in the row scratch
+    RecArgs ra;
+    ra.rows = record_rows; ra.goff = g.goff; ra.tiles_touched = g.tiles_touched;
+    ra.row_floats = bwd_row_floats(sc.S); ra.S = sc.S; ra.nch = 4 * ((sc.S + 3) / 4) + 4;
+    ra.dL_dopacity = dL_dopacity; ra.dL_dsemantic = dL_dsemantic;
+    const dim3 grid((sc.P + 255) / 256);
+    if (with_sh && record_rows)
+        preprocess_bwd_k<true, true><<<grid, dim3(256), lds, s>>>(
+            a, radii, g.counters, g.clamped, dL_dmean2D, dL_dconic, dL_dcolor, dL_ddepth, ra, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+    else if (with_sh)
+        preprocess_bwd_k<true, false><<<grid, dim3(256), lds, s>>>(
+            a, radii, g.counters, g.clamped, dL_dmean2D, dL_dconic, dL_dcolor, dL_ddepth, ra, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+    else if (record_rows)
+        preprocess_bwd_k<false, true><<<grid, dim3(256), 0, s>>>(
+            a, radii, g.counters, g.clamped, dL_dmean2D, dL_dconic, dL_dcolor, dL_ddepth, ra, dL_dmean3D, dL_dcov3D, nullptr, dL_dscale, dL_drot);
     else
-        preprocess_bwd_k<false><<<dim3((sc.P + 255) / 256), dim3(256), 0, s>>>(
-            a, radii, g.counters, g.clamped, dL_dmean2D, dL_dconic, dL_dcolor, dL_ddepth, dL_dmean3D, dL_dcov3D, nullptr, dL_dscale, dL_drot);
+        preprocess_bwd_k<false, false><<<grid, dim3(256), 0, s>>>(
+            a, radii, g.counters, g.clamped, dL_dmean2D, dL_dconic, dL_dcolor, dL_ddepth, ra, dL_dmean3D, dL_dcov3D, nullptr, dL_dscale, dL_drot);
 }
 
 void launch_sh_grad_from_views(int P, int D, int M, int V, const float* means3D, const float* campos, const float* gcol,
@@ -1209,20 +1318,33 @@ void launch_sh_grad_from_views(int P, int D, int M, int V, const float* means3D,
 #endif
 constexpr int REDUCE_GPQ = GOI_REDUCE_GPQ;  // Gaussians per quarter wave of reduce_rows_k
 
+// records: the sums stay in the row scratch as per-Gaussian records (see reduce_rows_k); the six arrays are not written
 void launch_reduce_rows(const GoiRasterScene& sc, const GeomView& g, int N, const BwdScratchView& scr, float* dL_dmean2D,
                         float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dsemantic, float* dL_ddepth,
-                        hipStream_t s) {
+                                hipStream_t s, bool records) {
     const int rf = bwd_row_floats(sc.S), nch = 4 * ((sc.S + 3) / 4) + 4;
     const dim3 grid((sc.P + 16 * REDUCE_GPQ - 1) / (16 * REDUCE_GPQ));
     const uint32_t* order = g.sort_vals[depth_sort_result_index()];
+    if (records) {
+        if (rf == 32)
+            reduce_rows_k<2, REDUCE_GPQ, true><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, g.tiles_touched, scr.rows, scr.flags,
+                                                              nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+        else if (rf == 16)
+            reduce_rows_k<1, REDUCE_GPQ, true><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, g.tiles_touched, scr.rows, scr.flags,
+                                                              nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+        else
+            reduce_rows_k<3, REDUCE_GPQ, true><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, g.tiles_touched, scr.rows, scr.flags,
+                                                              nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+        return;
+    }
     if (rf == 32)
-        reduce_rows_k<2, REDUCE_GPQ><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, g.tiles_touched, scr.rows, scr.flags,
+        reduce_rows_k<2, REDUCE_GPQ, false><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, g.tiles_touched, scr.rows, scr.flags,
                                                     dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dsemantic, dL_ddepth);
     else if (rf == 16)
-        reduce_rows_k<1, REDUCE_GPQ><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, g.tiles_touched, scr.rows, scr.flags,
+        reduce_rows_k<1, REDUCE_GPQ, false><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, g.tiles_touched, scr.rows, scr.flags,
                                                     dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dsemantic, dL_ddepth);
     else
-        reduce_rows_k<3, REDUCE_GPQ><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, g.tiles_touched, scr.rows, scr.flags,
+        reduce_rows_k<3, REDUCE_GPQ, false><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, g.tiles_touched, scr.rows, scr.flags,
                                                     dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dsemantic, dL_ddepth);
 }
 
@@ -1233,10 +1355,10 @@ void launch_reduce_sem_rows(const GoiRasterScene& sc, const GeomView& g, int N, 
     const dim3 grid((sc.P + 16 * REDUCE_GPQ - 1) / (16 * REDUCE_GPQ));
     const uint32_t* order = g.sort_vals[depth_sort_result_index()];
     if (row_floats == 16)
-        reduce_rows_k<1, REDUCE_GPQ><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, g.tiles_touched, rows, flags, nullptr,
+        reduce_rows_k<1, REDUCE_GPQ, false><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, g.tiles_touched, const_cast<float*>(rows), flags, nullptr,
                                                     nullptr, nullptr, nullptr, dL_dsemantic, nullptr);
     else
-        reduce_rows_k<2, REDUCE_GPQ><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, g.tiles_touched, rows, flags, nullptr,
+        reduce_rows_k<2, REDUCE_GPQ, false><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, g.tiles_touched, const_cast<float*>(rows), flags, nullptr,
                                                     nullptr, nullptr, nullptr, dL_dsemantic, nullptr);
 }
 

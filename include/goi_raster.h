@@ -151,6 +151,9 @@ int goi_raster_forward_reblend(const GoiRasterScene* scene, int R, const void* g
  * for: goi_raster_forward's return value, or the `capacity` of a goi_raster_forward_async frame (the kernels read the
  * true count from the geometry workspace), or num_rendered after goi_raster_forward_redo.
  * Any of the four upstream gradients dL_dout_* may be NULL (= zero).  dL_dconic is [P,4] (x: a, y: b, z: unused, w: c), dL_dsh [P,M,3] (may be NULL when M == 0).
+ * dL_dconic and dL_ddepth are WORKSPACES (CR/backward.cu hands them from its render pass to its preprocess pass; no caller of
+ * the reference reads them): with a scratch buffer and option "bwd_records" 1 (the default) the blend gradients travel
+ * between the two passes inside the scratch instead and these two arrays are left unwritten.
  * FACTORED mode: dL_dsh == NULL while the scene has SH colours.  dL/dSH is not formed (192 of the 300 bytes of
  * gradient per Gaussian at degree 3); dL_dcolor returns the colour gradient with the forward's clamp mask applied
  * (CR/backward.cu:44-47), the factor g of dL/dSH[k] = basis_k(view direction) * g -- see goi_raster_sh_grad_from_views. */
@@ -234,6 +237,9 @@ int goi_raster_profile_collect(double* ms, int* calls);
  *   "bwd_order"    1 (default) the backward's quadrant waves are launched longest-first inside each XCD's band (their
  *                  cost is known from the forward; cost classes of 16 list positions), 2 .. 4 the same with classes of 32 ..
  *                  128 positions (closer to tile order: less HBM traffic, less balance), 0 in tile order; same gradients
+ *   "bwd_records"  1 (default) the per-Gaussian sums of the atomic-free backward stay in the scratch as one record per
+ *                  listed Gaussian and the per-Gaussian pass writes every per-id output; 0 they go through six per-id
+ *                  arrays (dL_dconic, dL_ddepth, ... and zeros for the Gaussians that are not listed); same gradients, bit for bit
  * Thread safety: the set is changed under a mutex; an entry point snapshots it when it starts. */
 int goi_raster_set_option(const char* name, int value);
 

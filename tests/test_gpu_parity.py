@@ -560,6 +560,48 @@ def test_larger_scene_configs_properties(dev, P, S, masked):
         assert torch.equal(o3["render"], o1["render"]) and torch.equal(o3["semantics"], o1["semantics"])
 
 
+@pytest.mark.parametrize("P,W,H,S,factored", [(4000, 200, 152, 16, False), (2500, 97, 61, 10, False), (1500, 64, 48, 3, True),
+                                              (1200, 123, 77, 24, False), (200_000, 800, 528, 16, True)])
+def test_record_backward_is_bit_identical_to_the_array_backward(dev, P, W, H, S, factored):
+    """bwd_records 1 (default: per-Gaussian sums stay in the row scratch, preprocess_bwd_k writes every per-id output) against
+    bwd_records 0 (reduce_rows_k writes six per-id arrays + zeros, preprocess_bwd_k reads them back): every gradient of the
+    operator, bit for bit -- with dL/dSH formed by the kernel and in the factored form (dL_dsh = NULL: clamp-masked colour
+    gradients instead), which takes the other instantiation of preprocess_bwd_k."""
+    from goi_hyperplane_amd import _C, _lib
+    from goi_hyperplane_amd.render import GaussianSet, TorchCamera
+    from goi_hyperplane_amd.scene import make_camera, make_scene
+    sc = make_scene(P, S=S, sh_degree=3, seed=11, log_scale_mean=-2.6 if P < 10000 else -3.6)
+    cam = make_camera(W, H, yaw=-0.07)
+    tcam = TorchCamera(cam, dev)
+    pc = GaussianSet.from_scene(sc, dev)
+    gen = torch.Generator(device=dev).manual_seed(3)
+    ups = [torch.randn(shape, device=dev, generator=gen) for shape in ((3, H, W), (S, H, W), (1, H, W), (1, H, W))]
+    args = (torch.zeros(3, device=dev), pc._xyz.detach(), torch.Tensor([]), pc._semantics.detach(), pc._opacity.detach(),
+            pc._scaling.detach(), pc._rotation.detach(), 1.0, torch.Tensor([]), tcam.world_view_transform,
+            tcam.full_proj_transform, cam.tanfovx, cam.tanfovy, cam.image_height, cam.image_width, pc._features.detach(),
+            sc.sh_degree, tcam.camera_center, False, False)
+    n, color, sem, depth, alpha, radii, geom, binning, img = _C.rasterize_gaussians(*args)
+
+    def backward(records):
+        _lib.set_option("bwd_records", records)
+        try:
+            fn = _C.rasterize_gaussians_backward_sh_factored if factored else _C.rasterize_gaussians_backward
+            # (background, means3D, radii, colors, semantics, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+            #  projmatrix, tan_fovx, tan_fovy, the four upstream gradients, sh, degree, campos, workspaces, alphas, debug)
+            out = fn(args[0], args[1], radii, args[2], args[3], args[5], args[6], args[7], args[8], args[9], args[10], args[11],
+                     args[12], ups[0], ups[1], ups[2], ups[3], args[15], args[16], args[17], geom, n, binning, img, alpha, False)
+            torch.cuda.synchronize()
+            return [t.clone() for t in out if isinstance(t, torch.Tensor)]
+        finally:
+            _lib.set_option("bwd_records", 1)
+
+    a, b = backward(1), backward(0)
+    assert len(a) == len(b) and len(a) >= 8 - (1 if factored else 0)
+    for x, y in zip(a, b):
+        assert x.shape == y.shape and torch.equal(x, y)
+    assert any(float(x.abs().max()) > 0 for x in a)
+
+
 @pytest.mark.parametrize("P,W,H,S", [(4000, 200, 152, 16), (2500, 97, 61, 10), (1500, 64, 48, 3), (200_000, 800, 528, 16)])
 def test_semantics_only_backward_is_bit_identical_to_the_full_one(dev, P, W, H, S):
     """goi_raster_backward_semantics (the reference's default training configuration: only the semantic
@@ -693,7 +735,7 @@ def test_runs_on_a_side_stream_with_identical_results(dev):
         assert torch.equal(x, y)
 
 
-@pytest.mark.parametrize("option,value", [("bwd_variant", 1), ("bwd_variant", 2), ("fwd_variant", 0), ("sort_variant", 0), ("cull_variant", 0),
+@pytest.mark.parametrize("option,value", [("bwd_variant", 1), ("bwd_variant", 2), ("fwd_variant", 0), ("sort_variant", 0), ("cull_variant", 0), ("bwd_records", 0),
                                           ("cull_variant", 1)])
 def test_alternative_kernels_stay_correct(oracle_mod, dev, option, value):
     """The non-default variants kept behind goi_raster_set_option (tile + atomics backward, one-candidate forward
@@ -706,7 +748,7 @@ def test_alternative_kernels_stay_correct(oracle_mod, dev, option, value):
     grads = upstream_grads(S, H, W, seed=5)
     o = oracle_mod.from_scene(sc, cam, bg=bg)
     f = o.forward()
-    default = {"bwd_variant": 0, "fwd_variant": 1, "sort_variant": 1, "cull_variant": 2}[option]
+    default = {"bwd_variant": 0, "fwd_variant": 1, "sort_variant": 1, "cull_variant": 2, "bwd_records": 1}[option]
     _lib.set_option(option, value)
     try:
         res = run_hip(sc, cam, bg, dev, grads=grads)

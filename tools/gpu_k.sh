@@ -1,4 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests/test_gpu_losses.py -m gpu -x -q 2>&1 | tail -2
-GOI_SIMGRAD=2 timeout 300 python tools/fused_loss_time.py 2>&1 | tail -2
-GOI_SIMGRAD=2 bash tools/kstats.sh tools/fused_loss_time.py 2>&1 | grep -E "simgrad"
+timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "record_backward or alternative_kernels or forward_backward_match or golden or edge or metric_config" 2>&1 | tail -5
+python tools/ab_variants.py bwd_records 0 1 --bwd 2>&1 | tail -2 | cut -c1-60,190-520
