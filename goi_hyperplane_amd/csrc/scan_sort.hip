@@ -309,6 +309,23 @@ __global__ __launch_bounds__(THREADS) void sweep_pass_k(const uint32_t* __restri
     uint32_t* s_vals = s_dyn + TILE_KEYS;
     __shared__ uint32_t s_bid;
     const uint32_t radix = 1u << nbits, mask = radix - 1u;
+    // A TRIVIAL pass: every key has the same digit (the global histogram says so: one bin holds all n) -- the top byte of
+    // the depth keys of a scene whose depths span less than a factor of four, typically.  The pass is then the identity
+    // permutation: the tile is copied across, no ranking, no look-back, no ticket (nobody will look back at this pass).
+    if (n > 0) {
+        const uint32_t d0 = (keys_in[0] >> shift) & mask;
+        if (ghist[d0] == (uint32_t)n) {
+            const size_t base = (size_t)blockIdx.x * TILE_KEYS;
+            for (int r = 0; r < ITEMS; r++) {
+                const size_t i = base + (size_t)r * THREADS + threadIdx.x;
+                if (i < n) {
+                    keys_out[i] = keys_in[i];
+                    vals_out[i] = vals_in[i];
+                }
+            }
+            return;
+        }
+    }
     if (threadIdx.x == 0) s_bid = atomicAdd(ticket, 1u);
     for (int i = threadIdx.x; i < WAVES * RADIX_MAX; i += THREADS) (&cnt[0][0])[i] = 0;
     __syncthreads();
