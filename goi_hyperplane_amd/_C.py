@@ -168,7 +168,8 @@ def release_scratch(device=None) -> int:
 #     view, not a wrong one -- and FusedAdam.step(skip_if=truncated_flag()) leaves parameters and moments untouched.
 #     The host finds out at a later poll: a RasterOverflowWarning (GOI_OVERFLOW=raise: a RasterOverflowError) names
 #     the skipped view and the capacity is raised.
-#   * the first `min_history` frames of a scene on a device are exact (they teach the capacity policy);
+#   * the first `min_history` frames of a scene on a device are exact (they teach the capacity policy); a frame whose
+#     Gaussian count or image size (in tiles) differs from the previous frame's by more than a factor of two starts over;
 #   * at most `max_ahead` frames stay unresolved per device; the oldest is waited for beyond that (flow control: the
 #     host may run that far ahead of the GPU, which is what absorbs a host stall).  A pending frame pins no device
 #     memory: the LazyCount refers to the frame's tensors weakly (a frame whose outputs have died has no consumer
@@ -248,17 +249,32 @@ def _spec_state(dev):
     return st
 
 
-def _note_count(dev, P, n):
+def _other_scene(st, P, tiles):
+    """A frame that is not comparable with the ones the capacity policy has learnt from: the Gaussian count OR the image
+    (in tiles: num_rendered scales with it) changed by more than a factor of two.  tiles = 0: unknown (not checked)."""
+    if P > 2 * st["P"] or 2 * P < st["P"]:
+        return True
+    t0 = st.get("tiles", 0)
+    return bool(tiles and t0 and (tiles > 2 * t0 or 2 * tiles < t0))
+
+
+def _tiles(H, W):
+    return ((int(W) + 15) // 16) * ((int(H) + 15) // 16)
+
+
+def _note_count(dev, P, n, tiles=0):
     st = _spec_state(dev)
-    if P > 2 * st["P"] or 2 * P < st["P"]:  # another scene: forget what the previous one needed
+    if _other_scene(st, P, tiles):  # another scene / another image size: forget what the previous one needed
         st["high_water"] = 0
         st["seen"] = 0
     st["P"] = P
+    if tiles:
+        st["tiles"] = tiles
     st["high_water"] = max(st["high_water"], int(n))
     st["seen"] = st.get("seen", 0) + 1
 
 
-def _pick_capacity(dev, P, debug, prefiltered):
+def _pick_capacity(dev, P, debug, prefiltered, tiles=0):
     """Instances to size a speculative frame for, or None for an exact frame.  (prefiltered=True promises something the
     kernel checks and the reference traps on: that error must surface in THIS call, so such frames stay exact.)"""
     if (P == 0 or debug or prefiltered or _FWD["mode"] != "speculative"
@@ -269,7 +285,7 @@ def _pick_capacity(dev, P, debug, prefiltered):
     if _FWD["capacity"] is not None:
         return _FWD["capacity"]
     st = _spec_state(dev)
-    if st["high_water"] <= 0 or P > 2 * st["P"] or 2 * P < st["P"] or st.get("seen", 0) < _FWD["min_history"]:
+    if st["high_water"] <= 0 or _other_scene(st, P, tiles) or st.get("seen", 0) < _FWD["min_history"]:
         return None  # nothing (or too little) to go by yet: this frame is exact and teaches the policy
     return max(_MIN_CAPACITY, int(_FWD["headroom"] * st["high_water"]) + 4096)
 
@@ -293,12 +309,13 @@ class LazyCount:
     and, if the frame overflowed its capacity, redoes it in place first."""
 
     __slots__ = ("dev", "ticket", "capacity", "layout", "binning", "overflowed", "redone", "_n", "_redo", "_stream",
-                 "_error", "P", "_hold", "__weakref__")
+                 "_error", "P", "tiles", "_hold", "__weakref__")
 
     def __init__(self, dev, ticket, capacity, binning, stream, redo, P, workspaces=None):
         self.dev, self.ticket, self.capacity, self.layout, self.binning = dev, ticket, capacity, capacity, binning
         self.overflowed = self.redone = False
         self._n, self._redo, self._stream, self._error, self.P = None, redo, stream, None, P
+        self.tiles = 0  # (set by the caller: the image size is part of what the capacity policy compares)
         # The frame's workspaces (geometry / image state, radii) are needed for a redo but belong to nobody once the
         # operator has returned under no_grad: the newest few pending frames of a device keep them alive (a caller who
         # reads the count does so right after the forward), older ones let go (a pending frame must not pin memory).
@@ -341,7 +358,7 @@ class LazyCount:
             self._error = RuntimeError(_lib.last_error())
             raise self._error
         self._n = int(n.value)
-        _note_count(self.dev, self.P, self._n)
+        _note_count(self.dev, self.P, self._n, getattr(self, "tiles", 0))
         if self._n > self.capacity:
             self.overflowed = True
             SPECULATION_STATS["overflows"] += 1
@@ -629,13 +646,13 @@ def _rasterize_gaussians_frame(background, means3D, colors, semantics, opacity, 
         args = (background, means3D, _e(colors), _e(semantics), _e(opacity), _e(scales), _e(rotations),
                 float(scale_modifier), _e(cov3D_precomp), viewmatrix, projmatrix, float(tan_fovx), float(tan_fovy), H, W,
                 _e(sh), int(degree), campos, bool(prefiltered), bool(debug))
-        cap = _pick_capacity(dev, P, debug, prefiltered)
+        cap = _pick_capacity(dev, P, debug, prefiltered, _tiles(H, W))
         if cap is None:
             res = ext.rasterize_gaussians(*args)
             _note_frame(res[6], P)
             if P > 0:
                 SPECULATION_STATS["exact_frames"] += 1
-                _note_count(dev, P, res[0])
+                _note_count(dev, P, res[0], _tiles(H, W))
             return res
         ticket, out_color, out_sem, out_depth, out_alpha, radii, geom, binning, img = ext.rasterize_gaussians_async(*args, cap)
         _note_frame(geom, P)
@@ -648,6 +665,7 @@ def _rasterize_gaussians_frame(background, means3D, colors, semantics, opacity, 
                           None, False, False), (bg_c, sem_c)
         n = LazyCount(dev, ticket, cap, binning, torch.cuda.current_stream(dev).cuda_stream, (make_scene, refs), P,
                       workspaces=(geom, img, radii))
+        n.tiles = _tiles(H, W)
         return n, out_color, out_sem, out_depth, out_alpha, radii, geom, binning, img
     f32 = dict(dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
@@ -669,7 +687,7 @@ def _rasterize_gaussians_frame(background, means3D, colors, semantics, opacity, 
                     ten["scales"], ten["rotations"], scale_modifier, ten["cov3D"], ten["viewmatrix"],
                     ten["projmatrix"], tan_fovx, tan_fovy, degree, ten["campos"], prefiltered, debug)
         poll_counts(dev)
-        cap = _pick_capacity(dev, P, debug, prefiltered)
+        cap = _pick_capacity(dev, P, debug, prefiltered, _tiles(H, W))
         if cap is not None:
             # speculative frame: everything is enqueued now, the count arrives through the ticket
             step = 16 << 20
@@ -688,6 +706,7 @@ def _rasterize_gaussians_frame(background, means3D, colors, semantics, opacity, 
             refs = [weakref.ref(t) for t in (geom, img, radii) + outs]
             keep = (ten["semantics"], ten["bg"])
             n = LazyCount(dev, ticket, cap, binning, stream, (lambda: (sc, keep), refs), P, workspaces=(geom, img, radii))
+            n.tiles = _tiles(H, W)
             return n, out_color, out_sem, out_depth, out_alpha, radii, geom, binning, img
         alloc = _BinningAllocator(dev)
         n = lib.goi_raster_forward(C.byref(sc), _ptr(geom), _ptr(img), alloc.cb, None, _ptr(out_color), _ptr(out_sem),
@@ -698,7 +717,7 @@ def _rasterize_gaussians_frame(background, means3D, colors, semantics, opacity, 
             raise RuntimeError(_lib.last_error())
         if P > 0:
             SPECULATION_STATS["exact_frames"] += 1
-            _note_count(dev, P, n)
+            _note_count(dev, P, n, _tiles(H, W))
     return n, out_color, out_sem, out_depth, out_alpha, radii, geom, alloc.tensor, img
 
 
@@ -892,7 +911,7 @@ def rasterize_gaussians_trace(background, means3D, colors, img_sem, opacity, sca
                                             projmatrix, float(tan_fovx), float(tan_fovy), H, W, _e(sh), int(degree),
                                             campos, bool(prefiltered), bool(debug))
         if P > 0:
-            _note_count(dev, P, res[0])
+            _note_count(dev, P, res[0], _tiles(H, W))
         return res
     S = int(img_sem.size(0))
     f32 = dict(dtype=torch.float32, device=dev)
@@ -920,7 +939,7 @@ def rasterize_gaussians_trace(background, means3D, colors, img_sem, opacity, sca
         if n < 0:
             raise RuntimeError(_lib.last_error())
         if P > 0:
-            _note_count(dev, P, n)
+            _note_count(dev, P, n, _tiles(H, W))
     return n, out_color, gau_sem, num_gsem, geom, alloc.tensor, img
 
 

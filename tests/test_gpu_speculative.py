@@ -422,3 +422,25 @@ def test_image_only_frames_are_exact_by_default(dev):
     assert isinstance(rasterizer.last_num_rendered(), int)
     for x in (b, c, d):
         assert torch.equal(a["render"].detach(), x["render"]) and torch.equal(a["semantics"].detach(), x["semantics"])
+
+
+def test_a_much_larger_image_starts_the_capacity_policy_over(dev):
+    """The policy sizes a speculative frame from the counts it has seen.  num_rendered grows with the image: after frames of
+    a small image, the first frame of one with more than twice the tiles must be EXACT again (found by a fuzz soak: a frame
+    sized from a much smaller one overflowed and showed a truncated image)."""
+    from goi_hyperplane_amd import _C
+    sc = make_scene(3000, S=4, seed=5, log_scale_mean=-1.6)
+    bg = np.zeros(3, np.float32)
+    _C.poll_counts(wait=True)
+    _C.set_forward_mode(speculative=True, headroom=2.0, capacity=None, min_history=3)
+    small, large = make_camera(64, 48), make_camera(320, 240)
+    for _ in range(5):
+        n, *_ = _C.rasterize_gaussians(*_args(sc, small, dev, bg))
+    assert isinstance(n, _C.LazyCount), "the small image should be speculative by now"
+    n_small = int(n)
+    n, color, *_ = _C.rasterize_gaussians(*_args(sc, large, dev, bg))
+    assert not isinstance(n, _C.LazyCount), "first frame of a 25x larger image: exact"
+    assert int(n) > 4 * n_small  # (it would not have fitted 2 x the small image's count)
+    _C.set_forward_mode(speculative=False)
+    n_ref, color_ref, *_ = _C.rasterize_gaussians(*_args(sc, large, dev, bg))
+    assert int(n_ref) == int(n) and torch.equal(color_ref, color)
