@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_speculative.py tests/test_gpu_train_loop.py tests/test_gpu_geometry_cache.py tests/test_gpu_binding.py -m gpu -q 2>&1 | tail -3
+GOI_FUZZ_N=4000 GOI_FUZZ_SEED=424242 timeout 2400 python -m pytest tests/test_gpu_fuzz.py -m gpu -q -k "test_random_configuration" 2>&1 | grep -E "^E  .*Assertion|FAILED|passed|failed|Warning" | head -20
+cp gpurun_out/parity_stats.json gpurun_out/r03_f_soak3_parity_stats.json
