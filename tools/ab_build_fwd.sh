@@ -1,0 +1,7 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+for flags in "$@"; do
+  GOI_EXTRA_FLAGS="$flags" python -m goi_hyperplane_amd.build --force > /dev/null 2>&1
+  echo "== flags: [$flags]"
+  timeout 300 python tools/ab_variants.py fwd_variant 1 2>&1 | tail -1 | cut -c60-300
+done

@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 1800 python tools/soak_f64.py 2575 424242 2e-3 2>&1 | tail -12
+python tools/ab_variants.py fwd_variant 1 2>&1 | tail -1 | cut -c60-320
+python tools/ab_variants.py fwd_variant 1 2>&1 | tail -1 | cut -c60-320
