@@ -352,8 +352,7 @@ size_t geom_layout(int P, char* base, GeomView* v) {
     carve(p, g.sort_vals[0], n);
     carve(p, g.sort_vals[1], n);
     carve(p, g.offsets, n);
-    carve(p, g.goff, n);
-    carve(p, g.tmask, n);
+    carve(p, g.aux, n);
     carve(p, g.blk_agg, (n + PRE_BLOCK - 1) / PRE_BLOCK);
     carve(p, g.counters, COUNTER_WORDS);  // directly in front of the sort scratch: one memset clears both
     g.scratch_words = sort_scratch_words(n) + scan_scratch_words(n);

@@ -31,9 +31,12 @@ struct GeomView {
     uint32_t* sort_keys[2];   // [P] depth bits (ping-pong); preprocess leaves the RAW keys (by Gaussian id) in [1]
     uint32_t* sort_vals[2];   // [P] Gaussian ids (ping-pong); [final][0 .. V) = depth order of the V listed Gaussians
     uint32_t* offsets;        // [V] exclusive prefix of tiles_touched in DEPTH order: where emit puts a Gaussian's instances
-    uint32_t* goff;           // [P] the same prefix by Gaussian id (listed Gaussians only) = its first row slot in the backward
-    unsigned long long* tmask;  // [P] which tiles of the listed rectangle the Gaussian's ellipse reaches (cull_variant 2), row-major
-                                // bits; TMASK_FULL: all of them (rectangles of more than 64 tiles, cull_variant < 2)
+    // [P] what emit and the backward need of a Gaussian besides its record, in ONE 16-byte gather (they were three):
+    //   .x  the same prefix by Gaussian id (listed Gaussians only; written by emit) = its first row slot in the backward
+    //   .y  its radius in pixels (the int radii[] of the API)
+    //   .zw which tiles of the listed rectangle its ellipse reaches (cull_variant 2), row-major bits; TMASK_FULL: all of
+    //       them (rectangles of more than 64 tiles, cull_variant < 2)
+    uint4* aux;
     uint2* blk_agg;           // [ceil(P/256)] per preprocess block: (listed Gaussians, tiles touched)
     uint32_t* scratch;        // scan partials + radix histograms
     uint32_t* counters;       // [COUNTER_WORDS]: 1 = error flag, 2 = cull_variant of this forward, NR_BASE.. = num_rendered stripes
@@ -222,6 +225,7 @@ __device__ __forceinline__ void listed_rect(float px, float py, int r, float hx,
 }
 // Tiles of a Gaussian's listed rectangle that its contribution ellipse reaches (cull_variant 2): a 64-bit mask, bit
 // (row * width + column) of the rectangle.  The tile instance of tile (tx, ty) is then the mask's set bits below that bit.
+__host__ __device__ inline unsigned long long aux_mask(const uint4& a) { return (unsigned long long)a.z | ((unsigned long long)a.w << 32); }
 constexpr unsigned long long TMASK_FULL = ~0ull;
 __device__ __forceinline__ uint32_t tile_instance(unsigned long long mask, int tx, int ty, int x0, int y0, int x1) {
     const uint32_t bit = (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));

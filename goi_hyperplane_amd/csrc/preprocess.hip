@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_k(const PreArgs args, Gaus
                                                         float* __restrict__ cov3D_out,
                                                         uint32_t* __restrict__ tiles_touched,
                                                         uint8_t* __restrict__ clamped, uint32_t* __restrict__ raw_key,
-                                                        unsigned long long* __restrict__ tmask,
+                                                        uint4* __restrict__ aux,
                                                         uint2* __restrict__ blk_agg, int* __restrict__ radii,
                                                         uint32_t* __restrict__ counters, uint2* __restrict__ ranges,
                                                         int n_tiles) {
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void preprocess_fwd_k(const PreArgs args, Gaus
         tiles_touched[idx] = touched;
         clamped[idx] = clamp_bits;
         raw_key[idx] = key;  // depth bits by Gaussian id; compact_listed_k keeps the listed ones for the depth sort
-        tmask[idx] = tmask_v;
+        aux[idx] = make_uint4(0u, (uint32_t)my_radius_i, (uint32_t)tmask_v, (uint32_t)(tmask_v >> 32));  // (.x: emit)
     }
     // num_rendered = sum of tiles_touched: order-independent, so it is formed HERE (one integer atomic per wave)
     // instead of falling out of the prefix sum after the depth sort -- the host can read it while the sort runs
@@ -413,7 +413,7 @@ struct BwdArgs {
 // kernel's inputs.)
 struct RecArgs {
     const float* rows;              // row scratch
-    const uint32_t* goff;           // [P] first emit-order instance of a listed Gaussian
+    const uint4* aux;               // [P] .x: first emit-order instance of a listed Gaussian
     const uint32_t* tiles_touched;  // [P] 0: not listed (no record)
     int row_floats, S, nch;         // nch = padded semantic channels + 4 (see render_bwd.hip: BwdCfg)
     float* dL_dopacity;
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_k(const BwdArgs args, cons
     V3 in_col = {0.f, 0.f, 0.f};
     if constexpr (FROM_ROWS) {
         const bool listed = visible && ra.tiles_touched[idx] != 0;
-        const float* rec = ra.rows + (size_t)(listed ? ra.goff[idx] : 0u) * 4 * ra.row_floats;
+        const float* rec = ra.rows + (size_t)(listed ? ra.aux[idx].x : 0u) * 4 * ra.row_floats;
         const int nsem = ra.nch - 4;
         float opa = 0.f;
         if (listed) {
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_k(const BwdArgs args, cons
         // pieces of their records in, ONE contiguous kilobyte of the output out.
         if ((ra.S & 3) == 0 && ra.S <= 16) {
             const int lane = threadIdx.x & 63, sub = lane & 3, S4 = ra.S >> 2;
-            const uint32_t my = listed ? ra.goff[idx] : 0xFFFFFFFFu;
+            const uint32_t my = listed ? ra.aux[idx].x : 0xFFFFFFFFu;
             const int wave_first = gtid - lane;  // the Gaussian of lane 0
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -1043,8 +1043,7 @@ constexpr int EMIT_ROUNDS = 4;
 template <bool COUNT>
 __global__ __launch_bounds__(256) void emit_k(int P, int gx, int gy, const GaussRec* __restrict__ rec,
                                               const int* __restrict__ radii, const uint32_t* __restrict__ order,
-                                              const uint32_t* __restrict__ offsets, uint32_t* __restrict__ goff,
-                                              const unsigned long long* __restrict__ tmask,
+                                              const uint32_t* __restrict__ offsets, uint4* __restrict__ aux,
                                               uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
                                               uint32_t* __restrict__ tile_count, uint32_t* __restrict__ counters,
                                               uint32_t* __restrict__ clear, uint32_t clear_words, uint32_t cap) {
@@ -1088,10 +1087,11 @@ __global__ __launch_bounds__(256) void emit_k(int P, int gx, int gy, const Gauss
         if (rnd < ROUNDS && i < P) {
             f.g = order[i];
             f.off = offsets[i];
-            f.r = radii[f.g];
+            const uint4 a = aux[f.g];  // radius and tile mask: one gather
+            f.r = (int)a.y;
             f.q0 = rec[f.g].q0;
             f.q2 = rec[f.g].q2;
-            f.mask = tmask[f.g];
+            f.mask = aux_mask(a);
         }
         return f;
     };
@@ -1104,7 +1104,7 @@ __global__ __launch_bounds__(256) void emit_k(int P, int gx, int gy, const Gauss
         const uint32_t g = cur.g, off = cur.off;
         int x0 = 0, y0 = 0, w = 1, cnt = 0;
         if (i < P) {
-            goff[g] = off;  // the Gaussian's first row slot in the backward (slot space = emit order = depth order)
+            reinterpret_cast<uint32_t*>(aux + g)[0] = off;  // the Gaussian's first row slot in the backward (slot space = emit order = depth order)
             if (cur.r > 0) {
                 int x1, y1;
                 listed_rect(cur.q0.x, cur.q0.y, cur.r, cur.q2.z, cur.q2.w, cull, gx, gy, x0, y0, x1, y1);
@@ -1264,7 +1264,7 @@ void launch_preprocess_fwd(const GoiRasterScene& sc, const GeomView& g, int* rad
     a.view_p = sc.viewmatrix; a.proj_p = sc.projmatrix; a.campos_p = sc.campos;
     static_assert(PRE_BLOCK == 256, "preprocess_fwd_k is written for 256-thread workgroups");
     preprocess_fwd_k<<<dim3((sc.P + PRE_BLOCK - 1) / PRE_BLOCK), dim3(PRE_BLOCK), 0, s>>>(
-        a, g.rec, g.cov3D, g.tiles_touched, g.clamped, g.sort_keys[1], g.tmask, g.blk_agg, radii, g.counters, ranges, n_tiles);
+        a, g.rec, g.cov3D, g.tiles_touched, g.clamped, g.sort_keys[1], g.aux, g.blk_agg, radii, g.counters, ranges, n_tiles);
 }
 
 void launch_compact_listed(int P, const GeomView& g, uint32_t* ghist, bool pad, hipStream_t s) {
@@ -1289,7 +1289,7 @@ void launch_preprocess_bwd(const GoiRasterScene& sc, const GeomView& g, const in
     const size_t lds = with_sh ? (size_t)256 * (3 * sc.M + 1) * sizeof(float) : 0;  // 50 KB at M = 16
     // record_rows: the blend gradients are the records reduce_rows_k<.., RECORD> left in the row scratch
     RecArgs ra;
-    ra.rows = record_rows; ra.goff = g.goff; ra.tiles_touched = g.tiles_touched;
+    ra.rows = record_rows; ra.aux = g.aux; ra.tiles_touched = g.tiles_touched;
     ra.row_floats = bwd_row_floats(sc.S); ra.S = sc.S; ra.nch = 4 * ((sc.S + 3) / 4) + 4;
     ra.dL_dopacity = dL_dopacity; ra.dL_dsemantic = dL_dsemantic;
     const dim3 grid((sc.P + 255) / 256);
@@ -1365,7 +1365,7 @@ void launch_reduce_sem_rows(const GoiRasterScene& sc, const GeomView& g, int N, 
 void launch_emit(int P, int W, int H, const GeomView& g, const uint32_t* order, const int* radii, uint32_t* keys,
                  uint32_t* vals, uint32_t cap, hipStream_t s) {
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
-    emit_k<false><<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, gx, gy, g.rec, radii, order, g.offsets, g.goff, g.tmask, keys, vals,
+    emit_k<false><<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, gx, gy, g.rec, radii, order, g.offsets, g.aux, keys, vals,
                                                               nullptr, g.counters, nullptr, 0u, cap);
 }
 
@@ -1382,7 +1382,7 @@ void launch_emit_counting(int P, int W, int H, const GeomView& g, const uint32_t
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     // `ranges` was zeroed by preprocess_fwd_k
     emit_k<true><<<dim3((P + 256 * EMIT_ROUNDS - 1) / (256 * EMIT_ROUNDS)), dim3(256), (size_t)gx * gy * sizeof(uint32_t), s>>>(
-        P, gx, gy, g.rec, radii, order, g.offsets, g.goff, g.tmask, keys, vals, reinterpret_cast<uint32_t*>(ranges) + 1, g.counters,
+        P, gx, gy, g.rec, radii, order, g.offsets, g.aux, keys, vals, reinterpret_cast<uint32_t*>(ranges) + 1, g.counters,
         clear, (uint32_t)clear_words, cap);
 }
 

@@ -83,7 +83,7 @@ template <int S4, int MODE>
 __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int gx, int gy,
     int n_quads, int S, const GaussRec* __restrict__ rec, const float* __restrict__ semantics,
-    const int* __restrict__ radii, const uint32_t* __restrict__ goff, const unsigned long long* __restrict__ tmask, const float* __restrict__ bg,
+    const int* __restrict__ radii, const uint4* __restrict__ aux, const float* __restrict__ bg,
     const float* __restrict__ out_alpha, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
     const float* __restrict__ dL_dpixsem, const float* __restrict__ dL_dpixdepth, const float* __restrict__ dL_dalphas,
     float* __restrict__ rows, uint8_t* __restrict__ flags, int row_floats,
@@ -350,8 +350,9 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
             const float4* r4 = reinterpret_cast<const float4*>(rec + id);
             const float4 q1 = r4[1];
             int x0, y0, x1, y1;
-            listed_rect(q0.x, q0.y, radii[id], q2.z, q2.w, cull, gx, gy, x0, y0, x1, y1);
-            const uint32_t inst = goff[id] + tile_instance(tmask[id], t.tx, t.ty, x0, y0, x1);
+            const uint4 ax = aux[id];  // first slot, radius, tile mask: one 16-byte gather (three scattered ones before)
+            listed_rect(q0.x, q0.y, (int)ax.y, q2.z, q2.w, cull, gx, gy, x0, y0, x1, y1);
+            const uint32_t inst = ax.x + tile_instance(aux_mask(ax), t.tx, t.ty, x0, y0, x1);
             const PolyCoef pc = poly_coefs(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, QCX, QCY);
             // the staging addresses are formed HERE from an opaque copy of the lane id: hoisted out of the batch
             // loop they cost one live VGPR per destination (the compiler spilled four of them to scratch)
@@ -523,7 +524,7 @@ void launch_bwd_rows_s4(const GoiRasterScene& sc, const GeomView& g, const Image
     const int n_quads = gx * gy * 4;
 #define GOI_LAUNCH_ROWS(MODE)                                                                                          \
     render_bwd_rows_k<S4, MODE><<<dim3(quad_grid(n_quads)), dim3(64), 0, s>>>(                                           \
-        im.ranges, point_list, sc.W, sc.H, gx, gy, n_quads, sc.S, g.rec, sc.semantics, radii, g.goff, g.tmask, sc.bg, out_alpha, \
+        im.ranges, point_list, sc.W, sc.H, gx, gy, n_quads, sc.S, g.rec, sc.semantics, radii, g.aux, sc.bg, out_alpha, \
         im.n_contrib, dL_dpix, dL_dsem, dL_ddepth, dL_dalpha, scr.rows, scr.flags, bwd_row_floats(sc.S),                 \
         g.counters, quad_order_enabled(sc.W, sc.H) ? im.qorder : nullptr)
     if ((g_options.bwd_variant & 15) == 2)

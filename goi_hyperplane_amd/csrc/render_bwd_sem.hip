@@ -29,7 +29,7 @@ template <int S4, bool SPLIT>
 __global__ __launch_bounds__(64) void render_bwd_sem_k(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int gx, int gy,
     int n_quads, int S, const GaussRec* __restrict__ rec, const int* __restrict__ radii,
-    const uint32_t* __restrict__ goff, const unsigned long long* __restrict__ tmask, const float* __restrict__ out_alpha, const uint32_t* __restrict__ n_contrib,
+    const uint4* __restrict__ aux, const float* __restrict__ out_alpha, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dpixsem, float* __restrict__ rows, uint8_t* __restrict__ flags, int row_floats,
     const uint32_t* __restrict__ counters, const uint32_t* __restrict__ qorder) {
     const bool cull = counters[COUNTER_CULL] != 0;  // the rectangles the forward listed
@@ -162,8 +162,9 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
         if (hit) {
             const float4 q1 = reinterpret_cast<const float4*>(rec + id)[1];
             int x0, y0, x1, y1;
-            listed_rect(q0.x, q0.y, radii[id], q2.z, q2.w, cull, gx, gy, x0, y0, x1, y1);
-            const uint32_t inst = goff[id] + tile_instance(tmask[id], t.tx, t.ty, x0, y0, x1);
+            const uint4 ax = aux[id];  // first slot, radius, tile mask: one 16-byte gather (three scattered ones before)
+            listed_rect(q0.x, q0.y, (int)ax.y, q2.z, q2.w, cull, gx, gy, x0, y0, x1, y1);
+            const uint32_t inst = ax.x + tile_instance(aux_mask(ax), t.tx, t.ty, x0, y0, x1);
             const PolyCoef pc = poly_coefs(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, QCX, QCY);
             s_geo[lane] = f32x4{pc.A35.x, pc.A35.y, pc.A12.x, pc.A12.y};
             s_geo2[lane] = f32x4{pc.A0, pc.A4, pc.lim, __uint_as_float(inst * 4u + (uint32_t)t.q)};
@@ -216,11 +217,11 @@ void launch_bwd_sem_s4(const GoiRasterScene& sc, const GeomView& g, const ImageV
     const int n_quads = gx * gy * 4;
     if ((g_options.bwd_variant & 15) == 2)  // exact-fp32 flush, as in the full backward
         render_bwd_sem_k<S4, false><<<dim3(quad_grid(n_quads)), dim3(64), 0, s>>>(
-            im.ranges, point_list, sc.W, sc.H, gx, gy, n_quads, sc.S, g.rec, radii, g.goff, g.tmask, out_alpha, im.n_contrib, dL_dsem,
+            im.ranges, point_list, sc.W, sc.H, gx, gy, n_quads, sc.S, g.rec, radii, g.aux, out_alpha, im.n_contrib, dL_dsem,
             rows, flags, row_floats, g.counters, quad_order_enabled(sc.W, sc.H) ? im.qorder : nullptr);
     else
         render_bwd_sem_k<S4, true><<<dim3(quad_grid(n_quads)), dim3(64), 0, s>>>(
-            im.ranges, point_list, sc.W, sc.H, gx, gy, n_quads, sc.S, g.rec, radii, g.goff, g.tmask, out_alpha, im.n_contrib, dL_dsem,
+            im.ranges, point_list, sc.W, sc.H, gx, gy, n_quads, sc.S, g.rec, radii, g.aux, out_alpha, im.n_contrib, dL_dsem,
             rows, flags, row_floats, g.counters, quad_order_enabled(sc.W, sc.H) ? im.qorder : nullptr);
 }
 
