@@ -891,8 +891,8 @@ int goi_raster_debug_views(int P, int W, int H, int R, const void* geom_buffer, 
         GOI_HIP(hipMemcpy2DAsync(reinterpret_cast<char*>(conic_opacity) + 8, 16, rec + 16, pitch, 8, P,
                                  hipMemcpyDeviceToDevice, s));
     }
-    if (depths) GOI_HIP(hipMemcpy2DAsync(depths, 4, rec + 24, pitch, 4, P, hipMemcpyDeviceToDevice, s));
-    if (rgb) GOI_HIP(hipMemcpy2DAsync(rgb, 12, rec + 28, pitch, 12, P, hipMemcpyDeviceToDevice, s));
+    if (depths) GOI_HIP(hipMemcpy2DAsync(depths, 4, rec + 44, pitch, 4, P, hipMemcpyDeviceToDevice, s));
+    if (rgb) GOI_HIP(hipMemcpy2DAsync(rgb, 12, rec + 32, pitch, 12, P, hipMemcpyDeviceToDevice, s));
     if (tiles_touched)
         GOI_HIP(hipMemcpyAsync(tiles_touched, g.tiles_touched, sizeof(uint32_t) * P, hipMemcpyDeviceToDevice, s));
     if (ranges) GOI_HIP(hipMemcpyAsync(ranges, im.ranges, sizeof(uint2) * gx * gy, hipMemcpyDeviceToDevice, s));

@@ -15,7 +15,8 @@ constexpr int WAVE = 64;
 
 // Per-Gaussian render record written by the forward preprocess: everything the blend kernels
 // need about a Gaussian except its semantic row, in three 16-byte words (48 B, one gather).
-//   q0 = (x, y, conic.a, conic.b)   q1 = (conic.c, opacity, depth, r)   q2 = (g, b, hx, hy)
+//   q0 = (x, y, conic.a, conic.b)   q1 = (conic.c, opacity, hx, hy)   q2 = (r, g, b, depth)
+// q0 and q1 are what the hit test of a candidate reads; q2 is what only a hit needs (and IS its first staged feature quad).
 // hx / hy: half extents (pixels) of the axis-aligned box outside which alpha < 1/255 can be
 // proven; < 0 when the Gaussian can never reach 1/255, +inf when no bound is known.
 struct GaussRec {

@@ -213,8 +213,8 @@ __global__ __launch_bounds__(256) void preprocess_fwd_k(const PreArgs args, Gaus
         }
         GaussRec r;
         r.q0 = make_float4(pix, piy, con_a, con_b);
-        r.q1 = make_float4(con_c, o, p_view.z, cr);
-        r.q2 = make_float4(cg, cb, hx, hy);
+        r.q1 = make_float4(con_c, o, hx, hy);       // what the hit test needs beside q0: fetched for every CANDIDATE
+        r.q2 = make_float4(cr, cg, cb, p_view.z);   // what only a HIT needs (r, g, b, depth: the first staged feature quad as it is)
         rec[idx] = r;
         my_radius_i = (int)my_radius;
         listed_rect(pix, piy, my_radius_i, hx, hy, a.cull != 0, a.gx, a.gy, x0, y0, x1, y1);
@@ -1090,7 +1090,7 @@ __global__ __launch_bounds__(256) void emit_k(int P, int gx, int gy, const Gauss
             const uint4 a = aux[f.g];  // radius and tile mask: one gather
             f.r = (int)a.y;
             f.q0 = rec[f.g].q0;
-            f.q2 = rec[f.g].q2;
+            f.q2 = rec[f.g].q1;  // (conic c, opacity, hx, hy)
             f.mask = aux_mask(a);
         }
         return f;

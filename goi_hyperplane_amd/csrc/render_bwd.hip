@@ -224,17 +224,15 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
 
     // software prefetch of the next batch's id / position / box (one list entry per lane)
     uint32_t id_n = 0;
-    float4 q0_n = make_float4(0, 0, 0, 0), q2_n = make_float4(0, 0, -1.f, -1.f);
-    float2 co_n = make_float2(1.f, 0.f);  // conic c, opacity (first half of q1: the ellipse test needs them)
+    float4 q0_n = make_float4(0, 0, 0, 0), q1_n = make_float4(1.f, 0.f, -1.f, -1.f);  // (conic c, opacity, hx, hy)
     auto prefetch = [&](int b) {
         const int k = b * BATCH + lane;  // list position n_proc-1-k, walking back to front
-        q2_n.z = -1.f;
+        q1_n.z = -1.f;
         if (lane < BATCH && k < n_proc) {
             id_n = point_list[range.x + (n_proc - 1 - k)];
             const float4* r4 = reinterpret_cast<const float4*>(rec + id_n);
             q0_n = r4[0];
-            co_n = *reinterpret_cast<const float2*>(r4 + 1);
-            q2_n = r4[2];
+            q1_n = r4[1];
         }
     };
     prefetch(0);
@@ -339,19 +337,18 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
 
     for (int b = 0; b < rounds; b++) {
         const uint32_t id = id_n;
-        const float4 q0 = q0_n, q2 = q2_n;
-        const float2 co = co_n;
-        const bool hit = ellipse_hits_quadrant(q0.x, q0.y, q0.z, q0.w, co.x, co.y, q2.z, q2.w, t.QX0, t.QY0);  // hx < 0 for absent lanes
+        const float4 q0 = q0_n, q1 = q1_n;
+        const bool hit = ellipse_hits_quadrant(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, t.QX0, t.QY0);  // hx < 0 for absent lanes
         if (b + 1 < rounds) prefetch(b + 1);
         unsigned long long m = __ballot(hit);
         if (m == 0) continue;
         // ---- stage the hits (slot = lane)
         if (hit) {
             const float4* r4 = reinterpret_cast<const float4*>(rec + id);
-            const float4 q1 = r4[1];
+            const float4 q2 = r4[2];  // r, g, b, depth: the one thing only a hit needs of its record
             int x0, y0, x1, y1;
             const uint4 ax = aux[id];  // first slot, radius, tile mask: one 16-byte gather (three scattered ones before)
-            listed_rect(q0.x, q0.y, (int)ax.y, q2.z, q2.w, cull, gx, gy, x0, y0, x1, y1);
+            listed_rect(q0.x, q0.y, (int)ax.y, q1.z, q1.w, cull, gx, gy, x0, y0, x1, y1);
             const uint32_t inst = ax.x + tile_instance(aux_mask(ax), t.tx, t.ty, x0, y0, x1);
             const PolyCoef pc = poly_coefs(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, QCX, QCY);
             // the staging addresses are formed HERE from an opaque copy of the lane id: hoisted out of the batch
@@ -362,7 +359,7 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
             s_geo2[sl] = f32x4{pc.A0, pc.A4, pc.lim, __uint_as_float(inst * 4u + (uint32_t)t.q)};
             s_cen[sl] = make_float2(q0.x - QCX, q0.y - QCY);
             float4* fdst = &s_feat[sl * NF4];
-            fdst[0] = make_float4(q1.w, q2.x, q2.y, q1.z);
+            fdst[0] = q2;
             const float* srow = semantics + (size_t)id * S;
             if ((S & 3) == 0) {
 #pragma unroll

@@ -90,17 +90,15 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
     }
 
     uint32_t id_n = 0;
-    float4 q0_n = make_float4(0, 0, 0, 0), q2_n = make_float4(0, 0, -1.f, -1.f);
-    float2 co_n = make_float2(1.f, 0.f);  // conic c, opacity (first half of q1: the ellipse test needs them)
+    float4 q0_n = make_float4(0, 0, 0, 0), q1_n = make_float4(1.f, 0.f, -1.f, -1.f);  // (conic c, opacity, hx, hy)
     auto prefetch = [&](int b) {
         const int k = b * SBATCH + lane;
-        q2_n.z = -1.f;
+        q1_n.z = -1.f;
         if (lane < SBATCH && k < n_proc) {
             id_n = point_list[range.x + (n_proc - 1 - k)];
             const float4* r4 = reinterpret_cast<const float4*>(rec + id_n);
             q0_n = r4[0];
-            co_n = *reinterpret_cast<const float2*>(r4 + 1);
-            q2_n = r4[2];
+            q1_n = r4[1];
         }
     };
     prefetch(0);
@@ -153,17 +151,15 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
 
     for (int b = 0; b < rounds; b++) {
         const uint32_t id = id_n;
-        const float4 q0 = q0_n, q2 = q2_n;
-        const float2 co = co_n;
-        const bool hit = ellipse_hits_quadrant(q0.x, q0.y, q0.z, q0.w, co.x, co.y, q2.z, q2.w, t.QX0, t.QY0);
+        const float4 q0 = q0_n, q1 = q1_n;  // (this kernel needs nothing else of a record)
+        const bool hit = ellipse_hits_quadrant(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, t.QX0, t.QY0);
         if (b + 1 < rounds) prefetch(b + 1);
         unsigned long long m = __ballot(hit);
         if (m == 0) continue;
         if (hit) {
-            const float4 q1 = reinterpret_cast<const float4*>(rec + id)[1];
             int x0, y0, x1, y1;
             const uint4 ax = aux[id];  // first slot, radius, tile mask: one 16-byte gather (three scattered ones before)
-            listed_rect(q0.x, q0.y, (int)ax.y, q2.z, q2.w, cull, gx, gy, x0, y0, x1, y1);
+            listed_rect(q0.x, q0.y, (int)ax.y, q1.z, q1.w, cull, gx, gy, x0, y0, x1, y1);
             const uint32_t inst = ax.x + tile_instance(aux_mask(ax), t.tx, t.ty, x0, y0, x1);
             const PolyCoef pc = poly_coefs(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, QCX, QCY);
             s_geo[lane] = f32x4{pc.A35.x, pc.A35.y, pc.A12.x, pc.A12.y};

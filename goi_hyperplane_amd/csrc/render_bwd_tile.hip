@@ -156,8 +156,8 @@ __global__ __launch_bounds__(256) void render_bwd_tile_k(
                     s_id[slot] = id;
                 } else if (part == 1) {
                     const float4 q1 = r4[1], q2 = r4[2];
-                    s_geo2[slot] = make_float4(q1.x, q1.y, q2.z, q2.w);
-                    s_feat[slot * NF4] = make_float4(q1.w, q2.x, q2.y, q1.z);
+                    s_geo2[slot] = q1;                // conic c, opacity, hx, hy
+                    s_feat[slot * NF4] = q2;          // r, g, b, depth
                 } else {
                     const float* srow = semantics + (size_t)id * S;
                     if ((S & 3) == 0) {

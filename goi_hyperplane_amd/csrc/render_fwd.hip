@@ -68,18 +68,17 @@ __global__ __launch_bounds__(64) void render_fwd_k(const uint2* __restrict__ ran
 
     // software prefetch of the next batch's id / position / box (one Gaussian per lane)
     uint32_t id_n = 0;
-    float4 q0_n = make_float4(0, 0, 0, 0), q2_n = make_float4(0, 0, -1.f, -1.f);
-    // the whole of q1 (conic c and opacity for the ellipse test; depth and r only for hits, but a second 16-byte gather at
-    // staging time, when a round begins by waiting for it, cost 11 of the kernel's 280 us)
-    float4 co_n = make_float4(1.f, 0.f, 0.f, 0.f);
+    // q0, q1: what the hit test reads (position, conic, opacity, box); q2 (r, g, b, depth): only a hit needs it, but fetched at
+    // staging time -- a dependent 16-byte gather every round begins by waiting for -- it cost 11 of the kernel's 280 us
+    float4 q0_n = make_float4(0, 0, 0, 0), q1_n = make_float4(1.f, 0.f, -1.f, -1.f), q2_n = make_float4(0, 0, 0, 0);
     auto prefetch = [&](int b) {
         const int k = b * 64 + lane;
-        q2_n.z = -1.f;
+        q1_n.z = -1.f;
         if (k < len) {
             id_n = point_list[range.x + k];
             const float4* r4 = reinterpret_cast<const float4*>(rec + id_n);
             q0_n = r4[0];
-            co_n = r4[1];
+            q1_n = r4[1];
             q2_n = r4[2];
         }
     };
@@ -88,19 +87,17 @@ __global__ __launch_bounds__(64) void render_fwd_k(const uint2* __restrict__ ran
     for (int b = 0; b < rounds; b++) {
         if (all_done()) break;
         const uint32_t id = id_n;
-        const float4 q0 = q0_n, q2 = q2_n;
-        const float4 co = co_n;
-        const bool hit = ellipse_hits_quadrant(q0.x, q0.y, q0.z, q0.w, co.x, co.y, q2.z, q2.w, t.QX0, t.QY0);  // hx < 0 for absent lanes
+        const float4 q0 = q0_n, q1 = q1_n, q2 = q2_n;
+        const bool hit = ellipse_hits_quadrant(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, t.QX0, t.QY0);  // hx < 0 for absent lanes
         if (b + 1 < rounds) prefetch(b + 1);
         unsigned long long m = __ballot(hit);
         if (m == 0) continue;
         // ---- stage the hits (slot = lane)
         if (hit) {
-            const float4 q1 = co;
             const PolyCoef pc = poly_coefs(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, QCX, QCY);
             s_geo[lane] = f32x4{pc.A35.x, pc.A35.y, pc.A12.x, pc.A12.y};
             s_geo2[lane] = f32x4{pc.A0, pc.A4, pc.lim, 0.f};
-            s_feat[lane * NF4] = make_float4(q1.w, q2.x, q2.y, q1.z);
+            s_feat[lane * NF4] = q2;  // r, g, b, depth
             if constexpr (TRACE) {
                 s_id[lane] = id;
             } else {
