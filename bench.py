@@ -694,6 +694,12 @@ def main():
             roofline = {"bound": "hbm", "kernel": dominant, "achieved": d["alg_GBps"], "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": d["hbm_frac"], "traffic": None,
                         "bytes_per_launch": sb[dominant], "avg_ms": d["ms"]}
+            # the same formula on the instances this build actually LISTS (ellipse tile lists: about half of the reference's
+            # num_rendered): what the kernel walks, as opposed to what SURVEY.md 8(d) prices the reference's lists at
+            n_listed = stats["N_listed"] / max(stats["views"], 1)
+            sb_listed = stage_bytes(args.P, V, n_listed, T, HW, args.S)[dominant]
+            roofline["bytes_per_launch_listed"] = sb_listed
+            roofline["frac_listed"] = round(sb_listed / (d["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if d["ms"] > 0 else None
             # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process);
             # only quoted for the workload they were collected on
             import glob
