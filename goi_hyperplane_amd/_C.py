@@ -31,6 +31,8 @@ _EMPTY = torch.Tensor([])
 
 
 def _ext():
+    if _EXT.get("error") is not None:
+        raise _EXT["error"]  # (a stale binding fails EVERY call the same way -- never a quiet switch to ctypes)
     if not _EXT["tried"]:
         _EXT["tried"] = True
         path = os.path.join(os.path.dirname(_lib.LIB_PATH), "_goi_C.so")
@@ -41,10 +43,14 @@ def _ext():
             mod = importlib.util.module_from_spec(spec)
             spec.loader.exec_module(mod)
             # abi_version(): the header the binding was COMPILED against; library_abi_version(): what the library it is
-            # linked with reports -- a stale _goi_C.so next to a newer libgoi_raster.so fails the first test
-            if mod.abi_version() != _lib.ABI_VERSION or mod.library_abi_version() != _lib.ABI_VERSION:
-                raise ImportError(f"{path}: built against ABI {mod.abi_version()} (library: {mod.library_abi_version()}), "
-                                  f"expected {_lib.ABI_VERSION}; rebuild (python -m goi_hyperplane_amd.build)")
+            # linked with reports -- a stale _goi_C.so next to a newer libgoi_raster.so fails the first test, and one so old
+            # that it has no library_abi_version at all is a mismatch too (not an AttributeError)
+            built = getattr(mod, "abi_version", lambda: None)()
+            linked = getattr(mod, "library_abi_version", lambda: None)()
+            if built != _lib.ABI_VERSION or linked != _lib.ABI_VERSION:
+                _EXT["error"] = ImportError(f"{path}: built against ABI {built} (library: {linked}), expected "
+                                            f"{_lib.ABI_VERSION}; rebuild (python -m goi_hyperplane_amd.build)")
+                raise _EXT["error"]
             _EXT["mod"] = mod
     return _EXT["mod"]
 
@@ -53,7 +59,7 @@ def set_binding(name: str) -> None:
     """"compiled" (needs goi_hyperplane_amd/lib/_goi_C.so) or "ctypes"."""
     if name not in ("compiled", "ctypes"):
         raise ValueError("binding must be 'compiled' or 'ctypes'")
-    _EXT.update(want=name, tried=False, mod=None)
+    _EXT.update(want=name, tried=False, mod=None, error=None)
     if name == "compiled" and _ext() is None:
         raise ImportError("the compiled binding has not been built (python -m goi_hyperplane_amd.build)")
 
@@ -440,25 +446,67 @@ class LazyCount:
     __format__ = lambda self, spec: format(self.resolve(), spec)
 
 
-def _note_frame(geom, P):
-    """Remembers the geometry workspace of this thread's most recent frame (truncated_flag)."""
-    _CALL.last_frame = (geom, int(P))
-
-
-def truncated_flag():
-    """int32[1] device tensor: the "truncated" word of this thread's most recent forward (a view into its geometry
-    workspace), non-zero iff that frame's instance list did not fit the capacity of a speculative forward -- in which case
-    its backward writes zero gradients on the device.  FusedAdam.step(skip_if=truncated_flag()) then leaves parameters and
-    moments untouched for that view: nothing on the host ever waits.  None if there was no frame (or P == 0)."""
-    last = getattr(_CALL, "last_frame", None)
-    if last is None or last[1] <= 0 or last[0] is None or last[0].numel() == 0:
+def _flag_view(geom, P):
+    if geom is None or P <= 0 or geom.numel() == 0:
         return None
-    geom, P = last
     ptr = _lib.load().goi_raster_truncated_flag(C.c_void_p(geom.data_ptr()), P)
     if not ptr:
         return None
     off = int(ptr) - int(geom.data_ptr())
     return geom[off:off + 4].view(torch.int32)
+
+
+def _note_frame(geom, P):
+    """Remembers the geometry workspace of this thread's most recent frame (truncated_flag).  A STRONG reference, on purpose:
+    the natural caller asks for the flag after loss.backward() has released the frame's graph (opt.step(skip_if=...)), when
+    nothing else keeps the workspace alive; a 4-byte copy instead would cost every frame a kernel.  What it pins is ONE
+    geometry workspace (~105 bytes per Gaussian) until the thread's next frame replaces it -- release_last_frame() lets go
+    earlier.  With a truncation window open (accumulate_truncation) the frame's "truncated" word is also OR-ed into the
+    window's accumulator on the device."""
+    _CALL.last_frame = (geom if isinstance(geom, torch.Tensor) else None, int(P))
+    acc = getattr(_CALL, "trunc_acc", None)
+    if acc is not None:
+        f = _flag_view(geom, int(P))
+        if f is not None and f.device == acc.device:
+            acc.bitwise_or_(f)  # (enqueued behind the frame on the same stream: nothing waits)
+
+
+def accumulate_truncation(device=None):
+    """Opens (device given) or closes (None) a TRUNCATION WINDOW on this thread: from now on every forward ORs its frame's
+    "truncated" word into one int32[1] device tensor, which truncated_flag(accumulated=True) hands out -- the flag to pass
+    to FusedAdam.step(skip_if=...) when SEVERAL views are accumulated into one optimiser step (truncated_flag() alone
+    reports the last frame only and would miss a truncated earlier view).  Costs one 4-byte device operation per frame
+    while open.  reset_truncation() starts the next window."""
+    _CALL.trunc_acc = None if device is None else torch.zeros(1, dtype=torch.int32, device=device)
+
+
+def release_last_frame():
+    """Drops this thread's reference to its most recent frame's geometry workspace (truncated_flag() returns None until the
+    next forward)."""
+    _CALL.last_frame = None
+
+
+def reset_truncation():
+    acc = getattr(_CALL, "trunc_acc", None)
+    if acc is not None:
+        acc.zero_()
+
+
+def truncated_flag(accumulated: bool = False):
+    """int32[1] device tensor: the "truncated" word of this thread's most recent forward (a view into its geometry
+    workspace), non-zero iff that frame's instance list did not fit the capacity of a speculative forward (or its lists
+    could not be sorted) -- in which case its backward writes zero gradients on the device.
+    FusedAdam.step(skip_if=truncated_flag()) then leaves parameters and moments untouched for that view: nothing on the host
+    ever waits.  NOTE that the skip is the CALLER's to ask for: a plain step() after a truncated frame sees zero gradients,
+    which still moves every parameter by its momentum and decays both moments.
+    accumulated=True: the OR over every frame since the window was opened / reset (accumulate_truncation), for optimiser
+    steps that accumulate several views.  None if there was no frame (or P == 0)."""
+    if accumulated:
+        return getattr(_CALL, "trunc_acc", None)
+    last = getattr(_CALL, "last_frame", None)
+    if last is None or last[0] is None:
+        return None
+    return _flag_view(last[0], last[1])
 
 
 def _layout_of(R):

@@ -129,7 +129,13 @@ struct Ticket {
     hipEvent_t ev = nullptr;
     bool busy = false;
     int capacity = 0;  // instances the frame's binning buffer holds (speculative frames); 0: exact frame
+    bool head_only = false;  // only the first READBACK_HEAD_WORDS words were copied: num_rendered is counters[COUNTER_N]
 };
+// A read-back queued BEHIND the whole frame (speculative forward) finds num_rendered as one word (COUNTER_N, left by the
+// listed-Gaussian compaction / the scan): 128 bytes travel instead of the 4 KB of striped partial counters -- which the
+// runtime moved as three copy kernels per frame.
+constexpr int READBACK_HEAD_WORDS = 32;
+static_assert(COUNTER_N < READBACK_HEAD_WORDS && COUNTER_OVF < READBACK_HEAD_WORDS && NR_BASE >= READBACK_HEAD_WORDS, "head layout");
 std::mutex g_ticket_mu;
 std::vector<Ticket> g_tickets;
 constexpr int MAX_TICKETS = 4096;
@@ -185,10 +191,18 @@ int ticket_result(int id, int wait, long long* n) {
         }
     }
     unsigned long long total = 0;  // 64-bit: 32 stripes of up to 2^32-1 each
-    for (int i = 0; i < NR_STRIPES; i++) total += t.pinned[NR_BASE + NR_STRIDE * i];
+    if (t.head_only)
+        total = t.pinned[COUNTER_N];
+    else
+        for (int i = 0; i < NR_STRIPES; i++) total += t.pinned[NR_BASE + NR_STRIDE * i];
     const bool filtered = t.pinned[1] != 0;
+    // (a read-back queued behind the whole frame also carries the verdict of both sorts)
+    const bool missorted = t.head_only && (t.pinned[COUNTER_SORTERR] != 0 || (t.pinned[COUNTER_OVF] & 2u) != 0);
     ticket_release(id);
     if (filtered) return fail("Point is filtered although prefiltered is set. This shouldn't happen!");
+    if (missorted)
+        return fail("a look-back of the radix sort timed out (preempted or shared GPU?): the frame's lists are not sorted; its "
+                    "backward writes zero gradients, its image must not be used");
     if (total > 0x7FFFFFFFull) return fail("num_rendered overflows int32");
     *n = (long long)total;
     return 1;
@@ -198,10 +212,12 @@ int ticket_result(int id, int wait, long long* n) {
 // counters (queued BEFORE the depth sort: preprocess has already summed num_rendered, so a host that waits for it wakes
 // up while the GPU is still sorting), depth sort, scan.  The scan also leaves num_rendered in counters[COUNTER_N] for
 // the kernels of the back half.
-int enqueue_readback(const GeomView& g, int ticket, hipStream_t s) {
+int enqueue_readback(const GeomView& g, int ticket, hipStream_t s, bool head_only = false) {
     std::lock_guard<std::mutex> lk(g_ticket_mu);
-    const Ticket& t = g_tickets[ticket];
-    GOI_HIP(hipMemcpyAsync(t.pinned, g.counters, COUNTER_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    Ticket& t = g_tickets[ticket];
+    t.head_only = head_only;
+    GOI_HIP(hipMemcpyAsync(t.pinned, g.counters, (head_only ? READBACK_HEAD_WORDS : COUNTER_WORDS) * sizeof(uint32_t),
+                           hipMemcpyDeviceToHost, s));
     GOI_HIP(hipEventRecord(t.ev, s));
     return 0;
 }
@@ -236,7 +252,7 @@ int enqueue_front(const GoiRasterScene& sc, GeomView& g, ImageView& im, int* rad
         StageTimer t(GOI_STAGE_DEPTH_SORT, s);
         launch_compact_listed(P, g, onesweep ? radix_sort_ghist(g.scratch, (size_t)P, 0, 32) : nullptr, /*pad=*/!onesweep, s);
         order_idx = radix_sort_pairs(g.sort_keys, g.sort_vals, (size_t)P, 0, 32, g.scratch, s, /*cleared=*/true,
-                                     /*ghist_ready=*/onesweep, onesweep ? v_dev : nullptr);
+                                     /*ghist_ready=*/onesweep, onesweep ? v_dev : nullptr, g.counters + COUNTER_SORTERR);
     }
     if (check_stage(sc, s, "depth sort")) return -1;
     *order_out = g.sort_vals[order_idx];
@@ -252,7 +268,7 @@ int enqueue_front(const GoiRasterScene& sc, GeomView& g, ImageView& im, int* rad
 // counters[COUNTER_N], clamped to cap (an overflowed frame is truncated but memory-safe; the host redoes it).
 int enqueue_back(const GoiRasterScene& sc, GeomView& g, ImageView& im, const BinView& bv_in, int cap, bool exact,
                  const uint32_t* order, const int* radii, const uint32_t** plist, hipStream_t s) {
-    BinView bv = bv_in;
+    BinView bv = bv_in;  // (the caller hands bv_in.qmask to the blend itself)
     const int P = sc.P;
     const int gx = (sc.W + TILE - 1) / TILE, gy = (sc.H + TILE - 1) / TILE;
     const uint32_t* n_dev = exact ? nullptr : g.counters + COUNTER_N;
@@ -279,11 +295,12 @@ int enqueue_back(const GoiRasterScene& sc, GeomView& g, ImageView& im, const Bin
         }
         StageTimer t(GOI_STAGE_TILE_SORT, s);
         fin = radix_sort_pairs(bv.keys, bv.vals, (size_t)cap, 0, tile_bits, bv.scratch, s, /*cleared=*/true,
-                               /*ghist_ready=*/true, n_dev);
+                               /*ghist_ready=*/true, n_dev, g.counters + COUNTER_OVF);
     } else {
         {
             StageTimer t(GOI_STAGE_TILE_SORT, s);
-            fin = radix_sort_pairs(bv.keys, bv.vals, (size_t)cap, 0, tile_bits, bv.scratch, s, false, false, n_dev);
+            fin = radix_sort_pairs(bv.keys, bv.vals, (size_t)cap, 0, tile_bits, bv.scratch, s, false, false, n_dev,
+                                   g.counters + COUNTER_OVF);
         }
         if (check_stage(sc, s, "tile sort")) return -1;
         StageTimer t(GOI_STAGE_RANGES, s);
@@ -299,7 +316,7 @@ int enqueue_back(const GoiRasterScene& sc, GeomView& g, ImageView& im, const Bin
 // and enqueues the back half while the GPU is still busy with the depth sort and the scan -- no idle gap on the device.
 // Returns num_rendered (>= 0) and the final point list through *plist.
 int geometry_and_binning(const GoiRasterScene& sc, GeomView& g, ImageView& im, goi_alloc_fn alloc, void* user,
-                         int* radii, const uint32_t** plist, hipStream_t s) {
+                         int* radii, const uint32_t** plist, hipStream_t s, unsigned long long** qmask = nullptr) {
     const int ticket = ticket_acquire(0);
     if (ticket < 0) return -1;
     const uint32_t* order = nullptr;
@@ -315,6 +332,7 @@ int geometry_and_binning(const GoiRasterScene& sc, GeomView& g, ImageView& im, g
     if (!bin_mem && need > 0) return fail("binning allocation callback returned NULL");
     BinView bv;
     binning_layout(N, bin_mem, &bv);
+    if (qmask) *qmask = bv.qmask;
     if (enqueue_back(sc, g, im, bv, N, /*exact=*/true, order, radii, plist, s)) return -1;
     return N;
 }
@@ -369,6 +387,7 @@ size_t image_layout(int W, int H, char* base, ImageView* v) {
     carve(p, im.ranges, (size_t)gx * gy);
     carve(p, im.qcost, (size_t)gx * gy * 4);
     carve(p, im.qorder, (size_t)gx * gy * 4 + 8);
+    carve(p, im.qmask0, (size_t)gx * gy * 4);
     return (size_t)(p - base) + 256;
 }
 
@@ -393,6 +412,7 @@ size_t binning_layout(int N, char* base, BinView* v) {
     carve(p, b.vals[1], n);
     b.scratch_words = sort_scratch_words(n) + 8;
     carve(p, b.scratch, b.scratch_words);
+    carve(p, b.qmask, 4 * (n / 64 + 2));
     return (size_t)(p - base) + 256;
 }
 
@@ -433,11 +453,12 @@ int goi_raster_forward(const GoiRasterScene* scene, void* geom_buffer, void* ima
     geom_layout(sc.P, static_cast<char*>(geom_buffer), &g);
     image_layout(sc.W, sc.H, static_cast<char*>(image_buffer), &im);
     const uint32_t* plist = nullptr;
-    const int N = geometry_and_binning(sc, g, im, binning_alloc, alloc_user, radii, &plist, s);
+    unsigned long long* qmask = nullptr;
+    const int N = geometry_and_binning(sc, g, im, binning_alloc, alloc_user, radii, &plist, s, &qmask);
     if (N < 0) return -1;
     {
         StageTimer t(GOI_STAGE_BLEND_FWD, s);
-        launch_render_fwd(sc, g, im, plist, out_color, out_semantic, out_depth, out_alpha, s);
+        launch_render_fwd(sc, g, im, plist, out_color, out_semantic, out_depth, out_alpha, s, qmask);
     }
     if (check_stage(sc, s, "forward blend")) return -1;
     GOI_HIP(hipGetLastError());
@@ -473,9 +494,9 @@ int goi_raster_forward_async(const GoiRasterScene* scene, void* geom_buffer, voi
     }
     {
         StageTimer t(GOI_STAGE_BLEND_FWD, s);
-        launch_render_fwd(sc, g, im, plist, out_color, out_semantic, out_depth, out_alpha, s);
+        launch_render_fwd(sc, g, im, plist, out_color, out_semantic, out_depth, out_alpha, s, bv.qmask);
     }
-    if (enqueue_readback(g, ticket, s)) {
+    if (enqueue_readback(g, ticket, s, /*head_only=*/true)) {
         ticket_release(ticket);
         return -1;
     }
@@ -521,7 +542,7 @@ int goi_raster_forward_redo(const GoiRasterScene* scene, int num_rendered, void*
     if (enqueue_back(sc, g, im, bv, num_rendered, /*exact=*/true, order, radii, &plist, s)) return -1;
     {
         StageTimer t(GOI_STAGE_BLEND_FWD, s);
-        launch_render_fwd(sc, g, im, plist, out_color, out_semantic, out_depth, out_alpha, s);
+        launch_render_fwd(sc, g, im, plist, out_color, out_semantic, out_depth, out_alpha, s, bv.qmask);
     }
     GOI_HIP(hipGetLastError());
     return 0;
@@ -555,8 +576,10 @@ int goi_raster_forward_reblend(const GoiRasterScene* scene, int R, const void* g
     GOI_HIP(hipMemcpyAsync(im.ranges, im_old.ranges, sizeof(uint2) * (size_t)gx * gy, hipMemcpyDeviceToDevice, s));
     const uint32_t* plist = bv.vals[tile_sort_result_index(sc.W, sc.H, R)];
     {
+        // (the member masks of rounds >= 1 go into the CACHED binning workspace: they depend on geometry and tile lists only,
+        // so every reblend of this camera writes the words that are already there)
         StageTimer t(GOI_STAGE_BLEND_FWD, s);
-        launch_render_fwd(sc, g, im, plist, out_color, out_semantic, out_depth, out_alpha, s);
+        launch_render_fwd(sc, g, im, plist, out_color, out_semantic, out_depth, out_alpha, s, bv.qmask);
     }
     GOI_HIP(hipGetLastError());
     return 0;
@@ -617,10 +640,13 @@ int goi_raster_backward(const GoiRasterScene* scene, int R, const void* geom_buf
         {
             StageTimer t(GOI_STAGE_BLEND_BWD, s);
             if (R > 0) {
-                GOI_HIP(hipMemsetAsync(scr.flags, 0, round_up_256((size_t)R * 4), s));  // (the layout ends with 256 spare bytes)
-                launch_quad_order(sc, im, s);
+                // the validity bytes of the slots this frame can use are cleared by extra workgroups of the quadrant-order
+                // launch (count on the device: 4 x num_rendered bytes, not 4 x capacity) -- or by a memset where that
+                // launch does not exist
+                if (!launch_quad_order(sc, im, s, scr.flags, g.counters + COUNTER_N, (uint32_t)R))
+                    GOI_HIP(hipMemsetAsync(scr.flags, 0, round_up_256((size_t)R * 4), s));  // (the layout ends with 256 spare bytes)
                 launch_render_bwd_rows(sc, g, im, bv.vals[fin], radii, out_alpha, dL_dout_color, dL_dout_semantic,
-                                       dL_dout_depth, dL_dout_alpha, scr, s);
+                                       dL_dout_depth, dL_dout_alpha, scr, s, bv.qmask);
             }
         }
         if (check_stage(sc, s, "backward blend")) return -1;
@@ -683,8 +709,8 @@ int goi_raster_backward_semantics(const GoiRasterScene* scene, int R, const void
     {
         StageTimer t(GOI_STAGE_BLEND_BWD, s);
         if (R > 0) {
-            GOI_HIP(hipMemsetAsync(scr.flags, 0, round_up_256((size_t)R * 4), s));  // (the layout ends with 256 spare bytes)
-            launch_quad_order(sc, im, s);
+            if (!launch_quad_order(sc, im, s, scr.flags, g.counters + COUNTER_N, (uint32_t)R))
+                GOI_HIP(hipMemsetAsync(scr.flags, 0, round_up_256((size_t)R * 4), s));  // (the layout ends with 256 spare bytes)
             launch_render_bwd_sem(sc, g, im, bv.vals[fin], radii, out_alpha, dL_dout_semantic, scr.rows, scr.flags,
                                   row_floats, s);
         }
@@ -844,6 +870,10 @@ int goi_raster_set_option(const char* name, int value) {
         g_options.bwd_order = value;
     }
     else if (!strcmp(name, "decode_variant")) g_options.decode_variant = value;
+    else if (!strcmp(name, "bwd_masks")) {
+        if (value < 0 || value > 1) return fail("bwd_masks must be 0 or 1");
+        g_options.bwd_masks = value;
+    }
     else if (!strcmp(name, "bwd_records")) {
         if (value < 0 || value > 1) return fail("bwd_records must be 0 or 1");
         g_options.bwd_records = value;

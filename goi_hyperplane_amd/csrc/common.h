@@ -48,6 +48,10 @@ struct ImageView {
     uint2* ranges;        // [T]
     uint32_t* qcost;      // [4T] per 8x8 quadrant: list positions its wave has to walk in the backward (max n_contrib)
     uint32_t* qorder;     // [quad_grid(4T)] launch slot -> quadrant, heaviest first inside each XCD's band (backward)
+    // [4T] MEMBER mask of every quadrant's FIRST round of 64 list positions (bit j: the Gaussian at list position j
+    // contributed to some pixel of the quadrant); later rounds live in BinView::qmask (their number depends on N).
+    // Written by the forward blend, read by the backward blend: see member_mask_ptr.
+    unsigned long long* qmask0;
 };
 // Backward scratch (goi_raster_backward_scratch_bytes): one 128-byte partial-gradient row per
 // (emit-order instance, quadrant) and one validity byte per row.
@@ -64,7 +68,18 @@ struct BinView {
     uint32_t* vals[2];  // [N] Gaussian ids (ping-pong)
     uint32_t* scratch;
     size_t scratch_words;
+    unsigned long long* qmask;  // [4 (N / 64 + 2)] member masks of the rounds >= 1 (member_mask_ptr)
 };
+
+// Where the forward blend leaves, and the backward blend finds, the 64-bit MEMBER mask of round r (list positions
+// 64 r .. 64 r + 63) of quadrant q of a tile whose list starts at x0: round 0 in the image state (one word per quadrant),
+// round r >= 1 at word (x0 / 64 + r) of the binning state -- tile t's rounds 1 .. ceil(len / 64) - 1 end at word
+// floor((x0 + len - 1) / 64) < floor(x1 / 64) + 1, the first word of the next tile: no two tiles share a word, and the
+// array needs N / 64 + 1 words per quadrant whatever the tile grid is.
+__host__ __device__ inline unsigned long long* member_mask_ptr(unsigned long long* qmask0, unsigned long long* qmask, int tile,
+                                                                int q, uint32_t x0, int r) {
+    return r == 0 ? qmask0 + ((size_t)tile * 4 + q) : qmask + (((size_t)(x0 >> 6) + (size_t)r) * 4 + q);
+}
 
 size_t geom_layout(int P, char* base, GeomView* v);
 size_t image_layout(int W, int H, char* base, ImageView* v);
@@ -83,6 +98,9 @@ struct Options {
     int bwd_order = 1;     // backward blend: v >= 1 the quadrants of each XCD's band are launched longest-first (their cost is
                            // known from the forward's n_contrib; cost classes of 2^(3+v) list positions), 0 in tile order.
                            // Same rows, same gradients.
+    int bwd_masks = 1;     // atomic-free backward blend: 1 walks the MEMBER masks the forward blend left (no candidate tests, no
+                           // evaluation of pairs that contribute nowhere; default), 0 tests every candidate of its list against
+                           // the quadrant itself.  Same rows, same gradients, bit for bit.
     int bwd_records = 1;   // atomic-free backward: 1 the per-Gaussian sums stay in the row scratch as records and
                            // preprocess_bwd_k writes every per-id output (default), 0 reduce_rows_k writes six per-id arrays
                            // (and zeros for the unlisted Gaussians) that preprocess_bwd_k reads back.  Same gradients, bit for bit.
@@ -109,8 +127,12 @@ void exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* ou
 //                 ([pass][256] words at radix_sort_ghist(...)), so the sort's histogram kernel is skipped.
 //   n_dev       : (onesweep only) the element count lives on the DEVICE and `n` is a capacity: grids and control words
 //                 are sized for n, the kernels sort min(*n_dev, n) elements (speculative forward, api.hip).
+//   frame_error : (onesweep only) a device word that gets bit 1 OR-ed in when a look-back spin runs out of its budget (a
+//                 preempted or wedged GPU): the sort carries on -- it must never hang the device -- but its output is
+//                 garbage and the caller must not use the frame (COUNTER_SORTERR / COUNTER_OVF).
 int radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], size_t n, int lo, int hi, uint32_t* scratch,
-                     hipStream_t s, bool cleared = false, bool ghist_ready = false, const uint32_t* n_dev = nullptr);
+                     hipStream_t s, bool cleared = false, bool ghist_ready = false, const uint32_t* n_dev = nullptr,
+                     uint32_t* frame_error = nullptr);
 size_t radix_sort_control_words(size_t n, int lo, int hi);
 uint32_t* radix_sort_ghist(uint32_t* scratch, size_t n, int lo, int hi);
 
@@ -132,17 +154,22 @@ void launch_emit_counting(int P, int W, int H, const GeomView& g, const uint32_t
 void launch_tile_ranges_hist(int W, int H, uint2* ranges, uint32_t* ghist, hipStream_t s);
 void launch_ranges(int N, const uint32_t* n_dev, const uint32_t* sorted_keys, uint2* ranges, int T, hipStream_t s);
 void launch_render_fwd(const GoiRasterScene& sc, const GeomView& g, const ImageView& im, const uint32_t* point_list,
-                       float* out_color, float* out_sem, float* out_depth, float* out_alpha, hipStream_t s);
+                       float* out_color, float* out_sem, float* out_depth, float* out_alpha, hipStream_t s,
+                       unsigned long long* qmask = nullptr);
 void launch_trace_fwd(const GoiRasterScene& sc, const float* img_sem, const GeomView& g, const ImageView& im,
                       const uint32_t* point_list, float* out_color, float* gau_sem, int* num_gsem, hipStream_t s);
 // launch order of the backward's quadrant waves (render_bwd.hip): im.qcost -> im.qorder
 bool quad_order_enabled(int W, int H);
-void launch_quad_order(const GoiRasterScene& sc, const ImageView& im, hipStream_t s);
+// clear_flags != NULL: extra workgroups of the same launch zero the first 4 * min(*n_dev, cap) validity bytes of the backward
+// scratch (what a memset of 4 * cap bytes did).  Returns false -- nothing launched, nothing cleared -- where the quadrant
+// order is not used (quad_order_enabled).
+bool launch_quad_order(const GoiRasterScene& sc, const ImageView& im, hipStream_t s, uint8_t* clear_flags = nullptr,
+                       const uint32_t* n_dev = nullptr, uint32_t cap = 0);
 // atomic-free backward blend: partial rows + flags into the scratch (render_bwd.hip)
 void launch_render_bwd_rows(const GoiRasterScene& sc, const GeomView& g, const ImageView& im,
                             const uint32_t* point_list, const int* radii, const float* out_alpha, const float* dL_dpix,
                             const float* dL_dsem, const float* dL_ddepth, const float* dL_dalpha,
-                            const BwdScratchView& scr, hipStream_t s);
+                            const BwdScratchView& scr, hipStream_t s, const unsigned long long* qmask = nullptr);
 // feature-gradient-only backward blend (render_bwd_sem.hip) and its row reduction: dL/dsemantics only
 void launch_render_bwd_sem(const GoiRasterScene& sc, const GeomView& g, const ImageView& im, const uint32_t* point_list,
                            const int* radii, const float* out_alpha, const float* dL_dsem, float* rows, uint8_t* flags,
@@ -266,6 +293,10 @@ constexpr int COUNTER_OVF = 4;   // 1: this frame's instance list was TRUNCATED 
                                  // speculative forward).  Written by emit; every backward kernel reads it and, if set, produces
                                  // ZERO gradients: a truncated frame must never reach the optimiser (the reference sizes its
                                  // buffers from the true count, CR/rasterizer_impl.cu:283-289, and cannot truncate)
+
+constexpr int COUNTER_SORTERR = 6;  // != 0: a look-back of the DEPTH sort timed out (scan_sort.hip): emit folds it into
+                                    // COUNTER_OVF (the tile sort, which runs behind emit, sets bit 1 of COUNTER_OVF itself), so
+                                    // a mis-sorted frame back-propagates zeros like a truncated one, and the read-back fails
 
 // The depth sort runs ceil(32/8) = 4 ping-pong passes from buffer 0, so its result is in buffer 0.
 inline int depth_sort_result_index() { return ((32 + 7) / 8) & 1; }

@@ -1053,7 +1053,9 @@ __global__ __launch_bounds__(256) void emit_k(int P, int gx, int gy, const Gauss
     const bool cull = counters[COUNTER_CULL] != 0;
     P = min(P, (int)counters[COUNTER_V]);  // order[] / offsets[] hold the LISTED Gaussians only (front of the depth order)
     // the frame's "truncated" flag (COUNTER_OVF): emit is the first kernel that knows both the count and the capacity
-    if (blockIdx.x == 0 && threadIdx.x == 0) counters[COUNTER_OVF] = counters[COUNTER_N] > cap ? 1u : 0u;
+    // (... or was depth-sorted wrongly because a look-back of the sort timed out: COUNTER_SORTERR)
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        counters[COUNTER_OVF] = (counters[COUNTER_N] > cap ? 1u : 0u) | (counters[COUNTER_SORTERR] ? 2u : 0u);
     // COUNT: the blocks also zero the control words of the tile sort that follows (its own memset launch otherwise)
     if (COUNT)
         for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < clear_words; i += gridDim.x * 256u) clear[i] = 0u;

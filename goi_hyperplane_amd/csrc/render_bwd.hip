@@ -79,7 +79,13 @@ struct BwdCfg {
 };
 
 // MODE 0: split-bf16 flush (default).  MODE 1: exact-fp32 flush.
-template <int S4, int MODE>
+// MASKS (default): the forward blend has left the MEMBER mask of every (quadrant, 64 list positions) -- which Gaussians
+// contributed to some pixel of the quadrant (render_fwd.hip, member_mask_ptr).  The wave then walks its list in 32-entry
+// batches ALIGNED with the forward's rounds, fetches and stages members only, and evaluates members only: no candidate is
+// tested against the quadrant (ellipse_hits_quadrant: ~45 lane-parallel instructions per batch and a 32-byte gather per
+// candidate) and no hit that contributes nowhere is evaluated.  The member set is exactly the set of pairs the
+// candidate-testing form (MASKS = false, bwd_masks 0) ends up flushing, in the same order: same rows, same bits.
+template <int S4, int MODE, bool MASKS>
 __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int gx, int gy,
     int n_quads, int S, const GaussRec* __restrict__ rec, const float* __restrict__ semantics,
@@ -87,7 +93,8 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
     const float* __restrict__ out_alpha, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
     const float* __restrict__ dL_dpixsem, const float* __restrict__ dL_dpixdepth, const float* __restrict__ dL_dalphas,
     float* __restrict__ rows, uint8_t* __restrict__ flags, int row_floats,
-    const uint32_t* __restrict__ counters, const uint32_t* __restrict__ qorder) {
+    const uint32_t* __restrict__ counters, const uint32_t* __restrict__ qorder,
+    const unsigned long long* __restrict__ qmask0, const unsigned long long* __restrict__ qmask) {
     using Cfg = BwdCfg<S4>;
     const bool cull = counters[COUNTER_CULL] != 0;  // the rectangles the forward listed
     constexpr int NF4 = Cfg::NF4, NSEM = Cfg::NSEM, NCH = Cfg::NCH, NB = Cfg::NB;
@@ -223,19 +230,37 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
     const float half_W = 0.5f * W, half_H = 0.5f * H;
 
     // software prefetch of the next batch's id / position / box (one list entry per lane)
+    // MASKS: batch kb covers list positions [32 kb, 32 kb + 32), lane l position 32 kb + l, and is walked from its highest
+    // position down; its members are bits [32 (kb & 1), +32) of the forward's mask word kb >> 1 (wave-uniform, SGPRs).
+    // Otherwise: batch b covers positions n_proc-1-32b downwards, lane l position n_proc-1-(32 b + l), every lane a candidate.
     uint32_t id_n = 0;
+    uint32_t mem_n = 0;
     float4 q0_n = make_float4(0, 0, 0, 0), q1_n = make_float4(1.f, 0.f, -1.f, -1.f);  // (conic c, opacity, hx, hy)
+    const int tile_u = __builtin_amdgcn_readfirstlane(t.tile), q_u = __builtin_amdgcn_readfirstlane(t.q);
+    const uint32_t x0_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)range.x);
     auto prefetch = [&](int b) {
-        const int k = b * BATCH + lane;  // list position n_proc-1-k, walking back to front
-        q1_n.z = -1.f;
-        if (lane < BATCH && k < n_proc) {
-            id_n = point_list[range.x + (n_proc - 1 - k)];
-            const float4* r4 = reinterpret_cast<const float4*>(rec + id_n);
-            q0_n = r4[0];
-            q1_n = r4[1];
+        if constexpr (MASKS) {
+            const unsigned long long w = *member_mask_ptr(const_cast<unsigned long long*>(qmask0),
+                                                          const_cast<unsigned long long*>(qmask), tile_u, q_u, x0_u, b >> 1);
+            mem_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(w >> (32 * (b & 1))));
+            if (lane < BATCH && ((mem_n >> lane) & 1u)) {
+                id_n = point_list[range.x + (uint32_t)(b * BATCH + lane)];
+                const float4* r4 = reinterpret_cast<const float4*>(rec + id_n);
+                q0_n = r4[0];
+                q1_n = r4[1];
+            }
+        } else {
+            const int k = b * BATCH + lane;  // list position n_proc-1-k, walking back to front
+            q1_n.z = -1.f;
+            if (lane < BATCH && k < n_proc) {
+                id_n = point_list[range.x + (n_proc - 1 - k)];
+                const float4* r4 = reinterpret_cast<const float4*>(rec + id_n);
+                q0_n = r4[0];
+                q1_n = r4[1];
+            }
         }
     };
-    prefetch(0);
+    prefetch(MASKS ? rounds - 1 : 0);
 
     int nslot = 0;  // filled slots of the current MFMA group (wave-uniform)
     // staging slot of every group member, one byte per member, in SGPRs: the flush finds a member's coefficients,
@@ -335,12 +360,21 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
         __builtin_amdgcn_wave_barrier();
     };
 
-    for (int b = 0; b < rounds; b++) {
+    for (int bi = 0; bi < rounds; bi++) {
+        const int b = MASKS ? rounds - 1 - bi : bi;
         const uint32_t id = id_n;
         const float4 q0 = q0_n, q1 = q1_n;
-        const bool hit = ellipse_hits_quadrant(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, t.QX0, t.QY0);  // hx < 0 for absent lanes
-        if (b + 1 < rounds) prefetch(b + 1);
-        unsigned long long m = __ballot(hit);
+        bool hit;
+        unsigned long long m;
+        if constexpr (MASKS) {
+            m = mem_n;  // (wave-uniform)
+            hit = lane < BATCH && ((mem_n >> lane) & 1u);
+            if (bi + 1 < rounds) prefetch(b - 1);
+        } else {
+            hit = ellipse_hits_quadrant(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, t.QX0, t.QY0);  // hx < 0 for absent lanes
+            if (bi + 1 < rounds) prefetch(b + 1);
+            m = __ballot(hit);
+        }
         if (m == 0) continue;
         // ---- stage the hits (slot = lane)
         if (hit) {
@@ -379,14 +413,22 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
         __builtin_amdgcn_wave_barrier();
 
         while (m) {
-            const int j = __builtin_ctzll(m);
-            m &= m - 1;
-            const int pos0 = n_proc - 1 - (b * BATCH + j);  // 0-based list position
+            int j, pos0;  // staging slot, 0-based list position
+            if constexpr (MASKS) {
+                j = 31 - __builtin_clz((uint32_t)m);  // back to front: the batch's highest member first
+                m &= ~(1ull << j);
+                pos0 = b * BATCH + j;
+            } else {
+                j = __builtin_ctzll(m);
+                m &= m - 1;
+                pos0 = n_proc - 1 - (b * BATCH + j);
+            }
             const f32x4 g = s_geo[j];
             const f32x4 g2 = s_geo2[j];
             const PairEval e = eval_poly(g.xy, g.zw, g2.x, g2.y, g2.z, uv);
             const bool live = pos0 < last_contributor;
-            if (!any_all(live, e.below, e.seen)) continue;
+            if constexpr (!MASKS)  // (a member contributes somewhere by construction)
+                if (!any_all(live, e.below, e.seen)) continue;
             const bool c = live && e.hit;
 
             // <feature, dL/dpixel> as packed fp32 FMAs (v_pk_fma_f32: two channels per instruction)
@@ -423,7 +465,7 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
             }
         }
         __builtin_amdgcn_wave_barrier();
-        if (nslot > 0 && b + 1 < rounds) {
+        if (nslot > 0 && bi + 1 < rounds) {
             // the next batch overwrites the staging slots: move the unfinished group's members to the carry slots
             // (member l -> slot BATCH + l; a member carried before is already there)
             // (lane l reads slot idx_l -- below BATCH, or BATCH + l itself -- and writes BATCH + l: no lane writes
@@ -452,8 +494,21 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
 // heaviest-first map had lost more in L2 locality than it gained in balance.)  Which wave computes which row does not
 // change any result.
 constexpr int QO_THREADS = 1024, QO_WAVES = QO_THREADS / 64, QO_BUCKETS = 64, QO_ROUNDS = 16;
+constexpr int QO_CLEAR_BLOCKS = 248;  // workgroups 8 .. 255 of the launch clear the backward's validity bytes
 __global__ __launch_bounds__(QO_THREADS) void quad_order_k(const uint32_t* __restrict__ qcost, int n_quads, int per,
-                                                           uint32_t* __restrict__ qorder, int shift) {
+                                                           uint32_t* __restrict__ qorder, int shift,
+                                                           uint8_t* __restrict__ clear_flags,
+                                                           const uint32_t* __restrict__ n_dev, uint32_t cap) {
+    if (blockIdx.x >= 8) {
+        // validity bytes of the row slots this frame can use: 4 per instance, zeroed 16 bytes per lane (the scratch layout
+        // rounds the array up to 256 bytes, so the last partial quad is inside it)
+        if (!clear_flags) return;
+        const size_t nq = ((size_t)min(*n_dev, cap) * 4 + 15) / 16;
+        uint4* dst = reinterpret_cast<uint4*>(clear_flags);
+        for (size_t i = (size_t)(blockIdx.x - 8) * QO_THREADS + threadIdx.x; i < nq; i += (size_t)QO_CLEAR_BLOCKS * QO_THREADS)
+            dst[i] = make_uint4(0u, 0u, 0u, 0u);
+        return;
+    }
     __shared__ uint32_t cnt[QO_WAVES][QO_BUCKETS];
     const int band = blockIdx.x, base = band * per;
     const int n = max(0, min(per, n_quads - base));
@@ -516,18 +571,23 @@ __global__ __launch_bounds__(QO_THREADS) void quad_order_k(const uint32_t* __res
 template <int S4>
 void launch_bwd_rows_s4(const GoiRasterScene& sc, const GeomView& g, const ImageView& im, const uint32_t* point_list,
                         const int* radii, const float* out_alpha, const float* dL_dpix, const float* dL_dsem,
-                        const float* dL_ddepth, const float* dL_dalpha, const BwdScratchView& scr, hipStream_t s) {
+                        const float* dL_ddepth, const float* dL_dalpha, const BwdScratchView& scr, hipStream_t s,
+                        const unsigned long long* qmask) {
     const int gx = (sc.W + TILE - 1) / TILE, gy = (sc.H + TILE - 1) / TILE;
     const int n_quads = gx * gy * 4;
-#define GOI_LAUNCH_ROWS(MODE)                                                                                          \
-    render_bwd_rows_k<S4, MODE><<<dim3(quad_grid(n_quads)), dim3(64), 0, s>>>(                                           \
+#define GOI_LAUNCH_ROWS(MODE, MASKS)                                                                                   \
+    render_bwd_rows_k<S4, MODE, MASKS><<<dim3(quad_grid(n_quads)), dim3(64), 0, s>>>(                                    \
         im.ranges, point_list, sc.W, sc.H, gx, gy, n_quads, sc.S, g.rec, sc.semantics, radii, g.aux, sc.bg, out_alpha, \
         im.n_contrib, dL_dpix, dL_dsem, dL_ddepth, dL_dalpha, scr.rows, scr.flags, bwd_row_floats(sc.S),                 \
-        g.counters, quad_order_enabled(sc.W, sc.H) ? im.qorder : nullptr)
-    if ((g_options.bwd_variant & 15) == 2)
-        GOI_LAUNCH_ROWS(1);
-    else
-        GOI_LAUNCH_ROWS(0);
+        g.counters, quad_order_enabled(sc.W, sc.H) ? im.qorder : nullptr, im.qmask0, qmask)
+    const bool masks = qmask != nullptr && g_options.bwd_masks != 0;
+    if ((g_options.bwd_variant & 15) == 2) {
+        if (masks) GOI_LAUNCH_ROWS(1, true);
+        else GOI_LAUNCH_ROWS(1, false);
+    } else {
+        if (masks) GOI_LAUNCH_ROWS(0, true);
+        else GOI_LAUNCH_ROWS(0, false);
+    }
 #undef GOI_LAUNCH_ROWS
 }
 
@@ -540,19 +600,22 @@ bool quad_order_enabled(int W, int H) {
     return g_options.bwd_order != 0 && (per + QO_WAVES - 1) / QO_WAVES <= 64 * QO_ROUNDS;
 }
 
-void launch_quad_order(const GoiRasterScene& sc, const ImageView& im, hipStream_t s) {
-    if (!quad_order_enabled(sc.W, sc.H)) return;
+bool launch_quad_order(const GoiRasterScene& sc, const ImageView& im, hipStream_t s, uint8_t* clear_flags,
+                       const uint32_t* n_dev, uint32_t cap) {
+    if (!quad_order_enabled(sc.W, sc.H)) return false;
     const int gx = (sc.W + TILE - 1) / TILE, gy = (sc.H + TILE - 1) / TILE;
     const int n_quads = gx * gy * 4, per = quad_grid(n_quads) / 8;
-    quad_order_k<<<dim3(8), dim3(QO_THREADS), 0, s>>>(im.qcost, n_quads, per, im.qorder, 3 + g_options.bwd_order);
+    quad_order_k<<<dim3(clear_flags ? 8 + QO_CLEAR_BLOCKS : 8), dim3(QO_THREADS), 0, s>>>(
+        im.qcost, n_quads, per, im.qorder, 3 + g_options.bwd_order, clear_flags, n_dev, cap);
+    return true;
 }
 
 void launch_render_bwd_rows(const GoiRasterScene& sc, const GeomView& g, const ImageView& im,
                             const uint32_t* point_list, const int* radii, const float* out_alpha, const float* dL_dpix,
                             const float* dL_dsem, const float* dL_ddepth, const float* dL_dalpha,
-                            const BwdScratchView& scr, hipStream_t s) {
+                            const BwdScratchView& scr, hipStream_t s, const unsigned long long* qmask) {
 #define GOI_CALL(N) \
-    launch_bwd_rows_s4<N>(sc, g, im, point_list, radii, out_alpha, dL_dpix, dL_dsem, dL_ddepth, dL_dalpha, scr, s)
+    launch_bwd_rows_s4<N>(sc, g, im, point_list, radii, out_alpha, dL_dpix, dL_dsem, dL_ddepth, dL_dalpha, scr, s, qmask)
     GOI_DISPATCH_S4(sc.S, GOI_CALL)
 #undef GOI_CALL
 }

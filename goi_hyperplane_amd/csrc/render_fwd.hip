@@ -23,7 +23,7 @@ namespace goi {
 
 namespace {
 
-template <int S4, bool TRACE, bool UNROLL2>
+template <int S4, bool TRACE, bool UNROLL2, bool MASKS>
 __global__ __launch_bounds__(64) void render_fwd_k(const uint2* __restrict__ ranges,
                                                    const uint32_t* __restrict__ point_list, int W, int H, int gx,
                                                    int n_quads, int S, const GaussRec* __restrict__ rec,
@@ -32,7 +32,8 @@ __global__ __launch_bounds__(64) void render_fwd_k(const uint2* __restrict__ ran
                                                    float* __restrict__ out_depth, float* __restrict__ out_alpha,
                                                    uint32_t* __restrict__ n_contrib, const float* __restrict__ img_sem,
                                                    float* __restrict__ gau_sem, int* __restrict__ num_gsem,
-                                                   uint32_t* __restrict__ qcost) {
+                                                   uint32_t* __restrict__ qcost, unsigned long long* __restrict__ qmask0,
+                                                   unsigned long long* __restrict__ qmask) {
     constexpr int NF4 = TRACE ? 1 : 1 + S4;  // float4 words staged per Gaussian: (r,g,b,depth) + semantics
     constexpr int NSEM = TRACE ? 0 : 4 * S4;
     __shared__ f32x4 s_geo[64];   // (A3, A5, A1, A2) of the quadrant-centred log2-alpha polynomial (blend_common.h)
@@ -84,16 +85,30 @@ __global__ __launch_bounds__(64) void render_fwd_k(const uint2* __restrict__ ran
     };
     if (rounds > 0) prefetch(0);
 
+    // MEMBER mask of the round (bit j: the Gaussian at list position 64 b + j contributed to some pixel of this quadrant),
+    // in SGPRs; left for the backward blend (member_mask_ptr), which then neither tests a candidate against the quadrant
+    // nor evaluates a pair that cannot contribute: a (position, quadrant) pair is a member here iff some pixel has it
+    // below its last contributor and passes the two alpha guards there -- exactly the backward's own condition
+    // (everything the word's address is made of is wave-uniform: kept in SGPRs, or the compiler carries tile / quadrant /
+    // list start and the mask itself in vector registers -- 82 -> 114 VGPRs, four waves per SIMD instead of five)
+    const int tile_u = __builtin_amdgcn_readfirstlane(t.tile), q_u = __builtin_amdgcn_readfirstlane(t.q);
+    const uint32_t x0_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)range.x);
+    auto store_members = [&](int b, unsigned long long mm) {
+        if constexpr (MASKS)
+            if (lane == 0) *member_mask_ptr(qmask0, qmask, tile_u, q_u, x0_u, b) = mm;
+    };
     for (int b = 0; b < rounds; b++) {
         if (all_done()) break;
+        unsigned long long members = 0;
         const uint32_t id = id_n;
         const float4 q0 = q0_n, q1 = q1_n, q2 = q2_n;
         const bool hit = ellipse_hits_quadrant(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, t.QX0, t.QY0);  // hx < 0 for absent lanes
         if (b + 1 < rounds) prefetch(b + 1);
         unsigned long long m = __ballot(hit);
-        if (m == 0) continue;
+        // (a round without a hit falls through to the store of its -- empty -- member mask: a second store site in an
+        // early `continue` cost 32 VGPRs and the fifth wave per SIMD)
         // ---- stage the hits (slot = lane)
-        if (hit) {
+        if (m != 0 && hit) {
             const PolyCoef pc = poly_coefs(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, QCX, QCY);
             s_geo[lane] = f32x4{pc.A35.x, pc.A35.y, pc.A12.x, pc.A12.y};
             s_geo2[lane] = f32x4{pc.A0, pc.A4, pc.lim, 0.f};
@@ -129,6 +144,7 @@ __global__ __launch_bounds__(64) void render_fwd_k(const uint2* __restrict__ ran
             const bool c = c0 && ok;
             const bool some = any_all(e.below, e.seen, ok);  // (taken where the comparisons are: their masks are used as they are)
             if (valid && some) {                             // (valid is wave-uniform)
+                if constexpr (MASKS) asm("s_bitset1_b64 %0, %1" : "+s"(members) : "s"(j));  // members |= 1 << j, pinned to SGPRs
                 const float wgt = c ? e.alpha * T_live : 0.f;
                 const f32x2 w2 = {wgt, wgt};
                 const f32x4 f0 = s_feat4[j * NF4];
@@ -184,6 +200,7 @@ __global__ __launch_bounds__(64) void render_fwd_k(const uint2* __restrict__ ran
                 if (all_done()) m = 0;
             }
         }
+        store_members(b, members);
         __builtin_amdgcn_wave_barrier();
     }
 
@@ -211,24 +228,38 @@ __global__ __launch_bounds__(64) void render_fwd_k(const uint2* __restrict__ ran
 
 template <int S4>
 void launch_fwd_s4(const GoiRasterScene& sc, const GeomView& g, const ImageView& im, const uint32_t* point_list,
-                   float* out_color, float* out_sem, float* out_depth, float* out_alpha, hipStream_t s) {
+                   float* out_color, float* out_sem, float* out_depth, float* out_alpha, hipStream_t s,
+                   unsigned long long* qmask) {
     const int gx = (sc.W + TILE - 1) / TILE, gy = (sc.H + TILE - 1) / TILE;
     const int n_quads = gx * gy * 4;
-    if (g_options.fwd_variant == 1)
-        render_fwd_k<S4, false, true><<<dim3(quad_grid(n_quads)), dim3(64), 0, s>>>(
-            im.ranges, point_list, sc.W, sc.H, gx, n_quads, sc.S, g.rec, sc.semantics, sc.bg, out_color, out_sem,
-            out_depth, out_alpha, im.n_contrib, nullptr, nullptr, nullptr, im.qcost);
-    else
-        render_fwd_k<S4, false, false><<<dim3(quad_grid(n_quads)), dim3(64), 0, s>>>(
-            im.ranges, point_list, sc.W, sc.H, gx, n_quads, sc.S, g.rec, sc.semantics, sc.bg, out_color, out_sem,
-            out_depth, out_alpha, im.n_contrib, nullptr, nullptr, nullptr, im.qcost);
+#define GOI_LAUNCH_FWD(U2, MK)                                                                                         \
+    render_fwd_k<S4, false, U2, MK><<<dim3(quad_grid(n_quads)), dim3(64), 0, s>>>(                                      \
+        im.ranges, point_list, sc.W, sc.H, gx, n_quads, sc.S, g.rec, sc.semantics, sc.bg, out_color, out_sem, out_depth, \
+        out_alpha, im.n_contrib, nullptr, nullptr, nullptr, im.qcost, im.qmask0, qmask)
+    // The member masks are recorded by EVERY forward (a backward may follow with either setting of bwd_masks, and a frame
+    // without masks back-propagated through them would be garbage).  BUILD SWITCH for measuring what recording costs the
+    // forward: GOI_EXTRA_FLAGS=-DGOI_FWD_NO_MASKS (such a build must run with GOI_OPTIONS=bwd_masks=0).
+#ifdef GOI_FWD_NO_MASKS
+    const bool masks = false;
+#else
+    const bool masks = qmask != nullptr;
+#endif
+    if (g_options.fwd_variant == 1) {
+        if (masks) GOI_LAUNCH_FWD(true, true);
+        else GOI_LAUNCH_FWD(true, false);
+    } else {
+        if (masks) GOI_LAUNCH_FWD(false, true);
+        else GOI_LAUNCH_FWD(false, false);
+    }
+#undef GOI_LAUNCH_FWD
 }
 
 }  // namespace
 
 void launch_render_fwd(const GoiRasterScene& sc, const GeomView& g, const ImageView& im, const uint32_t* point_list,
-                       float* out_color, float* out_sem, float* out_depth, float* out_alpha, hipStream_t s) {
-#define GOI_CALL(N) launch_fwd_s4<N>(sc, g, im, point_list, out_color, out_sem, out_depth, out_alpha, s)
+                       float* out_color, float* out_sem, float* out_depth, float* out_alpha, hipStream_t s,
+                       unsigned long long* qmask) {
+#define GOI_CALL(N) launch_fwd_s4<N>(sc, g, im, point_list, out_color, out_sem, out_depth, out_alpha, s, qmask)
     GOI_DISPATCH_S4(sc.S, GOI_CALL)
 #undef GOI_CALL
 }
@@ -237,9 +268,9 @@ void launch_trace_fwd(const GoiRasterScene& sc, const float* img_sem, const Geom
                       const uint32_t* point_list, float* out_color, float* gau_sem, int* num_gsem, hipStream_t s) {
     const int gx = (sc.W + TILE - 1) / TILE, gy = (sc.H + TILE - 1) / TILE;
     const int n_quads = gx * gy * 4;
-    render_fwd_k<1, true, false><<<dim3(quad_grid(n_quads)), dim3(64), 0, s>>>(
+    render_fwd_k<1, true, false, false><<<dim3(quad_grid(n_quads)), dim3(64), 0, s>>>(
         im.ranges, point_list, sc.W, sc.H, gx, n_quads, sc.S, g.rec, nullptr, sc.bg, out_color, nullptr, nullptr, nullptr,
-        im.n_contrib, img_sem, gau_sem, num_gsem, nullptr);
+        im.n_contrib, img_sem, gau_sem, num_gsem, nullptr, nullptr, nullptr);
 }
 
 }  // namespace goi

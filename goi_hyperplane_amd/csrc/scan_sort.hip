@@ -298,7 +298,8 @@ __global__ __launch_bounds__(THREADS) void sweep_pass_k(const uint32_t* __restri
                                                              uint32_t* __restrict__ vals_out, size_t n_cap,
                                                              const uint32_t* __restrict__ n_dev, int shift,
                                                              int nbits, const uint32_t* __restrict__ ghist,
-                                                             uint32_t* status, uint32_t* ticket, uint32_t* error) {
+                                                             uint32_t* status, uint32_t* ticket, uint32_t* error,
+                                                             uint32_t* frame_error) {
     constexpr int TILE_KEYS = THREADS * ITEMS, WAVES = THREADS / WAVE, WAVE_ITEMS = TILE_KEYS / WAVES;
     const size_t n = effective_n(n_cap, n_dev);
     __shared__ uint32_t cnt[WAVES][RADIX_MAX];  // per-wave digit counts -> per-wave local offsets
@@ -411,9 +412,14 @@ __global__ __launch_bounds__(THREADS) void sweep_pass_k(const uint32_t* __restri
             }
             if (found) break;
             pb -= used;
+            if (used > 0) spins = 0;  // (the budget is per predecessor that keeps the tile waiting, not per look-back)
             if (used < LB) {  // tile pb has not published yet: wait for it
                 if (++spins > (1u << 22)) {
-                    atomicOr(error, 2u);  // never hang the device: report and carry on with garbage
+                    // never hang the device: carry on with garbage, but SAY so -- in the sort's own error word and in the
+                    // caller's (the frame's COUNTER_SORTERR / COUNTER_OVF: a frame sorted wrongly is treated as a truncated
+                    // one, its backward writes zero gradients and the host's read-back fails the call)
+                    atomicOr(error, 2u);
+                    if (frame_error) atomicOr(frame_error, 2u);
                     break;
                 }
                 __builtin_amdgcn_s_sleep(1);
@@ -513,7 +519,7 @@ uint32_t* radix_sort_ghist(uint32_t* scratch, size_t n, int lo, int hi) {
 }
 
 int radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], size_t n, int lo, int hi, uint32_t* scratch,
-                     hipStream_t s, bool cleared, bool ghist_ready, const uint32_t* n_dev) {
+                     hipStream_t s, bool cleared, bool ghist_ready, const uint32_t* n_dev, uint32_t* frame_error) {
     int cur = 0;
     if (n == 0) return cur;
     const uint32_t nblk = (uint32_t)div_up(n, SORT_TILE);
@@ -557,11 +563,11 @@ int radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], size_t n, int lo, int
             if (tile == 4096)
                 sweep_pass_k<1024, 4><<<dim3(nt), dim3(1024), lds, s>>>(
                     keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, n_dev, plan.shift[p], plan.nbits[p],
-                    ghist + (size_t)p * RADIX_MAX, status + (size_t)p * nt * RADIX_MAX, ticket + p, error);
+                    ghist + (size_t)p * RADIX_MAX, status + (size_t)p * nt * RADIX_MAX, ticket + p, error, frame_error);
             else
                 sweep_pass_k<512, 16><<<dim3(nt), dim3(512), lds, s>>>(
                     keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, n_dev, plan.shift[p], plan.nbits[p],
-                    ghist + (size_t)p * RADIX_MAX, status + (size_t)p * nt * RADIX_MAX, ticket + p, error);
+                    ghist + (size_t)p * RADIX_MAX, status + (size_t)p * nt * RADIX_MAX, ticket + p, error, frame_error);
             cur ^= 1;
         }
         return cur;

@@ -106,7 +106,7 @@ def allreduce_gradients(params, dist, bucket_bytes: int = 0):
             off += n
 
 
-def allreduce_gradients_visible(params, visible, dist, dense_above: float = 0.9):
+def allreduce_gradients_visible(params, visible, dist, dense_above: float = 0.9, per_gaussian=None, check_zero_rows=False):
     """Sum-all-reduce `.grad` of every parameter, sending only the rows of Gaussians that were VISIBLE in at least one
     rank's view(s) of this step.
 
@@ -117,9 +117,18 @@ def allreduce_gradients_visible(params, visible, dist, dense_above: float = 0.9)
     which IS the sum.  xGMI rings are per-link bound, so volume is what counts: at the headline scene a
     view sees 51 % of the Gaussians; BASELINE config 5 (6 M Gaussians, a 512 x 512 close-up per rank) sees far fewer.
 
+    PRECONDITION (hard): every gradient of a per-Gaussian tensor comes from the rasterizer's backward ALONE -- a row the
+    rasterizer did not see is exactly zero.  The reference's train.py has only render losses, so this holds there; a weight
+    decay or a regulariser on opacities / scales would leave non-zero rows outside the union and the ranks would diverge
+    silently.  check_zero_rows=True verifies the premise on every call (one more reduction + host read: debugging aid) and
+    raises if a row outside the union is non-zero.
+
     visible: bool / uint8 [P] of this rank -- `radii > 0` of its view, OR-ed over the views it accumulated locally.
-    Tensors whose leading dimension is not P (the decoder, the code book) are all-reduced whole.  If the union covers
-    more than `dense_above` of the Gaussians the plain all-reduce is used (the gather would only add copies).
+    per_gaussian: the parameters whose gradient rows are per Gaussian (sent by row); every other parameter (the decoder,
+    the code book) is all-reduced whole.  None: every parameter whose gradient's leading dimension is P -- only safe when
+    no other tensor happens to have P rows (a [P, ...] tensor that is NOT per Gaussian would only be row-reduced), so
+    callers with a decoder or a code book should pass the list.  If the union covers more than `dense_above` of the
+    Gaussians the plain all-reduce is used (the gather would only add copies).
     Costs one host synchronisation (the union's size); use it where the exchange is waited for anyway.
     Returns the number of rows sent (P when it fell back to the dense exchange)."""
     P = int(visible.shape[0])
@@ -128,15 +137,37 @@ def allreduce_gradients_visible(params, visible, dist, dense_above: float = 0.9)
     idx = torch.nonzero(vis, as_tuple=True)[0]
     n = int(idx.numel())
     with_grad = [p for p in params if p.grad is not None]
-    rows = [p for p in with_grad if p.grad.dim() >= 1 and p.grad.shape[0] == P]
-    rest = [p for p in with_grad if not (p.grad.dim() >= 1 and p.grad.shape[0] == P)]
+    if per_gaussian is None:
+        rows = [p for p in with_grad if p.grad.dim() >= 1 and p.grad.shape[0] == P]
+    else:
+        chosen = {id(p) for p in per_gaussian}
+        rows = [p for p in with_grad if id(p) in chosen]
+        for p in rows:
+            if p.grad.dim() < 1 or p.grad.shape[0] != P:
+                raise ValueError(f"per_gaussian parameter with gradient shape {tuple(p.grad.shape)}: leading dimension is not P={P}")
+    row_ids = {id(p) for p in rows}
+    rest = [p for p in with_grad if id(p) not in row_ids]
     if n >= dense_above * P or not rows:
         allreduce_gradients(with_grad, dist)
         return P
     works = [dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True)
              for g in coalesce_shared_storage([p.grad for p in rest])] if rest else []
-    views = [p.grad.reshape(P, -1) for p in rows]
+    views = []
+    for p in rows:
+        # .view, never .reshape: a reshape of a non-contiguous gradient is a COPY, and the index_copy_ below would write the
+        # reduced rows into that copy and lose them
+        if not p.grad.is_contiguous():
+            raise ValueError("allreduce_gradients_visible needs contiguous per-Gaussian gradients (got strides "
+                             f"{tuple(p.grad.stride())} for shape {tuple(p.grad.shape)})")
+        views.append(p.grad.view(P, -1))
     widths = [int(v.shape[1]) for v in views]
+    if check_zero_rows:
+        unseen = (vis == 0)
+        worst = max((float(v[unseen].abs().max()) if bool(unseen.any()) else 0.0) for v in views)
+        if worst != 0.0:
+            raise RuntimeError(f"allreduce_gradients_visible: a gradient row of a Gaussian no rank saw is non-zero (|g| up to "
+                               f"{worst:.3e}): some loss reaches the per-Gaussian tensors without going through the rasterizer "
+                               "(weight decay, a regulariser); use allreduce_gradients for such steps")
     pack = torch.cat([v.index_select(0, idx) for v in views], dim=1)
     dist.all_reduce(pack, op=dist.ReduceOp.SUM)
     off = 0
@@ -146,6 +177,80 @@ def allreduce_gradients_visible(params, visible, dist, dense_above: float = 0.9)
     for w in works:
         w.wait()
     return n
+
+
+# ---- direct exchange: reduce-scatter + all-gather over all links -----------------------------------------------------------
+def _direct_spans(grads, world):
+    """(span, padded) pairs for the direct exchange: the gradients coalesced as for the all-reduce; a span whose length is
+    not a multiple of `world` travels through a zero-padded copy (the rasterizer's flat gradient buffer is laid out in
+    64-float sections, so its span divides by 2, 4 and 8 as it stands: no copy on the data path)."""
+    out = []
+    for span in coalesce_shared_storage(grads):
+        flat = span if span.dim() == 1 and span.is_contiguous() else None
+        if flat is None and span.is_contiguous():
+            flat = span.view(-1)
+        n = span.numel()
+        if flat is not None and n % world == 0:
+            out.append((span, flat, False))
+        else:
+            padded = torch.zeros(-(-n // world) * world, dtype=span.dtype, device=span.device)
+            padded[:n].copy_(span.reshape(-1))
+            out.append((span, padded, True))
+    return out
+
+
+def allreduce_gradients_direct(params, dist, async_op: bool = False):
+    """The same sum as allreduce_gradients, spelled as the two collectives SURVEY.md 8(e) prefers on xGMI: ONE
+    reduce-scatter (rank r receives and sums shard r of every rank's flat gradient span: every rank talks to all G-1 peers
+    at once, 1/G of the bytes per link) followed by ONE all-gather of the reduced shards.  A ring all-reduce is bound by a
+    single 153 GB/s link (300 MB -> 3.4 ms at 8 GPUs); the direct form spreads the same bytes over all seven (0.49 ms in
+    the link model, exchange_model_ms).  Which algorithm RCCL picks for a plain all_reduce is RCCL's business; this form
+    fixes the communication PATTERN, whatever the library does inside each collective.
+
+    In place: the shard a rank reduces is a slice of its own span (reduce_scatter_tensor with output = input[rank]), and
+    the all-gather writes every shard back where it came from -- no staging copy for the rasterizer's flat gradient buffer.
+    Every rank ends up with the same bits (each shard is summed on one rank and copied to the others).
+    async_op: return a PendingExchange (wait() before reading the gradients) instead of waiting here."""
+    grads = [p.grad for p in params if p.grad is not None]
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if not grads:
+        return PendingExchange([], None) if async_op else None
+    spans = _direct_spans(grads, world)
+    # RCCL runs the collectives of one communicator in issue order on its stream: both can be queued at once.  Other
+    # backends (gloo in the CPU tests: a pool of worker threads) give no such order between asynchronous collectives, so
+    # there the all-gathers are issued once the reduce-scatters have completed (in wait()).
+    ordered = str(dist.get_backend()).lower() == "nccl"
+    shards, works, copies = [], [], []
+    for span, flat, padded in spans:
+        shard = flat.numel() // world
+        mine = flat[rank * shard:(rank + 1) * shard]
+        shards.append((flat, mine))
+        works.append(dist.reduce_scatter_tensor(mine, flat, op=dist.ReduceOp.SUM, async_op=True))
+        if ordered:
+            works.append(dist.all_gather_into_tensor(flat, mine, async_op=True))
+        if padded:
+            copies.append((span, flat))
+
+    def finish():
+        if not ordered:
+            for w in [dist.all_gather_into_tensor(flat, mine, async_op=True) for flat, mine in shards]:
+                w.wait()
+        for span, flat in copies:
+            span.copy_(flat[:span.numel()].view_as(span))
+    h = PendingExchange(works, (grads, spans), finish if (copies or not ordered) else None)
+    if async_op:
+        return h
+    h.wait()
+    return None
+
+
+def pick_exchange(nbytes: float, world: int) -> str:
+    """"direct" or "ring" (= a plain all_reduce, whatever RCCL makes of it): whichever SURVEY.md 8(e)'s link model prices
+    lower for `nbytes` over `world` GPUs.  With more than two fully connected GPUs that is the direct form for every size the
+    model distinguishes; with two the forms move the same bytes over the same single link and the plain all-reduce (one
+    collective instead of two) is kept."""
+    m = exchange_model_ms(nbytes, world)
+    return "direct" if world > 2 and m["direct"] < m["ring"] else "ring"
 
 
 def exchange_model_ms(nbytes: float, world: int, link_GBps: float = 153.0, links: int = 7) -> dict:

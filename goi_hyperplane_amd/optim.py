@@ -35,8 +35,14 @@ class FusedAdam(torch.optim.Optimizer):
         """One Adam update of every parameter that has a gradient.  nograd_mask: optional [P] bool/uint8
         tensor; Gaussians with a non-zero entry are updated as if their gradient rows were zero.
         skip_if: optional int32[1] DEVICE tensor read by the kernel: non-zero makes this step a no-op on the device
-        (parameters and both moments untouched; only the host-side step count advances).  Pass
-        rasterizer.truncated_flag() to skip the view of a truncated speculative forward without any host round trip."""
+        (parameters and both moments untouched).  Pass rasterizer.truncated_flag() to skip the view of a truncated
+        speculative forward without any host round trip -- or rasterizer.truncated_flag(accumulated=True) when the step
+        accumulates several views (a truncated EARLIER view must skip it too).  The skip is opt-in: without skip_if a
+        truncated frame's zero gradients still move every parameter by its momentum and decay both moments.
+        Known approximation: the step count lives on the host (as in torch.optim.Adam) and advances whether or not the
+        device skipped, so after k skipped steps the bias corrections 1 - beta^t are those of step t rather than t - k --
+        exact from a few hundred steps on (beta2^t -> 0), at most a factor 1 - beta2^(t-k) / 1 - beta2^t off before
+        (k = 1 at t = 10, beta2 = 0.999: 10 % on the second-moment correction of that one step)."""
         loss = None
         if closure is not None:
             with torch.enable_grad():

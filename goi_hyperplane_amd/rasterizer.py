@@ -117,11 +117,22 @@ def set_forward_mode(speculative=None, headroom=None, capacity="keep", on_overfl
     _C.set_forward_mode(speculative, headroom, capacity, on_overflow, max_ahead, inference_speculative, min_history)
 
 
-def truncated_flag():
+def truncated_flag(accumulated: bool = False):
     """int32[1] device tensor (or None): non-zero iff the most recent forward of this thread was a speculative frame
     whose instance list did not fit its capacity.  Such a frame back-propagates ZERO gradients on the device;
-    `FusedAdam.step(skip_if=truncated_flag())` skips its optimiser step on the device as well (see _C.truncated_flag)."""
-    return _C.truncated_flag()
+    `FusedAdam.step(skip_if=truncated_flag())` skips its optimiser step on the device as well -- the skip is opt-in: a plain
+    `step()` still applies momentum (see _C.truncated_flag).  accumulated=True: the OR over all frames of the open
+    truncation window (accumulate_truncation / reset_truncation), for steps that accumulate several views."""
+    return _C.truncated_flag(accumulated)
+
+
+def accumulate_truncation(device=None) -> None:
+    """Opens (device) / closes (None) this thread's truncation window: see _C.accumulate_truncation."""
+    _C.accumulate_truncation(device)
+
+
+def reset_truncation() -> None:
+    _C.reset_truncation()
 
 
 def speculation_stats() -> dict:

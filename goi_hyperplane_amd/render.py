@@ -122,14 +122,85 @@ class TorchCamera:
         self.camera_center = torch.tensor(cam.camera_center, device=device)
 
 
+class RenderResult(dict):
+    """The dictionary render() returns: the reference's keys (gaussian_renderer/__init__.py:99-105).  `visibility_filter`
+    (= radii > 0, :103) is formed when somebody first looks at it -- a caller that only consumes the images (a plain
+    training view whose loop has no densification, an evaluation render) does not pay the extra kernel in every frame.  Every
+    way of looking (indexing, get, in, iteration, keys / items / values, len, ==, repr, copy) sees the key."""
+
+    _LAZY = "visibility_filter"
+
+    def _fill(self):
+        if not dict.__contains__(self, self._LAZY):
+            dict.__setitem__(self, self._LAZY, dict.__getitem__(self, "radii") > 0)
+
+    def __missing__(self, key):
+        if key != self._LAZY:
+            raise KeyError(key)
+        self._fill()
+        return dict.__getitem__(self, key)
+
+    def get(self, key, default=None):
+        if key == self._LAZY:
+            self._fill()
+        return dict.get(self, key, default)
+
+    def __contains__(self, key):
+        return key == self._LAZY or dict.__contains__(self, key)
+
+    def __iter__(self):
+        self._fill()
+        return dict.__iter__(self)
+
+    def __len__(self):
+        self._fill()
+        return dict.__len__(self)
+
+    def keys(self):
+        self._fill()
+        return dict.keys(self)
+
+    def items(self):
+        self._fill()
+        return dict.items(self)
+
+    def values(self):
+        self._fill()
+        return dict.values(self)
+
+    def copy(self):
+        self._fill()
+        return dict(self)
+
+    def __eq__(self, other):
+        self._fill()
+        return dict.__eq__(self, other)
+
+    __hash__ = None
+
+    def __repr__(self):
+        self._fill()
+        return dict.__repr__(self)
+
+
+_ZERO_ROW = {}  # (device, dtype) -> a [1, 3] zero tensor the screen-space placeholders of every frame are views of
+
+
+def _screenspace_placeholder(xyz):
+    """The reference's `screenspace_points = torch.zeros_like(xyz, requires_grad=True) + 0` (gaussian_renderer/__init__.py:
+    27-31): a tensor of zeros whose only job is to RECEIVE the 2-D mean gradients.  Nothing reads its values (the rasterizer
+    ignores means2D in the forward), so here it is a stride-0 view of one resident zero row, made a leaf: the same zeros, the
+    gradient lands in `.grad` as before, and the frame pays neither the 12 MB fill nor the `+ 0` pass over it."""
+    key = (xyz.device, xyz.dtype)
+    z = _ZERO_ROW.get(key)
+    if z is None:
+        z = _ZERO_ROW[key] = torch.zeros((1, 3), dtype=xyz.dtype, device=xyz.device)
+    return z.expand(xyz.shape[0], 3).detach().requires_grad_(True)
+
+
 def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, gaussian_mask=None):
     """gaussian_renderer.render; `gaussian_mask` adds gui/gs_renderer.py:315-321's index-select."""
-    dev = pc.get_xyz.device
-    screenspace_points = torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True, device=dev) + 0
-    try:
-        screenspace_points.retain_grad()
-    except Exception:
-        pass
+    screenspace_points = _screenspace_placeholder(pc.get_xyz)
     raster_settings = GaussianRasterizationSettings(
         image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
         tanfovx=math.tan(viewpoint_camera.FoVx * 0.5), tanfovy=math.tan(viewpoint_camera.FoVy * 0.5), bg=bg_color,
@@ -165,8 +236,8 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
     rendered_image, rendered_sem, radii, depth, alpha = rasterizer(
         means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, semantics=semantics,
         opacities=opacity, scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
-    return {"render": rendered_image, "semantics": rendered_sem, "depth": depth, "alpha": alpha,
-            "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii}
+    return RenderResult({"render": rendered_image, "semantics": rendered_sem, "depth": depth, "alpha": alpha,
+                         "viewspace_points": screenspace_points, "radii": radii})
 
 
 _VIEW_STREAMS = {}  # device index -> list of side streams (created on first use, reused)

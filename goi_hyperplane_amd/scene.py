@@ -119,9 +119,19 @@ class GaussianScene:
 
 
 def make_scene(P: int, S: int = 16, sh_degree: int = 3, seed: int = 0,
-               extent=(2.0, 1.5, 1.0), log_scale_mean: float = -3.5, log_scale_std: float = 0.7) -> GaussianScene:
+               extent=(2.0, 1.5, 1.0), log_scale_mean: float = -3.5, log_scale_std: float = 0.7,
+               kind: str = "uniform") -> GaussianScene:
     """SURVEY.md 8(d) generator.  extent=(2,1.5,1) mu=-3.5 is BASELINE config 1;
-    extent=(4,2.64,1) with the calibrated mu of ``HEADLINE`` is the 1M-Gaussian target."""
+    extent=(4,2.64,1) with the calibrated mu of ``HEADLINE`` is the 1M-Gaussian target.
+
+    kind="clustered": the ADVERSARIAL workload (make_clustered_scene) -- what a reconstructed scene looks like to the
+    rasterizer rather than a uniform box: clustered density, heavy-tailed anisotropic sizes, opaque foreground."""
+    if kind == "clustered":
+        return make_clustered_scene(P, S=S, sh_degree=sh_degree, seed=seed, extent=extent, log_scale_mean=log_scale_mean,
+                                    log_scale_std=log_scale_std)
+    if kind != "uniform":
+        raise ValueError("kind must be 'uniform' or 'clustered'")
+
     def rng(i):
         return np.random.default_rng(seed + i)
 
@@ -138,13 +148,130 @@ def make_scene(P: int, S: int = 16, sh_degree: int = 3, seed: int = 0,
     sem = rng(6).normal(size=(P, S)).astype(np.float32)
     return GaussianScene(xyz, scales, q.astype(np.float32), opac, shs, sem, sh_degree,
                          meta=dict(P=P, S=S, seed=seed, extent=tuple(float(e) for e in ex),
-                                   log_scale_mean=log_scale_mean, log_scale_std=log_scale_std))
+                                   log_scale_mean=log_scale_mean, log_scale_std=log_scale_std, kind="uniform"))
+
+
+def make_clustered_scene(P: int, S: int = 16, sh_degree: int = 3, seed: int = 0, extent=(4.0, 2.64, 1.0),
+                         log_scale_mean: float = -5.2, log_scale_std: float = 1.1, n_clusters: int = 48,
+                         needle_frac: float = 0.02, giant_frac: float = 2e-5, occluder_frac: float = 0.12,
+                         background_frac: float = 0.10) -> GaussianScene:
+    """A scene with the statistics of a RECONSTRUCTION (BASELINE configs 2 / 3 / 5 name MipNeRF360 scenes whose PLYs are not
+    in this image) instead of SURVEY 8(d)'s uniform box -- everything the uniform scene is kind to is made hard here:
+
+      * positions: a mixture of `n_clusters` anisotropic Gaussian blobs with heavy-tailed (Zipf-like) weights and log-normal
+        sizes, over a thin uniform background -- some tiles see hundreds of times the Gaussians of others;
+      * scales: log-normal with a wide sigma (1.1 instead of 0.7) per axis, so most Gaussians are anisotropic; `needle_frac`
+        of them are needles (one axis x 25, the others x 0.25: tens to hundreds of pixels long, a pixel wide) and
+        `giant_frac` (at least 3) are frame-filling blobs (0.5 - 1.5 scene units): tile rectangles far beyond the 64-tile
+        ellipse masks;
+      * opacity: bimodal as in trained scenes -- a translucent mode (0.02 - 0.3; part of it below the 1/255 visibility floor
+        after multiplication with the falloff) and an opaque mode (0.85 - 0.999: the 0.99 clamp is hit);
+      * `occluder_frac` of the Gaussians form dense, opaque FOREGROUND sheets between the camera and everything else (the
+        canonical camera sits at z = -5 looking down +z): lists behind them run thousands deep and almost none of it
+        contributes -- the worst case for emit / tile sort, the best for the saturation front;
+      * the rest as in make_scene (own RNG stream per array: a prefix of a scene is the smaller scene only for
+        kind="uniform"; here the cluster assignment depends on P through the stream length, which is fine -- the scene is
+        frozen by (P, seed)).
+    tests/golden/calibration.json freezes the statistics of the two sizes the tests and the bench use."""
+    def rng(i):
+        return np.random.default_rng(seed + 1000 + i)
+
+    ex = np.asarray(extent, dtype=np.float32)
+    r0 = rng(0)
+    # ---- which population a Gaussian belongs to
+    u = r0.uniform(size=P)
+    is_occ = u < occluder_frac
+    is_bg = (u >= occluder_frac) & (u < occluder_frac + background_frac)
+    # ---- clusters: Zipf-like weights, log-normal radii, anisotropic axes
+    rc = rng(7)
+    w = 1.0 / np.arange(1, n_clusters + 1) ** 0.9
+    w /= w.sum()
+    centres = rc.uniform(-1.0, 1.0, size=(n_clusters, 3)) * ex * np.array([0.95, 0.9, 1.0])
+    radii = np.exp(rc.normal(-1.6, 0.7, size=(n_clusters, 1))) * np.exp(rc.normal(0.0, 0.5, size=(n_clusters, 3)))
+    which = r0.choice(n_clusters, size=P, p=w)
+    xyz = centres[which] + r0.normal(size=(P, 3)) * radii[which]
+    # thin uniform background (a little beyond the box: some Gaussians fall outside the frustum)
+    nb = int(is_bg.sum())
+    xyz[is_bg] = r0.uniform(-1.15, 1.15, size=(nb, 3)) * ex
+    # foreground sheets: three slightly curved, tilted layers at z = -2.6 .. -1.4 (camera at z = -5), each covering a part
+    # of the frame
+    no = int(is_occ.sum())
+    sheet = r0.integers(0, 3, size=no)
+    su, sv = r0.uniform(-1.0, 1.0, size=no), r0.uniform(-1.0, 1.0, size=no)
+    cx = np.array([-0.9, 0.7, 0.1])[sheet]
+    cy = np.array([0.3, -0.5, 0.6])[sheet]
+    hw = np.array([0.9, 0.7, 1.3])[sheet]
+    hh = np.array([0.8, 0.5, 0.3])[sheet]
+    z0 = np.array([-2.6, -2.0, -1.4])[sheet]
+    xo = cx + hw * su
+    yo = cy + hh * sv
+    zo = z0 + 0.25 * su * su - 0.15 * sv + 0.01 * r0.normal(size=no)
+    xyz[is_occ] = np.stack([xo, yo, zo], axis=1)
+    xyz = xyz.astype(np.float32)
+    # ---- scales: wide log-normal, needles, giants; the occluders are small and flat (surfels)
+    r1 = rng(1)
+    log_s = r1.normal(log_scale_mean, log_scale_std, size=(P, 3))
+    kind_u = r1.uniform(size=P)
+    needle = kind_u < needle_frac
+    axis = r1.integers(0, 3, size=P)
+    boost = np.full((P, 3), np.log(0.25))
+    boost[np.arange(P), axis] = np.log(25.0)
+    log_s[needle] += boost[needle]
+    n_giant = max(3, int(round(giant_frac * P)))
+    giant_idx = r1.choice(P, size=min(n_giant, P), replace=False)
+    log_s[giant_idx] = np.log(r1.uniform(0.5, 1.5, size=(len(giant_idx), 3)))
+    occ_ls = r1.normal(log_scale_mean + 0.5, 0.35, size=(no, 3))
+    occ_ls[:, 2] -= 1.5  # flat across the sheet
+    keep_giant = np.zeros(P, bool)
+    keep_giant[giant_idx] = True
+    sel = is_occ & ~keep_giant & ~needle
+    log_s[sel] = occ_ls[(np.cumsum(is_occ) - 1)[sel]]
+    scales = np.exp(log_s).astype(np.float32)
+    # ---- rotations: random, except the occluders (aligned with their sheet up to a small tilt)
+    q = rng(2).normal(size=(P, 4)).astype(np.float32)
+    q[is_occ] = np.array([1.0, 0.0, 0.0, 0.0], np.float32) + 0.08 * q[is_occ]
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    # ---- opacity: bimodal
+    r3 = rng(3)
+    opaque = r3.uniform(size=P) < 0.55
+    opac = np.where(opaque, 0.85 + 0.149 * r3.uniform(size=P) ** 0.5, 0.02 + 0.28 * r3.uniform(size=P) ** 2.0)
+    opac[is_occ] = 0.9 + 0.099 * r3.uniform(size=no)
+    opac[giant_idx] = 0.05 + 0.3 * r3.uniform(size=len(giant_idx))  # (translucent haze: they touch every list without ending it)
+    opac = opac.reshape(P, 1).astype(np.float32)
+    M = 16
+    shs = np.empty((P, M, 3), dtype=np.float32)
+    shs[:, :1, :] = rng(4).normal(size=(P, 1, 3)).astype(np.float32)
+    shs[:, 1:, :] = 0.2 * rng(5).normal(size=(P, M - 1, 3)).astype(np.float32)
+    sem = rng(6).normal(size=(P, S)).astype(np.float32)
+    return GaussianScene(xyz, scales, q.astype(np.float32), opac, shs, sem, sh_degree,
+                         meta=dict(P=P, S=S, seed=seed, extent=tuple(float(e) for e in ex), log_scale_mean=log_scale_mean,
+                                   log_scale_std=log_scale_std, kind="clustered", n_clusters=n_clusters,
+                                   needle_frac=needle_frac, giants=int(len(giant_idx)), occluder_frac=occluder_frac))
 
 
 # The headline workload of BASELINE.json: 1M Gaussians @1600x1056, RGB (SH deg 3) + 16-d feature.
 # log_scale_mean is calibrated once (tests/golden/calibration.json) so that N/P is about 8.
 HEADLINE = dict(P=1_000_000, S=16, W=1600, H=1056, extent=(4.0, 2.64, 1.0), log_scale_mean=-4.3,
                 log_scale_std=0.7, fovx=1.0)
+
+
+# The adversarial second workload (VERDICT r03 item 3): same size and image as the headline, the statistics of a
+# reconstruction; and BASELINE config 5's shape -- a 512 x 512 close-up (gui/main_edit.py:551-553) of a >= 3 M scene.
+CLUSTERED = dict(P=1_000_000, S=16, W=1600, H=1056, extent=(4.0, 2.64, 1.0), log_scale_mean=-5.2, log_scale_std=1.1, fovx=1.0)
+CLOSEUP = dict(P=3_000_000, S=16, W=512, H=512, extent=(4.0, 2.64, 1.0), log_scale_mean=-4.9, log_scale_std=1.1, fovx=0.6,
+               distance=3.2, yaw=0.3, pitch=-0.12)
+
+
+def make_workload(name: str, P: int | None = None, S: int | None = None, seed: int = 0):
+    """(scene, canonical camera, spec) of a named workload: "headline" (SURVEY 8(d)'s uniform box), "clustered" (the
+    adversarial scene at the headline's size and image) or "closeup" (BASELINE config 5's shape: a 512 x 512 close-up of a
+    3 M clustered scene)."""
+    spec = {"headline": HEADLINE, "clustered": CLUSTERED, "closeup": CLOSEUP}[name]
+    kind = "uniform" if name == "headline" else "clustered"
+    sc = make_scene(P or spec["P"], S or spec["S"], 3, seed, spec["extent"], spec["log_scale_mean"], spec["log_scale_std"], kind=kind)
+    cam = make_camera(spec["W"], spec["H"], fovx=spec["fovx"], yaw=spec.get("yaw", 0.0), pitch=spec.get("pitch", 0.0),
+                      distance=spec.get("distance", 5.0))
+    return sc, cam, spec
 
 
 def make_headline_scene(P: int | None = None, S: int | None = None, seed: int = 0) -> GaussianScene:

@@ -4,6 +4,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -83,6 +84,21 @@ def _worker(rank, world, port, bucket_bytes, q):
         sent = allreduce_gradients_visible(params + [extra], torch.tensor(fwd.radii > 0), dist, dense_above=2.0)
         assert 0 < sent < 300, sent  # a real subset: the test would be vacuous otherwise
         assert float(extra.grad[0, 0]) == sum(range(1, world + 1))
+    elif bucket_bytes == -3:  # reduce-scatter + all-gather over the flat span (SURVEY.md 8(e)'s direct exchange)
+        from goi_hyperplane_amd.dist import allreduce_gradients_direct
+        lone = torch.nn.Parameter(torch.zeros(7, 3))  # not part of the flat buffer, 21 elements: travels zero-padded
+        lone.grad = torch.arange(21, dtype=torch.float32).view(7, 3) * (rank + 1)
+        allreduce_gradients_direct(params + [lone], dist)
+        assert torch.equal(lone.grad, torch.arange(21, dtype=torch.float32).view(7, 3) * sum(range(1, world + 1)))
+    elif bucket_bytes == -4:  # the same, left in flight
+        from goi_hyperplane_amd.dist import allreduce_gradients_direct
+        held = [p.grad for p in params]
+        h = allreduce_gradients_direct(params, dist, async_op=True)
+        for p in params:
+            p.grad = None
+        h.wait()
+        for p, g_ in zip(params, held):
+            p.grad = g_
     else:
         allreduce_gradients(params, dist, bucket_bytes=bucket_bytes)
     q.put((rank, views[0], [x.numpy() for x in local], [p.grad.numpy() for p in params]))
@@ -147,6 +163,57 @@ def test_visible_rows_exchange_equals_sum_of_single_view_gradients():
     """allreduce_gradients_visible: only the rows of Gaussians visible to some rank are sent; the result is the plain sum."""
     _run(-2)
     _run(-2, world=3)
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_direct_exchange_equals_sum_of_single_view_gradients(world):
+    """allreduce_gradients_direct (reduce-scatter + all-gather over the flat gradient span, in place): the plain sum, the
+    same bits on every rank -- 2, 3 (the span does not divide: padded copy for the lone tensor) and 8 ranks (config 4)."""
+    _run(-3, world=world)
+
+
+def test_direct_exchange_in_flight_equals_sum_of_single_view_gradients():
+    _run(-4, world=3)
+
+
+def test_exchange_is_picked_by_the_link_model():
+    from goi_hyperplane_amd.dist import pick_exchange
+    assert pick_exchange(300e6, 8) == "direct" and pick_exchange(64e6, 4) == "direct"
+    assert pick_exchange(300e6, 2) == "ring" and pick_exchange(300e6, 1) == "ring"
+
+
+def test_visible_exchange_rejects_what_would_silently_lose_rows():
+    """a non-contiguous per-Gaussian gradient (its reshape would be a copy) and a per_gaussian entry whose
+    leading dimension is not P raise instead of returning a wrong sum (single process: the checks run before any collective
+    that matters -- a 1-rank gloo group is enough)."""
+    port = _free_port()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        from goi_hyperplane_amd.dist import allreduce_gradients_visible
+        P = 10
+        vis = torch.zeros(P, dtype=torch.bool)
+        vis[:4] = True
+        a = torch.nn.Parameter(torch.zeros(P, 3))
+        a.grad = torch.zeros(3, P).t()  # non-contiguous
+        with pytest.raises(ValueError, match="contiguous"):
+            allreduce_gradients_visible([a], vis, dist, dense_above=2.0)
+        b = torch.nn.Parameter(torch.zeros(5, 3))
+        b.grad = torch.ones(5, 3)
+        with pytest.raises(ValueError, match="leading dimension"):
+            allreduce_gradients_visible([b], vis, dist, dense_above=2.0, per_gaussian=[b])
+        # a [P, ...] tensor that is NOT per Gaussian is reduced whole when the caller names the per-Gaussian ones
+        c = torch.nn.Parameter(torch.zeros(P, 2))
+        c.grad = torch.ones(P, 2)
+        d = torch.nn.Parameter(torch.zeros(P, 3))
+        d.grad = torch.zeros(P, 3)
+        d.grad[:4] = 1.0
+        assert allreduce_gradients_visible([c, d], vis, dist, dense_above=2.0, per_gaussian=[d], check_zero_rows=True) == 4
+        d.grad[7] = 0.5  # a row no rank saw carries a gradient: the premise is violated
+        with pytest.raises(RuntimeError, match="no rank saw"):
+            allreduce_gradients_visible([d], vis, dist, dense_above=2.0, check_zero_rows=True)
+    finally:
+        dist.destroy_process_group()
 
 
 def test_exchange_cost_model_matches_the_survey_figures():
