@@ -113,6 +113,24 @@ def cpu_baseline(args, n_full_per_view, gpu_view=None):
                           f"({args.P} Gaussians, {args.W}x{args.H}, S={args.S}), dense random upstream gradients on colour, "
                           "semantics, depth and alpha; forward outside the oracle's fragile pixels, gradients relative to "
                           "each tensor's largest magnitude")
+        # the SAME view through the exact-fp32 flush of the backward (bwd_variant 2), and the two flushes against each other:
+        # what -- if anything -- the split-bf16 products of the default flush cost in accuracy at the metric's own size
+        from goi_hyperplane_amd import _lib as _l
+        _l.set_option("bwd_variant", 2)
+        try:
+            res2, g_hip2 = gpu_view(cam, bg, grads)
+        finally:
+            _l.set_option("bwd_variant", 0)
+        p2 = compare.summary(compare.forward_stats(res2, kept["f"]), compare.backward_stats(g_hip2, kept["g"]))
+        p2["what"] = "the same view and gradients with bwd_variant 2 (per-Gaussian sums as exact-fp32 MFMA products)"
+        between = {k: v["max"] for k, v in compare.backward_stats(g_hip, g_hip2).items()}
+        parity["fp32_flush"] = p2
+        parity["flush_equivalence_same_view"] = {
+            "default_vs_fp32_flush_max_by_tensor": between,
+            "default_minus_fp32_error_vs_oracle": {k: parity["grad_max_by_tensor"][k] - p2["grad_max_by_tensor"][k]
+                                                   for k in parity["grad_max_by_tensor"]},
+            "what": "max |g_default - g_fp32flush| / scale per gradient tensor, and the difference of the two flushes' max "
+                    "errors against the oracle (negative: the default flush is the closer one on that tensor)"}
         kept.clear()
     sample_s = fwd_s + bwd_s
     scale = 1.0 if Ps == args.P else max(n_full_per_view, 1) / max(n_s, 1)
@@ -151,6 +169,17 @@ def main():
                     help="--gpus > 1, --grads all: 'factored' all-gathers the factors of dL/dSH (12 B per Gaussian "
                          "and view) and all-reduces the other 27 gradient floats; 'allreduce' all-reduces all 75; "
                          "'visible' all-reduces all 75 but only for Gaussians some rank saw this step")
+    ap.add_argument("--collective", choices=["auto", "ring", "direct"], default="auto",
+                    help="--gpus > 1: how the sum inside the exchange travels -- 'ring' = one all_reduce (whatever algorithm RCCL "
+                         "picks; bound by one xGMI link if it is a ring), 'direct' = reduce-scatter + all-gather over the flat "
+                         "gradient span (all seven links at once), 'auto' = whichever SURVEY.md 8(e)'s link model prices lower "
+                         "for this exchange's bytes (dist.pick_exchange); the JSON line says which one ran")
+    ap.add_argument("--scene", choices=["headline", "clustered", "closeup"], default="headline",
+                    help="the workload `value` is measured on: 'headline' = BASELINE.json's metric configuration (SURVEY 8(d)'s "
+                         "uniform box); 'clustered' = the adversarial scene with a reconstruction's statistics at the same size; "
+                         "'closeup' = config 5's shape (512x512 close-up of 3 M clustered Gaussians).  The default line also "
+                         "carries the clustered scene as a secondary object (--no-clustered skips it)")
+    ap.add_argument("--no-clustered", action="store_true", help="skip the secondary clustered-workload object")
     ap.add_argument("--views-per-exchange", type=int, default=1,
                     help="--gpus > 1: every rank accumulates the gradients of this many views locally before one exchange "
                          "(an optimiser step per K x N views); 1 = one exchange per view, train.py's step semantics")
@@ -208,8 +237,16 @@ def main():
                                          allreduce_gradients_sh_factored_async, allreduce_gradients_visible,
                                          exchange_model_ms)
     from goi_hyperplane_amd.render import GaussianSet, PipelineParams, TorchCamera, render
-    from goi_hyperplane_amd.scene import make_camera, make_scene
+    from goi_hyperplane_amd.scene import CLOSEUP, CLUSTERED, make_camera, make_scene
+    from goi_hyperplane_amd.dist import allreduce_gradients_direct, pick_exchange
     _lib.load()
+
+    WL = {"headline": HEADLINE, "clustered": CLUSTERED, "closeup": CLOSEUP}[args.scene]
+    scene_kind = "uniform" if args.scene == "headline" else "clustered"
+    if args.scene != "headline":  # the named workload's own size, image and generator constants
+        args.P, args.S, args.W, args.H, args.mu = WL["P"], WL["S"], WL["W"], WL["H"], WL["log_scale_mean"]
+        args.no_cpu_baseline = True  # (the CPU baseline + parity object belong to the metric configuration; the clustered
+                                     # workloads have their oracle parity in tests/test_gpu_clustered.py)
 
     if args.ply:
         pc = GaussianSet.from_ply(args.ply, dev, sh_degree=3)  # the semantic width is the file's (10 for a default
@@ -218,13 +255,16 @@ def main():
         args.no_cpu_baseline = True  # the bounded CPU sample is defined on the synthetic scene
         sc = None
     else:
-        sc = make_scene(args.P, S=args.S, sh_degree=3, seed=0, extent=HEADLINE["extent"], log_scale_mean=args.mu,
-                        log_scale_std=HEADLINE["log_scale_std"])  # identical replica on every rank
+        sc = make_scene(args.P, S=args.S, sh_degree=3, seed=0, extent=WL["extent"], log_scale_mean=args.mu,
+                        log_scale_std=WL["log_scale_std"], kind=scene_kind)  # identical replica on every rank
         pc = GaussianSet.from_scene(sc, dev)
     params = [pc._xyz, pc._features, pc._semantics, pc._opacity, pc._scaling, pc._rotation]
     reduce_params = params if args.grads == "all" else [pc._semantics]
-    cams = [TorchCamera(make_camera(args.W, args.H, fovx=HEADLINE["fovx"], yaw=0.02 * (i - args.views / 2),
-                                    pitch=0.01 * ((i * 7) % 5 - 2)), dev) for i in range(args.views)]
+    def make_cams(spec, W_, H_, n):
+        return [TorchCamera(make_camera(W_, H_, fovx=spec["fovx"], yaw=spec.get("yaw", 0.0) + 0.02 * (i - n / 2),
+                                        pitch=spec.get("pitch", 0.0) + 0.01 * ((i * 7) % 5 - 2),
+                                        distance=spec.get("distance", 5.0)), dev) for i in range(n)]
+    cams = make_cams(WL, args.W, args.H, args.views)
     bg = torch.zeros(3, device=dev)
     pipe = PipelineParams()
     HW = args.W * args.H
@@ -247,6 +287,13 @@ def main():
     if K > 1 and args.exchange == "factored":
         args.exchange = "allreduce"  # (the factors are per view: K views would need K factor sets; the plain sum accumulates)
         exchange["note"] = "factored exchange needs one view per exchange: --views-per-exchange > 1 uses the plain all-reduce"
+    # which collective carries the sum: decided once from the bytes of one exchange (the factored form all-reduces 27 of
+    # the 75 gradient floats per Gaussian; the SH factors always travel by all-gather)
+    per_gauss = sum(p_.numel() // max(1, p_.shape[0]) for p_ in (non_sh_params if args.exchange == "factored" and args.grads == "all"
+                                                                   else reduce_params))
+    sum_bytes = 4.0 * per_gauss * args.P
+    collective = {"mode": (pick_exchange(sum_bytes, world) if args.collective == "auto" else args.collective)}
+    direct = collective["mode"] == "direct" and world > 1
     inflight = {"h": None}
     seen = {"vis": None}
 
@@ -272,20 +319,24 @@ def main():
             if not overlap:
                 drain()
                 if exchange["mode"] == "visible":
-                    stats["rows_sent"] = allreduce_gradients_visible(reduce_params, seen["vis"], dist)
+                    stats["rows_sent"] = allreduce_gradients_visible(reduce_params, seen["vis"], dist, per_gaussian=reduce_params,
+                                                                     direct=direct)
                 elif exchange["mode"] == "factored":
-                    allreduce_gradients_sh_factored(non_sh_params, (pc._features,), pc._xyz, rasterizer.take_sh_factor(), dist)
+                    allreduce_gradients_sh_factored(non_sh_params, (pc._features,), pc._xyz, rasterizer.take_sh_factor(), dist,
+                                                    direct=direct)
+                elif direct:
+                    allreduce_gradients_direct(reduce_params, dist)
                 else:
                     allreduce_gradients(reduce_params, dist)
             else:
                 prev = inflight["h"]
                 if exchange["mode"] == "visible":  # (its host synchronisation makes "in flight" meaningless: plain form)
-                    inflight["h"] = allreduce_gradients_async(reduce_params, dist)
+                    inflight["h"] = allreduce_gradients_async(reduce_params, dist, direct=direct)
                 elif exchange["mode"] == "factored":
                     inflight["h"] = allreduce_gradients_sh_factored_async(non_sh_params, (pc._features,), pc._xyz,
-                                                                          rasterizer.take_sh_factor(), dist)
+                                                                          rasterizer.take_sh_factor(), dist, direct=direct)
                 else:
-                    inflight["h"] = allreduce_gradients_async(reduce_params, dist)
+                    inflight["h"] = allreduce_gradients_async(reduce_params, dist, direct=direct)
                 if prev is not None:
                     prev.wait()
         if record:
@@ -656,6 +707,89 @@ def main():
                        "what": "two independent views in flight on two HIP streams of one GPU (same work per view)"}
         del pcs, streams
 
+    # Secondary object: the ADVERSARIAL workload -- a scene with the statistics of a reconstruction (clustered density,
+    # heavy-tailed anisotropic sizes, opaque foreground with lists thousands deep behind it: scene.make_clustered_scene) at the
+    # headline's size and image, through the same step.  Not `value`; its oracle parity is tests/test_gpu_clustered.py.
+    clustered = None
+    if world == 1 and args.scene == "headline" and not args.no_clustered and not args.ply:
+        from goi_hyperplane_amd.scene import make_workload
+        sc2, _cam2, spec2 = make_workload("clustered")
+        pc2 = GaussianSet.from_scene(sc2, dev)
+        del sc2
+        cams2 = make_cams(spec2, spec2["W"], spec2["H"], 16)
+        gen2 = torch.Generator(device=dev).manual_seed(777)
+        inv2 = 1.0 / (spec2["W"] * spec2["H"])
+        gc2 = torch.randn((3, spec2["H"], spec2["W"]), device=dev, generator=gen2) * inv2
+        gs2 = torch.randn((spec2["S"], spec2["H"], spec2["W"]), device=dev, generator=gen2) * inv2
+        params2 = list(pc2.parameters())
+
+        def step_c(i):
+            for p_ in params2:
+                p_.grad = None
+            o_ = render(cams2[i % len(cams2)], pc2, pipe, bg)
+            torch.autograd.backward((o_["render"], o_["semantics"]), (gc2, gs2))
+            return o_
+        sp0 = rasterizer.speculation_stats()
+        for i in range(8):  # (the first frames of a scene are exact and teach the capacity policy)
+            step_c(i)
+        torch.cuda.synchronize(dev)
+        n_last = rasterizer.last_num_rendered()
+        cap2 = int(getattr(n_last, "capacity", 0) or 0)
+        # instance counts: the reference's lists (cull_variant 0) and this build's, over four of the cameras
+        nstat = {"N": 0, "N_listed": 0, "V": 0, "views": 0}
+        with torch.no_grad():
+            spec_saved2 = {k: dict(v, pending=v["pending"]) for k, v in _C._SPEC.items()}
+            fm = _C._FWD["mode"]
+            _C.set_forward_mode(speculative=False)
+            for cam_ in cams2[:4]:
+                for variant in (0, 2):
+                    _lib.set_option("cull_variant", variant)
+                    n_, *_r = _C.rasterize_gaussians(bg, pc2._xyz, torch.Tensor([]), pc2._semantics, pc2._opacity, pc2._scaling,
+                                                     pc2._rotation, 1.0, torch.Tensor([]), cam_.world_view_transform,
+                                                     cam_.full_proj_transform, np.tan(cam_.FoVx * 0.5), np.tan(cam_.FoVy * 0.5),
+                                                     spec2["H"], spec2["W"], pc2._features, 3, cam_.camera_center, False, False)
+                    if variant == 0:
+                        nstat["N"] += n_
+                        nstat["V"] += int((_r[4] > 0).sum())
+                        nstat["views"] += 1
+                    else:
+                        nstat["N_listed"] += n_
+                    del _r
+            _C._SPEC.clear()
+            _C._SPEC.update(spec_saved2)
+            _C.set_forward_mode(speculative=fm == "speculative")
+        st2 = {}
+        if timing:
+            _lib.profile_collect()
+            _lib.profile_enable(True)
+            for i in range(8):
+                step_c(i)
+            torch.cuda.synchronize(dev)
+            _lib.profile_enable(False)
+            st2 = {k: round(ms / max(c, 1), 4) for k, (ms, c) in _lib.profile_collect().items() if c}
+        torch.cuda.synchronize(dev)
+        c0 = time.perf_counter()
+        nc = max(5, min(args.steps, 30))
+        for i in range(nc):
+            step_c(i)
+        torch.cuda.synchronize(dev)
+        c_el = time.perf_counter() - c0
+        sp1 = rasterizer.speculation_stats()
+        clustered = {"views_per_s": nc / c_el, "ms_per_step": c_el / nc * 1e3, "steps": nc,
+                     "P": spec2["P"], "W": spec2["W"], "H": spec2["H"], "S": spec2["S"],
+                     "V": nstat["V"] / nstat["views"], "N_per_view": nstat["N"] / nstat["views"],
+                     "N_listed_per_view": nstat["N_listed"] / nstat["views"],
+                     "speculation": {k: sp1[k] - sp0[k] for k in sp1}, "binning_capacity": cap2,
+                     "backward_scratch_bytes": int(_lib.load().goi_raster_backward_scratch_bytes(cap2, spec2["S"])) if cap2 else None,
+                     "binning_bytes": int(_lib.load().goi_raster_binning_bytes(cap2)) if cap2 else None,
+                     "stages_ms": st2,
+                     "what": "the same step (forward + backward, all gradients, dense upstream gradients) on "
+                             "scene.make_clustered_scene: mixture-of-clusters positions, log-normal scales (sigma 1.1) with 2 % "
+                             "needles and frame-filling blobs, bimodal opacity, opaque foreground sheets; 16 cameras"}
+        del pc2, cams2, gc2, gs2, params2
+        _C.release_scratch(dev)
+        torch.cuda.empty_cache()
+
     # bytes one exchange puts on the wire per rank, and SURVEY.md 8(e)'s link model for them
     row_bytes = int(sum(p_.numel() // max(1, p_.shape[0]) for p_ in reduce_params) * 4)
     if world <= 1:
@@ -725,7 +859,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": ms_per_step, "repeats_ms_per_step": repeats_ms,
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not args.ply else "ply scene, synthetic cameras",
-            "config": {"workload": f"{args.P} Gaussians @{args.W}x{args.H}, SH deg 3 RGB + {args.S}-d semantic, fwd+bwd"
+            "config": {"workload": f"{args.scene}: {args.P} Gaussians @{args.W}x{args.H}, SH deg 3 RGB + {args.S}-d semantic, fwd+bwd"
                                    f"{' + RCCL all-reduce(' + args.grads + ' grads)' if world > 1 else ''}",
                        "P": args.P, "V": V, "N_per_view": N, "N_listed_per_view": stats["N_listed"] / stats["views"],
                        "tiles": T, "HW": HW, "S": args.S,
@@ -733,6 +867,12 @@ def main():
                        "allreduce_bytes": ar_bytes, "allgather_bytes": ag_bytes,
                        "rows_sent": (stats.get("rows_sent") if exchange["mode"] == "visible" else None),
                        "exchange": exchange["mode"] if world > 1 else None, "exchange_note": exchange["note"],
+                       "collective": (None if world <= 1 else
+                                      ("reduce_scatter + all_gather over the flat gradient span (dist.allreduce_gradients_direct)"
+                                       if direct else "all_reduce (the algorithm is RCCL's choice)")),
+                       "collective_chosen_by": (None if world <= 1 else
+                                                ("the link model (dist.pick_exchange)" if args.collective == "auto"
+                                                 else "--collective")),
                        "exchange_semantics": (None if world <= 1 else
                                               f"one sum all-reduce per {K} view(s) per rank, " +
                                               ("left in flight behind the next step (stale by one step)" if overlap_default
@@ -742,6 +882,7 @@ def main():
             "render_ms_per_frame_speculative": render_ms_spec,
             "gui_frame_ms": gui_ms,  # render + fused semantic decode (300 codes)
             "step_enqueue_ms": step_enqueue_ms,  # host-side, informational (stall detector; not used for value)
+            "workload_clustered": clustered,
             "semantic_finetune": sem_only,
             "value_fp32_flush": None if fp32_flush is None else fp32_flush["views_per_s"],
             "semantic_train_iteration": train_iter,

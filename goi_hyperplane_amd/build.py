@@ -27,7 +27,9 @@ COMMON = ["--offload-arch=" + ARCH] + os.environ.get("GOI_EXTRA_FLAGS", "").spli
 UNITS = {
     "api.hip": [],
     "scan_sort.hip": [],
-    "preprocess.hip": ["-ffp-contract=off"],
+    "preprocess.hip": ["-ffp-contract=off"],  # only the per-Gaussian arithmetic: radii / rectangles / depth keys integer-exact
+    "binning.hip": [],
+    "reduce_rows.hip": [],
     "render_fwd.hip": ["-fno-slp-vectorize"],
     "render_bwd.hip": [],
     "render_bwd_tile.hip": [],

@@ -1,0 +1,378 @@
+// Binning between the per-Gaussian preprocess and the tile blend: compaction of the listed Gaussians for the depth sort,
+// the load-balanced emit of (tile, Gaussian) instances in depth order, tile ranges.  Integer work (the one float divide in
+// emit is corrected to the exact quotient), so this unit is compiled with the default contraction -- only the per-Gaussian
+// arithmetic of preprocess.hip needs -ffp-contract=off to keep the reference's operation order.
+// Reference: duplicateWithKeys / identifyTileRanges, cuda_rasterizer/rasterizer_impl.cu:70-138.
+#include "common.h"
+
+namespace goi {
+
+namespace {
+
+// Compaction of the LISTED Gaussians (tiles_touched > 0) for the depth sort.  A workgroup covers COMPACT_ROUNDS
+// consecutive blocks of preprocess_fwd_k (2048 Gaussians).  Its base rank is the sum of the per-block aggregates
+// preprocess left behind for the blocks in front of it -- every workgroup adds them up itself (at most 3907 pairs at
+// 1 M Gaussians, out of L2: cheaper than a scan kernel of its own plus the launch) -- and workgroup 0 also leaves the
+// totals in counters[COUNTER_V] (listed Gaussians) and counters[COUNTER_N] (tiles touched = num_rendered).  A listed
+// Gaussian puts (depth key, id) at its rank among the listed ones, i.e. in id order: the sort is stable, so ties keep
+// ascending id as in the reference.  Reading the keys anyway, the workgroup counts their four digits for the onesweep
+// sort (which then skips its own histogram pass); 2048 keys per workgroup keep the global atomics of that flush at the
+// level of sweep_hist_k (one flush per 256 keys cost 2.3 M same-line atomics: +45 us).
+// pad (a sort that cannot take its count from the device): the unlisted Gaussians follow with key 0xFFFFFFFF.
+constexpr int COMPACT_ROUNDS = 8;
+__global__ __launch_bounds__(PRE_BLOCK) void compact_listed_k(int P, const uint32_t* __restrict__ tiles_touched,
+                                                              const uint32_t* __restrict__ raw_key,
+                                                              const uint2* __restrict__ blk_agg,
+                                                              uint32_t* __restrict__ counters,
+                                                              uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                              uint32_t* __restrict__ ghist, int pad) {
+    __shared__ uint32_t s_h[4][256];
+    __shared__ uint32_t s_wv[COMPACT_ROUNDS][4];
+    __shared__ uint32_t s_red[3][4];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int nblk = (P + PRE_BLOCK - 1) / PRE_BLOCK;
+    const int blk0 = blockIdx.x * COMPACT_ROUNDS;
+    // ---- all of this workgroup's Gaussians are requested before anything is waited for
+    uint32_t t[COMPACT_ROUNDS], key[COMPACT_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < COMPACT_ROUNDS; r++) {
+        const int i = (blk0 + r) * PRE_BLOCK + tid;
+        const bool live = i < P;
+        t[r] = live ? tiles_touched[i] : 0u;
+        key[r] = live ? raw_key[i] : 0xFFFFFFFFu;
+    }
+    // ---- base rank (blocks in front) and totals
+    uint32_t before = 0, all_v = 0, all_t = 0;
+    for (int i = tid; i < nblk; i += PRE_BLOCK) {
+        const uint2 a = blk_agg[i];
+        before += i < blk0 ? a.x : 0u;
+        all_v += a.x;
+        all_t += a.y;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        before += (uint32_t)__shfl_xor((int)before, d, 64);
+        all_v += (uint32_t)__shfl_xor((int)all_v, d, 64);
+        all_t += (uint32_t)__shfl_xor((int)all_t, d, 64);
+    }
+    if (lane == 0) {
+        s_red[0][w] = before;
+        s_red[1][w] = all_v;
+        s_red[2][w] = all_t;
+    }
+    if (ghist) {
+#pragma unroll
+        for (int p = 0; p < 4; p++) s_h[p][tid] = 0;
+    }
+    unsigned long long bal[COMPACT_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < COMPACT_ROUNDS; r++) {
+        bal[r] = __ballot(t[r] > 0);
+        if (lane == 0) s_wv[r][w] = (uint32_t)__popcll(bal[r]);
+    }
+    __syncthreads();
+    uint32_t base = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+    const uint32_t V = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
+    if (blockIdx.x == 0 && tid == 0) {
+        counters[COUNTER_V] = V;
+        counters[COUNTER_N] = s_red[2][0] + s_red[2][1] + s_red[2][2] + s_red[2][3];
+    }
+#pragma unroll
+    for (int r = 0; r < COMPACT_ROUNDS; r++) {
+        const int i = (blk0 + r) * PRE_BLOCK + tid;
+        uint32_t v_ex = base + (uint32_t)__popcll(bal[r] & ((1ull << lane) - 1ull));
+        for (int k = 0; k < w; k++) v_ex += s_wv[r][k];
+        base += s_wv[r][0] + s_wv[r][1] + s_wv[r][2] + s_wv[r][3];
+        if (i < P) {
+            if (t[r] > 0) {
+                keys[v_ex] = key[r];
+                vals[v_ex] = (uint32_t)i;
+                if (ghist) {
+#pragma unroll
+                    for (int p = 0; p < 4; p++) atomicAdd(&s_h[p][(key[r] >> (8 * p)) & 255u], 1u);
+                }
+            } else if (pad) {
+                const uint32_t pos = V + ((uint32_t)i - v_ex);  // unlisted Gaussians before i
+                keys[pos] = 0xFFFFFFFFu;
+                vals[pos] = (uint32_t)i;
+            }
+        }
+    }
+    if (ghist) {
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const uint32_t c = s_h[p][tid];
+            if (c) atomicAdd(&ghist[p * 256 + tid], c);
+        }
+    }
+}
+
+// Emits the (tile id, Gaussian id) instances of every visible Gaussian, walking the Gaussians in
+// depth order so that a stable sort by tile alone reproduces the reference's (tile, depth, id)
+// order (CR/rasterizer_impl.cu:70-111 emits 64-bit tile|depth keys in id order instead).
+// Wave-cooperative: each lane prepares one Gaussian (rectangle, output offset), then the wave walks
+// its 64 Gaussians one at a time and all lanes write that Gaussian's instances side by side, so every
+// store instruction covers one contiguous run instead of 64 scattered words.
+// COUNT: the block also histograms its keys per tile in LDS and adds the non-empty bins to tile_count[]
+// (stride 2: the .y words of the ranges array).  The per-tile counts are the tile ranges before their
+// prefix sum AND, folded by digit, the global histograms the onesweep tile sort needs: counting here
+// removes the sort's histogram pass over the 8 M keys and the ranges pass over the sorted keys.
+constexpr int EMIT_ROUNDS = 4;
+
+template <bool COUNT>
+__global__ __launch_bounds__(256) void emit_k(int P, int gx, int gy, const GaussRec* __restrict__ rec,
+                                              const int* __restrict__ radii, const uint32_t* __restrict__ order,
+                                              const uint32_t* __restrict__ offsets, uint4* __restrict__ aux,
+                                              uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                              uint32_t* __restrict__ tile_count, uint32_t* __restrict__ counters,
+                                              uint32_t* __restrict__ clear, uint32_t clear_words, uint32_t cap) {
+    // cap: number of instances keys[] / vals[] can hold.  The exact forward sizes them for num_rendered, so the
+    // guard below never fires; the speculative forward sizes them from a guess, and a frame that overflows must
+    // stay memory-safe and self-consistent (the tile counts only count what was stored) until the host notices.
+    const bool cull = counters[COUNTER_CULL] != 0;
+    P = min(P, (int)counters[COUNTER_V]);  // order[] / offsets[] hold the LISTED Gaussians only (front of the depth order)
+    // the frame's "truncated" flag (COUNTER_OVF): emit is the first kernel that knows both the count and the capacity
+    // (... or was depth-sorted wrongly because a look-back of the sort timed out: COUNTER_SORTERR)
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        counters[COUNTER_OVF] = (counters[COUNTER_N] > cap ? 1u : 0u) | (counters[COUNTER_SORTERR] ? 2u : 0u);
+    // COUNT: the blocks also zero the control words of the tile sort that follows (its own memset launch otherwise)
+    if (COUNT)
+        for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < clear_words; i += gridDim.x * 256u) clear[i] = 0u;
+    constexpr int ROUNDS_PER_BLOCK = COUNT ? EMIT_ROUNDS : 1;
+    if ((int)blockIdx.x * ROUNDS_PER_BLOCK * 256 >= P) return;  // (block-uniform) nothing listed left for this block
+    extern __shared__ uint32_t s_cnt[];  // [gx * gy] when COUNT
+    __shared__ unsigned long long s_mask[4][64];  // the rectangles' tile masks (cull_variant 2)
+    __shared__ unsigned long long s_mark[4];  // per wave and trip: bit p = some rectangle's last instance is at position p
+    __shared__ uint4 s_info[4][64];  // (x0 | y0 << 16, exclusive count, offsets[] - exclusive count, Gaussian id)
+    __shared__ int s_w[4][64];       // rectangle width in tiles
+    const int T = gx * gy;
+    if (COUNT) {
+        for (int t = threadIdx.x; t < T; t += 256) s_cnt[t] = 0;
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // the counting variant amortises zeroing and flushing its tile histogram over EMIT_ROUNDS x 256 Gaussians
+    constexpr int ROUNDS = COUNT ? EMIT_ROUNDS : 1;
+    // a round's Gaussian: id -> radius, position and box are dependent gathers (two DRAM round trips); the next round's
+    // are requested before this round's instances are written, or every round would start with both exposed (emit is a
+    // small kernel: two waves per SIMD have nothing to hide them behind)
+    struct Fetched {
+        uint32_t g, off;
+        int r;
+        float4 q0, q2;
+        unsigned long long mask;
+    };
+    auto fetch = [&](int rnd) {
+        Fetched f{0u, 0u, 0, make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, -1.f, -1.f), TMASK_FULL};
+        const int i = (blockIdx.x * ROUNDS + rnd) * 256 + threadIdx.x;
+        if (rnd < ROUNDS && i < P) {
+            f.g = order[i];
+            f.off = offsets[i];
+            const uint4 a = aux[f.g];  // radius and tile mask: one gather
+            f.r = (int)a.y;
+            f.q0 = rec[f.g].q0;
+            f.q2 = rec[f.g].q1;  // (conic c, opacity, hx, hy)
+            f.mask = aux_mask(a);
+        }
+        return f;
+    };
+    Fetched nxt = fetch(0);
+#pragma unroll 1
+    for (int rnd = 0; rnd < ROUNDS; rnd++) {
+        const int i = (blockIdx.x * ROUNDS + rnd) * 256 + threadIdx.x;
+        const Fetched cur = nxt;
+        nxt = fetch(rnd + 1);
+        const uint32_t g = cur.g, off = cur.off;
+        int x0 = 0, y0 = 0, w = 1, cnt = 0;
+        if (i < P) {
+            reinterpret_cast<uint32_t*>(aux + g)[0] = off;  // the Gaussian's first row slot in the backward (slot space = emit order = depth order)
+            if (cur.r > 0) {
+                int x1, y1;
+                listed_rect(cur.q0.x, cur.q0.y, cur.r, cur.q2.z, cur.q2.w, cull, gx, gy, x0, y0, x1, y1);
+                w = x1 - x0;
+                cnt = cur.mask == TMASK_FULL ? w * (y1 - y0) : __popcll(cur.mask);  // (cull_variant 2: the ellipse's tiles)
+            }
+        }
+        // Load-balanced expansion: the wave's 64 rectangles hold `total` (tile, Gaussian) instances; lane l of trip
+        // t0 produces instance t0 + l, whichever rectangle it falls into.  A rectangle has ~10 tiles on average: one
+        // rectangle per trip would leave 5/6 of the lanes idle.  Consecutive instances are consecutive addresses
+        // (offsets[] is the exclusive scan of the same counts in the same order): full-line stores.
+        // Which rectangle: the non-empty rectangles are numbered in lane order (their records sit at that number in
+        // LDS); each marks the position of its LAST instance in a 64-bit word for the trip it falls into, and an
+        // instance belongs to rectangle (rectangles that ended before the trip) + (marks below its own position).  Two
+        // dependent LDS round trips per trip; the binary search in the scanned counts this replaces had seven, and with
+        // two waves per SIMD (emit is a small kernel) their latency was the kernel: 59 -> 3x us.
+        int incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += o;
+        }
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        const int excl = incl - cnt;
+        const int my_rank = __popcll(__ballot(cnt > 0) & ((1ull << lane) - 1ull));
+        if (cnt > 0) {
+            s_info[wv][my_rank] = make_uint4((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)excl, off - (uint32_t)excl, g);
+            s_w[wv][my_rank] = w;
+            s_mask[wv][my_rank] = cur.mask;
+        }
+        int ended = 0;  // non-empty rectangles that end before the current trip (wave-uniform)
+        for (int t0 = 0; t0 < total; t0 += 64) {
+            const int t = t0 + lane;
+            if (lane == 0) s_mark[wv] = 0ull;
+            const int last = incl - 1 - t0;  // position of this rectangle's last instance relative to the trip
+            if (cnt > 0 && last >= 0 && last < 64)
+                atomicOr(reinterpret_cast<unsigned int*>(&s_mark[wv]) + (last >> 5), 1u << (last & 31));
+            __builtin_amdgcn_wave_barrier();
+            const unsigned long long marks = s_mark[wv];
+            __builtin_amdgcn_wave_barrier();
+            const int lo = ended + __popcll(marks & ((1ull << lane) - 1ull));
+            ended += __popcll(marks);
+            if (t >= total) continue;
+            const uint4 info = s_info[wv][lo];
+            const int wl = s_w[wv][lo];
+            const unsigned long long mk = s_mask[wv][lo];
+            int k = t - (int)info.y;
+            if (mk != TMASK_FULL) k = select_bit(mk, k);  // the k-th tile the ellipse reaches -> its index in the rectangle
+            int row = (int)((float)k * __builtin_amdgcn_rcpf((float)wl));  // k / wl, off by at most one
+            row -= (row * wl > k);
+            row += ((row + 1) * wl <= k);
+            const int col = k - row * wl;
+            const uint32_t key = (uint32_t)(((int)(info.x >> 16) + row) * gx + (int)(info.x & 0xFFFFu) + col);
+            const uint32_t pos = info.z + (uint32_t)t;
+            if (pos < cap) {
+                keys[pos] = key;
+                vals[pos] = info.w;
+                if (COUNT) atomicAdd(&s_cnt[key], 1u);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (COUNT) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < T; t += 256) {
+            const uint32_t c = s_cnt[t];
+            if (c) atomicAdd(&tile_count[2 * t], c);
+        }
+    }
+}
+
+// One workgroup: per-tile counts (in ranges[t].y) -> ranges[t] = [start, end) ((0,0) for an empty tile, as
+// the reference leaves it) and the global digit histograms of the tile sort's passes.  A thread owns IT = ceil(T / 1024)
+// consecutive tiles (IT <= 12: emit only counts grids of at most 12288 tiles), so the prefix sum is ONE block scan
+// (chunks of 1024 tiles with three barriers each took 14 us at 6600 tiles: pure latency).
+constexpr int TRH_MAX_IT = 12;
+__global__ __launch_bounds__(1024) void tile_ranges_hist_k(int T, uint2* __restrict__ ranges, int passes, int shift0,
+                                                           int nbits0, int shift1, int nbits1,
+                                                           uint32_t* __restrict__ ghist) {
+    __shared__ uint32_t s_h[2][256];
+    __shared__ uint32_t s_wave[16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid < 512) (&s_h[0][0])[tid] = 0;
+    const int IT = (T + 1023) / 1024;
+    const int t0 = tid * IT;
+    uint32_t c[TRH_MAX_IT];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < TRH_MAX_IT; k++) {
+        c[k] = (k < IT && t0 + k < T) ? ranges[t0 + k].y : 0u;
+        sum += c[k];
+    }
+    uint32_t v = sum;  // inclusive scan of the 1024 per-thread sums
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    if (lane == 63) s_wave[w] = v;
+    __syncthreads();  // (also orders the zeroing of s_h before the atomics below)
+    uint32_t run = v - sum;
+    for (int k = 0; k < w; k++) run += s_wave[k];
+#pragma unroll
+    for (int k = 0; k < TRH_MAX_IT; k++) {
+        const int t = t0 + k;
+        if (k < IT && t < T) {
+            const uint32_t ck = c[k];
+            ranges[t] = ck ? make_uint2(run, run + ck) : make_uint2(0u, 0u);
+            if (ck) {
+                atomicAdd(&s_h[0][((uint32_t)t >> shift0) & ((1u << nbits0) - 1u)], ck);
+                if (passes > 1) atomicAdd(&s_h[1][((uint32_t)t >> shift1) & ((1u << nbits1) - 1u)], ck);
+            }
+            run += ck;
+        }
+    }
+    __syncthreads();
+    if (tid < 256) {
+        ghist[tid] = s_h[0][tid];
+        ghist[256 + tid] = s_h[1][tid];
+    }
+}
+
+// Per-tile [start,end) from the tile-sorted key list (CR/rasterizer_impl.cu:116-138).
+__global__ __launch_bounds__(256) void ranges_k(int N_cap, const uint32_t* __restrict__ n_dev,
+                                                const uint32_t* __restrict__ keys, uint2* __restrict__ ranges) {
+    const int N = n_dev ? (int)min((uint32_t)N_cap, *n_dev) : N_cap;  // (speculative forward: the count is on the device)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const uint32_t cur = keys[i];
+    if (i == 0)
+        ranges[cur].x = 0;
+    else {
+        const uint32_t prev = keys[i - 1];
+        if (cur != prev) {
+            ranges[prev].y = i;
+            ranges[cur].x = i;
+        }
+    }
+    if (i == N - 1) ranges[cur].y = N;
+}
+
+}  // namespace
+
+void launch_compact_listed(int P, const GeomView& g, uint32_t* ghist, bool pad, hipStream_t s) {
+    const int nblk = (P + PRE_BLOCK - 1) / PRE_BLOCK;
+    compact_listed_k<<<dim3((nblk + COMPACT_ROUNDS - 1) / COMPACT_ROUNDS), dim3(PRE_BLOCK), 0, s>>>(
+        P, g.tiles_touched, g.sort_keys[1], g.blk_agg, g.counters, g.sort_keys[0], g.sort_vals[0], ghist, pad ? 1 : 0);
+}
+
+void launch_emit(int P, int W, int H, const GeomView& g, const uint32_t* order, const int* radii, uint32_t* keys,
+                 uint32_t* vals, uint32_t cap, hipStream_t s) {
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+    emit_k<false><<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, gx, gy, g.rec, radii, order, g.offsets, g.aux, keys, vals,
+                                                              nullptr, g.counters, nullptr, 0u, cap);
+}
+
+bool emit_can_count_tiles(int W, int H) {
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+    // (tile_ranges_hist_k: at most TRH_MAX_IT x 1024 tiles; the per-tile LDS counters of emit: 48 KB)
+    return (size_t)gx * gy <= (size_t)TRH_MAX_IT * 1024 && (size_t)gx * gy * sizeof(uint32_t) <= 48 * 1024 &&
+           tile_key_bits((uint32_t)(gx * gy)) <= 16;
+}
+
+// emit + per-tile counts; ranges must be zeroed by the caller's stream order (done here)
+void launch_emit_counting(int P, int W, int H, const GeomView& g, const uint32_t* order, const int* radii, uint32_t* keys,
+                          uint32_t* vals, uint2* ranges, uint32_t* clear, size_t clear_words, uint32_t cap, hipStream_t s) {
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+    // `ranges` was zeroed by preprocess_fwd_k
+    emit_k<true><<<dim3((P + 256 * EMIT_ROUNDS - 1) / (256 * EMIT_ROUNDS)), dim3(256), (size_t)gx * gy * sizeof(uint32_t), s>>>(
+        P, gx, gy, g.rec, radii, order, g.offsets, g.aux, keys, vals, reinterpret_cast<uint32_t*>(ranges) + 1, g.counters,
+        clear, (uint32_t)clear_words, cap);
+}
+
+// per-tile counts -> ranges and the two digit histograms (written to ghist[0..511]) of a sort on
+// key bits [0, bits) split as radix_sort_pairs splits them
+void launch_tile_ranges_hist(int W, int H, uint2* ranges, uint32_t* ghist, hipStream_t s) {
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+    const int bits = tile_key_bits((uint32_t)(gx * gy));
+    const int passes = (bits + 7) / 8;
+    const int n0 = (bits + passes - 1) / passes, n1 = bits - n0;
+    tile_ranges_hist_k<<<dim3(1), dim3(1024), 0, s>>>(gx * gy, ranges, passes, 0, n0, n0, n1 > 0 ? n1 : 1, ghist);
+}
+
+void launch_ranges(int N, const uint32_t* n_dev, const uint32_t* sorted_keys, uint2* ranges, int T, hipStream_t s) {
+    (void)hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)T, s);
+    if (N > 0) ranges_k<<<dim3((N + 255) / 256), dim3(256), 0, s>>>(N, n_dev, sorted_keys, ranges);
+}
+
+}  // namespace goi

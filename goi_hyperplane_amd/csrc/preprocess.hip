@@ -291,105 +291,6 @@ __global__ __launch_bounds__(256) void preprocess_fwd_k(const PreArgs args, Gaus
     }
 }
 
-// Compaction of the LISTED Gaussians (tiles_touched > 0) for the depth sort.  A workgroup covers COMPACT_ROUNDS
-// consecutive blocks of preprocess_fwd_k (2048 Gaussians).  Its base rank is the sum of the per-block aggregates
-// preprocess left behind for the blocks in front of it -- every workgroup adds them up itself (at most 3907 pairs at
-// 1 M Gaussians, out of L2: cheaper than a scan kernel of its own plus the launch) -- and workgroup 0 also leaves the
-// totals in counters[COUNTER_V] (listed Gaussians) and counters[COUNTER_N] (tiles touched = num_rendered).  A listed
-// Gaussian puts (depth key, id) at its rank among the listed ones, i.e. in id order: the sort is stable, so ties keep
-// ascending id as in the reference.  Reading the keys anyway, the workgroup counts their four digits for the onesweep
-// sort (which then skips its own histogram pass); 2048 keys per workgroup keep the global atomics of that flush at the
-// level of sweep_hist_k (one flush per 256 keys cost 2.3 M same-line atomics: +45 us).
-// pad (a sort that cannot take its count from the device): the unlisted Gaussians follow with key 0xFFFFFFFF.
-constexpr int COMPACT_ROUNDS = 8;
-__global__ __launch_bounds__(PRE_BLOCK) void compact_listed_k(int P, const uint32_t* __restrict__ tiles_touched,
-                                                              const uint32_t* __restrict__ raw_key,
-                                                              const uint2* __restrict__ blk_agg,
-                                                              uint32_t* __restrict__ counters,
-                                                              uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                              uint32_t* __restrict__ ghist, int pad) {
-    __shared__ uint32_t s_h[4][256];
-    __shared__ uint32_t s_wv[COMPACT_ROUNDS][4];
-    __shared__ uint32_t s_red[3][4];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int nblk = (P + PRE_BLOCK - 1) / PRE_BLOCK;
-    const int blk0 = blockIdx.x * COMPACT_ROUNDS;
-    // ---- all of this workgroup's Gaussians are requested before anything is waited for
-    uint32_t t[COMPACT_ROUNDS], key[COMPACT_ROUNDS];
-#pragma unroll
-    for (int r = 0; r < COMPACT_ROUNDS; r++) {
-        const int i = (blk0 + r) * PRE_BLOCK + tid;
-        const bool live = i < P;
-        t[r] = live ? tiles_touched[i] : 0u;
-        key[r] = live ? raw_key[i] : 0xFFFFFFFFu;
-    }
-    // ---- base rank (blocks in front) and totals
-    uint32_t before = 0, all_v = 0, all_t = 0;
-    for (int i = tid; i < nblk; i += PRE_BLOCK) {
-        const uint2 a = blk_agg[i];
-        before += i < blk0 ? a.x : 0u;
-        all_v += a.x;
-        all_t += a.y;
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        before += (uint32_t)__shfl_xor((int)before, d, 64);
-        all_v += (uint32_t)__shfl_xor((int)all_v, d, 64);
-        all_t += (uint32_t)__shfl_xor((int)all_t, d, 64);
-    }
-    if (lane == 0) {
-        s_red[0][w] = before;
-        s_red[1][w] = all_v;
-        s_red[2][w] = all_t;
-    }
-    if (ghist) {
-#pragma unroll
-        for (int p = 0; p < 4; p++) s_h[p][tid] = 0;
-    }
-    unsigned long long bal[COMPACT_ROUNDS];
-#pragma unroll
-    for (int r = 0; r < COMPACT_ROUNDS; r++) {
-        bal[r] = __ballot(t[r] > 0);
-        if (lane == 0) s_wv[r][w] = (uint32_t)__popcll(bal[r]);
-    }
-    __syncthreads();
-    uint32_t base = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
-    const uint32_t V = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
-    if (blockIdx.x == 0 && tid == 0) {
-        counters[COUNTER_V] = V;
-        counters[COUNTER_N] = s_red[2][0] + s_red[2][1] + s_red[2][2] + s_red[2][3];
-    }
-#pragma unroll
-    for (int r = 0; r < COMPACT_ROUNDS; r++) {
-        const int i = (blk0 + r) * PRE_BLOCK + tid;
-        uint32_t v_ex = base + (uint32_t)__popcll(bal[r] & ((1ull << lane) - 1ull));
-        for (int k = 0; k < w; k++) v_ex += s_wv[r][k];
-        base += s_wv[r][0] + s_wv[r][1] + s_wv[r][2] + s_wv[r][3];
-        if (i < P) {
-            if (t[r] > 0) {
-                keys[v_ex] = key[r];
-                vals[v_ex] = (uint32_t)i;
-                if (ghist) {
-#pragma unroll
-                    for (int p = 0; p < 4; p++) atomicAdd(&s_h[p][(key[r] >> (8 * p)) & 255u], 1u);
-                }
-            } else if (pad) {
-                const uint32_t pos = V + ((uint32_t)i - v_ex);  // unlisted Gaussians before i
-                keys[pos] = 0xFFFFFFFFu;
-                vals[pos] = (uint32_t)i;
-            }
-        }
-    }
-    if (ghist) {
-        __syncthreads();
-#pragma unroll
-        for (int p = 0; p < 4; p++) {
-            const uint32_t c = s_h[p][tid];
-            if (c) atomicAdd(&ghist[p * 256 + tid], c);
-        }
-    }
-}
-
 struct BwdArgs {
     int P, D, M, W, H;
     const float* means3D;
@@ -823,431 +724,6 @@ __global__ __launch_bounds__(256) void mark_visible_k(int P, const float* __rest
     present[idx] = xform_point_4x3(p, m).z > 0.2f ? 1 : 0;
 }
 
-// Sums the partial-gradient rows of every Gaussian (written by render_bwd_rows_k, one row per
-// (emit-order instance, quadrant) slot, a Gaussian's slots contiguous) in a fixed order and writes
-// the six blend-gradient arrays for ALL Gaussians (zeros where nothing contributed): no memsets, no
-// atomics, bit-reproducible.  A quarter wave (16 lanes) owns one Gaussian.  Memory-level parallelism
-// is what matters here: the lanes fetch 16 instances x 4 validity bytes in one load, the flagged
-// slots of the chunk are packed into a 64-bit mask (quadrant-major), and up to 16 rows are requested
-// back to back before the first is consumed (lane e reads row elements e, e+16, ...: coalesced).
-// The kernel is LATENCY bound, not bandwidth bound: a Gaussian costs a chain of three dependent memory round trips
-// (slot range -> validity bytes -> rows) for ~8 rows of payload, and with one Gaussian per quarter wave the chip works
-// through 250 K short-lived waves in ~30 rounds of that chain (223 us for 0.5 GB).  So every quarter wave walks GPQ
-// Gaussians in a software pipeline: while the rows of Gaussian k are summed, the validity word of k+1 and the slot
-// range of k+2 are already on their way -- one exposed round trip per Gaussian instead of three, 1/GPQ of the waves.
-// The order in which a Gaussian's rows are added is unchanged (bit-identical gradients).
-// RECORD (the full backward): the sums do not leave as six per-Gaussian arrays at all.  A Gaussian's record -- its summed
-// row, 128 bytes at S <= 16 -- goes back into the row scratch, over the first slot the Gaussian owns (every listed
-// Gaussian owns at least four; its rows have all been read by then): ONE full-line store per Gaussian instead of six
-// scattered partial ones, no zeros for the unlisted Gaussians (the old form wrote 104 bytes of them for each), and
-// preprocess_bwd_k, which runs over the ids anyway, fetches the line through goff[] and writes every per-id output itself,
-// coalesced.  Measured on the headline view before it was built (timing builds): the zero phase 21 us, the scattered
-// stores 40 us of the kernel's 213; a dense 128-byte store instead 8 us.
-template <int K, int GPQ, bool RECORD>  // K = row_floats / 16; GPQ = Gaussians per quarter wave
-__global__ __launch_bounds__(256) void reduce_rows_k(int P, int S, int nch, uint32_t N_cap, const uint32_t* __restrict__ n_dev,
-                                                     const uint32_t* __restrict__ order,
-                                                     const uint32_t* __restrict__ offsets,
-                                                     const uint32_t* __restrict__ tiles_touched,
-                                                     float* rows, const uint8_t* __restrict__ flags,
-                                                     float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic,
-                                                     float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor,
-                                                     float* __restrict__ dL_dsemantic, float* __restrict__ dL_ddepth) {
-    constexpr int RF = 16 * K;
-#ifndef GOI_REDUCE_INFLIGHT
-#define GOI_REDUCE_INFLIGHT 32
-#endif
-    constexpr int INFLIGHT = GOI_REDUCE_INFLIGHT;
-    // N_cap: the slot capacity the scratch was laid out for; n_dev: the forward's instance count on the device (the
-    // exact forward passes N_cap = num_rendered; the speculative one a capacity, and an overflowed frame stored only
-    // the first N_cap instances)
-    // a TRUNCATED frame (COUNTER_OVF, set by emit) has no valid rows: every Gaussian gets zeros
-    const bool truncated = n_dev[COUNTER_OVF - COUNTER_N] != 0;
-    const uint32_t N = truncated ? 0u : min(N_cap, *n_dev);
-    const int V = truncated ? 0 : (int)n_dev[COUNTER_V - COUNTER_N];  // listed Gaussians: the only ones that own rows
-    const int lane = threadIdx.x & 63, quarter = lane >> 4, e = lane & 15;
-    const uint32_t* flags32 = reinterpret_cast<const uint32_t*>(flags);
-    const int nsem = nch - 4;
-    // ---- phase 0 (the first ceil(P/256) workgroups): zeros for the Gaussians that are NOT listed (culled, or a culled
-    // rectangle without tiles; all of them for a truncated frame) -- one Gaussian per lane.  The listed ones are written
-    // by phase 1 below, so every element of the six arrays is written exactly once.
-    if constexpr (!RECORD) {
-        const int i = blockIdx.x * 256 + threadIdx.x;
-        if (i < P && (truncated || tiles_touched[i] == 0)) {
-            if ((S & 3) == 0) {
-                float4* d4 = reinterpret_cast<float4*>(dL_dsemantic + (size_t)i * S);
-                for (int ch = 0; ch < S / 4; ch++) d4[ch] = make_float4(0.f, 0.f, 0.f, 0.f);
-            } else {
-                for (int ch = 0; ch < S; ch++) dL_dsemantic[(size_t)i * S + ch] = 0.f;
-            }
-            if (dL_dopacity) {  // (NULL in the feature-gradient-only reduction)
-                dL_dopacity[i] = 0.f;
-                dL_ddepth[i] = 0.f;
-#pragma unroll
-                for (int k = 0; k < 3; k++) dL_dcolor[(size_t)i * 3 + k] = dL_dmean2D[(size_t)i * 3 + k] = 0.f;
-#pragma unroll
-                for (int k = 0; k < 4; k++) dL_dconic[(size_t)i * 4 + k] = 0.f;
-            }
-        }
-    }
-    // ---- phase 1: the V LISTED Gaussians in DEPTH order.  That is the order of the slot space (emit order), so
-    // consecutive quarter waves stream through rows[] and flags[] front to back -- and it is the order in which the valid
-    // rows are DENSE: near Gaussians contribute in most of their tiles, far ones are behind the saturation front and own
-    // hardly any row, so the rows that exist sit close together at the front of the slot space (DRAM pages, TLB).  A
-    // slot space in id order (tried: the outputs then leave as neighbouring lines instead of six scattered partial
-    // stores per Gaussian) spreads the same rows evenly over 2.6 GB and costs more than the scatter saves (0.235 ->
-    // 0.32 ms).  Step k of the block covers 16 consecutive listed Gaussians.
-    const int i0 = blockIdx.x * (16 * GPQ) + (threadIdx.x >> 4);
-    if (blockIdx.x * (16 * GPQ) >= V) return;  // (block-uniform)
-    struct Meta {
-        uint32_t g, off0, off1;
-    };
-    // slots of the i-th listed Gaussian in depth order: [offsets[i], offsets[i+1]) -- straight from the prefix sum; the
-    // Gaussian's id is only needed for the final store
-    auto load_meta = [&](int k) {
-        const int i = i0 + 16 * k;
-        Meta m{0u, 0u, 0u};
-        if (k < GPQ && i < V) {
-            m.g = order[i];
-            m.off0 = min(offsets[i], N);
-            m.off1 = i + 1 < V ? min(offsets[i + 1], N) : N;
-        }
-        return m;
-    };
-    // the 4 quadrant bytes of instance off0 + c + e (first chunk of a Gaussian: c = 0)
-    auto load_flags = [&](const Meta& m, uint32_t c) { return (c + e < m.off1 - m.off0) ? flags32[m.off0 + c + e] : 0u; };
-
-    Meta cur = load_meta(0), nxt = load_meta(1);
-    uint32_t w_cur = load_flags(cur, 0);
-#pragma unroll 1
-    for (int k = 0; k < GPQ; k++) {
-        if (i0 + 16 * k - (int)(threadIdx.x >> 4) >= V) break;  // (block-uniform: nothing left for any quarter wave)
-        const Meta nn = load_meta(k + 2);        // two Gaussians ahead: slot range
-        const uint32_t w_nxt = load_flags(nxt, 0);  // one ahead: validity bytes of its first 16 instances
-        const bool live = i0 + 16 * k < V;
-        const uint32_t cnt = cur.off1 - cur.off0;
-        const size_t inst0 = cur.off0;
-        float sum[K];
-#pragma unroll
-        for (int kk = 0; kk < K; kk++) sum[kk] = 0.f;
-        // every lane of the wave must reach the ballots: loop to the wave's largest count
-        uint32_t cmax = cnt;
-#pragma unroll
-        for (int d = 32; d >= 16; d >>= 1) cmax = max(cmax, (uint32_t)__shfl_xor((int)cmax, d, 64));
-        uint32_t w_chunk = w_cur;
-        for (uint32_t c = 0; c < cmax; c += 16) {
-            const uint32_t w = w_chunk;                          // 4 quadrant bytes of instance c+e
-            if (c + 16 < cmax) w_chunk = load_flags(cur, c + 16);  // (the next chunk's, under this chunk's rows)
-            unsigned long long m = 0;  // bit 16q + i: quadrant q of instance c+i is valid
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const unsigned long long bal = __ballot(((w >> (8 * q)) & 0xFFu) != 0);
-                m |= ((bal >> (16 * quarter)) & 0xFFFFull) << (16 * q);
-            }
-            const float* chunk = rows + (inst0 + c) * 4 * RF;
-            // NF rows requested back to back, then added in slot order (absent slots add +0: the sums do not depend on
-            // NF).  Most Gaussians own a handful of rows -- 6 on average, half of them at most 4 -- and the 16-slot trip
-            // costs ~160 vector instructions whatever it finds (the kernel issued 60 M of them: 44 % VALU-busy on top
-            // of its memory waits): when no quarter of the wave has more than 4 rows left, a 4-slot trip does.
-            auto trip = [&](auto nf_c) {
-                constexpr int NF = decltype(nf_c)::value;
-                float v[NF][K];
-#pragma unroll
-                for (int i = 0; i < NF; i++) {
-                    const bool have = m != 0;
-                    const int bit = have ? __builtin_ctzll(m) : 0;
-                    if (have) m &= m - 1;
-                    const float* r = chunk + (size_t)((bit & 15) * 4 + (bit >> 4)) * RF;
-                    if (K == 2) {  // one 8-byte load per lane: the quarter wave reads the 128-byte row in one request
-                        const float2 t = have ? reinterpret_cast<const float2*>(r)[e] : make_float2(0.f, 0.f);
-                        v[i][0] = t.x;
-                        v[i][K - 1] = t.y;
-                    } else {
-#pragma unroll
-                        for (int kk = 0; kk < K; kk++) v[i][kk] = have ? r[e + 16 * kk] : 0.f;
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < NF; i++)
-#pragma unroll
-                    for (int kk = 0; kk < K; kk++) sum[kk] += v[i][kk];
-            };
-            int left = __popcll(m);  // rows this quarter still has to fetch; the wave's largest decides the trip
-#pragma unroll
-            for (int d = 32; d >= 16; d >>= 1) left = max(left, __shfl_xor(left, d, 64));
-            left = __builtin_amdgcn_readfirstlane(left);
-            while (left > 0) {
-                if (left <= 4) {
-                    trip(std::integral_constant<int, 4>{});
-                    left -= 4;
-                } else if (left <= 12) {
-                    trip(std::integral_constant<int, 12>{});
-                    left -= 12;
-                } else {
-                    trip(std::integral_constant<int, INFLIGHT>{});
-                    left -= INFLIGHT;
-                }
-            }
-        }
-        if constexpr (RECORD) {
-            if (live && cnt > 0) {  // (the row elements this lane summed, back where it read them)
-                float* dst = rows + inst0 * 4 * RF;
-                if (K == 2) {
-                    reinterpret_cast<float2*>(dst)[e] = make_float2(sum[0], sum[K - 1]);
-                } else {
-#pragma unroll
-                    for (int kk = 0; kk < K; kk++) dst[e + 16 * kk] = sum[kk];
-                }
-            }
-        } else if (live) {
-            const uint32_t g = cur.g;
-#pragma unroll
-            for (int kk = 0; kk < K; kk++) {
-                const float v = sum[kk];
-                const int el = K == 2 ? 2 * e + kk : e + 16 * kk;  // element of the row this lane summed
-                if (el < nsem) {
-                    if (el < S) dL_dsemantic[(size_t)g * S + el] = v;
-                } else if (el < nsem + 3) {
-                    dL_dcolor[(size_t)g * 3 + (el - nsem)] = v;
-                } else if (el == nsem + 3) {
-                    dL_ddepth[g] = v;
-                } else if (el < nch + 2) {
-                    dL_dmean2D[(size_t)g * 3 + (el - nch)] = v;
-                    if (el == nch + 1) dL_dmean2D[(size_t)g * 3 + 2] = 0.f;
-                } else if (el < nch + 5) {
-                    const int c = el - nch - 2;  // a, b, c -> x, y, w of the [P,2,2] conic gradient
-                    dL_dconic[(size_t)g * 4 + (c == 2 ? 3 : c)] = v;
-                    if (c == 2) dL_dconic[(size_t)g * 4 + 2] = 0.f;
-                } else if (el == nch + 5) {
-                    dL_dopacity[g] = v;
-                }
-            }
-        }
-        cur = nxt;
-        nxt = nn;
-        w_cur = w_nxt;
-    }
-}
-
-// Emits the (tile id, Gaussian id) instances of every visible Gaussian, walking the Gaussians in
-// depth order so that a stable sort by tile alone reproduces the reference's (tile, depth, id)
-// order (CR/rasterizer_impl.cu:70-111 emits 64-bit tile|depth keys in id order instead).
-// Wave-cooperative: each lane prepares one Gaussian (rectangle, output offset), then the wave walks
-// its 64 Gaussians one at a time and all lanes write that Gaussian's instances side by side, so every
-// store instruction covers one contiguous run instead of 64 scattered words.
-// COUNT: the block also histograms its keys per tile in LDS and adds the non-empty bins to tile_count[]
-// (stride 2: the .y words of the ranges array).  The per-tile counts are the tile ranges before their
-// prefix sum AND, folded by digit, the global histograms the onesweep tile sort needs: counting here
-// removes the sort's histogram pass over the 8 M keys and the ranges pass over the sorted keys.
-constexpr int EMIT_ROUNDS = 4;
-
-template <bool COUNT>
-__global__ __launch_bounds__(256) void emit_k(int P, int gx, int gy, const GaussRec* __restrict__ rec,
-                                              const int* __restrict__ radii, const uint32_t* __restrict__ order,
-                                              const uint32_t* __restrict__ offsets, uint4* __restrict__ aux,
-                                              uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                              uint32_t* __restrict__ tile_count, uint32_t* __restrict__ counters,
-                                              uint32_t* __restrict__ clear, uint32_t clear_words, uint32_t cap) {
-    // cap: number of instances keys[] / vals[] can hold.  The exact forward sizes them for num_rendered, so the
-    // guard below never fires; the speculative forward sizes them from a guess, and a frame that overflows must
-    // stay memory-safe and self-consistent (the tile counts only count what was stored) until the host notices.
-    const bool cull = counters[COUNTER_CULL] != 0;
-    P = min(P, (int)counters[COUNTER_V]);  // order[] / offsets[] hold the LISTED Gaussians only (front of the depth order)
-    // the frame's "truncated" flag (COUNTER_OVF): emit is the first kernel that knows both the count and the capacity
-    // (... or was depth-sorted wrongly because a look-back of the sort timed out: COUNTER_SORTERR)
-    if (blockIdx.x == 0 && threadIdx.x == 0)
-        counters[COUNTER_OVF] = (counters[COUNTER_N] > cap ? 1u : 0u) | (counters[COUNTER_SORTERR] ? 2u : 0u);
-    // COUNT: the blocks also zero the control words of the tile sort that follows (its own memset launch otherwise)
-    if (COUNT)
-        for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < clear_words; i += gridDim.x * 256u) clear[i] = 0u;
-    constexpr int ROUNDS_PER_BLOCK = COUNT ? EMIT_ROUNDS : 1;
-    if ((int)blockIdx.x * ROUNDS_PER_BLOCK * 256 >= P) return;  // (block-uniform) nothing listed left for this block
-    extern __shared__ uint32_t s_cnt[];  // [gx * gy] when COUNT
-    __shared__ unsigned long long s_mask[4][64];  // the rectangles' tile masks (cull_variant 2)
-    __shared__ unsigned long long s_mark[4];  // per wave and trip: bit p = some rectangle's last instance is at position p
-    __shared__ uint4 s_info[4][64];  // (x0 | y0 << 16, exclusive count, offsets[] - exclusive count, Gaussian id)
-    __shared__ int s_w[4][64];       // rectangle width in tiles
-    const int T = gx * gy;
-    if (COUNT) {
-        for (int t = threadIdx.x; t < T; t += 256) s_cnt[t] = 0;
-        __syncthreads();
-    }
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    // the counting variant amortises zeroing and flushing its tile histogram over EMIT_ROUNDS x 256 Gaussians
-    constexpr int ROUNDS = COUNT ? EMIT_ROUNDS : 1;
-    // a round's Gaussian: id -> radius, position and box are dependent gathers (two DRAM round trips); the next round's
-    // are requested before this round's instances are written, or every round would start with both exposed (emit is a
-    // small kernel: two waves per SIMD have nothing to hide them behind)
-    struct Fetched {
-        uint32_t g, off;
-        int r;
-        float4 q0, q2;
-        unsigned long long mask;
-    };
-    auto fetch = [&](int rnd) {
-        Fetched f{0u, 0u, 0, make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, -1.f, -1.f), TMASK_FULL};
-        const int i = (blockIdx.x * ROUNDS + rnd) * 256 + threadIdx.x;
-        if (rnd < ROUNDS && i < P) {
-            f.g = order[i];
-            f.off = offsets[i];
-            const uint4 a = aux[f.g];  // radius and tile mask: one gather
-            f.r = (int)a.y;
-            f.q0 = rec[f.g].q0;
-            f.q2 = rec[f.g].q1;  // (conic c, opacity, hx, hy)
-            f.mask = aux_mask(a);
-        }
-        return f;
-    };
-    Fetched nxt = fetch(0);
-#pragma unroll 1
-    for (int rnd = 0; rnd < ROUNDS; rnd++) {
-        const int i = (blockIdx.x * ROUNDS + rnd) * 256 + threadIdx.x;
-        const Fetched cur = nxt;
-        nxt = fetch(rnd + 1);
-        const uint32_t g = cur.g, off = cur.off;
-        int x0 = 0, y0 = 0, w = 1, cnt = 0;
-        if (i < P) {
-            reinterpret_cast<uint32_t*>(aux + g)[0] = off;  // the Gaussian's first row slot in the backward (slot space = emit order = depth order)
-            if (cur.r > 0) {
-                int x1, y1;
-                listed_rect(cur.q0.x, cur.q0.y, cur.r, cur.q2.z, cur.q2.w, cull, gx, gy, x0, y0, x1, y1);
-                w = x1 - x0;
-                cnt = cur.mask == TMASK_FULL ? w * (y1 - y0) : __popcll(cur.mask);  // (cull_variant 2: the ellipse's tiles)
-            }
-        }
-        // Load-balanced expansion: the wave's 64 rectangles hold `total` (tile, Gaussian) instances; lane l of trip
-        // t0 produces instance t0 + l, whichever rectangle it falls into.  A rectangle has ~10 tiles on average: one
-        // rectangle per trip would leave 5/6 of the lanes idle.  Consecutive instances are consecutive addresses
-        // (offsets[] is the exclusive scan of the same counts in the same order): full-line stores.
-        // Which rectangle: the non-empty rectangles are numbered in lane order (their records sit at that number in
-        // LDS); each marks the position of its LAST instance in a 64-bit word for the trip it falls into, and an
-        // instance belongs to rectangle (rectangles that ended before the trip) + (marks below its own position).  Two
-        // dependent LDS round trips per trip; the binary search in the scanned counts this replaces had seven, and with
-        // two waves per SIMD (emit is a small kernel) their latency was the kernel: 59 -> 3x us.
-        int incl = cnt;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int o = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += o;
-        }
-        const int total = __builtin_amdgcn_readlane(incl, 63);
-        const int excl = incl - cnt;
-        const int my_rank = __popcll(__ballot(cnt > 0) & ((1ull << lane) - 1ull));
-        if (cnt > 0) {
-            s_info[wv][my_rank] = make_uint4((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)excl, off - (uint32_t)excl, g);
-            s_w[wv][my_rank] = w;
-            s_mask[wv][my_rank] = cur.mask;
-        }
-        int ended = 0;  // non-empty rectangles that end before the current trip (wave-uniform)
-        for (int t0 = 0; t0 < total; t0 += 64) {
-            const int t = t0 + lane;
-            if (lane == 0) s_mark[wv] = 0ull;
-            const int last = incl - 1 - t0;  // position of this rectangle's last instance relative to the trip
-            if (cnt > 0 && last >= 0 && last < 64)
-                atomicOr(reinterpret_cast<unsigned int*>(&s_mark[wv]) + (last >> 5), 1u << (last & 31));
-            __builtin_amdgcn_wave_barrier();
-            const unsigned long long marks = s_mark[wv];
-            __builtin_amdgcn_wave_barrier();
-            const int lo = ended + __popcll(marks & ((1ull << lane) - 1ull));
-            ended += __popcll(marks);
-            if (t >= total) continue;
-            const uint4 info = s_info[wv][lo];
-            const int wl = s_w[wv][lo];
-            const unsigned long long mk = s_mask[wv][lo];
-            int k = t - (int)info.y;
-            if (mk != TMASK_FULL) k = select_bit(mk, k);  // the k-th tile the ellipse reaches -> its index in the rectangle
-            int row = (int)((float)k * __builtin_amdgcn_rcpf((float)wl));  // k / wl, off by at most one
-            row -= (row * wl > k);
-            row += ((row + 1) * wl <= k);
-            const int col = k - row * wl;
-            const uint32_t key = (uint32_t)(((int)(info.x >> 16) + row) * gx + (int)(info.x & 0xFFFFu) + col);
-            const uint32_t pos = info.z + (uint32_t)t;
-            if (pos < cap) {
-                keys[pos] = key;
-                vals[pos] = info.w;
-                if (COUNT) atomicAdd(&s_cnt[key], 1u);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-    if (COUNT) {
-        __syncthreads();
-        for (int t = threadIdx.x; t < T; t += 256) {
-            const uint32_t c = s_cnt[t];
-            if (c) atomicAdd(&tile_count[2 * t], c);
-        }
-    }
-}
-
-// One workgroup: per-tile counts (in ranges[t].y) -> ranges[t] = [start, end) ((0,0) for an empty tile, as
-// the reference leaves it) and the global digit histograms of the tile sort's passes.  A thread owns IT = ceil(T / 1024)
-// consecutive tiles (IT <= 12: emit only counts grids of at most 12288 tiles), so the prefix sum is ONE block scan
-// (chunks of 1024 tiles with three barriers each took 14 us at 6600 tiles: pure latency).
-constexpr int TRH_MAX_IT = 12;
-__global__ __launch_bounds__(1024) void tile_ranges_hist_k(int T, uint2* __restrict__ ranges, int passes, int shift0,
-                                                           int nbits0, int shift1, int nbits1,
-                                                           uint32_t* __restrict__ ghist) {
-    __shared__ uint32_t s_h[2][256];
-    __shared__ uint32_t s_wave[16];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (tid < 512) (&s_h[0][0])[tid] = 0;
-    const int IT = (T + 1023) / 1024;
-    const int t0 = tid * IT;
-    uint32_t c[TRH_MAX_IT];
-    uint32_t sum = 0;
-#pragma unroll
-    for (int k = 0; k < TRH_MAX_IT; k++) {
-        c[k] = (k < IT && t0 + k < T) ? ranges[t0 + k].y : 0u;
-        sum += c[k];
-    }
-    uint32_t v = sum;  // inclusive scan of the 1024 per-thread sums
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(v, d, 64);
-        if (lane >= d) v += o;
-    }
-    if (lane == 63) s_wave[w] = v;
-    __syncthreads();  // (also orders the zeroing of s_h before the atomics below)
-    uint32_t run = v - sum;
-    for (int k = 0; k < w; k++) run += s_wave[k];
-#pragma unroll
-    for (int k = 0; k < TRH_MAX_IT; k++) {
-        const int t = t0 + k;
-        if (k < IT && t < T) {
-            const uint32_t ck = c[k];
-            ranges[t] = ck ? make_uint2(run, run + ck) : make_uint2(0u, 0u);
-            if (ck) {
-                atomicAdd(&s_h[0][((uint32_t)t >> shift0) & ((1u << nbits0) - 1u)], ck);
-                if (passes > 1) atomicAdd(&s_h[1][((uint32_t)t >> shift1) & ((1u << nbits1) - 1u)], ck);
-            }
-            run += ck;
-        }
-    }
-    __syncthreads();
-    if (tid < 256) {
-        ghist[tid] = s_h[0][tid];
-        ghist[256 + tid] = s_h[1][tid];
-    }
-}
-
-// Per-tile [start,end) from the tile-sorted key list (CR/rasterizer_impl.cu:116-138).
-__global__ __launch_bounds__(256) void ranges_k(int N_cap, const uint32_t* __restrict__ n_dev,
-                                                const uint32_t* __restrict__ keys, uint2* __restrict__ ranges) {
-    const int N = n_dev ? (int)min((uint32_t)N_cap, *n_dev) : N_cap;  // (speculative forward: the count is on the device)
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    const uint32_t cur = keys[i];
-    if (i == 0)
-        ranges[cur].x = 0;
-    else {
-        const uint32_t prev = keys[i - 1];
-        if (cur != prev) {
-            ranges[prev].y = i;
-            ranges[cur].x = i;
-        }
-    }
-    if (i == N - 1) ranges[cur].y = N;
-}
-
 }  // namespace
 
 void launch_preprocess_fwd(const GoiRasterScene& sc, const GeomView& g, int* radii, uint2* ranges, int n_tiles,
@@ -1267,12 +743,6 @@ void launch_preprocess_fwd(const GoiRasterScene& sc, const GeomView& g, int* rad
     static_assert(PRE_BLOCK == 256, "preprocess_fwd_k is written for 256-thread workgroups");
     preprocess_fwd_k<<<dim3((sc.P + PRE_BLOCK - 1) / PRE_BLOCK), dim3(PRE_BLOCK), 0, s>>>(
         a, g.rec, g.cov3D, g.tiles_touched, g.clamped, g.sort_keys[1], g.aux, g.blk_agg, radii, g.counters, ranges, n_tiles);
-}
-
-void launch_compact_listed(int P, const GeomView& g, uint32_t* ghist, bool pad, hipStream_t s) {
-    const int nblk = (P + PRE_BLOCK - 1) / PRE_BLOCK;
-    compact_listed_k<<<dim3((nblk + COMPACT_ROUNDS - 1) / COMPACT_ROUNDS), dim3(PRE_BLOCK), 0, s>>>(
-        P, g.tiles_touched, g.sort_keys[1], g.blk_agg, g.counters, g.sort_keys[0], g.sort_vals[0], ghist, pad ? 1 : 0);
 }
 
 void launch_preprocess_bwd(const GoiRasterScene& sc, const GeomView& g, const int* radii, float* dL_dmean2D,
@@ -1313,94 +783,6 @@ void launch_sh_grad_from_views(int P, int D, int M, int V, const float* means3D,
                                float* dL_dsh, hipStream_t s) {
     const size_t lds = (size_t)256 * (3 * M + 1) * sizeof(float);
     sh_grad_from_views_k<<<dim3((P + 255) / 256), dim3(256), lds, s>>>(P, D, M, V, means3D, campos, gcol, dL_dsh);
-}
-
-#ifndef GOI_REDUCE_GPQ
-#define GOI_REDUCE_GPQ 2
-#endif
-constexpr int REDUCE_GPQ = GOI_REDUCE_GPQ;  // Gaussians per quarter wave of reduce_rows_k
-
-// records: the sums stay in the row scratch as per-Gaussian records (see reduce_rows_k); the six arrays are not written
-void launch_reduce_rows(const GoiRasterScene& sc, const GeomView& g, int N, const BwdScratchView& scr, float* dL_dmean2D,
-                        float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dsemantic, float* dL_ddepth,
-                                hipStream_t s, bool records) {
-    const int rf = bwd_row_floats(sc.S), nch = 4 * ((sc.S + 3) / 4) + 4;
-    const dim3 grid((sc.P + 16 * REDUCE_GPQ - 1) / (16 * REDUCE_GPQ));
-    const uint32_t* order = g.sort_vals[depth_sort_result_index()];
-    if (records) {
-        if (rf == 32)
-            reduce_rows_k<2, REDUCE_GPQ, true><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, g.tiles_touched, scr.rows, scr.flags,
-                                                              nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
-        else if (rf == 16)
-            reduce_rows_k<1, REDUCE_GPQ, true><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, g.tiles_touched, scr.rows, scr.flags,
-                                                              nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
-        else
-            reduce_rows_k<3, REDUCE_GPQ, true><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, g.tiles_touched, scr.rows, scr.flags,
-                                                              nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
-        return;
-    }
-    if (rf == 32)
-        reduce_rows_k<2, REDUCE_GPQ, false><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, g.tiles_touched, scr.rows, scr.flags,
-                                                    dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dsemantic, dL_ddepth);
-    else if (rf == 16)
-        reduce_rows_k<1, REDUCE_GPQ, false><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, g.tiles_touched, scr.rows, scr.flags,
-                                                    dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dsemantic, dL_ddepth);
-    else
-        reduce_rows_k<3, REDUCE_GPQ, false><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, g.tiles_touched, scr.rows, scr.flags,
-                                                    dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dsemantic, dL_ddepth);
-}
-
-void launch_reduce_sem_rows(const GoiRasterScene& sc, const GeomView& g, int N, const float* rows, const uint8_t* flags,
-                            int row_floats, float* dL_dsemantic, hipStream_t s) {
-    // rows hold semantic channels only: with nch = row_floats + 4 every element index is a semantic one
-    const int nch = row_floats + 4;
-    const dim3 grid((sc.P + 16 * REDUCE_GPQ - 1) / (16 * REDUCE_GPQ));
-    const uint32_t* order = g.sort_vals[depth_sort_result_index()];
-    if (row_floats == 16)
-        reduce_rows_k<1, REDUCE_GPQ, false><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, g.tiles_touched, const_cast<float*>(rows), flags, nullptr,
-                                                    nullptr, nullptr, nullptr, dL_dsemantic, nullptr);
-    else
-        reduce_rows_k<2, REDUCE_GPQ, false><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, g.tiles_touched, const_cast<float*>(rows), flags, nullptr,
-                                                    nullptr, nullptr, nullptr, dL_dsemantic, nullptr);
-}
-
-void launch_emit(int P, int W, int H, const GeomView& g, const uint32_t* order, const int* radii, uint32_t* keys,
-                 uint32_t* vals, uint32_t cap, hipStream_t s) {
-    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
-    emit_k<false><<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, gx, gy, g.rec, radii, order, g.offsets, g.aux, keys, vals,
-                                                              nullptr, g.counters, nullptr, 0u, cap);
-}
-
-bool emit_can_count_tiles(int W, int H) {
-    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
-    // (tile_ranges_hist_k: at most TRH_MAX_IT x 1024 tiles; the per-tile LDS counters of emit: 48 KB)
-    return (size_t)gx * gy <= (size_t)TRH_MAX_IT * 1024 && (size_t)gx * gy * sizeof(uint32_t) <= 48 * 1024 &&
-           tile_key_bits((uint32_t)(gx * gy)) <= 16;
-}
-
-// emit + per-tile counts; ranges must be zeroed by the caller's stream order (done here)
-void launch_emit_counting(int P, int W, int H, const GeomView& g, const uint32_t* order, const int* radii, uint32_t* keys,
-                          uint32_t* vals, uint2* ranges, uint32_t* clear, size_t clear_words, uint32_t cap, hipStream_t s) {
-    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
-    // `ranges` was zeroed by preprocess_fwd_k
-    emit_k<true><<<dim3((P + 256 * EMIT_ROUNDS - 1) / (256 * EMIT_ROUNDS)), dim3(256), (size_t)gx * gy * sizeof(uint32_t), s>>>(
-        P, gx, gy, g.rec, radii, order, g.offsets, g.aux, keys, vals, reinterpret_cast<uint32_t*>(ranges) + 1, g.counters,
-        clear, (uint32_t)clear_words, cap);
-}
-
-// per-tile counts -> ranges and the two digit histograms (written to ghist[0..511]) of a sort on
-// key bits [0, bits) split as radix_sort_pairs splits them
-void launch_tile_ranges_hist(int W, int H, uint2* ranges, uint32_t* ghist, hipStream_t s) {
-    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
-    const int bits = tile_key_bits((uint32_t)(gx * gy));
-    const int passes = (bits + 7) / 8;
-    const int n0 = (bits + passes - 1) / passes, n1 = bits - n0;
-    tile_ranges_hist_k<<<dim3(1), dim3(1024), 0, s>>>(gx * gy, ranges, passes, 0, n0, n0, n1 > 0 ? n1 : 1, ghist);
-}
-
-void launch_ranges(int N, const uint32_t* n_dev, const uint32_t* sorted_keys, uint2* ranges, int T, hipStream_t s) {
-    (void)hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)T, s);
-    if (N > 0) ranges_k<<<dim3((N + 255) / 256), dim3(256), 0, s>>>(N, n_dev, sorted_keys, ranges);
 }
 
 void launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s) {

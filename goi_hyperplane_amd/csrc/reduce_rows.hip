@@ -1,0 +1,293 @@
+// Row reduction of the atomic-free backward: sums the partial-gradient rows render_bwd_rows_k (render_bwd.hip) leaves per
+// (emit-order instance, quadrant) into one record (or six per-id arrays) per Gaussian, in a fixed order.  Pure additions:
+// compiled with the default flags (it used to sit in preprocess.hip under -ffp-contract=off for no reason).
+// Reference: the float atomicAdd accumulation of cuda_rasterizer/backward.cu:565-621, which this replaces.
+#include <type_traits>
+
+#include "common.h"
+
+namespace goi {
+
+namespace {
+
+// Sums the partial-gradient rows of every Gaussian (written by render_bwd_rows_k, one row per
+// (emit-order instance, quadrant) slot, a Gaussian's slots contiguous) in a fixed order and writes
+// the six blend-gradient arrays for ALL Gaussians (zeros where nothing contributed): no memsets, no
+// atomics, bit-reproducible.  A quarter wave (16 lanes) owns one Gaussian.  Memory-level parallelism
+// is what matters here: the lanes fetch 16 instances x 4 validity bytes in one load, the flagged
+// slots of the chunk are packed into a 64-bit mask (quadrant-major), and up to 16 rows are requested
+// back to back before the first is consumed (lane e reads row elements e, e+16, ...: coalesced).
+// The kernel is LATENCY bound, not bandwidth bound: a Gaussian costs a chain of three dependent memory round trips
+// (slot range -> validity bytes -> rows) for ~8 rows of payload, and with one Gaussian per quarter wave the chip works
+// through 250 K short-lived waves in ~30 rounds of that chain (223 us for 0.5 GB).  So every quarter wave walks GPQ
+// Gaussians in a software pipeline: while the rows of Gaussian k are summed, the validity word of k+1 and the slot
+// range of k+2 are already on their way -- one exposed round trip per Gaussian instead of three, 1/GPQ of the waves.
+// The order in which a Gaussian's rows are added is unchanged (bit-identical gradients).
+// RECORD (the full backward): the sums do not leave as six per-Gaussian arrays at all.  A Gaussian's record -- its summed
+// row, 128 bytes at S <= 16 -- goes back into the row scratch, over the first slot the Gaussian owns (every listed
+// Gaussian owns at least four; its rows have all been read by then): ONE full-line store per Gaussian instead of six
+// scattered partial ones, no zeros for the unlisted Gaussians (the old form wrote 104 bytes of them for each), and
+// preprocess_bwd_k, which runs over the ids anyway, fetches the line through goff[] and writes every per-id output itself,
+// coalesced.  Measured on the headline view before it was built (timing builds): the zero phase 21 us, the scattered
+// stores 40 us of the kernel's 213; a dense 128-byte store instead 8 us.
+template <int K, int GPQ, bool RECORD>  // K = row_floats / 16; GPQ = Gaussians per quarter wave
+__global__ __launch_bounds__(256) void reduce_rows_k(int P, int S, int nch, uint32_t N_cap, const uint32_t* __restrict__ n_dev,
+                                                     const uint32_t* __restrict__ order,
+                                                     const uint32_t* __restrict__ offsets,
+                                                     const uint32_t* __restrict__ tiles_touched,
+                                                     float* rows, const uint8_t* __restrict__ flags,
+                                                     float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic,
+                                                     float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor,
+                                                     float* __restrict__ dL_dsemantic, float* __restrict__ dL_ddepth) {
+    constexpr int RF = 16 * K;
+#ifndef GOI_REDUCE_INFLIGHT
+#define GOI_REDUCE_INFLIGHT 32
+#endif
+    constexpr int INFLIGHT = GOI_REDUCE_INFLIGHT;
+    // N_cap: the slot capacity the scratch was laid out for; n_dev: the forward's instance count on the device (the
+    // exact forward passes N_cap = num_rendered; the speculative one a capacity, and an overflowed frame stored only
+    // the first N_cap instances)
+    // a TRUNCATED frame (COUNTER_OVF, set by emit) has no valid rows: every Gaussian gets zeros
+    const bool truncated = n_dev[COUNTER_OVF - COUNTER_N] != 0;
+    const uint32_t N = truncated ? 0u : min(N_cap, *n_dev);
+    const int V = truncated ? 0 : (int)n_dev[COUNTER_V - COUNTER_N];  // listed Gaussians: the only ones that own rows
+    const int lane = threadIdx.x & 63, quarter = lane >> 4, e = lane & 15;
+    const uint32_t* flags32 = reinterpret_cast<const uint32_t*>(flags);
+    const int nsem = nch - 4;
+    // ---- phase 0 (the first ceil(P/256) workgroups): zeros for the Gaussians that are NOT listed (culled, or a culled
+    // rectangle without tiles; all of them for a truncated frame) -- one Gaussian per lane.  The listed ones are written
+    // by phase 1 below, so every element of the six arrays is written exactly once.
+    if constexpr (!RECORD) {
+        const int i = blockIdx.x * 256 + threadIdx.x;
+        if (i < P && (truncated || tiles_touched[i] == 0)) {
+            if ((S & 3) == 0) {
+                float4* d4 = reinterpret_cast<float4*>(dL_dsemantic + (size_t)i * S);
+                for (int ch = 0; ch < S / 4; ch++) d4[ch] = make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                for (int ch = 0; ch < S; ch++) dL_dsemantic[(size_t)i * S + ch] = 0.f;
+            }
+            if (dL_dopacity) {  // (NULL in the feature-gradient-only reduction)
+                dL_dopacity[i] = 0.f;
+                dL_ddepth[i] = 0.f;
+#pragma unroll
+                for (int k = 0; k < 3; k++) dL_dcolor[(size_t)i * 3 + k] = dL_dmean2D[(size_t)i * 3 + k] = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; k++) dL_dconic[(size_t)i * 4 + k] = 0.f;
+            }
+        }
+    }
+    // ---- phase 1: the V LISTED Gaussians in DEPTH order.  That is the order of the slot space (emit order), so
+    // consecutive quarter waves stream through rows[] and flags[] front to back -- and it is the order in which the valid
+    // rows are DENSE: near Gaussians contribute in most of their tiles, far ones are behind the saturation front and own
+    // hardly any row, so the rows that exist sit close together at the front of the slot space (DRAM pages, TLB).  A
+    // slot space in id order (tried: the outputs then leave as neighbouring lines instead of six scattered partial
+    // stores per Gaussian) spreads the same rows evenly over 2.6 GB and costs more than the scatter saves (0.235 ->
+    // 0.32 ms).  Step k of the block covers 16 consecutive listed Gaussians.
+    const int i0 = blockIdx.x * (16 * GPQ) + (threadIdx.x >> 4);
+    if (blockIdx.x * (16 * GPQ) >= V) return;  // (block-uniform)
+    struct Meta {
+        uint32_t g, off0, off1;
+    };
+    // slots of the i-th listed Gaussian in depth order: [offsets[i], offsets[i+1]) -- straight from the prefix sum; the
+    // Gaussian's id is only needed for the final store
+    auto load_meta = [&](int k) {
+        const int i = i0 + 16 * k;
+        Meta m{0u, 0u, 0u};
+        if (k < GPQ && i < V) {
+            m.g = order[i];
+            m.off0 = min(offsets[i], N);
+            m.off1 = i + 1 < V ? min(offsets[i + 1], N) : N;
+        }
+        return m;
+    };
+    // the 4 quadrant bytes of instance off0 + c + e (first chunk of a Gaussian: c = 0)
+    auto load_flags = [&](const Meta& m, uint32_t c) { return (c + e < m.off1 - m.off0) ? flags32[m.off0 + c + e] : 0u; };
+
+    Meta cur = load_meta(0), nxt = load_meta(1);
+    uint32_t w_cur = load_flags(cur, 0);
+#pragma unroll 1
+    for (int k = 0; k < GPQ; k++) {
+        if (i0 + 16 * k - (int)(threadIdx.x >> 4) >= V) break;  // (block-uniform: nothing left for any quarter wave)
+        const Meta nn = load_meta(k + 2);        // two Gaussians ahead: slot range
+        const uint32_t w_nxt = load_flags(nxt, 0);  // one ahead: validity bytes of its first 16 instances
+        const bool live = i0 + 16 * k < V;
+        const uint32_t cnt = cur.off1 - cur.off0;
+        const size_t inst0 = cur.off0;
+        float sum[K];
+#pragma unroll
+        for (int kk = 0; kk < K; kk++) sum[kk] = 0.f;
+        // every lane of the wave must reach the ballots: loop to the wave's largest count
+        uint32_t cmax = cnt;
+#pragma unroll
+        for (int d = 32; d >= 16; d >>= 1) cmax = max(cmax, (uint32_t)__shfl_xor((int)cmax, d, 64));
+        // A Gaussian's instances are looked at 64 at a time: four validity words per lane, requested together (and the next
+        // 64 under this block's rows), and a 16-instance chunk in which no quarter of the wave has a row is skipped on one
+        // ballot.  A needle or a frame-filling blob owns thousands of slots of which a few hundred hold a row (its rectangle
+        // is listed whole beyond 64 tiles): walked 16 at a time behind one dependent load each, ONE such Gaussian kept its
+        // quarter wave busy for a millisecond (clustered workload: this kernel 1.1 of the step's 2.6 ms).
+        uint32_t wq[4] = {w_cur, 0u, 0u, 0u};
+        if (cmax > 16) {
+#pragma unroll
+            for (int sblk = 1; sblk < 4; sblk++) wq[sblk] = load_flags(cur, 16u * sblk);
+        }
+        for (uint32_t c = 0; c < cmax; c += 64) {
+            uint32_t wn[4] = {0u, 0u, 0u, 0u};
+            if (c + 64 < cmax) {
+#pragma unroll
+                for (int sblk = 0; sblk < 4; sblk++) wn[sblk] = load_flags(cur, c + 64 + 16u * sblk);
+            }
+#pragma unroll 1
+            for (int sblk = 0; sblk < 4; sblk++) {  // (not unrolled: the queue is rotated instead of indexed)
+                const uint32_t cc = c + 16u * sblk;
+                if (cc >= cmax) break;                  // (wave-uniform)
+                const uint32_t w = wq[0];               // 4 quadrant bytes of instance cc+e
+                wq[0] = wq[1];
+                wq[1] = wq[2];
+                wq[2] = wq[3];
+                if (__ballot(w != 0u) == 0) continue;   // (wave-uniform) no quarter has a row in this chunk
+                unsigned long long m = 0;  // bit 16q + i: quadrant q of instance c+i is valid
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const unsigned long long bal = __ballot(((w >> (8 * q)) & 0xFFu) != 0);
+                    m |= ((bal >> (16 * quarter)) & 0xFFFFull) << (16 * q);
+                }
+                const float* chunk = rows + (inst0 + cc) * 4 * RF;
+                // NF rows requested back to back, then added in slot order (absent slots add +0: the sums do not depend on
+                // NF).  Most Gaussians own a handful of rows -- 6 on average, half of them at most 4 -- and the 16-slot trip
+                // costs ~160 vector instructions whatever it finds (the kernel issued 60 M of them: 44 % VALU-busy on top
+                // of its memory waits): when no quarter of the wave has more than 4 rows left, a 4-slot trip does.
+                auto trip = [&](auto nf_c) {
+                    constexpr int NF = decltype(nf_c)::value;
+                    float v[NF][K];
+#pragma unroll
+                    for (int i = 0; i < NF; i++) {
+                        const bool have = m != 0;
+                        const int bit = have ? __builtin_ctzll(m) : 0;
+                        if (have) m &= m - 1;
+                        const float* r = chunk + (size_t)((bit & 15) * 4 + (bit >> 4)) * RF;
+                        if (K == 2) {  // one 8-byte load per lane: the quarter wave reads the 128-byte row in one request
+                            const float2 t = have ? reinterpret_cast<const float2*>(r)[e] : make_float2(0.f, 0.f);
+                            v[i][0] = t.x;
+                            v[i][K - 1] = t.y;
+                        } else {
+#pragma unroll
+                            for (int kk = 0; kk < K; kk++) v[i][kk] = have ? r[e + 16 * kk] : 0.f;
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < NF; i++)
+#pragma unroll
+                        for (int kk = 0; kk < K; kk++) sum[kk] += v[i][kk];
+                };
+                int left = __popcll(m);  // rows this quarter still has to fetch; the wave's largest decides the trip
+#pragma unroll
+                for (int d = 32; d >= 16; d >>= 1) left = max(left, __shfl_xor(left, d, 64));
+                left = __builtin_amdgcn_readfirstlane(left);
+                while (left > 0) {
+                    if (left <= 4) {
+                        trip(std::integral_constant<int, 4>{});
+                        left -= 4;
+                    } else if (left <= 12) {
+                        trip(std::integral_constant<int, 12>{});
+                        left -= 12;
+                    } else {
+                        trip(std::integral_constant<int, INFLIGHT>{});
+                        left -= INFLIGHT;
+                    }
+                }
+            }
+#pragma unroll
+            for (int sblk = 0; sblk < 4; sblk++) wq[sblk] = wn[sblk];
+        }
+        if constexpr (RECORD) {
+            if (live && cnt > 0) {  // (the row elements this lane summed, back where it read them)
+                float* dst = rows + inst0 * 4 * RF;
+                if (K == 2) {
+                    reinterpret_cast<float2*>(dst)[e] = make_float2(sum[0], sum[K - 1]);
+                } else {
+#pragma unroll
+                    for (int kk = 0; kk < K; kk++) dst[e + 16 * kk] = sum[kk];
+                }
+            }
+        } else if (live) {
+            const uint32_t g = cur.g;
+#pragma unroll
+            for (int kk = 0; kk < K; kk++) {
+                const float v = sum[kk];
+                const int el = K == 2 ? 2 * e + kk : e + 16 * kk;  // element of the row this lane summed
+                if (el < nsem) {
+                    if (el < S) dL_dsemantic[(size_t)g * S + el] = v;
+                } else if (el < nsem + 3) {
+                    dL_dcolor[(size_t)g * 3 + (el - nsem)] = v;
+                } else if (el == nsem + 3) {
+                    dL_ddepth[g] = v;
+                } else if (el < nch + 2) {
+                    dL_dmean2D[(size_t)g * 3 + (el - nch)] = v;
+                    if (el == nch + 1) dL_dmean2D[(size_t)g * 3 + 2] = 0.f;
+                } else if (el < nch + 5) {
+                    const int c = el - nch - 2;  // a, b, c -> x, y, w of the [P,2,2] conic gradient
+                    dL_dconic[(size_t)g * 4 + (c == 2 ? 3 : c)] = v;
+                    if (c == 2) dL_dconic[(size_t)g * 4 + 2] = 0.f;
+                } else if (el == nch + 5) {
+                    dL_dopacity[g] = v;
+                }
+            }
+        }
+        cur = nxt;
+        nxt = nn;
+        w_cur = w_nxt;
+    }
+}
+
+}  // namespace
+
+#ifndef GOI_REDUCE_GPQ
+#define GOI_REDUCE_GPQ 2
+#endif
+constexpr int REDUCE_GPQ = GOI_REDUCE_GPQ;  // Gaussians per quarter wave of reduce_rows_k
+
+// records: the sums stay in the row scratch as per-Gaussian records (see reduce_rows_k); the six arrays are not written
+void launch_reduce_rows(const GoiRasterScene& sc, const GeomView& g, int N, const BwdScratchView& scr, float* dL_dmean2D,
+                        float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dsemantic, float* dL_ddepth,
+                                hipStream_t s, bool records) {
+    const int rf = bwd_row_floats(sc.S), nch = 4 * ((sc.S + 3) / 4) + 4;
+    const dim3 grid((sc.P + 16 * REDUCE_GPQ - 1) / (16 * REDUCE_GPQ));
+    const uint32_t* order = g.sort_vals[depth_sort_result_index()];
+    if (records) {
+        if (rf == 32)
+            reduce_rows_k<2, REDUCE_GPQ, true><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, g.tiles_touched, scr.rows, scr.flags,
+                                                              nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+        else if (rf == 16)
+            reduce_rows_k<1, REDUCE_GPQ, true><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, g.tiles_touched, scr.rows, scr.flags,
+                                                              nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+        else
+            reduce_rows_k<3, REDUCE_GPQ, true><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, g.tiles_touched, scr.rows, scr.flags,
+                                                              nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+        return;
+    }
+    if (rf == 32)
+        reduce_rows_k<2, REDUCE_GPQ, false><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, g.tiles_touched, scr.rows, scr.flags,
+                                                    dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dsemantic, dL_ddepth);
+    else if (rf == 16)
+        reduce_rows_k<1, REDUCE_GPQ, false><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, g.tiles_touched, scr.rows, scr.flags,
+                                                    dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dsemantic, dL_ddepth);
+    else
+        reduce_rows_k<3, REDUCE_GPQ, false><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, g.tiles_touched, scr.rows, scr.flags,
+                                                    dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dsemantic, dL_ddepth);
+}
+
+void launch_reduce_sem_rows(const GoiRasterScene& sc, const GeomView& g, int N, const float* rows, const uint8_t* flags,
+                            int row_floats, float* dL_dsemantic, hipStream_t s) {
+    // rows hold semantic channels only: with nch = row_floats + 4 every element index is a semantic one
+    const int nch = row_floats + 4;
+    const dim3 grid((sc.P + 16 * REDUCE_GPQ - 1) / (16 * REDUCE_GPQ));
+    const uint32_t* order = g.sort_vals[depth_sort_result_index()];
+    if (row_floats == 16)
+        reduce_rows_k<1, REDUCE_GPQ, false><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, g.tiles_touched, const_cast<float*>(rows), flags, nullptr,
+                                                    nullptr, nullptr, nullptr, dL_dsemantic, nullptr);
+    else
+        reduce_rows_k<2, REDUCE_GPQ, false><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, g.tiles_touched, const_cast<float*>(rows), flags, nullptr,
+                                                    nullptr, nullptr, nullptr, dL_dsemantic, nullptr);
+}
+
+}  // namespace goi

@@ -106,7 +106,8 @@ def allreduce_gradients(params, dist, bucket_bytes: int = 0):
             off += n
 
 
-def allreduce_gradients_visible(params, visible, dist, dense_above: float = 0.9, per_gaussian=None, check_zero_rows=False):
+def allreduce_gradients_visible(params, visible, dist, dense_above: float = 0.9, per_gaussian=None, check_zero_rows=False,
+                                direct: bool = False):
     """Sum-all-reduce `.grad` of every parameter, sending only the rows of Gaussians that were VISIBLE in at least one
     rank's view(s) of this step.
 
@@ -148,7 +149,7 @@ def allreduce_gradients_visible(params, visible, dist, dense_above: float = 0.9,
     row_ids = {id(p) for p in rows}
     rest = [p for p in with_grad if id(p) not in row_ids]
     if n >= dense_above * P or not rows:
-        allreduce_gradients(with_grad, dist)
+        (allreduce_gradients_direct if direct else allreduce_gradients)(with_grad, dist)
         return P
     works = [dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True)
              for g in coalesce_shared_storage([p.grad for p in rest])] if rest else []
@@ -169,7 +170,10 @@ def allreduce_gradients_visible(params, visible, dist, dense_above: float = 0.9,
                                f"{worst:.3e}): some loss reaches the per-Gaussian tensors without going through the rasterizer "
                                "(weight decay, a regulariser); use allreduce_gradients for such steps")
     pack = torch.cat([v.index_select(0, idx) for v in views], dim=1)
-    dist.all_reduce(pack, op=dist.ReduceOp.SUM)
+    if direct:
+        allreduce_gradients_direct([_G(pack)], dist)
+    else:
+        dist.all_reduce(pack, op=dist.ReduceOp.SUM)
     off = 0
     for v, w in zip(views, widths):
         v.index_copy_(0, idx, pack[:, off:off + w])
@@ -197,6 +201,26 @@ def _direct_spans(grads, world):
             padded[:n].copy_(span.reshape(-1))
             out.append((span, padded, True))
     return out
+
+
+def _issue_sum(grads, dist, direct: bool):
+    """Issues the sum of `grads` over the ranks without waiting: (works, finish, keep).  direct=False: one asynchronous
+    all_reduce per coalesced span; direct=True: reduce-scatter + all-gather per span (allreduce_gradients_direct)."""
+    if not grads:
+        return [], None, None
+    if not direct:
+        spans = coalesce_shared_storage(grads)
+        return [dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True) for g in spans], None, spans
+    h = allreduce_gradients_direct([_G(g) for g in grads], dist, async_op=True)
+    return h.works, h._finish, h.keep
+
+
+class _G:
+    """(a bare gradient tensor dressed as a parameter for the functions that take parameters)"""
+    __slots__ = ("grad",)
+
+    def __init__(self, g):
+        self.grad = g
 
 
 def allreduce_gradients_direct(params, dist, async_op: bool = False):
@@ -264,7 +288,7 @@ def exchange_model_ms(nbytes: float, world: int, link_GBps: float = 153.0, links
     return {"ring": ring, "direct": direct}
 
 
-def allreduce_gradients_sh_factored(params, sh_leaves, means3D, factor, dist, reconstruct=None):
+def allreduce_gradients_sh_factored(params, sh_leaves, means3D, factor, dist, reconstruct=None, direct: bool = False):
     """Data-parallel gradient exchange with the SH gradient sent as its FACTORS.
 
     One view per rank.  dL/dSH is 48 of the 75 gradient floats of a Gaussian, but for one view it is the outer
@@ -300,7 +324,7 @@ def allreduce_gradients_sh_factored(params, sh_leaves, means3D, factor, dist, re
     # one communicator runs its collectives in order: the (small) gathers go first, then the all-reduce of the other
     # gradients is queued and the reconstruction kernel runs on the compute stream while it is on the wire
     grads = [p.grad for p in params if p.grad is not None]
-    works = [dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True) for g in coalesce_shared_storage(grads)]
+    works, fin, _keep = _issue_sum(grads, dist, direct)  # (direct: reduce-scatter + all-gather instead of RCCL's all_reduce)
     dsh = reconstruct(means3D.detach(), all_c, all_g, int(factor["degree"]), int(factor["M"]))
     k = 0
     for leaf in sh_leaves:
@@ -315,6 +339,8 @@ def allreduce_gradients_sh_factored(params, sh_leaves, means3D, factor, dist, re
         raise ValueError(f"sh_leaves hold {k} coefficients, the rasterizer was given {dsh.shape[1]}")
     for w in works:
         w.wait()
+    if fin is not None:
+        fin()
 
 
 # ---- exchange in flight: overlap the collective with the next view's render ---------------------------------------------
@@ -336,7 +362,7 @@ class PendingExchange:
         self.done, self.works, self._finish = True, [], None
 
 
-def allreduce_gradients_async(params, dist) -> PendingExchange:
+def allreduce_gradients_async(params, dist, direct: bool = False) -> PendingExchange:
     """allreduce_gradients without the wait: the collectives are issued (RCCL runs them on its own stream, ordered
     after the work already queued on the current one) and the handle is returned at once.  The next view's forward and
     backward can be enqueued while the reduction is on the wire -- the backward writes its gradients into a fresh flat
@@ -345,12 +371,12 @@ def allreduce_gradients_async(params, dist) -> PendingExchange:
     or one-step-delayed updates.  wait() before reading the reduced `.grad` tensors (they are the ones the parameters
     held when this was called)."""
     grads = [p.grad for p in params if p.grad is not None]
-    spans = coalesce_shared_storage(grads) if grads else []
-    works = [dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True) for g in spans]
-    return PendingExchange(works, (grads, spans))
+    works, fin, keep = _issue_sum(grads, dist, direct)
+    return PendingExchange(works, (grads, keep), fin)
 
 
-def allreduce_gradients_sh_factored_async(params, sh_leaves, means3D, factor, dist, reconstruct=None) -> PendingExchange:
+def allreduce_gradients_sh_factored_async(params, sh_leaves, means3D, factor, dist, reconstruct=None,
+                                          direct: bool = False) -> PendingExchange:
     """allreduce_gradients_sh_factored with the collectives left in flight; wait() rebuilds dL/dSH from the gathered
     factors and hands each SH leaf its part exactly as the blocking variant does: assigned to `leaf.grad`, or added to a
     gradient that is already there (in sh_factored mode autograd gives the SH leaves none of its own).  The same tensors
@@ -372,13 +398,15 @@ def allreduce_gradients_sh_factored_async(params, sh_leaves, means3D, factor, di
         works = [dist.all_gather(list(all_g.unbind(0)), gcol, async_op=True),
                  dist.all_gather(list(all_c.unbind(0)), campos.reshape(3), async_op=True)]
     grads = [p.grad for p in params if p.grad is not None]
-    spans = coalesce_shared_storage(grads) if grads else []
-    works += [dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True) for g in spans]
+    sum_works, sum_fin, spans = _issue_sum(grads, dist, direct)
+    works += sum_works
     means = means3D.detach()
     degree, M = int(factor["degree"]), int(factor["M"])
     result = {}
 
     def finish():
+        if sum_fin is not None:
+            sum_fin()
         dsh = reconstruct(means, all_c, all_g, degree, M)
         k = 0
         for leaf in sh_leaves:

@@ -154,14 +154,15 @@ def make_scene(P: int, S: int = 16, sh_degree: int = 3, seed: int = 0,
 def make_clustered_scene(P: int, S: int = 16, sh_degree: int = 3, seed: int = 0, extent=(4.0, 2.64, 1.0),
                          log_scale_mean: float = -5.2, log_scale_std: float = 1.1, n_clusters: int = 48,
                          needle_frac: float = 0.02, giant_frac: float = 2e-5, occluder_frac: float = 0.12,
-                         background_frac: float = 0.10) -> GaussianScene:
+                         background_frac: float = 0.10, max_scale: float = 3.0, max_aspect: float = 300.0) -> GaussianScene:
     """A scene with the statistics of a RECONSTRUCTION (BASELINE configs 2 / 3 / 5 name MipNeRF360 scenes whose PLYs are not
     in this image) instead of SURVEY 8(d)'s uniform box -- everything the uniform scene is kind to is made hard here:
 
       * positions: a mixture of `n_clusters` anisotropic Gaussian blobs with heavy-tailed (Zipf-like) weights and log-normal
         sizes, over a thin uniform background -- some tiles see hundreds of times the Gaussians of others;
       * scales: log-normal with a wide sigma (1.1 instead of 0.7) per axis, so most Gaussians are anisotropic; `needle_frac`
-        of them are needles (one axis x 25, the others x 0.25: tens to hundreds of pixels long, a pixel wide) and
+        of them are needles (one axis x 25, the others x 0.25: tens to hundreds of pixels long, a pixel wide; aspect ratios
+        are capped at 300 : 1 and the longest axis at 3 scene units) and
         `giant_frac` (at least 3) are frame-filling blobs (0.5 - 1.5 scene units): tile rectangles far beyond the 64-tile
         ellipse masks;
       * opacity: bimodal as in trained scenes -- a translucent mode (0.02 - 0.3; part of it below the 1/255 visibility floor
@@ -226,6 +227,11 @@ def make_clustered_scene(P: int, S: int = 16, sh_degree: int = 3, seed: int = 0,
     keep_giant[giant_idx] = True
     sel = is_occ & ~keep_giant & ~needle
     log_s[sel] = occ_ls[(np.cumsum(is_occ) - 1)[sel]]
+    # what a trained scene can hold: the longest axis at most `max_scale` scene units, the aspect ratio at most `max_aspect`
+    # (beyond ~1e3 : 1 the reference's own fp32 cov2D -> cov3D -> scale / rotation backward returns noise: two legal builds of
+    # it disagree by the size of the gradient itself, and nothing can be pinned on such a Gaussian)
+    log_s = np.minimum(log_s, np.log(max_scale))
+    log_s = np.maximum(log_s, log_s.max(axis=1, keepdims=True) - np.log(max_aspect))
     scales = np.exp(log_s).astype(np.float32)
     # ---- rotations: random, except the occluders (aligned with their sheet up to a small tilt)
     q = rng(2).normal(size=(P, 4)).astype(np.float32)

@@ -28,6 +28,20 @@
  *     block-wide early exit only fires when every pixel is already done.
  *   - trace (CR/forward.cu:521-526) is racy in the reference; here it is a deterministic sum
  *     (gau_sem) and count (num_gsem += S per hit, as the reference's inner loop does).
+ *
+ * Where the reference's OWN fp32 arithmetic is the noise (round 4).  The pair exponent
+ *     power = -0.5f * (a dx dx + c dy dy) - b dx dy                      (CR/forward.cu:341, CR/backward.cu:527)
+ *   is a difference of terms that, for a needle-shaped Gaussian hundreds of pixels long, are 1e3..1e6 times the
+ *   result: its fp32 value depends on the compiler's contraction choices by up to several per cent of alpha (this
+ *   file's plain and FMA-contracted builds -- two legal compilations of the reference's statement; nvcc contracts by
+ *   default -- differ by 0.04 in colour on 3 % of the pixels of scene.make_clustered_scene).  Two instruments:
+ *     - the forward's per-pixel flag byte gets a second bit: bit 0 = a guard within fragile_eps of flipping (as
+ *       before), bit 1 = ILL-CONDITIONED: the accumulated first-order effect of the exponents' fp32 rounding bounds
+ *       (2^-22 x the sum of the terms' magnitudes per pair, weighted by the pair's alpha T) exceeds 2.5e-5, a quarter
+ *       of the forward tolerance.  `flag == 0` keeps meaning "two correct fp32 implementations agree here".
+ *     - the build -DGOI_ORACLE_POWER_F64 (liboracle_f64p.so, variant "f64power") evaluates that one statement in
+ *       double from the same fp32 operands and rounds once: the exact value of the reference's formula on the
+ *       reference's inputs, which is what an ill-conditioned pixel is compared with instead.
  */
 #include "goi_oracle.h"
 
@@ -37,6 +51,19 @@
 #include <cstring>
 #include <numeric>
 #include <vector>
+// the pair exponent of CR/forward.cu:341 / CR/backward.cu:527 / CR/forward.cu:508 (see the header: GOI_ORACLE_POWER_F64)
+static inline float pair_power(const float* co, float dx, float dy) {
+#ifdef GOI_ORACLE_POWER_F64
+    return (float)(-0.5 * ((double)co[0] * dx * dx + (double)co[2] * dy * dy) - (double)co[1] * dx * dy);
+#else
+    return -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+#endif
+}
+// bound on the fp32 rounding error of that statement: a handful of roundings of its largest terms
+static inline float pair_power_noise(const float* co, float dx, float dy) {
+    return 2.4e-7f * (0.5f * std::fabs(co[0]) * dx * dx + 0.5f * std::fabs(co[2]) * dy * dy + std::fabs(co[1] * dx * dy));
+}
+
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -463,21 +490,27 @@ int goi_oracle_forward(const GoiOracleScene* sc, GoiOracleState* st, float* out_
                 std::fill(Cs.begin(), Cs.end(), 0.f);
                 float D = 0;
                 bool frag = false;
+                float noise = 0.f;  // accumulated first-order effect of the exponents' fp32 rounding on this pixel
                 for (uint32_t k = r0; k < r1; k++) {
                     contributor++;
                     const uint32_t g = st->point_list[k];
                     const float dx = st->means2D[2 * g] - pixfx, dy = st->means2D[2 * g + 1] - pixfy;
                     const float* co = &st->conic_opacity[4 * g];
-                    const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
-                    if (std::fabs(power) < 1e-6f) frag = true;
+                    const float power = pair_power(co, dx, dy);
+                    const float pn = pair_power_noise(co, dx, dy);
+                    if (std::fabs(power) < std::max(1e-6f, pn)) frag = true;
                     if (power > 0.0f) continue;
                     const float ea = co[3] * std::exp(power);
                     const float alpha = std::min(0.99f, ea);
                     if (std::fabs(alpha - 1.0f / 255.0f) < fragile_eps * (1.0f / 255.0f)) frag = true;
+                    // (... or the exponent is within its own rounding bound of the one at which alpha crosses 1/255)
+                    if (pn > 1e-5f && std::fabs(power - std::log(1.0f / (255.0f * co[3]))) < pn) frag = true;
                     if (alpha < 1.0f / 255.0f) continue;
                     const float test_T = T * (1 - alpha);
-                    if (std::fabs(test_T - 0.0001f) < fragile_eps * 0.0001f) frag = true;
+                    // (the stopping test moves with alpha: d test_T = T alpha pn)
+                    if (std::fabs(test_T - 0.0001f) < fragile_eps * 0.0001f + T * alpha * pn) frag = true;
                     if (test_T < 0.0001f) break;  // done = true (CR/forward.cu:353-357)
+                    if (ea < 0.99f) noise += alpha * T * pn;
                     for (int ch = 0; ch < 3; ch++) C[ch] += features[(size_t)g * 3 + ch] * alpha * T;
                     for (int ch = 0; ch < S; ch++) Cs[ch] += sc->semantics[(size_t)g * S + ch] * alpha * T;
                     D += st->depths[g] * alpha * T;
@@ -489,7 +522,7 @@ int goi_oracle_forward(const GoiOracleScene* sc, GoiOracleState* st, float* out_
                 for (int ch = 0; ch < S; ch++) out_semantic[ch * HW + pix_id] = Cs[ch];
                 out_alpha[pix_id] = 1 - T;
                 out_depth[pix_id] = D;
-                if (fragile) fragile[pix_id] = frag ? 1 : 0;
+                if (fragile) fragile[pix_id] = (uint8_t)((frag ? 1 : 0) | (noise > 2.5e-5f ? 2 : 0));
             }
     }
     return N;
@@ -660,7 +693,7 @@ int goi_oracle_backward(const GoiOracleScene* sc, const GoiOracleState* st, cons
                     const uint32_t g = st->point_list[k];
                     const float dx = st->means2D[2 * g] - pixfx, dy = st->means2D[2 * g + 1] - pixfy;
                     const float* co = &st->conic_opacity[4 * g];
-                    const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                    const float power = pair_power(co, dx, dy);
                     if (power > 0.0f) continue;
                     const float G = std::exp(power);
                     const float alpha = std::min(0.99f, co[3] * G);
@@ -883,7 +916,7 @@ int goi_oracle_trace(const GoiOracleScene* sc, GoiOracleState* st, const float* 
                     const uint32_t g = st->point_list[k];
                     const float dx = st->means2D[2 * g] - (float)px, dy = st->means2D[2 * g + 1] - (float)py;
                     const float* co = &st->conic_opacity[4 * g];
-                    const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                    const float power = pair_power(co, dx, dy);
                     if (power > 0.0f) continue;
                     const float alpha = std::min(0.99f, co[3] * std::exp(power));
                     if (alpha < 1.0f / 255.0f) continue;

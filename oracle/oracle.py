@@ -28,7 +28,7 @@ class _Scene(C.Structure):
 
 def build(force: bool = False) -> None:
     """Compile liboracle.so / liboracle_fma.so with the committed Makefile (g++ only)."""
-    if force or not all(os.path.exists(os.path.join(_HERE, n)) for n in ("liboracle.so", "libknn_oracle.so")):
+    if force or not all(os.path.exists(os.path.join(_HERE, n)) for n in ("liboracle.so", "liboracle_f64p.so", "libknn_oracle.so")):
         subprocess.check_call(["make", "-C", _HERE, "all"], stdout=subprocess.DEVNULL)
 
 
@@ -36,7 +36,7 @@ _libs: dict = {}
 
 
 def _lib(variant: str = ""):
-    name = "liboracle_fma.so" if variant == "fma" else "liboracle.so"
+    name = {"fma": "liboracle_fma.so", "f64power": "liboracle_f64p.so"}.get(variant, "liboracle.so")
     if name not in _libs:
         path = os.path.join(_HERE, name)
         if not os.path.exists(path):

@@ -231,7 +231,7 @@ def test_eight_ranks_allreduce_equals_sum_of_eight_single_view_gradients():
     _run(0, world=8)
 
 
-def _worker_factored(rank, world, port, q, in_flight=False):
+def _worker_factored(rank, world, port, q, in_flight=False, direct=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -260,11 +260,12 @@ def _worker_factored(rank, world, port, q, in_flight=False):
     means = torch.tensor(np.asarray(sc.means3D, np.float32))
     if in_flight:
         from goi_hyperplane_amd.dist import allreduce_gradients_sh_factored_async
-        h = allreduce_gradients_sh_factored_async(params, (dc, rest), means, factor, dist, reconstruct=sh_grad_from_views)
+        h = allreduce_gradients_sh_factored_async(params, (dc, rest), means, factor, dist, reconstruct=sh_grad_from_views,
+                                                  direct=direct)
         h.wait()
         dc.grad, rest.grad = h.sh_grads[id(dc)], h.sh_grads[id(rest)]
     else:
-        allreduce_gradients_sh_factored(params, (dc, rest), means, factor, dist, reconstruct=sh_grad_from_views)
+        allreduce_gradients_sh_factored(params, (dc, rest), means, factor, dist, reconstruct=sh_grad_from_views, direct=direct)
     q.put((rank, local, dsh.numpy(), [p.grad.numpy() for p in params],
            torch.cat([dc.grad, rest.grad], dim=1).numpy()))
     dist.barrier()
@@ -274,15 +275,15 @@ def _worker_factored(rank, world, port, q, in_flight=False):
 import pytest  # noqa: E402
 
 
-@pytest.mark.parametrize("in_flight", [False, True])
-def test_sh_factored_exchange_equals_sum_of_single_view_gradients(in_flight):
+@pytest.mark.parametrize("in_flight,direct", [(False, False), (True, False), (False, True), (True, True)])
+def test_sh_factored_exchange_equals_sum_of_single_view_gradients(in_flight, direct):
     """SURVEY.md 8(e) with the SH gradient exchanged as factors (all-gather of the masked colour gradients + local
     reconstruction): same sums as the plain all-reduce, on every rank; blocking and in-flight forms."""
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_factored, args=(r, world, port, q, in_flight)) for r in range(world)]
+    procs = [ctx.Process(target=_worker_factored, args=(r, world, port, q, in_flight, direct)) for r in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=120) for _ in range(world)]

@@ -1,0 +1,121 @@
+"""Does the default (split-bf16) flush of the backward cost accuracy against the exact-fp32 flush (bwd_variant 2)?
+
+    python tools/flush_soak.py <n configurations> <seed> [time budget s] [out.json]
+
+For every random configuration of the fuzz sweep (tests/test_gpu_fuzz.py::configs) the SAME frame is back-propagated with
+both flushes; per gradient tensor (relative to the tensor's scale in the oracle's result):
+    d_flush = |g_default - g_fp32flush|          spread = |oracle_plain - oracle_fma|  (two legal builds of the reference)
+    e_def / e_fp32 = error of either flush against the oracle.
+If d_flush <= spread the two flushes are indistinguishable at the reference's own noise level (and then
+e_def <= e_fp32 + spread against ANY yardstick, by the triangle inequality).  Where d_flush > spread on some tensor the
+float64 dense-autograd reference (tests/torch_reference.py) is evaluated as the yardstick and the criterion
+    e_def(float64) <= e_fp32(float64) + spread
+is checked directly.  Reports only ("flush_equivalence").  Test infrastructure: oracle/ is the checker."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from goi_hyperplane_amd import _lib
+from goi_hyperplane_amd.scene import make_camera, make_scene
+from oracle import oracle
+from tests.golden.make_golden import upstream_grads
+from tests.test_gpu_fuzz import configs
+from tests.test_gpu_parity import run_hip
+from tests.torch_reference import float64_gradients
+
+NAMES = ("means3D", "sh", "semantics", "opacity", "scales", "rotations", "means2D")
+
+
+def rel(a, b, scale):
+    return float(np.abs(np.asarray(a, np.float64).reshape(np.asarray(b).shape) - np.asarray(b, np.float64)).max() / scale)
+
+
+def main():
+    n, seed = int(sys.argv[1]), int(sys.argv[2])
+    budget = float(sys.argv[3]) if len(sys.argv) > 3 else 1e9
+    out_path = sys.argv[4] if len(sys.argv) > 4 else None
+    dev = torch.device("cuda:0")
+    t0 = time.time()
+    rows, f64_rows, skipped_f64 = [], [], 0
+    for (k, P, S, W, H, mu, deg, yaw, pitch) in configs(n, seed):
+        if time.time() - t0 > budget:
+            break
+        sc = make_scene(P, S=S, sh_degree=deg, seed=100 + k, log_scale_mean=mu)
+        cam = make_camera(W, H, yaw=yaw, pitch=pitch)
+        bg = np.random.default_rng(k).random(3).astype(np.float32)
+        grads = upstream_grads(S, H, W, seed=k)
+        o = oracle.from_scene(sc, cam, bg=bg)
+        o.forward()
+        g = o.backward(*grads)
+        o2 = oracle.from_scene(sc, cam, bg=bg, variant="fma")
+        o2.forward()
+        g2 = o2.backward(*grads)
+        res = {}
+        for v in (0, 2):
+            _lib.set_option("bwd_variant", v)
+            try:
+                res[v] = run_hip(sc, cam, bg, dev, grads=grads)["grads"]
+            finally:
+                _lib.set_option("bwd_variant", 0)
+        per = {}
+        need64 = False
+        for name in NAMES:
+            scale = float(np.abs(g[name]).max()) + 1e-30
+            d = dict(d_flush=rel(res[0][name], res[2][name], scale), spread=rel(g2[name], g[name], scale),
+                     e_def=rel(res[0][name], g[name], scale), e_fp32=rel(res[2][name], g[name], scale))
+            per[name] = d
+            need64 |= d["d_flush"] > d["spread"] and d["d_flush"] > 1e-7
+        row = dict(k=k, P=P, S=S, W=W, H=H, per=per, needs_float64=bool(need64))
+        if need64:
+            if P * W * H <= 4e7:
+                t64 = float64_gradients(sc, cam, bg, grads, deg)
+                viol = {}
+                for name in NAMES:
+                    scale = float(np.abs(g[name]).max()) + 1e-30
+                    t = np.asarray(t64[name]).reshape(np.asarray(g[name]).shape)
+                    e0, e2 = rel(res[0][name], t, scale), rel(res[2][name], t, scale)
+                    per[name].update(e_def_f64=e0, e_fp32_f64=e2, e_oracle_f64=rel(g[name], t, scale))
+                    if e0 > e2 + per[name]["spread"] + 1e-7:
+                        viol[name] = e0 - e2 - per[name]["spread"]
+                row["violations"] = viol
+                f64_rows.append(row)
+            else:
+                skipped_f64 += 1
+                row["float64"] = "skipped (too large for the dense reference)"
+        rows.append(row)
+    done = len(rows)
+    summ = {"configurations": done, "seed": seed, "seconds": round(time.time() - t0, 1)}
+    for name in NAMES:
+        dfl = np.array([r["per"][name]["d_flush"] for r in rows])
+        spr = np.array([r["per"][name]["spread"] for r in rows])
+        e0 = np.array([r["per"][name]["e_def"] for r in rows])
+        e2 = np.array([r["per"][name]["e_fp32"] for r in rows])
+        summ[name] = {"d_flush_median": float(np.median(dfl)), "d_flush_p99": float(np.quantile(dfl, 0.99)), "d_flush_max": float(dfl.max()),
+                      "spread_median": float(np.median(spr)), "frac_d_flush_le_spread": float((dfl <= np.maximum(spr, 1e-7)).mean()),
+                      "e_def_vs_oracle_median": float(np.median(e0)), "e_fp32_vs_oracle_median": float(np.median(e2)),
+                      "e_def_vs_oracle_max": float(e0.max()), "e_fp32_vs_oracle_max": float(e2.max()),
+                      "configs_where_default_is_worse_by_more_than_1e-4": int((e0 - e2 > 1e-4).sum()),
+                      "configs_where_fp32_is_worse_by_more_than_1e-4": int((e2 - e0 > 1e-4).sum())}
+    n_viol = sum(1 for r in f64_rows if r["violations"])
+    worst = max([max(r["violations"].values()) for r in f64_rows if r["violations"]] or [0.0])
+    summ["float64"] = {"evaluated": len(f64_rows), "skipped_too_large": skipped_f64,
+                       "configs_violating_e_def_le_e_fp32_plus_spread": n_viol, "largest_violation": worst,
+                       "violating": [dict(k=r["k"], P=r["P"], S=r["S"], W=r["W"], H=r["H"], violations=r["violations"])
+                                     for r in f64_rows if r["violations"]][:20]}
+    summ["criterion"] = ("per configuration and gradient tensor: |g_default - g_fp32flush| <= |oracle_plain - oracle_fma| (the "
+                         "flushes differ by less than two legal builds of the reference do), or else, against the float64 "
+                         "dense-autograd reference, err(default) <= err(fp32 flush) + that spread")
+    summ["equivalent"] = bool(n_viol == 0)
+    print(json.dumps(summ, indent=1))
+    if out_path:
+        with open(out_path, "w") as fh:
+            json.dump(summ, fh, indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,6 +1,6 @@
 # usage: tools/kstats.sh <python script> -- per-kernel average durations of our kernels (rocprofv3 --kernel-trace --stats)
 OUT=$GRAFT_REPO_ROOT/gpurun_out/ks; rm -rf $OUT; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ks -- python $GRAFT_REPO_ROOT/$1 > $OUT/log.txt 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ks -- python $GRAFT_REPO_ROOT/$1 ${@:2} > $OUT/log.txt 2>&1
 rm -f $OUT/*kernel_trace.csv
 python - <<PY
 import csv

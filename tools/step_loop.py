@@ -1,5 +1,5 @@
 """A plain loop of training steps on the headline workload (for rocprofv3 --kernel-trace --stats via tools/kstats.sh).
-usage: python tools/step_loop.py [steps]"""
+usage: python tools/step_loop.py [steps] [headline|clustered|closeup]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -7,11 +7,13 @@ from goi_hyperplane_amd.render import GaussianSet, PipelineParams, TorchCamera, 
 from goi_hyperplane_amd.scene import HEADLINE, make_camera, make_scene
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+name = sys.argv[2] if len(sys.argv) > 2 else "headline"  # headline | clustered | closeup (scene.make_workload)
 dev = torch.device("cuda:0")
-h = HEADLINE
-sc = make_scene(h["P"], S=h["S"], seed=0, extent=h["extent"], log_scale_mean=h["log_scale_mean"], log_scale_std=h["log_scale_std"])
+from goi_hyperplane_amd.scene import make_workload
+sc, _cam, h = make_workload(name)
 pc = GaussianSet.from_scene(sc, dev)
-cams = [TorchCamera(make_camera(h["W"], h["H"], fovx=h["fovx"], yaw=0.02 * (i - 8), pitch=0.01 * ((i * 7) % 5 - 2)), dev) for i in range(16)]
+cams = [TorchCamera(make_camera(h["W"], h["H"], fovx=h["fovx"], yaw=h.get("yaw", 0.0) + 0.02 * (i - 8),
+                                pitch=h.get("pitch", 0.0) + 0.01 * ((i * 7) % 5 - 2), distance=h.get("distance", 5.0)), dev) for i in range(16)]
 bg = torch.zeros(3, device=dev)
 gen = torch.Generator(device=dev).manual_seed(1234)
 inv = 1.0 / (h["W"] * h["H"])
