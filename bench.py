@@ -180,6 +180,9 @@ def main():
                          "'closeup' = config 5's shape (512x512 close-up of 3 M clustered Gaussians).  The default line also "
                          "carries the clustered scene as a secondary object (--no-clustered skips it)")
     ap.add_argument("--no-clustered", action="store_true", help="skip the secondary clustered-workload object")
+    ap.add_argument("--depth-cut", action="store_true",
+                    help="turn the opt-in speculative depth cut-off of the tile lists ON for the whole run (default: off, the "
+                         "package default; the default line reports the step with it as `value_with_depth_cut`)")
     ap.add_argument("--views-per-exchange", type=int, default=1,
                     help="--gpus > 1: every rank accumulates the gradients of this many views locally before one exchange "
                          "(an optimiser step per K x N views); 1 = one exchange per view, train.py's step semantics")
@@ -233,6 +236,8 @@ def main():
     from goi_hyperplane_amd import rasterizer
     if args.forward:
         rasterizer.set_forward_mode(speculative=args.forward == "speculative")
+    if args.depth_cut:
+        rasterizer.set_forward_mode(depth_cut=True)
     from goi_hyperplane_amd.dist import (allreduce_gradients, allreduce_gradients_async, allreduce_gradients_sh_factored,
                                          allreduce_gradients_sh_factored_async, allreduce_gradients_visible,
                                          exchange_model_ms)
@@ -373,6 +378,13 @@ def main():
     for i in range(args.warmup):
         step(i)
     drain()
+    # The steady state of a training run: every camera has been rendered before (an epoch ago), so its frames list, per tile,
+    # only what that earlier frame found worth listing (the speculative depth cut-off, _C._depth_cut_for).  Two untimed passes
+    # over the cameras put the run there: the first frames of a scene are exact, the next learn, the following ones are cut.
+    if _C._FWD["depth_cut"] and _C._FWD["mode"] == "speculative":
+        for i in range(2 * len(cams) + 4):
+            step(i)
+        drain()
     # workload statistics of the views this rank will time (outside the timed region).  N is SURVEY 8(d)'s instance
     # count -- every tile of every Gaussian's 3-sigma rectangle, what the reference lists and what the algorithmic
     # bytes are charged on (cull_variant 0); N_listed is what this build actually emits, sorts and walks.
@@ -417,12 +429,17 @@ def main():
     if timing:
         _lib.profile_collect()  # drop anything recorded so far
         _lib.profile_enable(True)
+        counts_seen = []
         for i in range(min(args.steps, 10)):
             step(args.warmup + i)
+            counts_seen.append(rasterizer.last_num_rendered())
         drain()
         barrier()
         _lib.profile_enable(False)
         stages = _lib.profile_collect()
+        stats["N_emitted"] = float(np.mean([int(c_) for c_ in counts_seen])) if counts_seen else None
+        stats["cut_frames_in_profile_pass"] = sum(1 for c_ in counts_seen if getattr(c_, "cut_key", None) is not None)
+        del counts_seen
         dominant = max(stages, key=lambda k: stages[k][0])
         # ... and, live over the timed region, events around the dominant kernel only.
         _lib.profile_stages([dominant])
@@ -636,6 +653,43 @@ def main():
         fp32_flush = {"views_per_s": nf * world / f_elapsed, "ms_per_step": f_elapsed / nf * 1e3, "steps": nf,
                       "what": "bwd_variant 2: per-Gaussian sums of the backward on v_mfma_f32_16x16x4_f32 (exact fp32 "
                               "products) instead of split-bf16 operands"}
+
+    # Secondary figure: the same step with the OPT-IN speculative depth cut-off of the tile lists (frames of a camera that was
+    # rendered before list, per tile, only what that earlier frame found worth listing): two untimed passes over the cameras
+    # (the first frames are exact, the next learn, the following ones are cut), then the timed steps.
+    with_cut = None
+    if not _C._FWD["depth_cut"] and _C._FWD["mode"] == "speculative":
+        rasterizer.set_forward_mode(depth_cut=True)
+        try:
+            for i in range(2 * len(cams) + 4):
+                step(i)
+            drain()
+            barrier()
+            sp_c0 = rasterizer.speculation_stats()
+            f0 = time.perf_counter()
+            nf = max(5, min(args.steps, 30))
+            seen_c = []
+            for i in range(nf):
+                step(args.warmup + i)
+                seen_c.append(rasterizer.last_num_rendered())
+            drain()
+            barrier()
+            wc_elapsed = time.perf_counter() - f0
+            sp_c1 = rasterizer.speculation_stats()
+            n_cut_mean = float(np.mean([int(c_) for c_ in seen_c]))
+            del seen_c
+        finally:
+            rasterizer.set_forward_mode(depth_cut=False)
+        if dist is not None:
+            tt = torch.tensor([wc_elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            wc_elapsed = float(tt.item())
+        with_cut = {"views_per_s": nf * world / wc_elapsed, "ms_per_step": wc_elapsed / nf * 1e3, "steps": nf,
+                    "N_emitted_per_view": n_cut_mean, "cut_frames": sp_c1["cut_frames"] - sp_c0["cut_frames"],
+                    "cut_failures": sp_c1["cut_failures"] - sp_c0["cut_failures"]}
+        for i in range(4):
+            step(i)
+        drain()
 
     # Secondary figure: one iteration of the reference's semantic stage (train.py:112-199) with this build's pieces at the
     # workload's size: render -> code-book losses (goi_codebook_fused) -> backward -> three fused Adam steps; only the semantic
@@ -885,6 +939,13 @@ def main():
             "workload_clustered": clustered,
             "semantic_finetune": sem_only,
             "value_fp32_flush": None if fp32_flush is None else fp32_flush["views_per_s"],
+            "value_with_depth_cut": None if with_cut is None else with_cut["views_per_s"],
+            "depth_cut": {"enabled_for_value": bool(_C._FWD["depth_cut"]), "opt_in_figure": with_cut,
+                          "N_emitted_per_view_in_profile_pass": stats.get("N_emitted"),
+                          "what": "OPT-IN (GOI_DEPTH_CUT=1): speculative training frames of a camera that was rendered before list, "
+                                  "per tile, only Gaussians up to the depth that camera's previous frame found worth listing (+1/8 + "
+                                  "32 list positions); bit-identical outputs, gradients equal up to one fp32 summation order while the "
+                                  "cut holds (tests/test_gpu_depth_cut.py), a redone or skipped view when it does not"},
             "semantic_train_iteration": train_iter,
             "value_two_views_in_flight": None if two_streams is None else two_streams["views_per_s"],
             "two_views_in_flight": two_streams,

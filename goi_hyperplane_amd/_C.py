@@ -212,17 +212,18 @@ _FWD = {"mode": _env_forward_mode(), "inference": _env_inference_mode(),
         "headroom": float(os.environ.get("GOI_BINNING_HEADROOM", "2.0")),
         "capacity": None, "on_overflow": os.environ.get("GOI_OVERFLOW", "warn").strip().lower(),
         "max_ahead": int(os.environ.get("GOI_MAX_AHEAD", "64")),
-        "min_history": int(os.environ.get("GOI_SPECULATE_AFTER", "3"))}
+        "min_history": int(os.environ.get("GOI_SPECULATE_AFTER", "3")),
+        "depth_cut": os.environ.get("GOI_DEPTH_CUT", "0").strip().lower() in ("1", "on", "true", "yes")}
 _SPEC = {}  # device index -> {"high_water": int, "P": int, "pending": deque of LazyCount}
 _SPEC_LOCK = threading.RLock()
 SPECULATION_STATS = {"exact_frames": 0, "speculative_frames": 0, "overflows": 0, "redone": 0, "waits": 0, "cached_frames": 0,
-                     "skipped_views": 0}
+                     "skipped_views": 0, "cut_frames": 0, "cut_failures": 0}
 _MIN_CAPACITY = 1 << 16
 _KEEP_WORKSPACES = 2  # pending frames per device whose workspaces stay alive for a possible redo
 
 
 def set_forward_mode(speculative=None, headroom=None, capacity="keep", on_overflow=None, max_ahead=None,
-                     inference_speculative=None, min_history=None):
+                     inference_speculative=None, min_history=None, depth_cut=None):
     """speculative: True / False (exact, the reference's synchronous forward) for frames a backward may follow.
     inference_speculative: the same for frames rendered without autograd (default False: exact).  headroom: capacity = headroom x the
     largest num_rendered seen on the device.  capacity: an int forces that capacity for every frame (tests), None returns
@@ -246,6 +247,10 @@ def set_forward_mode(speculative=None, headroom=None, capacity="keep", on_overfl
         _FWD["max_ahead"] = max(1, int(max_ahead))
     if min_history is not None:  # counts seen on a device (for the current scene) before frames are speculative
         _FWD["min_history"] = max(1, int(min_history))
+    if depth_cut is not None:  # speculative depth cut-off of the tile lists (see _depth_cut_for): False also forgets what was learnt
+        _FWD["depth_cut"] = bool(depth_cut)
+        if not depth_cut:
+            forget_depth_cuts()
 
 
 def _spec_state(dev):
@@ -268,19 +273,23 @@ def _tiles(H, W):
     return ((int(W) + 15) // 16) * ((int(H) + 15) // 16)
 
 
-def _note_count(dev, P, n, tiles=0):
+def _note_count(dev, P, n, tiles=0, cut=False):
     st = _spec_state(dev)
     if _other_scene(st, P, tiles):  # another scene / another image size: forget what the previous one needed
         st["high_water"] = 0
+        st["high_water_cut"] = 0
         st["seen"] = 0
     st["P"] = P
     if tiles:
         st["tiles"] = tiles
+    if cut:  # a frame whose lists were cut at its camera's learnt depths holds far fewer instances: its own high-water mark
+        st["high_water_cut"] = max(st.get("high_water_cut", 0), int(n))
+        return
     st["high_water"] = max(st["high_water"], int(n))
     st["seen"] = st.get("seen", 0) + 1
 
 
-def _pick_capacity(dev, P, debug, prefiltered, tiles=0):
+def _pick_capacity(dev, P, debug, prefiltered, tiles=0, cut=False):
     """Instances to size a speculative frame for, or None for an exact frame.  (prefiltered=True promises something the
     kernel checks and the reference traps on: that error must surface in THIS call, so such frames stay exact.)"""
     if (P == 0 or debug or prefiltered or _FWD["mode"] != "speculative"
@@ -293,6 +302,8 @@ def _pick_capacity(dev, P, debug, prefiltered, tiles=0):
     st = _spec_state(dev)
     if st["high_water"] <= 0 or _other_scene(st, P, tiles) or st.get("seen", 0) < _FWD["min_history"]:
         return None  # nothing (or too little) to go by yet: this frame is exact and teaches the policy
+    if cut and st.get("high_water_cut", 0) > 0:  # (the first cut frames of a scene are sized like uncut ones)
+        return max(_MIN_CAPACITY, int(_FWD["headroom"] * st["high_water_cut"]) + 4096)
     return max(_MIN_CAPACITY, int(_FWD["headroom"] * st["high_water"]) + 4096)
 
 
@@ -315,13 +326,17 @@ class LazyCount:
     and, if the frame overflowed its capacity, redoes it in place first."""
 
     __slots__ = ("dev", "ticket", "capacity", "layout", "binning", "overflowed", "redone", "_n", "_redo", "_stream",
-                 "_error", "P", "tiles", "_hold", "__weakref__")
+                 "_error", "P", "tiles", "_hold", "cut_key", "cam_key", "cut_failed", "_full_args", "__weakref__")
 
     def __init__(self, dev, ticket, capacity, binning, stream, redo, P, workspaces=None):
         self.dev, self.ticket, self.capacity, self.layout, self.binning = dev, ticket, capacity, capacity, binning
         self.overflowed = self.redone = False
         self._n, self._redo, self._stream, self._error, self.P = None, redo, stream, None, P
         self.tiles = 0  # (set by the caller: the image size is part of what the capacity policy compares)
+        self.cam_key = None      # key of this frame's camera in the depth-cut registry (its count is reported back there)
+        self.cut_key = None      # ... set iff the frame's lists were built with the camera's learnt depth cut
+        self.cut_failed = False  # ... and the cut turned out too tight for this frame
+        self._full_args = None   # the operator's arguments: what rendering the frame AGAIN without a cut needs
         # The frame's workspaces (geometry / image state, radii) are needed for a redo but belong to nobody once the
         # operator has returned under no_grad: the newest few pending frames of a device keep them alive (a caller who
         # reads the count does so right after the forward), older ones let go (a pending frame must not pin memory).
@@ -330,6 +345,7 @@ class LazyCount:
         pend.append(self)
         if len(pend) > _KEEP_WORKSPACES:
             pend[-1 - _KEEP_WORKSPACES]._hold = None
+            pend[-1 - _KEEP_WORKSPACES]._full_args = None
 
     @property
     def resolved(self):
@@ -348,9 +364,10 @@ class LazyCount:
             return True
         lib = _lib.load()
         n = C.c_int(0)
+        fl = C.c_uint(0)
         if wait:
             SPECULATION_STATS["waits"] += 1
-        r = lib.goi_raster_ticket_result(self.ticket, 1 if wait else 0, C.byref(n))
+        r = lib.goi_raster_ticket_result2(self.ticket, 1 if wait else 0, C.byref(n), C.byref(fl))
         if r == 0:
             return False
         self.ticket = None
@@ -364,7 +381,34 @@ class LazyCount:
             self._error = RuntimeError(_lib.last_error())
             raise self._error
         self._n = int(n.value)
-        _note_count(self.dev, self.P, self._n, getattr(self, "tiles", 0))
+        _note_count(self.dev, self.P, self._n, getattr(self, "tiles", 0), cut=self.cut_key is not None)
+        if self.cam_key is not None:
+            ce = _DEPTH_CUTS["entries"].get(self.cam_key)
+            if ce is not None:
+                ce["n"] = self._n  # (the camera's most recent count: sizes its next frame)
+        if (fl.value & 4) and self.cut_key is not None and self._n <= self.capacity:
+            # The depth cut this frame's lists were built with was TOO TIGHT: some pixel reached the end of a cut list
+            # unsaturated.  The device has already made the frame harmless (zero gradients); the camera forgets its cut.
+            self.cut_failed = True
+            SPECULATION_STATS["cut_failures"] += 1
+            _DEPTH_CUTS["entries"].pop(self.cut_key, None)
+            if lazy:
+                self._redo = self._hold = self._full_args = None
+                SPECULATION_STATS["skipped_views"] += 1
+                if not _DEPTH_CUTS.get("warned"):
+                    _DEPTH_CUTS["warned"] = True
+                    warnings.warn("goi_hyperplane_amd: a frame's speculative depth cut-off was too tight (the scene has moved since "
+                                  "its camera was rendered last) and nobody read num_rendered before using the frame: its "
+                                  "backward produced ZERO gradients (the view was skipped); the camera re-learns its cut on its "
+                                  "next visit.  GOI_DEPTH_CUT=0 / set_forward_mode(depth_cut=False) turns the cut-off off. "
+                                  "(Further occurrences are only counted: speculation_stats()['cut_failures'].)",
+                                  RasterOverflowWarning, stacklevel=3)
+            else:
+                try:
+                    self._render_again_uncut()
+                finally:
+                    self._redo = self._hold = self._full_args = None
+            return True
         if self._n > self.capacity:
             self.overflowed = True
             SPECULATION_STATS["overflows"] += 1
@@ -413,6 +457,46 @@ class LazyCount:
             raise RuntimeError(_lib.last_error())
         self.binning, self.layout, self.redone = binning, self._n, True
         SPECULATION_STATS["redone"] += 1
+
+    def _render_again_uncut(self):
+        """The frame once more, whole and exact (goi_raster_forward), into the same outputs and workspaces."""
+        lib = _lib.load()
+        if self._full_args is None or self._redo is None:
+            raise RasterOverflowError("a frame's depth cut-off was too tight and the frame cannot be rendered again: its inputs "
+                                      f"have been released (the count was read too late -- the last {_KEEP_WORKSPACES} frames of "
+                                      "a device keep theirs)")
+        _mk, refs = self._redo
+        live = [r() for r in refs]
+        if all(t is None for t in live[3:7]):
+            return
+        if any(t is None for t in live):
+            raise RasterOverflowError("a frame's depth cut-off was too tight and the frame cannot be rendered again: its "
+                                      "workspaces have already been released")
+        geom, img, radii, outs = live[0], live[1], live[2], live[3:7]
+        (background, means3D, colors, semantics, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+         projmatrix, tan_fovx, tan_fovy, H, W, sh, degree, campos, prefiltered, debug) = self._full_args
+        dev = self.dev
+        stream = torch.cuda.ExternalStream(self._stream, device=dev)
+        with torch.cuda.device(dev), torch.cuda.stream(stream):
+            ten = dict(bg=_prep(background, "background", dev), means3D=_prep(means3D, "means3D", dev), sh=_prep(sh, "sh", dev),
+                       colors=_prep(colors, "colors_precomp", dev), semantics=_prep(semantics, "semantics", dev),
+                       opacity=_prep(opacity, "opacities", dev), scales=_prep(scales, "scales", dev),
+                       rotations=_prep(rotations, "rotations", dev), cov3D=_prep(cov3D_precomp, "cov3D_precomp", dev),
+                       viewmatrix=_prep(viewmatrix, "viewmatrix", dev), projmatrix=_prep(projmatrix, "projmatrix", dev),
+                       campos=_prep(campos, "campos", dev))
+            sc = _scene(self.P, int(semantics.size(1)), int(H), int(W), ten["bg"], ten["means3D"], ten["sh"], ten["colors"],
+                        ten["semantics"], ten["opacity"], ten["scales"], ten["rotations"], scale_modifier, ten["cov3D"],
+                        ten["viewmatrix"], ten["projmatrix"], tan_fovx, tan_fovy, degree, ten["campos"], prefiltered, False)
+            alloc = _BinningAllocator(dev)
+            n = lib.goi_raster_forward(C.byref(sc), _ptr(geom), _ptr(img), alloc.cb, None, *[_ptr(o) for o in outs], _ptr(radii),
+                                       C.c_void_p(self._stream))
+        if alloc.error is not None:
+            raise alloc.error
+        if n < 0:
+            raise RuntimeError(_lib.last_error())
+        self.binning, self.layout, self.redone, self._n = alloc.tensor, int(n), True, int(n)
+        SPECULATION_STATS["redone"] += 1
+        _note_count(dev, self.P, int(n), getattr(self, "tiles", 0))
 
     def resolve(self) -> int:
         """Waits for the count; an overflowed frame is redone in place (exact outputs from here on)."""
@@ -507,6 +591,55 @@ def truncated_flag(accumulated: bool = False):
     if last is None or last[0] is None:
         return None
     return _flag_view(last[0], last[1])
+
+
+# ---- speculative depth cut-off of the tile lists (include/goi_raster.h, goi_raster_forward_async_cut) ----------------------------
+# On an opaque scene three quarters of the (tile, Gaussian) instances lie behind their tile's saturation front: emitted, sorted
+# and never looked at.  A training loop renders the same cameras epoch after epoch, so every speculative training frame LEARNS, per
+# tile, the depth up to which its list was worth listing (with a margin of a quarter + 64 list positions), and the next frame of
+# the same camera lists nothing deeper.  A frame whose pixels all saturate inside their cut lists is bit-identical to the uncut
+# one.  If the scene has moved so far that a pixel wants more than its cut list holds, the DEVICE notices (the forward blend raises
+# the frame's flag), the frame back-propagates zeros like a truncated one, and the host -- at its next poll, or at once if the
+# count is read before the frame is used -- renders it again without a cut / counts a skipped view and forgets the camera's cut.
+# Keyed like the geometry cache: by the identity and version of the camera's three tensors (kept alive by the entry), the image
+# and the Gaussian count.  OPT-IN (GOI_DEPTH_CUT=1 / set_forward_mode(depth_cut=True)): measured on the headline workload it lists
+# 1.90 M instead of 4.10 M instances per view but returns only 8 us of the 1451 us step (emit is bound by its
+# per-Gaussian gathers, not by the instances it writes; the per-tile depth lookups cost preprocess what the sorts gain).
+_DEPTH_CUTS = {"entries": collections.OrderedDict(), "max_entries": int(os.environ.get("GOI_DEPTH_CUT_CAMERAS", "4096"))}
+
+
+def forget_depth_cuts() -> None:
+    _DEPTH_CUTS["entries"].clear()
+
+
+def depth_cut_stats() -> dict:
+    return {"cameras": len(_DEPTH_CUTS["entries"]), "cut_frames": SPECULATION_STATS["cut_frames"],
+            "cut_failures": SPECULATION_STATS["cut_failures"]}
+
+
+def _depth_cut_for(dev, P, H, W, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, scale_modifier):
+    """-> (key, zcut_in or None, zcut_out, n_prev) for a speculative frame, or (None, None, None, 0) when the cut-off does not
+    apply.  n_prev: num_rendered of this camera's most recent frame whose count has arrived (0: none yet) -- what a cut frame's
+    binning capacity is sized from: a cut frame holds no more instances than the camera's last frame did, and the counts of
+    OTHER cameras (or of another scene of the same size) say nothing about it."""
+    if not _FWD["depth_cut"] or _lib.OPTIONS.get("cull_variant", 2) != 2:
+        return None, None, None, 0
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, int(P), int(H), int(W), float(tan_fovx), float(tan_fovy),
+           float(scale_modifier), _ident(viewmatrix), _ident(projmatrix), _ident(campos))
+    ents = _DEPTH_CUTS["entries"]
+    e = ents.get(key)
+    z_in = None
+    if e is not None:
+        ents.move_to_end(key)
+        z_in = e["z"]
+    n_prev = e.get("n", 0) if e is not None else 0
+    z_out = torch.empty(_tiles(H, W), dtype=torch.float32, device=dev)  # (cleared by the frame's first kernel)
+    # what this frame learns is the camera's cut from now on: the next frame of the camera runs behind this one on the same
+    # stream.  (A too-tight frame learns +inf for the tiles that failed: the array is conservative whatever became of the frame.)
+    ents[key] = {"z": z_out, "keyed": (viewmatrix, projmatrix, campos), "n": n_prev}
+    while len(ents) > _DEPTH_CUTS["max_entries"]:
+        ents.popitem(last=False)
+    return key, z_in, z_out, n_prev
 
 
 def _layout_of(R):
@@ -702,7 +835,12 @@ def _rasterize_gaussians_frame(background, means3D, colors, semantics, opacity, 
                 SPECULATION_STATS["exact_frames"] += 1
                 _note_count(dev, P, res[0], _tiles(H, W))
             return res
-        ticket, out_color, out_sem, out_depth, out_alpha, radii, geom, binning, img = ext.rasterize_gaussians_async(*args, cap)
+        cut_key, z_in, z_out, n_prev = _depth_cut_for(dev, P, H, W, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy,
+                                                      scale_modifier)
+        if z_in is not None and n_prev > 0 and _FWD["capacity"] is None:
+            cap = min(cap, max(_MIN_CAPACITY, int(_FWD["headroom"] * n_prev) + 4096))
+        ticket, out_color, out_sem, out_depth, out_alpha, radii, geom, binning, img = ext.rasterize_gaussians_async(
+            *args, cap, z_in, z_out)
         _note_frame(geom, P)
         SPECULATION_STATS["speculative_frames"] += 1
         refs = [weakref.ref(t) for t in (geom, img, radii, out_color, out_sem, out_depth, out_alpha)]
@@ -714,6 +852,12 @@ def _rasterize_gaussians_frame(background, means3D, colors, semantics, opacity, 
         n = LazyCount(dev, ticket, cap, binning, torch.cuda.current_stream(dev).cuda_stream, (make_scene, refs), P,
                       workspaces=(geom, img, radii))
         n.tiles = _tiles(H, W)
+        n.cam_key = cut_key
+        if z_in is not None:
+            n.cut_key = cut_key
+            n._full_args = (background, means3D, colors, semantics, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                            viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, sh, degree, campos, prefiltered, debug)
+            SPECULATION_STATS["cut_frames"] += 1
         return n, out_color, out_sem, out_depth, out_alpha, radii, geom, binning, img
     f32 = dict(dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
@@ -738,13 +882,18 @@ def _rasterize_gaussians_frame(background, means3D, colors, semantics, opacity, 
         cap = _pick_capacity(dev, P, debug, prefiltered, _tiles(H, W))
         if cap is not None:
             # speculative frame: everything is enqueued now, the count arrives through the ticket
+            cut_key, z_in, z_out, n_prev = _depth_cut_for(dev, P, H, W, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy,
+                                                          scale_modifier)
+            if z_in is not None and n_prev > 0 and _FWD["capacity"] is None:
+                cap = min(cap, max(_MIN_CAPACITY, int(_FWD["headroom"] * n_prev) + 4096))
             step = 16 << 20
             binning = torch.empty((int(lib.goi_raster_binning_bytes(cap)) + step - 1) // step * step, dtype=torch.uint8,
                                   device=dev)
             stream = torch.cuda.current_stream(dev).cuda_stream
             outs = (out_color, out_sem, out_depth, out_alpha)
-            ticket = lib.goi_raster_forward_async(C.byref(sc), _ptr(geom), _ptr(img), _ptr(binning), cap,
-                                                  *[_ptr(o) for o in outs], _ptr(radii), C.c_void_p(stream))
+            ticket = lib.goi_raster_forward_async_cut(C.byref(sc), _ptr(geom), _ptr(img), _ptr(binning), cap,
+                                                      *[_ptr(o) for o in outs], _ptr(radii), _ptr(z_in), _ptr(z_out),
+                                                      C.c_void_p(stream))
             if ticket < 0:
                 raise RuntimeError(_lib.last_error())
             SPECULATION_STATS["speculative_frames"] += 1
@@ -755,6 +904,13 @@ def _rasterize_gaussians_frame(background, means3D, colors, semantics, opacity, 
             keep = (ten["semantics"], ten["bg"])
             n = LazyCount(dev, ticket, cap, binning, stream, (lambda: (sc, keep), refs), P, workspaces=(geom, img, radii))
             n.tiles = _tiles(H, W)
+            n.cam_key = cut_key
+            if z_in is not None:
+                n.cut_key = cut_key
+                n._full_args = (background, means3D, colors, semantics, opacity, scales, rotations, scale_modifier,
+                                cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, sh, degree, campos, prefiltered,
+                                debug)
+                SPECULATION_STATS["cut_frames"] += 1
             return n, out_color, out_sem, out_depth, out_alpha, radii, geom, binning, img
         alloc = _BinningAllocator(dev)
         n = lib.goi_raster_forward(C.byref(sc), _ptr(geom), _ptr(img), alloc.cb, None, _ptr(out_color), _ptr(out_sem),

@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libgoi_raster.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 STAGES = ("preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges", "blend_fwd", "blend_bwd",
           "preprocess_bwd")
@@ -45,6 +45,9 @@ SYMBOLS = {
     "goi_raster_forward_async": (C.c_int, [C.POINTER(GoiRasterScene), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
                                  + [C.c_void_p] * 5 + [C.c_void_p]),
     "goi_raster_ticket_result": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "goi_raster_forward_async_cut": (C.c_int, [C.POINTER(GoiRasterScene), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+                                     + [C.c_void_p] * 5 + [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "goi_raster_ticket_result2": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_uint)]),
     "goi_raster_forward_redo": (C.c_int, [C.POINTER(GoiRasterScene), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
                                 + [C.c_void_p] * 5 + [C.c_void_p]),
     "goi_raster_forward_reblend": (C.c_int, [C.POINTER(GoiRasterScene), C.c_int] + [C.c_void_p] * 9),

@@ -169,7 +169,7 @@ void ticket_release(int id) {
 
 // wait != 0: block until the frame's counters have arrived.  Returns 1 (done: *n = num_rendered), 0 (not yet; only
 // when wait == 0) or -1 (error; the ticket is released).  A finished ticket is released.
-int ticket_result(int id, int wait, long long* n) {
+int ticket_result(int id, int wait, long long* n, unsigned* frame_flags = nullptr) {
     Ticket t;
     {
         std::lock_guard<std::mutex> lk(g_ticket_mu);
@@ -197,7 +197,8 @@ int ticket_result(int id, int wait, long long* n) {
         for (int i = 0; i < NR_STRIPES; i++) total += t.pinned[NR_BASE + NR_STRIDE * i];
     const bool filtered = t.pinned[1] != 0;
     // (a read-back queued behind the whole frame also carries the verdict of both sorts)
-    const bool missorted = t.head_only && (t.pinned[COUNTER_SORTERR] != 0 || (t.pinned[COUNTER_OVF] & 2u) != 0);
+    const bool missorted = t.head_only && (t.pinned[COUNTER_SORTERR] != 0 || (t.pinned[COUNTER_OVF] & OVF_MISSORTED) != 0);
+    if (frame_flags) *frame_flags = t.head_only ? t.pinned[COUNTER_OVF] : 0u;
     ticket_release(id);
     if (filtered) return fail("Point is filtered although prefiltered is set. This shouldn't happen!");
     if (missorted)
@@ -225,7 +226,7 @@ int enqueue_readback(const GeomView& g, int ticket, hipStream_t s, bool head_onl
 // ticket < 0: no read-back here (the speculative forward queues it behind the blend instead: nobody is waiting for it,
 // and a device-to-host copy in the middle of the frame costs the stream a ~10 us bubble)
 int enqueue_front(const GoiRasterScene& sc, GeomView& g, ImageView& im, int* radii, int ticket, const uint32_t** order_out,
-                  hipStream_t s) {
+                  hipStream_t s, const float* zcut = nullptr, uint32_t* zlearn = nullptr) {
     const int P = sc.P;
     const int gx = (sc.W + TILE - 1) / TILE, gy = (sc.H + TILE - 1) / TILE;
     // one memset: the counters and, right behind them, the control words of the depth sort
@@ -237,7 +238,7 @@ int enqueue_front(const GoiRasterScene& sc, GeomView& g, ImageView& im, int* rad
                                                  reinterpret_cast<char*>(g.counters))), s));
     {
         StageTimer t(GOI_STAGE_PREPROCESS, s);
-        launch_preprocess_fwd(sc, g, radii, im.ranges, gx * gy, s);  // also zeroes the tile ranges
+        launch_preprocess_fwd(sc, g, radii, im.ranges, gx * gy, s, zcut, zlearn);  // also zeroes the tile ranges
     }
     if (check_stage(sc, s, "preprocess")) return -1;
     if (ticket >= 0 && enqueue_readback(g, ticket, s)) return -1;
@@ -398,6 +399,10 @@ size_t bwd_scratch_layout(int N, int S, char* base, BwdScratchView* v) {
     BwdScratchView& b = v ? *v : tmp;
     carve(p, b.rows, n * (size_t)bwd_row_floats(S));
     carve(p, b.flags, n);
+    // big Gaussians (more than 1024 instances each): at most N / 1024 of them
+    b.cap_big = n / 4 / 1024 + 2;
+    carve(p, b.big_ctl, 8);
+    carve(p, b.big_desc, b.cap_big);
     return (size_t)(p - base) + 256;
 }
 
@@ -468,6 +473,13 @@ int goi_raster_forward(const GoiRasterScene* scene, void* geom_buffer, void* ima
 int goi_raster_forward_async(const GoiRasterScene* scene, void* geom_buffer, void* image_buffer, void* binning_buffer,
                              int capacity, float* out_color, float* out_semantic, float* out_depth, float* out_alpha,
                              int* radii, void* stream) {
+    return goi_raster_forward_async_cut(scene, geom_buffer, image_buffer, binning_buffer, capacity, out_color, out_semantic,
+                                        out_depth, out_alpha, radii, nullptr, nullptr, stream);
+}
+
+int goi_raster_forward_async_cut(const GoiRasterScene* scene, void* geom_buffer, void* image_buffer, void* binning_buffer,
+                                 int capacity, float* out_color, float* out_semantic, float* out_depth, float* out_alpha,
+                                 int* radii, const float* zcut_in, float* zcut_out, void* stream) {
     refresh_options();
     if (validate(scene, true)) return -1;
     const GoiRasterScene& sc = *scene;
@@ -487,14 +499,15 @@ int goi_raster_forward_async(const GoiRasterScene* scene, void* geom_buffer, voi
     if (ticket < 0) return -1;
     const uint32_t* order = nullptr;
     const uint32_t* plist = nullptr;
-    if (enqueue_front(sc, g, im, radii, /*ticket=*/-1, &order, s) ||
+    uint32_t* zlearn = reinterpret_cast<uint32_t*>(zcut_out);  // (positive floats: the kernels take their maximum as integers)
+    if (enqueue_front(sc, g, im, radii, /*ticket=*/-1, &order, s, zcut_in, zlearn) ||
         enqueue_back(sc, g, im, bv, capacity, /*exact=*/false, order, radii, &plist, s)) {
         ticket_release(ticket);
         return -1;
     }
     {
         StageTimer t(GOI_STAGE_BLEND_FWD, s);
-        launch_render_fwd(sc, g, im, plist, out_color, out_semantic, out_depth, out_alpha, s, bv.qmask);
+        launch_render_fwd(sc, g, im, plist, out_color, out_semantic, out_depth, out_alpha, s, bv.qmask, zcut_in, zlearn);
     }
     if (enqueue_readback(g, ticket, s, /*head_only=*/true)) {
         ticket_release(ticket);
@@ -508,9 +521,15 @@ int goi_raster_forward_async(const GoiRasterScene* scene, void* geom_buffer, voi
 }
 
 int goi_raster_ticket_result(int ticket, int wait, int* num_rendered) {
+    return goi_raster_ticket_result2(ticket, wait, num_rendered, nullptr);
+}
+
+int goi_raster_ticket_result2(int ticket, int wait, int* num_rendered, unsigned* frame_flags) {
     long long n = 0;
-    const int r = ticket_result(ticket, wait, &n);
+    unsigned fl = 0;
+    const int r = ticket_result(ticket, wait, &n, &fl);
     if (r == 1 && num_rendered) *num_rendered = (int)n;
+    if (r == 1 && frame_flags) *frame_flags = fl;
     return r;
 }
 
@@ -643,8 +662,10 @@ int goi_raster_backward(const GoiRasterScene* scene, int R, const void* geom_buf
                 // the validity bytes of the slots this frame can use are cleared by extra workgroups of the quadrant-order
                 // launch (count on the device: 4 x num_rendered bytes, not 4 x capacity) -- or by a memset where that
                 // launch does not exist
-                if (!launch_quad_order(sc, im, s, scr.flags, g.counters + COUNTER_N, (uint32_t)R))
+                if (!launch_quad_order(sc, im, s, scr.flags, g.counters + COUNTER_N, (uint32_t)R, scr.big_ctl)) {
                     GOI_HIP(hipMemsetAsync(scr.flags, 0, round_up_256((size_t)R * 4), s));  // (the layout ends with 256 spare bytes)
+                    GOI_HIP(hipMemsetAsync(scr.big_ctl, 0, 8 * sizeof(uint32_t), s));
+                }
                 launch_render_bwd_rows(sc, g, im, bv.vals[fin], radii, out_alpha, dL_dout_color, dL_dout_semantic,
                                        dL_dout_depth, dL_dout_alpha, scr, s, bv.qmask);
             }
@@ -709,15 +730,17 @@ int goi_raster_backward_semantics(const GoiRasterScene* scene, int R, const void
     {
         StageTimer t(GOI_STAGE_BLEND_BWD, s);
         if (R > 0) {
-            if (!launch_quad_order(sc, im, s, scr.flags, g.counters + COUNTER_N, (uint32_t)R))
+            if (!launch_quad_order(sc, im, s, scr.flags, g.counters + COUNTER_N, (uint32_t)R, scr.big_ctl)) {
                 GOI_HIP(hipMemsetAsync(scr.flags, 0, round_up_256((size_t)R * 4), s));  // (the layout ends with 256 spare bytes)
+                GOI_HIP(hipMemsetAsync(scr.big_ctl, 0, 8 * sizeof(uint32_t), s));
+            }
             launch_render_bwd_sem(sc, g, im, bv.vals[fin], radii, out_alpha, dL_dout_semantic, scr.rows, scr.flags,
                                   row_floats, s);
         }
     }
     if (check_stage(sc, s, "backward blend (semantics)")) return -1;
     StageTimer t(GOI_STAGE_PREPROCESS_BWD, s);
-    launch_reduce_sem_rows(sc, g, R, scr.rows, scr.flags, row_floats, dL_dsemantic, s);
+    launch_reduce_sem_rows(sc, g, R, scr, row_floats, dL_dsemantic, s);
     GOI_HIP(hipGetLastError());
     return 0;
 }

@@ -60,6 +60,10 @@ inline int bwd_row_floats(int S) { return ((4 * ((S + 3) / 4) + 4 + 6 + 15) / 16
 struct BwdScratchView {
     float* rows;     // [4N][bwd_row_floats(S)]: slot = (emit-order instance) * 4 + quadrant
     uint8_t* flags;  // [4N] validity bytes
+    // Gaussians with more than 1024 instances get a workgroup of their own (reduce_rows.hip, "BIG Gaussians"):
+    uint32_t* big_ctl;  // [8]: word 1 = big Gaussians registered (zeroed with the validity bytes)
+    uint4* big_desc;    // [cap_big] (first instance, instances, -, Gaussian id)
+    size_t cap_big;
 };
 size_t bwd_scratch_layout(int N, int S, char* base, BwdScratchView* v);
 
@@ -138,7 +142,7 @@ uint32_t* radix_sort_ghist(uint32_t* scratch, size_t n, int lo, int hi);
 
 // ---- stages ---------------------------------------------------------------------------------------
 void launch_preprocess_fwd(const GoiRasterScene& sc, const GeomView& g, int* radii, uint2* ranges, int n_tiles,
-                           hipStream_t s);
+                           hipStream_t s, const float* zcut = nullptr, uint32_t* zlearn = nullptr);
 // Listed Gaussians (tiles_touched > 0) compacted in id order into sort_keys[0] / sort_vals[0] (the depth sort's input),
 // counters[COUNTER_V / COUNTER_N], and -- ghist != NULL -- the four digit histograms of the compacted keys (the onesweep
 // sort's prologue).  pad: entries [V, P) get key 0xFFFFFFFF (a sort
@@ -153,18 +157,20 @@ void launch_emit_counting(int P, int W, int H, const GeomView& g, const uint32_t
                           uint32_t* vals, uint2* ranges, uint32_t* clear, size_t clear_words, uint32_t cap, hipStream_t s);
 void launch_tile_ranges_hist(int W, int H, uint2* ranges, uint32_t* ghist, hipStream_t s);
 void launch_ranges(int N, const uint32_t* n_dev, const uint32_t* sorted_keys, uint2* ranges, int T, hipStream_t s);
+// zcut / zlearn: the speculative depth cut-off (goi_raster_forward_async_cut): per tile, the cut this frame's lists were built
+// with (or NULL) and what the frame learns for the camera's next visit (float bits, max over the tile's quadrants; or NULL)
 void launch_render_fwd(const GoiRasterScene& sc, const GeomView& g, const ImageView& im, const uint32_t* point_list,
                        float* out_color, float* out_sem, float* out_depth, float* out_alpha, hipStream_t s,
-                       unsigned long long* qmask = nullptr);
+                       unsigned long long* qmask = nullptr, const float* zcut = nullptr, uint32_t* zlearn = nullptr);
 void launch_trace_fwd(const GoiRasterScene& sc, const float* img_sem, const GeomView& g, const ImageView& im,
                       const uint32_t* point_list, float* out_color, float* gau_sem, int* num_gsem, hipStream_t s);
 // launch order of the backward's quadrant waves (render_bwd.hip): im.qcost -> im.qorder
 bool quad_order_enabled(int W, int H);
 // clear_flags != NULL: extra workgroups of the same launch zero the first 4 * min(*n_dev, cap) validity bytes of the backward
-// scratch (what a memset of 4 * cap bytes did).  Returns false -- nothing launched, nothing cleared -- where the quadrant
+// scratch (what a memset of 4 * cap bytes did) and the 8 control words at clear_ctl (BwdScratchView::big_ctl).  Returns false -- nothing launched, nothing cleared -- where the quadrant
 // order is not used (quad_order_enabled).
 bool launch_quad_order(const GoiRasterScene& sc, const ImageView& im, hipStream_t s, uint8_t* clear_flags = nullptr,
-                       const uint32_t* n_dev = nullptr, uint32_t cap = 0);
+                       const uint32_t* n_dev = nullptr, uint32_t cap = 0, uint32_t* clear_ctl = nullptr);
 // atomic-free backward blend: partial rows + flags into the scratch (render_bwd.hip)
 void launch_render_bwd_rows(const GoiRasterScene& sc, const GeomView& g, const ImageView& im,
                             const uint32_t* point_list, const int* radii, const float* out_alpha, const float* dL_dpix,
@@ -174,8 +180,8 @@ void launch_render_bwd_rows(const GoiRasterScene& sc, const GeomView& g, const I
 void launch_render_bwd_sem(const GoiRasterScene& sc, const GeomView& g, const ImageView& im, const uint32_t* point_list,
                            const int* radii, const float* out_alpha, const float* dL_dsem, float* rows, uint8_t* flags,
                            int row_floats, hipStream_t s);
-void launch_reduce_sem_rows(const GoiRasterScene& sc, const GeomView& g, int N, const float* rows, const uint8_t* flags,
-                            int row_floats, float* dL_dsemantic, hipStream_t s);
+void launch_reduce_sem_rows(const GoiRasterScene& sc, const GeomView& g, int N, const BwdScratchView& scr, int row_floats,
+                            float* dL_dsemantic, hipStream_t s);
 // sums every Gaussian's partial rows (fixed order) into the six blend-gradient arrays (writes all P rows) -- or, `records`,
 // into one record per listed Gaussian, left in the row scratch over the Gaussian's first slot (the arrays may be NULL then)
 void launch_reduce_rows(const GoiRasterScene& sc, const GeomView& g, int N, const BwdScratchView& scr, float* dL_dmean2D,
@@ -294,6 +300,7 @@ constexpr int COUNTER_OVF = 4;   // 1: this frame's instance list was TRUNCATED 
                                  // ZERO gradients: a truncated frame must never reach the optimiser (the reference sizes its
                                  // buffers from the true count, CR/rasterizer_impl.cu:283-289, and cannot truncate)
 
+constexpr uint32_t OVF_TRUNCATED = 1u, OVF_MISSORTED = 2u, OVF_CUT_TOO_TIGHT = 4u;  // bits of counters[COUNTER_OVF]
 constexpr int COUNTER_SORTERR = 6;  // != 0: a look-back of the DEPTH sort timed out (scan_sort.hip): emit folds it into
                                     // COUNTER_OVF (the tile sort, which runs behind emit, sets bit 1 of COUNTER_OVF itself), so
                                     // a mis-sorted frame back-propagates zeros like a truncated one, and the read-back fails

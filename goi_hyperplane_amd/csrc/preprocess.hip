@@ -64,6 +64,11 @@ struct PreArgs {
     const float* view_p;    // device, [16]
     const float* proj_p;    // device, [16]
     const float* campos_p;  // device, [3]
+    // speculative depth cut-off of the tile lists (api.hip, goi_raster_forward_async_cut): zcut[t] = view depth beyond which
+    // tile t's list was never walked when this camera was rendered last (NULL: no cut); zlearn[t]: what this frame learns
+    // (cleared here, written by the forward blend)
+    const float* zcut;
+    uint32_t* zlearn;
 };
 
 // The camera arrays are tiny, uniform device arrays: every thread reads them through the scalar
@@ -94,6 +99,8 @@ __global__ __launch_bounds__(256) void preprocess_fwd_k(const PreArgs args, Gaus
     const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
     // the tile ranges start from zero (emit accumulates per-tile counts into them): cleared here for free
     for (int t = gtid; t < n_tiles; t += gridDim.x * blockDim.x) ranges[t] = make_uint2(0u, 0u);
+    if (args.zlearn)
+        for (int t = gtid; t < n_tiles; t += gridDim.x * blockDim.x) args.zlearn[t] = 0u;
     if (gtid == 0) counters[COUNTER_CULL] = (uint32_t)args.cull;  // emit and the backward list the same rectangles
     // every lane reaches the wave reduction at the end: lanes past P redo the last Gaussian and write nothing
     const bool live = gtid < args.P;
@@ -257,6 +264,30 @@ __global__ __launch_bounds__(256) void preprocess_fwd_k(const PreArgs args, Gaus
                 c0 = max(c0, x0);
                 c1 = min(c1, x1);
                 if (c1 > c0) mask |= ((c1 - c0 >= 64) ? ~0ull : ((1ull << (c1 - c0)) - 1ull)) << (ry * w + (c0 - x0));
+            }
+            // speculative depth cut-off: a tile whose list was not needed beyond depth zcut[t] the last time this camera was
+            // rendered does not list a deeper Gaussian (the forward blend raises the frame's flag if a pixel of such a tile
+            // turns out to want more: api.hip).  Eight tiles per trip, their cut depths requested together (one load round
+            // trip for the typical 3 x 3 rectangle; tile by tile this loop cost the kernel 28 us).
+            if (a.zcut) {
+                unsigned long long todo = mask;
+                while (todo) {
+                    int bits[8];
+                    float zc[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        bits[i] = todo ? __builtin_ctzll(todo) : -1;
+                        if (todo) todo &= todo - 1;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const int bsafe = max(bits[i], 0);
+                        zc[i] = a.zcut[(size_t)(y0 + bsafe / w) * a.gx + (x0 + bsafe % w)];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; i++)
+                        if (bits[i] >= 0 && zc[i] < p_view.z) mask &= ~(1ull << bits[i]);
+                }
             }
             tmask_v = mask;
             touched = (uint32_t)__popcll(mask);
@@ -727,8 +758,10 @@ __global__ __launch_bounds__(256) void mark_visible_k(int P, const float* __rest
 }  // namespace
 
 void launch_preprocess_fwd(const GoiRasterScene& sc, const GeomView& g, int* radii, uint2* ranges, int n_tiles,
-                           hipStream_t s) {
+                           hipStream_t s, const float* zcut, uint32_t* zlearn) {
     PreArgs a;
+    a.zcut = g_options.cull_variant >= 2 ? zcut : nullptr;  // (the cut lives in the ellipse tile masks)
+    a.zlearn = zlearn;
     a.P = sc.P; a.D = sc.D; a.M = sc.M; a.W = sc.W; a.H = sc.H;
     a.gx = (sc.W + TILE - 1) / TILE;
     a.gy = (sc.H + TILE - 1) / TILE;

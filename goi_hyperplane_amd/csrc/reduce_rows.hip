@@ -2,6 +2,7 @@
 // (emit-order instance, quadrant) into one record (or six per-id arrays) per Gaussian, in a fixed order.  Pure additions:
 // compiled with the default flags (it used to sit in preprocess.hip under -ffp-contract=off for no reason).
 // Reference: the float atomicAdd accumulation of cuda_rasterizer/backward.cu:565-621, which this replaces.
+#include <algorithm>
 #include <type_traits>
 
 #include "common.h"
@@ -30,20 +31,164 @@ namespace {
 // preprocess_bwd_k, which runs over the ids anyway, fetches the line through goff[] and writes every per-id output itself,
 // coalesced.  Measured on the headline view before it was built (timing builds): the zero phase 21 us, the scattered
 // stores 40 us of the kernel's 213; a dense 128-byte store instead 8 us.
+#ifndef GOI_REDUCE_INFLIGHT
+#define GOI_REDUCE_INFLIGHT 32
+#endif
+
+// BIG Gaussians.  A quarter wave sums ITS Gaussian's rows one trip after the other; a frame-filling blob or a long needle
+// of a reconstructed scene owns thousands of slots and ten thousand rows (clustered workload: 20 blobs x 6600 tiles, needles
+// with whole-frame rectangles), and ONE quarter wave working through them kept this kernel running for 1.2 ms while the chip
+// idled.  A Gaussian with more than BIG_INST instances is therefore not summed here: its quarter wave registers it (a
+// descriptor in the scratch, slots handed out by an atomic counter), and reduce_big_k gives it a whole WORKGROUP: the sixteen
+// quarter waves sum sixteen contiguous parts of its slot range (same walk, same order inside a part), the partial rows meet
+// in LDS and are added in part order.  Which path a Gaussian takes depends on its instance count alone and every order is
+// fixed: bit-reproducible as before.  (The counter is zeroed with the validity bytes: quad_order_k's extra workgroups, or a
+// memset.  A frame without big Gaussians -- the headline scene has none -- pays one launch that finds nothing to do.)
+constexpr uint32_t BIG_INST = 1024;
+
+// Sums the rows of `cnt` consecutive instances starting at instance `inst0` (their validity words at flags32[inst0 ..]) into
+// sum[] -- the lane's elements of the row -- in slot order.  Wave-synchronous: the four quarter waves of a wave call it
+// together, each for its own (inst0, cnt); w_first = the validity word of instance inst0 + e (prefetched by the caller).
+template <int K>
+__device__ __forceinline__ void sum_instances(const float* __restrict__ rows, const uint32_t* __restrict__ flags32,
+                                              size_t inst0, uint32_t cnt, uint32_t w_first, int quarter, int e,
+                                              float (&sum)[K]) {
+    constexpr int RF = 16 * K;
+    constexpr int INFLIGHT = GOI_REDUCE_INFLIGHT;
+    auto load_flags = [&](uint32_t c) { return (c + e < cnt) ? flags32[inst0 + c + e] : 0u; };
+    // every lane of the wave must reach the ballots: loop to the wave's largest count
+    uint32_t cmax = cnt;
+#pragma unroll
+    for (int d = 32; d >= 16; d >>= 1) cmax = max(cmax, (uint32_t)__shfl_xor((int)cmax, d, 64));
+    // The instances are looked at 64 at a time: four validity words per lane, requested together (and the next 64 under this
+    // block's rows), and a 16-instance chunk in which no quarter of the wave has a row is skipped on one ballot.
+    uint32_t wq[4] = {w_first, 0u, 0u, 0u};
+    if (cmax > 16) {
+#pragma unroll
+        for (int sblk = 1; sblk < 4; sblk++) wq[sblk] = load_flags(16u * sblk);
+    }
+    for (uint32_t c = 0; c < cmax; c += 64) {
+        uint32_t wn[4] = {0u, 0u, 0u, 0u};
+        if (c + 64 < cmax) {
+#pragma unroll
+            for (int sblk = 0; sblk < 4; sblk++) wn[sblk] = load_flags(c + 64 + 16u * sblk);
+        }
+#pragma unroll 1
+        for (int sblk = 0; sblk < 4; sblk++) {  // (not unrolled: the queue is rotated instead of indexed)
+            const uint32_t cc = c + 16u * sblk;
+            if (cc >= cmax) break;                  // (wave-uniform)
+            const uint32_t w = wq[0];               // 4 quadrant bytes of instance cc+e
+            wq[0] = wq[1];
+            wq[1] = wq[2];
+            wq[2] = wq[3];
+            if (__ballot(w != 0u) == 0) continue;   // (wave-uniform) no quarter has a row in this chunk
+            unsigned long long m = 0;  // bit 16q + i: quadrant q of instance cc+i is valid
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const unsigned long long bal = __ballot(((w >> (8 * q)) & 0xFFu) != 0);
+                m |= ((bal >> (16 * quarter)) & 0xFFFFull) << (16 * q);
+            }
+            const float* chunk = rows + (inst0 + cc) * 4 * RF;
+            // NF rows requested back to back, then added in slot order (absent slots add +0: the sums do not depend on
+            // NF).  Most Gaussians own a handful of rows -- 6 on average, half of them at most 4 -- and the 16-slot trip
+            // costs ~160 vector instructions whatever it finds (the kernel issued 60 M of them: 44 % VALU-busy on top
+            // of its memory waits): when no quarter of the wave has more than 4 rows left, a 4-slot trip does.
+            auto trip = [&](auto nf_c) {
+                constexpr int NF = decltype(nf_c)::value;
+                float v[NF][K];
+#pragma unroll
+                for (int i = 0; i < NF; i++) {
+                    const bool have = m != 0;
+                    const int bit = have ? __builtin_ctzll(m) : 0;
+                    if (have) m &= m - 1;
+                    const float* r = chunk + (size_t)((bit & 15) * 4 + (bit >> 4)) * RF;
+                    if (K == 2) {  // one 8-byte load per lane: the quarter wave reads the 128-byte row in one request
+                        const float2 t = have ? reinterpret_cast<const float2*>(r)[e] : make_float2(0.f, 0.f);
+                        v[i][0] = t.x;
+                        v[i][K - 1] = t.y;
+                    } else {
+#pragma unroll
+                        for (int kk = 0; kk < K; kk++) v[i][kk] = have ? r[e + 16 * kk] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < NF; i++)
+#pragma unroll
+                    for (int kk = 0; kk < K; kk++) sum[kk] += v[i][kk];
+            };
+            int left = __popcll(m);  // rows this quarter still has to fetch; the wave's largest decides the trip
+#pragma unroll
+            for (int d = 32; d >= 16; d >>= 1) left = max(left, __shfl_xor(left, d, 64));
+            left = __builtin_amdgcn_readfirstlane(left);
+            while (left > 0) {
+                if (left <= 4) {
+                    trip(std::integral_constant<int, 4>{});
+                    left -= 4;
+                } else if (left <= 12) {
+                    trip(std::integral_constant<int, 12>{});
+                    left -= 12;
+                } else {
+                    trip(std::integral_constant<int, INFLIGHT>{});
+                    left -= INFLIGHT;
+                }
+            }
+        }
+#pragma unroll
+        for (int sblk = 0; sblk < 4; sblk++) wq[sblk] = wn[sblk];
+    }
+}
+
+struct ReduceOut {
+    float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dsemantic, *dL_ddepth;
+};
+
+// What a Gaussian's summed row turns into: its RECORD (back into the row scratch, over the first slot it owns), or the six
+// per-id arrays.  Lane e of the quarter wave holds elements 2e, 2e+1 (K == 2) or e, e + 16, .. of the row.
+template <int K, bool RECORD>
+__device__ __forceinline__ void store_sums(const float (&sum)[K], float* rows, size_t inst0, uint32_t g, int e, int S, int nch,
+                                           const ReduceOut& o) {
+    constexpr int RF = 16 * K;
+    if constexpr (RECORD) {
+        float* dst = rows + inst0 * 4 * RF;  // (the row elements this lane summed, back where it read them)
+        if (K == 2) {
+            reinterpret_cast<float2*>(dst)[e] = make_float2(sum[0], sum[K - 1]);
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < K; kk++) dst[e + 16 * kk] = sum[kk];
+        }
+    } else {
+        const int nsem = nch - 4;
+#pragma unroll
+        for (int kk = 0; kk < K; kk++) {
+            const float v = sum[kk];
+            const int el = K == 2 ? 2 * e + kk : e + 16 * kk;  // element of the row this lane summed
+            if (el < nsem) {
+                if (el < S) o.dL_dsemantic[(size_t)g * S + el] = v;
+            } else if (el < nsem + 3) {
+                o.dL_dcolor[(size_t)g * 3 + (el - nsem)] = v;
+            } else if (el == nsem + 3) {
+                o.dL_ddepth[g] = v;
+            } else if (el < nch + 2) {
+                o.dL_dmean2D[(size_t)g * 3 + (el - nch)] = v;
+                if (el == nch + 1) o.dL_dmean2D[(size_t)g * 3 + 2] = 0.f;
+            } else if (el < nch + 5) {
+                const int c = el - nch - 2;  // a, b, c -> x, y, w of the [P,2,2] conic gradient
+                o.dL_dconic[(size_t)g * 4 + (c == 2 ? 3 : c)] = v;
+                if (c == 2) o.dL_dconic[(size_t)g * 4 + 2] = 0.f;
+            } else if (el == nch + 5) {
+                o.dL_dopacity[g] = v;
+            }
+        }
+    }
+}
+
 template <int K, int GPQ, bool RECORD>  // K = row_floats / 16; GPQ = Gaussians per quarter wave
 __global__ __launch_bounds__(256) void reduce_rows_k(int P, int S, int nch, uint32_t N_cap, const uint32_t* __restrict__ n_dev,
                                                      const uint32_t* __restrict__ order,
                                                      const uint32_t* __restrict__ offsets,
                                                      const uint32_t* __restrict__ tiles_touched,
-                                                     float* rows, const uint8_t* __restrict__ flags,
-                                                     float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic,
-                                                     float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor,
-                                                     float* __restrict__ dL_dsemantic, float* __restrict__ dL_ddepth) {
-    constexpr int RF = 16 * K;
-#ifndef GOI_REDUCE_INFLIGHT
-#define GOI_REDUCE_INFLIGHT 32
-#endif
-    constexpr int INFLIGHT = GOI_REDUCE_INFLIGHT;
+                                                     float* rows, const uint8_t* __restrict__ flags, ReduceOut out,
+                                                     uint32_t* __restrict__ big_ctl, uint4* __restrict__ big_desc) {
     // N_cap: the slot capacity the scratch was laid out for; n_dev: the forward's instance count on the device (the
     // exact forward passes N_cap = num_rendered; the speculative one a capacity, and an overflowed frame stored only
     // the first N_cap instances)
@@ -53,7 +198,6 @@ __global__ __launch_bounds__(256) void reduce_rows_k(int P, int S, int nch, uint
     const int V = truncated ? 0 : (int)n_dev[COUNTER_V - COUNTER_N];  // listed Gaussians: the only ones that own rows
     const int lane = threadIdx.x & 63, quarter = lane >> 4, e = lane & 15;
     const uint32_t* flags32 = reinterpret_cast<const uint32_t*>(flags);
-    const int nsem = nch - 4;
     // ---- phase 0 (the first ceil(P/256) workgroups): zeros for the Gaussians that are NOT listed (culled, or a culled
     // rectangle without tiles; all of them for a truncated frame) -- one Gaussian per lane.  The listed ones are written
     // by phase 1 below, so every element of the six arrays is written exactly once.
@@ -61,18 +205,18 @@ __global__ __launch_bounds__(256) void reduce_rows_k(int P, int S, int nch, uint
         const int i = blockIdx.x * 256 + threadIdx.x;
         if (i < P && (truncated || tiles_touched[i] == 0)) {
             if ((S & 3) == 0) {
-                float4* d4 = reinterpret_cast<float4*>(dL_dsemantic + (size_t)i * S);
+                float4* d4 = reinterpret_cast<float4*>(out.dL_dsemantic + (size_t)i * S);
                 for (int ch = 0; ch < S / 4; ch++) d4[ch] = make_float4(0.f, 0.f, 0.f, 0.f);
             } else {
-                for (int ch = 0; ch < S; ch++) dL_dsemantic[(size_t)i * S + ch] = 0.f;
+                for (int ch = 0; ch < S; ch++) out.dL_dsemantic[(size_t)i * S + ch] = 0.f;
             }
-            if (dL_dopacity) {  // (NULL in the feature-gradient-only reduction)
-                dL_dopacity[i] = 0.f;
-                dL_ddepth[i] = 0.f;
+            if (out.dL_dopacity) {  // (NULL in the feature-gradient-only reduction)
+                out.dL_dopacity[i] = 0.f;
+                out.dL_ddepth[i] = 0.f;
 #pragma unroll
-                for (int k = 0; k < 3; k++) dL_dcolor[(size_t)i * 3 + k] = dL_dmean2D[(size_t)i * 3 + k] = 0.f;
+                for (int k = 0; k < 3; k++) out.dL_dcolor[(size_t)i * 3 + k] = out.dL_dmean2D[(size_t)i * 3 + k] = 0.f;
 #pragma unroll
-                for (int k = 0; k < 4; k++) dL_dconic[(size_t)i * 4 + k] = 0.f;
+                for (int k = 0; k < 4; k++) out.dL_dconic[(size_t)i * 4 + k] = 0.f;
             }
         }
     }
@@ -100,142 +244,73 @@ __global__ __launch_bounds__(256) void reduce_rows_k(int P, int S, int nch, uint
         }
         return m;
     };
-    // the 4 quadrant bytes of instance off0 + c + e (first chunk of a Gaussian: c = 0)
-    auto load_flags = [&](const Meta& m, uint32_t c) { return (c + e < m.off1 - m.off0) ? flags32[m.off0 + c + e] : 0u; };
+    // the 4 quadrant bytes of instance off0 + e (the first chunk of a Gaussian; a BIG one is not walked here)
+    auto load_first = [&](const Meta& m) {
+        const uint32_t c = m.off1 - m.off0;
+        return (c <= BIG_INST && (uint32_t)e < c) ? flags32[m.off0 + e] : 0u;
+    };
 
     Meta cur = load_meta(0), nxt = load_meta(1);
-    uint32_t w_cur = load_flags(cur, 0);
+    uint32_t w_cur = load_first(cur);
 #pragma unroll 1
     for (int k = 0; k < GPQ; k++) {
         if (i0 + 16 * k - (int)(threadIdx.x >> 4) >= V) break;  // (block-uniform: nothing left for any quarter wave)
         const Meta nn = load_meta(k + 2);        // two Gaussians ahead: slot range
-        const uint32_t w_nxt = load_flags(nxt, 0);  // one ahead: validity bytes of its first 16 instances
+        const uint32_t w_nxt = load_first(nxt);  // one ahead: validity bytes of its first 16 instances
         const bool live = i0 + 16 * k < V;
-        const uint32_t cnt = cur.off1 - cur.off0;
+        const uint32_t cnt_all = cur.off1 - cur.off0;
+        const bool big = cnt_all > BIG_INST;
         const size_t inst0 = cur.off0;
+        if (big && e == 0)  // hand the Gaussian over to reduce_big_k
+            big_desc[atomicAdd(&big_ctl[1], 1u)] = make_uint4((uint32_t)inst0, cnt_all, 0u, cur.g);
+        const uint32_t cnt = big ? 0u : cnt_all;
         float sum[K];
 #pragma unroll
         for (int kk = 0; kk < K; kk++) sum[kk] = 0.f;
-        // every lane of the wave must reach the ballots: loop to the wave's largest count
-        uint32_t cmax = cnt;
-#pragma unroll
-        for (int d = 32; d >= 16; d >>= 1) cmax = max(cmax, (uint32_t)__shfl_xor((int)cmax, d, 64));
-        // A Gaussian's instances are looked at 64 at a time: four validity words per lane, requested together (and the next
-        // 64 under this block's rows), and a 16-instance chunk in which no quarter of the wave has a row is skipped on one
-        // ballot.  A needle or a frame-filling blob owns thousands of slots of which a few hundred hold a row (its rectangle
-        // is listed whole beyond 64 tiles): walked 16 at a time behind one dependent load each, ONE such Gaussian kept its
-        // quarter wave busy for a millisecond (clustered workload: this kernel 1.1 of the step's 2.6 ms).
-        uint32_t wq[4] = {w_cur, 0u, 0u, 0u};
-        if (cmax > 16) {
-#pragma unroll
-            for (int sblk = 1; sblk < 4; sblk++) wq[sblk] = load_flags(cur, 16u * sblk);
-        }
-        for (uint32_t c = 0; c < cmax; c += 64) {
-            uint32_t wn[4] = {0u, 0u, 0u, 0u};
-            if (c + 64 < cmax) {
-#pragma unroll
-                for (int sblk = 0; sblk < 4; sblk++) wn[sblk] = load_flags(cur, c + 64 + 16u * sblk);
-            }
-#pragma unroll 1
-            for (int sblk = 0; sblk < 4; sblk++) {  // (not unrolled: the queue is rotated instead of indexed)
-                const uint32_t cc = c + 16u * sblk;
-                if (cc >= cmax) break;                  // (wave-uniform)
-                const uint32_t w = wq[0];               // 4 quadrant bytes of instance cc+e
-                wq[0] = wq[1];
-                wq[1] = wq[2];
-                wq[2] = wq[3];
-                if (__ballot(w != 0u) == 0) continue;   // (wave-uniform) no quarter has a row in this chunk
-                unsigned long long m = 0;  // bit 16q + i: quadrant q of instance c+i is valid
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const unsigned long long bal = __ballot(((w >> (8 * q)) & 0xFFu) != 0);
-                    m |= ((bal >> (16 * quarter)) & 0xFFFFull) << (16 * q);
-                }
-                const float* chunk = rows + (inst0 + cc) * 4 * RF;
-                // NF rows requested back to back, then added in slot order (absent slots add +0: the sums do not depend on
-                // NF).  Most Gaussians own a handful of rows -- 6 on average, half of them at most 4 -- and the 16-slot trip
-                // costs ~160 vector instructions whatever it finds (the kernel issued 60 M of them: 44 % VALU-busy on top
-                // of its memory waits): when no quarter of the wave has more than 4 rows left, a 4-slot trip does.
-                auto trip = [&](auto nf_c) {
-                    constexpr int NF = decltype(nf_c)::value;
-                    float v[NF][K];
-#pragma unroll
-                    for (int i = 0; i < NF; i++) {
-                        const bool have = m != 0;
-                        const int bit = have ? __builtin_ctzll(m) : 0;
-                        if (have) m &= m - 1;
-                        const float* r = chunk + (size_t)((bit & 15) * 4 + (bit >> 4)) * RF;
-                        if (K == 2) {  // one 8-byte load per lane: the quarter wave reads the 128-byte row in one request
-                            const float2 t = have ? reinterpret_cast<const float2*>(r)[e] : make_float2(0.f, 0.f);
-                            v[i][0] = t.x;
-                            v[i][K - 1] = t.y;
-                        } else {
-#pragma unroll
-                            for (int kk = 0; kk < K; kk++) v[i][kk] = have ? r[e + 16 * kk] : 0.f;
-                        }
-                    }
-#pragma unroll
-                    for (int i = 0; i < NF; i++)
-#pragma unroll
-                        for (int kk = 0; kk < K; kk++) sum[kk] += v[i][kk];
-                };
-                int left = __popcll(m);  // rows this quarter still has to fetch; the wave's largest decides the trip
-#pragma unroll
-                for (int d = 32; d >= 16; d >>= 1) left = max(left, __shfl_xor(left, d, 64));
-                left = __builtin_amdgcn_readfirstlane(left);
-                while (left > 0) {
-                    if (left <= 4) {
-                        trip(std::integral_constant<int, 4>{});
-                        left -= 4;
-                    } else if (left <= 12) {
-                        trip(std::integral_constant<int, 12>{});
-                        left -= 12;
-                    } else {
-                        trip(std::integral_constant<int, INFLIGHT>{});
-                        left -= INFLIGHT;
-                    }
-                }
-            }
-#pragma unroll
-            for (int sblk = 0; sblk < 4; sblk++) wq[sblk] = wn[sblk];
-        }
-        if constexpr (RECORD) {
-            if (live && cnt > 0) {  // (the row elements this lane summed, back where it read them)
-                float* dst = rows + inst0 * 4 * RF;
-                if (K == 2) {
-                    reinterpret_cast<float2*>(dst)[e] = make_float2(sum[0], sum[K - 1]);
-                } else {
-#pragma unroll
-                    for (int kk = 0; kk < K; kk++) dst[e + 16 * kk] = sum[kk];
-                }
-            }
-        } else if (live) {
-            const uint32_t g = cur.g;
-#pragma unroll
-            for (int kk = 0; kk < K; kk++) {
-                const float v = sum[kk];
-                const int el = K == 2 ? 2 * e + kk : e + 16 * kk;  // element of the row this lane summed
-                if (el < nsem) {
-                    if (el < S) dL_dsemantic[(size_t)g * S + el] = v;
-                } else if (el < nsem + 3) {
-                    dL_dcolor[(size_t)g * 3 + (el - nsem)] = v;
-                } else if (el == nsem + 3) {
-                    dL_ddepth[g] = v;
-                } else if (el < nch + 2) {
-                    dL_dmean2D[(size_t)g * 3 + (el - nch)] = v;
-                    if (el == nch + 1) dL_dmean2D[(size_t)g * 3 + 2] = 0.f;
-                } else if (el < nch + 5) {
-                    const int c = el - nch - 2;  // a, b, c -> x, y, w of the [P,2,2] conic gradient
-                    dL_dconic[(size_t)g * 4 + (c == 2 ? 3 : c)] = v;
-                    if (c == 2) dL_dconic[(size_t)g * 4 + 2] = 0.f;
-                } else if (el == nch + 5) {
-                    dL_dopacity[g] = v;
-                }
-            }
-        }
+        sum_instances<K>(rows, flags32, inst0, cnt, w_cur, quarter, e, sum);
+        if (live && !big && (!RECORD || cnt > 0)) store_sums<K, RECORD>(sum, rows, inst0, cur.g, e, S, nch, out);
         cur = nxt;
         nxt = nn;
         w_cur = w_nxt;
+    }
+}
+
+// One WORKGROUP per big Gaussian (persistent: the grid is fixed, the count lives on the device): quarter wave p of the 16 sums
+// part p of the Gaussian's instances -- contiguous, a multiple of 64 instances long -- and quarter wave 0 adds the 16 partial
+// rows in part order and writes what reduce_rows_k writes for a Gaussian.
+template <int K, bool RECORD>
+__global__ __launch_bounds__(256) void reduce_big_k(const uint32_t* __restrict__ big_ctl, const uint4* __restrict__ big_desc,
+                                                    float* rows, const uint8_t* __restrict__ flags, int S, int nch,
+                                                    ReduceOut out) {
+    constexpr int RF = 16 * K;
+    __shared__ float s_part[16][RF];
+    const uint32_t nbig = big_ctl[1];
+    const int lane = threadIdx.x & 63, quarter = lane >> 4, e = lane & 15, part = threadIdx.x >> 4;
+    const uint32_t* flags32 = reinterpret_cast<const uint32_t*>(flags);
+    for (uint32_t b = blockIdx.x; b < nbig; b += gridDim.x) {  // (block-uniform)
+        const uint4 d = big_desc[b];  // (first instance, instances, -, Gaussian id)
+        const uint32_t per = ((d.y + 15u) / 16u + 63u) & ~63u;  // instances per part
+        const uint32_t p0 = min(d.y, (uint32_t)part * per), p1 = min(d.y, (uint32_t)(part + 1) * per);
+        const uint32_t cnt = p1 - p0;
+        const size_t inst0 = (size_t)d.x + p0;
+        const uint32_t w0 = ((uint32_t)e < cnt) ? flags32[inst0 + e] : 0u;
+        float sum[K];
+#pragma unroll
+        for (int kk = 0; kk < K; kk++) sum[kk] = 0.f;
+        sum_instances<K>(rows, flags32, inst0, cnt, w0, quarter, e, sum);
+#pragma unroll
+        for (int kk = 0; kk < K; kk++) s_part[part][K == 2 ? 2 * e + kk : e + 16 * kk] = sum[kk];
+        __syncthreads();
+        if (part == 0) {
+            float tot[K];
+#pragma unroll
+            for (int kk = 0; kk < K; kk++) tot[kk] = 0.f;
+            for (int pp = 0; pp < 16; pp++)
+#pragma unroll
+                for (int kk = 0; kk < K; kk++) tot[kk] += s_part[pp][K == 2 ? 2 * e + kk : e + 16 * kk];
+            store_sums<K, RECORD>(tot, rows, (size_t)d.x, d.w, e, S, nch, out);
+        }
+        __syncthreads();
     }
 }
 
@@ -246,48 +321,45 @@ __global__ __launch_bounds__(256) void reduce_rows_k(int P, int S, int nch, uint
 #endif
 constexpr int REDUCE_GPQ = GOI_REDUCE_GPQ;  // Gaussians per quarter wave of reduce_rows_k
 
+template <int K, bool RECORD>
+static void launch_reduce_k(const GoiRasterScene& sc, const GeomView& g, int N, int nch, float* rows, const uint8_t* flags,
+                            const BwdScratchView& scr, const ReduceOut& out, hipStream_t s) {
+    const dim3 grid((sc.P + 16 * REDUCE_GPQ - 1) / (16 * REDUCE_GPQ));
+    const uint32_t* order = g.sort_vals[depth_sort_result_index()];
+    reduce_rows_k<K, REDUCE_GPQ, RECORD><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order,
+                                                                    g.offsets, g.tiles_touched, rows, flags, out, scr.big_ctl,
+                                                                    scr.big_desc);
+    // the big Gaussians: a fixed, small grid of persistent workgroups (their number is on the device; N == 0: no blend ran,
+    // nothing cleared the counter and nothing can be registered)
+    if (N > 0)
+        reduce_big_k<K, RECORD><<<dim3((unsigned)std::min<size_t>(256, scr.cap_big)), dim3(256), 0, s>>>(
+            scr.big_ctl, scr.big_desc, rows, flags, sc.S, nch, out);
+}
+
 // records: the sums stay in the row scratch as per-Gaussian records (see reduce_rows_k); the six arrays are not written
 void launch_reduce_rows(const GoiRasterScene& sc, const GeomView& g, int N, const BwdScratchView& scr, float* dL_dmean2D,
                         float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dsemantic, float* dL_ddepth,
-                                hipStream_t s, bool records) {
+                        hipStream_t s, bool records) {
     const int rf = bwd_row_floats(sc.S), nch = 4 * ((sc.S + 3) / 4) + 4;
-    const dim3 grid((sc.P + 16 * REDUCE_GPQ - 1) / (16 * REDUCE_GPQ));
-    const uint32_t* order = g.sort_vals[depth_sort_result_index()];
-    if (records) {
-        if (rf == 32)
-            reduce_rows_k<2, REDUCE_GPQ, true><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, g.tiles_touched, scr.rows, scr.flags,
-                                                              nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
-        else if (rf == 16)
-            reduce_rows_k<1, REDUCE_GPQ, true><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, g.tiles_touched, scr.rows, scr.flags,
-                                                              nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
-        else
-            reduce_rows_k<3, REDUCE_GPQ, true><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, g.tiles_touched, scr.rows, scr.flags,
-                                                              nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
-        return;
-    }
-    if (rf == 32)
-        reduce_rows_k<2, REDUCE_GPQ, false><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, g.tiles_touched, scr.rows, scr.flags,
-                                                    dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dsemantic, dL_ddepth);
-    else if (rf == 16)
-        reduce_rows_k<1, REDUCE_GPQ, false><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, g.tiles_touched, scr.rows, scr.flags,
-                                                    dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dsemantic, dL_ddepth);
-    else
-        reduce_rows_k<3, REDUCE_GPQ, false><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, g.tiles_touched, scr.rows, scr.flags,
-                                                    dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dsemantic, dL_ddepth);
+    const ReduceOut out{dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dsemantic, dL_ddepth};
+#define GOI_REDUCE(K)                                                                   \
+    do {                                                                                \
+        if (records) launch_reduce_k<K, true>(sc, g, N, nch, scr.rows, scr.flags, scr, out, s);  \
+        else launch_reduce_k<K, false>(sc, g, N, nch, scr.rows, scr.flags, scr, out, s);         \
+    } while (0)
+    if (rf == 32) GOI_REDUCE(2);
+    else if (rf == 16) GOI_REDUCE(1);
+    else GOI_REDUCE(3);
+#undef GOI_REDUCE
 }
 
-void launch_reduce_sem_rows(const GoiRasterScene& sc, const GeomView& g, int N, const float* rows, const uint8_t* flags,
-                            int row_floats, float* dL_dsemantic, hipStream_t s) {
+void launch_reduce_sem_rows(const GoiRasterScene& sc, const GeomView& g, int N, const BwdScratchView& scr, int row_floats,
+                            float* dL_dsemantic, hipStream_t s) {
     // rows hold semantic channels only: with nch = row_floats + 4 every element index is a semantic one
     const int nch = row_floats + 4;
-    const dim3 grid((sc.P + 16 * REDUCE_GPQ - 1) / (16 * REDUCE_GPQ));
-    const uint32_t* order = g.sort_vals[depth_sort_result_index()];
-    if (row_floats == 16)
-        reduce_rows_k<1, REDUCE_GPQ, false><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, g.tiles_touched, const_cast<float*>(rows), flags, nullptr,
-                                                    nullptr, nullptr, nullptr, dL_dsemantic, nullptr);
-    else
-        reduce_rows_k<2, REDUCE_GPQ, false><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order, g.offsets, g.tiles_touched, const_cast<float*>(rows), flags, nullptr,
-                                                    nullptr, nullptr, nullptr, dL_dsemantic, nullptr);
+    const ReduceOut out{nullptr, nullptr, nullptr, nullptr, dL_dsemantic, nullptr};
+    if (row_floats == 16) launch_reduce_k<1, false>(sc, g, N, nch, scr.rows, scr.flags, scr, out, s);
+    else launch_reduce_k<2, false>(sc, g, N, nch, scr.rows, scr.flags, scr, out, s);
 }
 
 }  // namespace goi

@@ -498,8 +498,10 @@ constexpr int QO_CLEAR_BLOCKS = 248;  // workgroups 8 .. 255 of the launch clear
 __global__ __launch_bounds__(QO_THREADS) void quad_order_k(const uint32_t* __restrict__ qcost, int n_quads, int per,
                                                            uint32_t* __restrict__ qorder, int shift,
                                                            uint8_t* __restrict__ clear_flags,
-                                                           const uint32_t* __restrict__ n_dev, uint32_t cap) {
+                                                           const uint32_t* __restrict__ n_dev, uint32_t cap,
+                                                           uint32_t* __restrict__ clear_ctl) {
     if (blockIdx.x >= 8) {
+        if (clear_ctl && blockIdx.x == 8 && threadIdx.x < 8) clear_ctl[threadIdx.x] = 0u;  // (BwdScratchView::big_ctl)
         // validity bytes of the row slots this frame can use: 4 per instance, zeroed 16 bytes per lane (the scratch layout
         // rounds the array up to 256 bytes, so the last partial quad is inside it)
         if (!clear_flags) return;
@@ -601,12 +603,12 @@ bool quad_order_enabled(int W, int H) {
 }
 
 bool launch_quad_order(const GoiRasterScene& sc, const ImageView& im, hipStream_t s, uint8_t* clear_flags,
-                       const uint32_t* n_dev, uint32_t cap) {
+                       const uint32_t* n_dev, uint32_t cap, uint32_t* clear_ctl) {
     if (!quad_order_enabled(sc.W, sc.H)) return false;
     const int gx = (sc.W + TILE - 1) / TILE, gy = (sc.H + TILE - 1) / TILE;
     const int n_quads = gx * gy * 4, per = quad_grid(n_quads) / 8;
     quad_order_k<<<dim3(clear_flags ? 8 + QO_CLEAR_BLOCKS : 8), dim3(QO_THREADS), 0, s>>>(
-        im.qcost, n_quads, per, im.qorder, 3 + g_options.bwd_order, clear_flags, n_dev, cap);
+        im.qcost, n_quads, per, im.qorder, 3 + g_options.bwd_order, clear_flags, n_dev, cap, clear_ctl);
     return true;
 }
 

@@ -23,7 +23,9 @@ namespace goi {
 
 namespace {
 
-template <int S4, bool TRACE, bool UNROLL2, bool MASKS>
+// LEARN: the speculative depth cut-off's per-tile learning / checking (opt-in; a template parameter because the pixel's stop
+// position costs the default kernel its fifth wave per SIMD: 82 -> 99 VGPRs)
+template <int S4, bool TRACE, bool UNROLL2, bool MASKS, bool LEARN = false>
 __global__ __launch_bounds__(64) void render_fwd_k(const uint2* __restrict__ ranges,
                                                    const uint32_t* __restrict__ point_list, int W, int H, int gx,
                                                    int n_quads, int S, const GaussRec* __restrict__ rec,
@@ -33,7 +35,8 @@ __global__ __launch_bounds__(64) void render_fwd_k(const uint2* __restrict__ ran
                                                    uint32_t* __restrict__ n_contrib, const float* __restrict__ img_sem,
                                                    float* __restrict__ gau_sem, int* __restrict__ num_gsem,
                                                    uint32_t* __restrict__ qcost, unsigned long long* __restrict__ qmask0,
-                                                   unsigned long long* __restrict__ qmask) {
+                                                   unsigned long long* __restrict__ qmask, const float* __restrict__ zcut,
+                                                   uint32_t* __restrict__ zlearn, uint32_t* __restrict__ frame_flags) {
     constexpr int NF4 = TRACE ? 1 : 1 + S4;  // float4 words staged per Gaussian: (r,g,b,depth) + semantics
     constexpr int NSEM = TRACE ? 0 : 4 * S4;
     __shared__ f32x4 s_geo[64];   // (A3, A5, A1, A2) of the quadrant-centred log2-alpha polynomial (blend_common.h)
@@ -59,6 +62,7 @@ __global__ __launch_bounds__(64) void render_fwd_k(const uint2* __restrict__ ran
                                             // the T(1-alpha) >= 1e-4 test by itself, no separate flag to test
     auto all_done = [&]() { return __builtin_amdgcn_ballot_w64(T_live != 0.0f) == 0; };
     uint32_t last_contributor = 0;
+    uint32_t stop_pos = 0;  // 1-based list position of the entry that ENDED this pixel (T (1 - alpha) < 1e-4); 0: still live
     // accumulators as register pairs: one v_pk_fma_f32 adds two channels (this TU is compiled with the SLP
     // vectoriser off -- it packs the alpha evaluations of two candidates at the price of six moves -- so the
     // packing is spelled out)
@@ -97,8 +101,12 @@ __global__ __launch_bounds__(64) void render_fwd_k(const uint2* __restrict__ ran
         if constexpr (MASKS)
             if (lane == 0) *member_mask_ptr(qmask0, qmask, tile_u, q_u, x0_u, b) = mm;
     };
+    int b_end = rounds;  // rounds of 64 list positions this wave looked at
     for (int b = 0; b < rounds; b++) {
-        if (all_done()) break;
+        if (all_done()) {
+            b_end = b;
+            break;
+        }
         unsigned long long members = 0;
         const uint32_t id = id_n;
         const float4 q0 = q0_n, q1 = q1_n, q2 = q2_n;
@@ -170,6 +178,8 @@ __global__ __launch_bounds__(64) void render_fwd_k(const uint2* __restrict__ ran
                     last_contributor = (uint32_t)(b * 64 + j + 1);
                 }
             }
+            if constexpr (LEARN)
+                if (c0 && !ok) stop_pos = (uint32_t)(b * 64 + j + 1);  // (the depth cut-off must keep this entry)
             T_live = c0 ? (ok ? test_T : 0.0f) : T_live;
         };
         if constexpr (UNROLL2) {
@@ -204,6 +214,37 @@ __global__ __launch_bounds__(64) void render_fwd_k(const uint2* __restrict__ ran
         __builtin_amdgcn_wave_barrier();
     }
 
+    // Speculative depth cut-off (api.hip, goi_raster_forward_async_cut).  LEARN: the view depth up to which this tile's list
+    // is worth listing the next time this camera is rendered -- the depth of the entry an eighth (and 32 positions) beyond
+    // the last entry that ended a pixel of the tile (max over its four quadrant waves); +inf when a pixel reached the end of its list
+    // unsaturated (such a tile is never cut).  CHECK: a pixel that reaches the end of a list that WAS cut (zcut finite) without
+    // saturating may have wanted what was dropped: the frame's flag is raised -- its backward writes zero gradients, the host
+    // redoes or skips the view and forgets the camera's cut.
+    if constexpr (LEARN) {
+        {
+            const bool unsat = !all_done();
+            const float zc_in = zcut ? zcut[tile_u] : __builtin_inff();
+            float zc = __builtin_inff();
+            if (unsat) {
+                if (zc_in < 3.0e38f && lane == 0) atomicOr(frame_flags, OVF_CUT_TOO_TIGHT);
+            } else {
+                // every pixel has stopped: what the tile needs of its list ends at the LAST stopping entry (a pixel that has
+                // not met its stopping entry keeps walking: the cut must contain it); lanes outside the image never started
+                int seen = (int)stop_pos;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) seen = max(seen, __shfl_xor(seen, d, 64));
+                seen = min(len, seen);
+                (void)b_end;
+                const int pos = seen + (seen >> 3) + 32;  // margin: an eighth + 32 list positions
+                if (pos < len)
+                    zc = rec[point_list[range.x + (uint32_t)pos]].q2.w;  // (depth of that entry: the list is in depth order)
+                else
+                    zc = zc_in;  // the margin runs past the end of the list: keep the cut the list was built with (or none)
+            }
+            if (lane == 0) atomicMax(&zlearn[tile_u], __float_as_uint(zc));  // (depths are positive: their bits order like uints)
+        }
+    }
+
     {   // how far the backward's wave of this quadrant has to walk: the largest last contributor of its 64 pixels
         int qc = (int)last_contributor;
 #pragma unroll
@@ -229,13 +270,22 @@ __global__ __launch_bounds__(64) void render_fwd_k(const uint2* __restrict__ ran
 template <int S4>
 void launch_fwd_s4(const GoiRasterScene& sc, const GeomView& g, const ImageView& im, const uint32_t* point_list,
                    float* out_color, float* out_sem, float* out_depth, float* out_alpha, hipStream_t s,
-                   unsigned long long* qmask) {
+                   unsigned long long* qmask, const float* zcut, uint32_t* zlearn) {
     const int gx = (sc.W + TILE - 1) / TILE, gy = (sc.H + TILE - 1) / TILE;
     const int n_quads = gx * gy * 4;
 #define GOI_LAUNCH_FWD(U2, MK)                                                                                         \
-    render_fwd_k<S4, false, U2, MK><<<dim3(quad_grid(n_quads)), dim3(64), 0, s>>>(                                      \
-        im.ranges, point_list, sc.W, sc.H, gx, n_quads, sc.S, g.rec, sc.semantics, sc.bg, out_color, out_sem, out_depth, \
-        out_alpha, im.n_contrib, nullptr, nullptr, nullptr, im.qcost, im.qmask0, qmask)
+    do {                                                                                                               \
+        if (zlearn)                                                                                                    \
+            render_fwd_k<S4, false, U2, MK, true><<<dim3(quad_grid(n_quads)), dim3(64), 0, s>>>(                        \
+                im.ranges, point_list, sc.W, sc.H, gx, n_quads, sc.S, g.rec, sc.semantics, sc.bg, out_color, out_sem,   \
+                out_depth, out_alpha, im.n_contrib, nullptr, nullptr, nullptr, im.qcost, im.qmask0, qmask, zcut,        \
+                zlearn, g.counters + COUNTER_OVF);                                                                      \
+        else                                                                                                           \
+            render_fwd_k<S4, false, U2, MK><<<dim3(quad_grid(n_quads)), dim3(64), 0, s>>>(                              \
+                im.ranges, point_list, sc.W, sc.H, gx, n_quads, sc.S, g.rec, sc.semantics, sc.bg, out_color, out_sem,   \
+                out_depth, out_alpha, im.n_contrib, nullptr, nullptr, nullptr, im.qcost, im.qmask0, qmask, zcut,        \
+                zlearn, g.counters + COUNTER_OVF);                                                                      \
+    } while (0)
     // The member masks are recorded by EVERY forward (a backward may follow with either setting of bwd_masks, and a frame
     // without masks back-propagated through them would be garbage).  BUILD SWITCH for measuring what recording costs the
     // forward: GOI_EXTRA_FLAGS=-DGOI_FWD_NO_MASKS (such a build must run with GOI_OPTIONS=bwd_masks=0).
@@ -258,8 +308,8 @@ void launch_fwd_s4(const GoiRasterScene& sc, const GeomView& g, const ImageView&
 
 void launch_render_fwd(const GoiRasterScene& sc, const GeomView& g, const ImageView& im, const uint32_t* point_list,
                        float* out_color, float* out_sem, float* out_depth, float* out_alpha, hipStream_t s,
-                       unsigned long long* qmask) {
-#define GOI_CALL(N) launch_fwd_s4<N>(sc, g, im, point_list, out_color, out_sem, out_depth, out_alpha, s, qmask)
+                       unsigned long long* qmask, const float* zcut, uint32_t* zlearn) {
+#define GOI_CALL(N) launch_fwd_s4<N>(sc, g, im, point_list, out_color, out_sem, out_depth, out_alpha, s, qmask, zcut, zlearn)
     GOI_DISPATCH_S4(sc.S, GOI_CALL)
 #undef GOI_CALL
 }
@@ -270,7 +320,7 @@ void launch_trace_fwd(const GoiRasterScene& sc, const float* img_sem, const Geom
     const int n_quads = gx * gy * 4;
     render_fwd_k<1, true, false, false><<<dim3(quad_grid(n_quads)), dim3(64), 0, s>>>(
         im.ranges, point_list, sc.W, sc.H, gx, n_quads, sc.S, g.rec, nullptr, sc.bg, out_color, nullptr, nullptr, nullptr,
-        im.n_contrib, img_sem, gau_sem, num_gsem, nullptr, nullptr, nullptr);
+        im.n_contrib, img_sem, gau_sem, num_gsem, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
 }
 
 }  // namespace goi

@@ -169,8 +169,10 @@ std::tuple<int, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> 
 }
 
 // speculative forward: nothing waits; returns the read-back ticket instead of num_rendered (include/goi_raster.h)
+// zcut_in / zcut_out: the speculative depth cut-off of the tile lists (goi_raster_forward_async_cut): per-tile float32 arrays on
+// the device, either may be absent (None)
 std::tuple<int, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> rasterize_gaussians_async(
-    GOI_FORWARD_ARGS, const int capacity) {
+    GOI_FORWARD_ARGS, const int capacity, const c10::optional<Tensor>& zcut_in, const c10::optional<Tensor>& zcut_out) {
     Prepared f = prepare(background, means3D, colors, semantics, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                          viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
                          prefiltered, debug, true);
@@ -184,10 +186,21 @@ std::tuple<int, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> 
     Tensor img = torch::empty({(long long)goi_raster_image_bytes(f.W, f.H)}, bytes);
     const long long step = 16ll << 20;
     Tensor binning = torch::empty({((long long)goi_raster_binning_bytes(capacity) + step - 1) / step * step}, bytes);
-    const int ticket = goi_raster_forward_async(&f.sc, geom.data_ptr(), img.data_ptr(), binning.data_ptr(), capacity,
-                                                out_color.data_ptr<float>(), out_sem.data_ptr<float>(),
-                                                out_depth.data_ptr<float>(), out_alpha.data_ptr<float>(),
-                                                radii.data_ptr<int>(), stream_of(f.dev));
+    const long long tiles = ((long long)(f.W + 15) / 16) * ((f.H + 15) / 16);
+    const float* zin = nullptr;
+    float* zout = nullptr;
+    for (int k = 0; k < 2; k++) {
+        const auto& z = k == 0 ? zcut_in : zcut_out;
+        if (!z.has_value() || !z->defined()) continue;
+        TORCH_CHECK(z->scalar_type() == torch::kFloat32 && z->is_contiguous() && z->device() == f.dev && z->numel() == tiles,
+                    "zcut arrays must be contiguous float32 [tiles] tensors on the frame's device");
+        if (k == 0) zin = z->data_ptr<float>();
+        else zout = z->data_ptr<float>();
+    }
+    const int ticket = goi_raster_forward_async_cut(&f.sc, geom.data_ptr(), img.data_ptr(), binning.data_ptr(), capacity,
+                                                    out_color.data_ptr<float>(), out_sem.data_ptr<float>(),
+                                                    out_depth.data_ptr<float>(), out_alpha.data_ptr<float>(),
+                                                    radii.data_ptr<int>(), zin, zout, stream_of(f.dev));
     if (ticket < 0) raise_last();
     return std::make_tuple(ticket, out_color, out_sem, out_depth, out_alpha, radii, geom, binning, img);
 }
@@ -376,7 +389,13 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("rasterize_gaussians_backward", &rasterize_gaussians_backward);
     m.def("rasterize_gaussians_trace", &rasterize_gaussians_trace);
     m.def("mark_visible", &mark_visible);
-    m.def("rasterize_gaussians_async", &rasterize_gaussians_async);
+    m.def("rasterize_gaussians_async", &rasterize_gaussians_async, "speculative forward", pybind11::arg("background"),
+          pybind11::arg("means3D"), pybind11::arg("colors"), pybind11::arg("semantics"), pybind11::arg("opacity"),
+          pybind11::arg("scales"), pybind11::arg("rotations"), pybind11::arg("scale_modifier"), pybind11::arg("cov3D_precomp"),
+          pybind11::arg("viewmatrix"), pybind11::arg("projmatrix"), pybind11::arg("tan_fovx"), pybind11::arg("tan_fovy"),
+          pybind11::arg("image_height"), pybind11::arg("image_width"), pybind11::arg("sh"), pybind11::arg("degree"),
+          pybind11::arg("campos"), pybind11::arg("prefiltered"), pybind11::arg("debug"), pybind11::arg("capacity"),
+          pybind11::arg("zcut_in") = pybind11::none(), pybind11::arg("zcut_out") = pybind11::none());
     m.def("backward_ex", &backward_ex);
     m.def("backward_semantics", &backward_semantics);
     m.def("release_scratch", &release_scratch);

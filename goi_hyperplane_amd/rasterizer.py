@@ -109,12 +109,15 @@ def set_backward_mode(semantics_only=None, sh_factored: bool = None) -> None:
 
 
 def set_forward_mode(speculative=None, headroom=None, capacity="keep", on_overflow=None, max_ahead=None,
-                     inference_speculative=None, min_history=None) -> None:
+                     inference_speculative=None, min_history=None, depth_cut=None) -> None:
     """Forward without the host round trip (default for frames a backward may follow) or the reference's synchronous
     forward (default for frames rendered without autograd: their image is the product): see _C.set_forward_mode and
     include/goi_raster.h (goi_raster_forward_async).  GOI_FORWARD=exact|speculative, GOI_FORWARD_INFERENCE=exact|speculative,
-    GOI_BINNING_HEADROOM, GOI_OVERFLOW=warn|raise set the process defaults."""
-    _C.set_forward_mode(speculative, headroom, capacity, on_overflow, max_ahead, inference_speculative, min_history)
+    GOI_BINNING_HEADROOM, GOI_OVERFLOW=warn|raise set the process defaults.  depth_cut (GOI_DEPTH_CUT=0|1, default OFF: opt-in):
+    speculative training frames of a camera that was rendered before list, per tile, only Gaussians up to the depth the
+    camera's previous frame found worth listing (_C._depth_cut_for): bit-identical frames while the learnt cut holds, a redone
+    or skipped view when it does not."""
+    _C.set_forward_mode(speculative, headroom, capacity, on_overflow, max_ahead, inference_speculative, min_history, depth_cut)
 
 
 def truncated_flag(accumulated: bool = False):

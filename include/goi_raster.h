@@ -46,9 +46,11 @@
 extern "C" {
 #endif
 
-/* 4: + goi_raster_truncated_flag, goi_adam_step_guarded; a truncated speculative frame back-propagates ZERO gradients
+/* 5: + goi_raster_forward_async_cut, goi_raster_ticket_result2 (speculative depth cut-off of the tile lists); the binning and
+ *    backward-scratch workspaces grew (member masks; descriptors of big Gaussians): sizes come from goi_raster_*_bytes as ever
+ * 4: + goi_raster_truncated_flag, goi_adam_step_guarded; a truncated speculative frame back-propagates ZERO gradients
  * (3: + goi_raster_forward_reblend, goi_codebook_sim, goi_codebook_fused; 2: + the asynchronous forward; additions only) */
-#define GOI_RASTER_ABI_VERSION 4
+#define GOI_RASTER_ABI_VERSION 5
 
 typedef struct GoiRasterScene {
     int P;                       /* number of Gaussians */
@@ -125,6 +127,32 @@ int goi_raster_forward_async(const GoiRasterScene* scene, void* geom_buffer, voi
                              int capacity, float* out_color, float* out_semantic, float* out_depth, float* out_alpha,
                              int* radii, void* stream);
 int goi_raster_ticket_result(int ticket, int wait, int* num_rendered);
+
+/* SPECULATIVE DEPTH CUT-OFF of the tile lists (no counterpart in the reference, which lists every Gaussian in every tile of its
+ * rectangle, CR/rasterizer_impl.cu:70-111, although a pixel stops at T < 1e-4, CR/forward.cu:352-357: on an opaque scene three
+ * quarters of the instances lie behind their tile's saturation front and are emitted, sorted and never looked at).
+ *
+ * goi_raster_forward_async_cut is goi_raster_forward_async with two per-TILE arrays (ceil(W/16) * ceil(H/16) floats, row-major):
+ *   zcut_out (or NULL): LEARNT by this frame -- for every tile, the view depth up to which its list is worth listing the next
+ *       time the same camera is rendered: the depth of the list entry a quarter (+ 64 positions) beyond the last position any
+ *       pixel of the tile looked at; +inf for a tile in which some pixel reached the end of its list unsaturated.
+ *   zcut_in (or NULL): APPLIED to this frame -- a Gaussian deeper than zcut_in[t] is not listed in tile t (rectangles of up to
+ *       64 tiles, cull_variant 2: the cut lives in the ellipse tile masks).  Hand in what an earlier frame of the SAME camera
+ *       learnt (never an uninitialised array).
+ * A frame whose pixels all saturate inside their cut lists is bit-identical to the uncut frame: outputs, n_contrib, every
+ * gradient (the dropped instances were never looked at).  If a pixel of a cut tile reaches the end of its list unsaturated the
+ * cut was TOO TIGHT for this frame (the geometry has moved since it was learnt): the forward blend raises bit 2 of the frame's
+ * flag word (goi_raster_truncated_flag; bit 0 = the instance list was truncated, bit 1 = a sort timed out), the frame's
+ * backward writes ZERO gradients like a truncated frame's, and goi_raster_ticket_result2 hands the word to the host, which
+ * renders the frame again without a cut (goi_raster_forward) and forgets what the camera had learnt.
+ * goi_raster_ticket_result2: as goi_raster_ticket_result, plus the frame's flag word (0 for a frame of goi_raster_forward). */
+int goi_raster_forward_async_cut(const GoiRasterScene* scene, void* geom_buffer, void* image_buffer, void* binning_buffer,
+                                 int capacity, float* out_color, float* out_semantic, float* out_depth, float* out_alpha,
+                                 int* radii, const float* zcut_in, float* zcut_out, void* stream);
+int goi_raster_ticket_result2(int ticket, int wait, int* num_rendered, unsigned* frame_flags);
+#define GOI_FRAME_TRUNCATED 1u
+#define GOI_FRAME_MISSORTED 2u
+#define GOI_FRAME_CUT_TOO_TIGHT 4u
 /* Device pointer (inside the geometry workspace of a frame over P Gaussians) of the frame's "truncated" word: non-zero
  * iff the frame's instance list did not fit its binning capacity.  Written by every forward (0 for goi_raster_forward
  * and after goi_raster_forward_redo); read on the device by the backward kernels and, if handed over, by

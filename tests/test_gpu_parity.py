@@ -138,6 +138,9 @@ CASES = [
     (500, 32, 80, 64, -2.5, 3),       # widest supported S
     (20000, 16, 400, 300, -3.5, 3),   # BASELINE config 1 shape at S = 16
     (1500, 4, 3840, 2160, -2.0, 1),   # 32 400 tiles: per-tile counters no longer fit LDS -> separate histogram / ranges passes
+    (300, 16, 400, 300, -0.6, 2),     # every Gaussian covers most of the 475 tiles: rectangles beyond the 64-tile ellipse masks
+    (150, 16, 1280, 720, -0.4, 1),    # ... and most of 3600 tiles: > 1024 instances each -> the row reduction's workgroup-per-
+                                      # Gaussian path for BIG Gaussians (reduce_rows.hip)
 ]
 
 
@@ -583,7 +586,8 @@ def test_larger_scene_configs_properties(dev, P, S, masked):
 
 
 @pytest.mark.parametrize("P,W,H,S,factored", [(4000, 200, 152, 16, False), (2500, 97, 61, 10, False), (1500, 64, 48, 3, True),
-                                              (1200, 123, 77, 24, False), (200_000, 800, 528, 16, True)])
+                                              (1200, 123, 77, 24, False), (200_000, 800, 528, 16, True),
+                                              (400, 1280, 720, 16, False)])  # (the last: big Gaussians, workgroup-per-Gaussian reduction)
 def test_record_backward_is_bit_identical_to_the_array_backward(dev, P, W, H, S, factored):
     """bwd_records 1 (default: per-Gaussian sums stay in the row scratch, preprocess_bwd_k writes every per-id output) against
     bwd_records 0 (reduce_rows_k writes six per-id arrays + zeros, preprocess_bwd_k reads them back): every gradient of the
@@ -592,7 +596,7 @@ def test_record_backward_is_bit_identical_to_the_array_backward(dev, P, W, H, S,
     from goi_hyperplane_amd import _C, _lib
     from goi_hyperplane_amd.render import GaussianSet, TorchCamera
     from goi_hyperplane_amd.scene import make_camera, make_scene
-    sc = make_scene(P, S=S, sh_degree=3, seed=11, log_scale_mean=-2.6 if P < 10000 else -3.6)
+    sc = make_scene(P, S=S, sh_degree=3, seed=11, log_scale_mean=(-0.8 if P == 400 else -2.6) if P < 10000 else -3.6)
     cam = make_camera(W, H, yaw=-0.07)
     tcam = TorchCamera(cam, dev)
     pc = GaussianSet.from_scene(sc, dev)
@@ -677,14 +681,16 @@ def test_member_mask_backward_is_bit_identical_to_the_candidate_testing_backward
         assert torch.equal(x, y)
 
 
-@pytest.mark.parametrize("P,W,H,S", [(4000, 200, 152, 16), (2500, 97, 61, 10), (1500, 64, 48, 3), (200_000, 800, 528, 16)])
+@pytest.mark.parametrize("P,W,H,S", [(4000, 200, 152, 16), (2500, 97, 61, 10), (1500, 64, 48, 3), (200_000, 800, 528, 16),
+                                     (400, 1280, 720, 16)])
 def test_semantics_only_backward_is_bit_identical_to_the_full_one(dev, P, W, H, S):
     """goi_raster_backward_semantics (the reference's default training configuration: only the semantic
     features are optimised) against the dL/dsemantics of the full backward."""
     from goi_hyperplane_amd import rasterizer
     from goi_hyperplane_amd.render import GaussianSet, PipelineParams, TorchCamera, render
     from goi_hyperplane_amd.scene import make_camera, make_scene
-    sc = make_scene(P, S=S, sh_degree=3, seed=5, log_scale_mean=-2.6 if P < 10000 else -3.6)
+    # (P = 400: Gaussians that cover most of the 3600 tiles -- the row reduction's path for big Gaussians)
+    sc = make_scene(P, S=S, sh_degree=3, seed=5, log_scale_mean=(-0.8 if P == 400 else -2.6) if P < 10000 else -3.6)
     cam = TorchCamera(make_camera(W, H, yaw=0.1), dev)
     pc = GaussianSet.from_scene(sc, dev)
     bg = torch.zeros(3, device=dev)
