@@ -984,6 +984,25 @@ def main():
                             means2D=o_["viewspace_points"].grad)
                 return out_np, {k: v.detach().cpu().numpy() for k, v in g_np.items()}
             res["parity"], res["cpu_baseline"] = cpu_baseline(args, int(N), gpu_view)
+            # Does the default (split-bf16) flush of the backward cost accuracy against the exact-fp32 flush?  On THIS run's
+            # metric view: both flushes against the oracle and against each other (parity.fp32_flush, .flush_equivalence_same_
+            # view); over the fuzz sweep's random configurations: the committed soak (tools/flush_soak.py, profiles/).
+            import glob
+            soaks = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_flush_equivalence.json")))
+            soak = json.load(open(soaks[-1])) if soaks else None
+            same = (res["parity"] or {}).get("flush_equivalence_same_view")
+            res["flush_equivalence"] = {
+                "same_view": same,
+                "soak": None if soak is None else {k: soak[k] for k in soak if k in ("configurations", "seed", "float64", "criterion",
+                                                                                    "equivalent")},
+                "soak_source": ("profiles/" + os.path.basename(soaks[-1])) if soaks else None,
+                "value_is_fp32_grade": bool(soak and soak.get("equivalent") and same is not None and res["parity"]["ok"]
+                                            and res["parity"]["fp32_flush"]["ok"]),
+                "what": "`value` is measured with the backward's per-Gaussian sums formed from split-bf16 operands (hi*hi + lo*hi + "
+                        "hi*lo, a third plane for the moments); `value_fp32_flush` with exact fp32 products.  Equivalent means: on "
+                        "every soaked configuration and gradient tensor the two flushes differ by no more than two legal builds of "
+                        "the reference differ from each other, or else the default flush is not further from the float64 "
+                        "reference than the fp32 flush by more than that spread"}
         else:
             res["parity"], res["cpu_baseline"] = None, None
         print(json.dumps(res))

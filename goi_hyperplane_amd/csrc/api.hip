@@ -130,6 +130,7 @@ struct Ticket {
     bool busy = false;
     int capacity = 0;  // instances the frame's binning buffer holds (speculative frames); 0: exact frame
     bool head_only = false;  // only the first READBACK_HEAD_WORDS words were copied: num_rendered is counters[COUNTER_N]
+    uint32_t* pinned_dev = nullptr;  // the same words as the device sees them (the pinned allocation is mapped)
 };
 // A read-back queued BEHIND the whole frame (speculative forward) finds num_rendered as one word (COUNTER_N, left by the
 // listed-Gaussian compaction / the scan): 128 bytes travel instead of the 4 KB of striped partial counters -- which the
@@ -154,7 +155,9 @@ int ticket_acquire(int capacity) {
         return fail("too many unresolved speculative forwards (goi_raster_ticket_result was never called for them)");
     Ticket t;
     t.dev = dev;
-    GOI_HIP(hipHostMalloc(reinterpret_cast<void**>(&t.pinned), COUNTER_WORDS * sizeof(uint32_t), hipHostMallocDefault));
+    GOI_HIP(hipHostMalloc(reinterpret_cast<void**>(&t.pinned), COUNTER_WORDS * sizeof(uint32_t),
+                          hipHostMallocMapped | hipHostMallocCoherent));  // (coherent: a kernel's stores go straight to the host)
+    if (hipHostGetDevicePointer(reinterpret_cast<void**>(&t.pinned_dev), t.pinned, 0) != hipSuccess) t.pinned_dev = nullptr;
     GOI_HIP(hipEventCreateWithFlags(&t.ev, hipEventDisableTiming));
     t.busy = true;
     t.capacity = capacity;
@@ -505,11 +508,28 @@ int goi_raster_forward_async_cut(const GoiRasterScene* scene, void* geom_buffer,
         ticket_release(ticket);
         return -1;
     }
+    // The frame's counters reach the host without a copy of their own: a wave of the forward blend stores the 32 head words
+    // into the ticket's pinned (device-mapped) words, and the event behind the blend says when (the runtime moved the 128-byte
+    // device-to-host copy as two copy kernels per frame).  A frame that LEARNS a depth cut may still raise its flag inside the
+    // blend, so it keeps the copy behind the kernel.
+    uint32_t* host_words = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_ticket_mu);
+        if (!zlearn) host_words = g_tickets[ticket].pinned_dev;
+    }
     {
         StageTimer t(GOI_STAGE_BLEND_FWD, s);
-        launch_render_fwd(sc, g, im, plist, out_color, out_semantic, out_depth, out_alpha, s, bv.qmask, zcut_in, zlearn);
+        launch_render_fwd(sc, g, im, plist, out_color, out_semantic, out_depth, out_alpha, s, bv.qmask, zcut_in, zlearn,
+                          host_words);
     }
-    if (enqueue_readback(g, ticket, s, /*head_only=*/true)) {
+    if (host_words) {
+        std::lock_guard<std::mutex> lk(g_ticket_mu);
+        g_tickets[ticket].head_only = true;
+        if (hipEventRecord(g_tickets[ticket].ev, s) != hipSuccess) {
+            g_tickets[ticket].busy = false;
+            return fail("goi_raster_forward_async: hipEventRecord failed");
+        }
+    } else if (enqueue_readback(g, ticket, s, /*head_only=*/true)) {
         ticket_release(ticket);
         return -1;
     }
@@ -637,6 +657,18 @@ int goi_raster_backward(const GoiRasterScene* scene, int R, const void* geom_buf
                         float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dsemantic,
                         float* dL_ddepth, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
                         float* dL_drot, void* scratch, void* stream) {
+    return goi_raster_backward2(scene, R, geom_buffer, binning_buffer, image_buffer, radii, out_alpha, dL_dout_color,
+                                dL_dout_semantic, dL_dout_depth, dL_dout_alpha, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor,
+                                dL_dsemantic, dL_ddepth, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, scratch, nullptr,
+                                stream);
+}
+
+int goi_raster_backward2(const GoiRasterScene* scene, int R, const void* geom_buffer, const void* binning_buffer,
+                         const void* image_buffer, const int* radii, const float* out_alpha, const float* dL_dout_color,
+                         const float* dL_dout_semantic, const float* dL_dout_depth, const float* dL_dout_alpha,
+                         float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dsemantic,
+                         float* dL_ddepth, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
+                         float* dL_drot, void* scratch, const int* prev_radii, void* stream) {
     refresh_options();
     if (validate(scene, true, false)) return -1;  // opacity lives in the forward's records
     const GoiRasterScene& sc = *scene;
@@ -676,7 +708,7 @@ int goi_raster_backward(const GoiRasterScene* scene, int R, const void* geom_buf
             // the sums stay in the row scratch (one record per listed Gaussian); preprocess_bwd_k writes the per-id outputs
             launch_reduce_rows(sc, g, R, scr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, s, true);
             launch_preprocess_bwd(sc, g, radii, dL_dmean2D, dL_dconic, dL_dcolor, dL_ddepth, dL_dmean3D, dL_dcov3D, dL_dsh,
-                                  dL_dscale, dL_drot, s, scr.rows, dL_dopacity, dL_dsemantic);
+                                  dL_dscale, dL_drot, s, scr.rows, dL_dopacity, dL_dsemantic, prev_radii);
         } else {
             launch_reduce_rows(sc, g, R, scr, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dsemantic, dL_ddepth, s);
             launch_preprocess_bwd(sc, g, radii, dL_dmean2D, dL_dconic, dL_dcolor, dL_ddepth, dL_dmean3D, dL_dcov3D, dL_dsh,
@@ -735,7 +767,7 @@ int goi_raster_backward_semantics(const GoiRasterScene* scene, int R, const void
                 GOI_HIP(hipMemsetAsync(scr.big_ctl, 0, 8 * sizeof(uint32_t), s));
             }
             launch_render_bwd_sem(sc, g, im, bv.vals[fin], radii, out_alpha, dL_dout_semantic, scr.rows, scr.flags,
-                                  row_floats, s);
+                                  row_floats, s, bv.qmask);
         }
     }
     if (check_stage(sc, s, "backward blend (semantics)")) return -1;

@@ -161,7 +161,8 @@ void launch_ranges(int N, const uint32_t* n_dev, const uint32_t* sorted_keys, ui
 // with (or NULL) and what the frame learns for the camera's next visit (float bits, max over the tile's quadrants; or NULL)
 void launch_render_fwd(const GoiRasterScene& sc, const GeomView& g, const ImageView& im, const uint32_t* point_list,
                        float* out_color, float* out_sem, float* out_depth, float* out_alpha, hipStream_t s,
-                       unsigned long long* qmask = nullptr, const float* zcut = nullptr, uint32_t* zlearn = nullptr);
+                       unsigned long long* qmask = nullptr, const float* zcut = nullptr, uint32_t* zlearn = nullptr,
+                       uint32_t* host_words = nullptr);  // host_words: pinned, device-mapped words that get counters[0 .. 32)
 void launch_trace_fwd(const GoiRasterScene& sc, const float* img_sem, const GeomView& g, const ImageView& im,
                       const uint32_t* point_list, float* out_color, float* gau_sem, int* num_gsem, hipStream_t s);
 // launch order of the backward's quadrant waves (render_bwd.hip): im.qcost -> im.qorder
@@ -179,7 +180,7 @@ void launch_render_bwd_rows(const GoiRasterScene& sc, const GeomView& g, const I
 // feature-gradient-only backward blend (render_bwd_sem.hip) and its row reduction: dL/dsemantics only
 void launch_render_bwd_sem(const GoiRasterScene& sc, const GeomView& g, const ImageView& im, const uint32_t* point_list,
                            const int* radii, const float* out_alpha, const float* dL_dsem, float* rows, uint8_t* flags,
-                           int row_floats, hipStream_t s);
+                           int row_floats, hipStream_t s, const unsigned long long* qmask = nullptr);
 void launch_reduce_sem_rows(const GoiRasterScene& sc, const GeomView& g, int N, const BwdScratchView& scr, int row_floats,
                             float* dL_dsemantic, hipStream_t s);
 // sums every Gaussian's partial rows (fixed order) into the six blend-gradient arrays (writes all P rows) -- or, `records`,
@@ -199,7 +200,8 @@ void launch_sh_grad_from_views(int P, int D, int M, int V, const float* means3D,
 void launch_preprocess_bwd(const GoiRasterScene& sc, const GeomView& g, const int* radii, float* dL_dmean2D,
                            const float* dL_dconic, float* dL_dcolor, const float* dL_ddepth, float* dL_dmean3D,
                            float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, hipStream_t s,
-                           const float* record_rows = nullptr, float* dL_dopacity = nullptr, float* dL_dsemantic = nullptr);
+                           const float* record_rows = nullptr, float* dL_dopacity = nullptr, float* dL_dsemantic = nullptr,
+                           const int* prev_radii = nullptr);  // prev_radii: BwdArgs (rows that already hold zeros)
 int launch_semantic_decode(const float* sem, int S, long long HW, const float* W, const float* bias, int n_codes,
                            const float* code_score, float thresh, float* sim_out, int* idx_out, uint8_t* bg_mask_out,
                            hipStream_t s);

@@ -333,6 +333,10 @@ struct BwdArgs {
     const float* view_p;
     const float* proj_p;
     const float* campos_p;
+    // radii of the backward that LAST WROTE these very output buffers (nothing has touched them since), or NULL: a Gaussian that
+    // was invisible then and is invisible now already has zeros in every output row -- nothing is written for it (half of the
+    // headline scene: 170 MB of zeros per step).  goi_raster_backward2, csrc/torch_binding.cpp: the gradient-buffer pool.
+    const int* prev_radii;
 };
 
 // WITH_DSH: dL/dSH is formed ([P,M,3], staged through LDS).  Otherwise (the caller passed dL_dsh = NULL with SH
@@ -383,6 +387,10 @@ __global__ __launch_bounds__(256) void preprocess_bwd_k(const BwdArgs args, cons
     float4 grot = make_float4(0, 0, 0, 0);
     // (a truncated frame -- COUNTER_OVF -- is treated as if nothing were visible: all gradients zero)
     const bool visible = radii[idx] > 0 && counters[COUNTER_OVF] == 0;
+    // rows that already hold zeros (see BwdArgs::prev_radii) are not written again
+    const bool keep = live && !visible && args.prev_radii != nullptr && args.prev_radii[idx] == 0;
+    __shared__ uint8_t s_keep[256];
+    if constexpr (WITH_DSH) s_keep[threadIdx.x] = keep ? 1 : 0;
     // ---- the blend gradients: from the per-id arrays, or from the Gaussian's record
     float in_conic[3] = {0.f, 0.f, 0.f}, in_m2d[2] = {0.f, 0.f}, in_depth = 0.f;
     V3 in_col = {0.f, 0.f, 0.f};
@@ -404,7 +412,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_k(const BwdArgs args, cons
             in_conic[2] = co.x;
             opa = co.y;
         }
-        if (live) {
+        if (live && !keep) {
             ra.dL_dopacity[idx] = opa;
             dL_dmean2D[3 * idx] = in_m2d[0];
             dL_dmean2D[3 * idx + 1] = in_m2d[1];
@@ -418,20 +426,20 @@ __global__ __launch_bounds__(256) void preprocess_bwd_k(const BwdArgs args, cons
         // pieces of their records in, ONE contiguous kilobyte of the output out.
         if ((ra.S & 3) == 0 && ra.S <= 16) {
             const int lane = threadIdx.x & 63, sub = lane & 3, S4 = ra.S >> 2;
-            const uint32_t my = listed ? ra.aux[idx].x : 0xFFFFFFFFu;
+            const uint32_t my = listed ? ra.aux[idx].x : (keep ? 0xFFFFFFFEu : 0xFFFFFFFFu);  // (..FE: its zeros are there already)
             const int wave_first = gtid - lane;  // the Gaussian of lane 0
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const int src = (lane >> 2) + 16 * k;
                 const uint32_t o = (uint32_t)__shfl((int)my, src, 64);
                 const int id2 = wave_first + src;
-                if (sub < S4 && id2 < args.P) {
+                if (sub < S4 && id2 < args.P && o != 0xFFFFFFFEu) {
                     const float4 v = o != 0xFFFFFFFFu ? *reinterpret_cast<const float4*>(ra.rows + (size_t)o * 4 * ra.row_floats + 4 * sub)
                                                       : make_float4(0.f, 0.f, 0.f, 0.f);
                     *reinterpret_cast<float4*>(ra.dL_dsemantic + (size_t)id2 * ra.S + 4 * sub) = v;
                 }
             }
-        } else if (live) {
+        } else if (live && !keep) {
             float* ds = ra.dL_dsemantic + (size_t)idx * ra.S;
             if ((ra.S & 3) == 0) {
                 for (int ch = 0; ch < ra.S; ch += 4)
@@ -650,7 +658,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_k(const BwdArgs args, cons
     } else if (WITH_DSH) {
         for (int k = 0; k < a.M; k++) put(k, V3{0, 0, 0});
     }
-    if (live) {
+    if (live && !keep) {
         dL_dmean3D[3 * idx] = gmean.x;
         dL_dmean3D[3 * idx + 1] = gmean.y;
         dL_dmean3D[3 * idx + 2] = gmean.z;
@@ -668,7 +676,7 @@ __global__ __launch_bounds__(256) void preprocess_bwd_k(const BwdArgs args, cons
         float* out = dL_dsh + (size_t)blockIdx.x * blockDim.x * w;
         for (int i = threadIdx.x; i < rows * w; i += 256) {
             const int row = i / w, col = i - row * w;
-            out[i] = s_dsh[row * (w + 1) + col];
+            if (!s_keep[row]) out[i] = s_dsh[row * (w + 1) + col];
         }
     }
 }
@@ -781,8 +789,9 @@ void launch_preprocess_fwd(const GoiRasterScene& sc, const GeomView& g, int* rad
 void launch_preprocess_bwd(const GoiRasterScene& sc, const GeomView& g, const int* radii, float* dL_dmean2D,
                            const float* dL_dconic, float* dL_dcolor, const float* dL_ddepth, float* dL_dmean3D,
                            float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, hipStream_t s,
-                           const float* record_rows, float* dL_dopacity, float* dL_dsemantic) {
+                           const float* record_rows, float* dL_dopacity, float* dL_dsemantic, const int* prev_radii) {
     BwdArgs a;
+    a.prev_radii = prev_radii;
     a.P = sc.P; a.D = sc.D; a.M = sc.M; a.W = sc.W; a.H = sc.H;
     a.means3D = sc.means3D; a.shs = sc.shs; a.scales = sc.scales; a.rotations = sc.rotations;
     a.cov3D = sc.cov3D_precomp ? sc.cov3D_precomp : g.cov3D;

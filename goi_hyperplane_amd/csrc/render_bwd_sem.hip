@@ -25,13 +25,16 @@ constexpr int SGROUP = 16;
 constexpr int SBATCH = 32;
 constexpr int STSTRIDE = 66;
 
-template <int S4, bool SPLIT>
+// MASKS: the wave walks the member masks the forward blend left instead of testing every list entry against its quadrant
+// (render_bwd.hip, render_bwd_rows_k: same batches, same order, same bits).
+template <int S4, bool SPLIT, bool MASKS>
 __global__ __launch_bounds__(64) void render_bwd_sem_k(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int gx, int gy,
     int n_quads, int S, const GaussRec* __restrict__ rec, const int* __restrict__ radii,
     const uint4* __restrict__ aux, const float* __restrict__ out_alpha, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dpixsem, float* __restrict__ rows, uint8_t* __restrict__ flags, int row_floats,
-    const uint32_t* __restrict__ counters, const uint32_t* __restrict__ qorder) {
+    const uint32_t* __restrict__ counters, const uint32_t* __restrict__ qorder,
+    const unsigned long long* __restrict__ qmask0, const unsigned long long* __restrict__ qmask) {
     const bool cull = counters[COUNTER_CULL] != 0;  // the rectangles the forward listed
     constexpr int NSEM = 4 * S4, NB = (NSEM + 15) / 16;
     __shared__ f32x4 s_geo[SBATCH];           // (A3, A5, A1, A2) of the quadrant-centred log2-alpha polynomial
@@ -90,18 +93,33 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
     }
 
     uint32_t id_n = 0;
+    uint32_t mem_n = 0;
     float4 q0_n = make_float4(0, 0, 0, 0), q1_n = make_float4(1.f, 0.f, -1.f, -1.f);  // (conic c, opacity, hx, hy)
+    const int tile_u = __builtin_amdgcn_readfirstlane(t.tile), q_u = __builtin_amdgcn_readfirstlane(t.q);
+    const uint32_t x0_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)range.x);
     auto prefetch = [&](int b) {
-        const int k = b * SBATCH + lane;
-        q1_n.z = -1.f;
-        if (lane < SBATCH && k < n_proc) {
-            id_n = point_list[range.x + (n_proc - 1 - k)];
-            const float4* r4 = reinterpret_cast<const float4*>(rec + id_n);
-            q0_n = r4[0];
-            q1_n = r4[1];
+        if constexpr (MASKS) {  // batch b = list positions [32 b, 32 b + 32), lane l position 32 b + l; members only
+            const unsigned long long w = *member_mask_ptr(const_cast<unsigned long long*>(qmask0),
+                                                          const_cast<unsigned long long*>(qmask), tile_u, q_u, x0_u, b >> 1);
+            mem_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(w >> (32 * (b & 1))));
+            if (lane < SBATCH && ((mem_n >> lane) & 1u)) {
+                id_n = point_list[range.x + (uint32_t)(b * SBATCH + lane)];
+                const float4* r4 = reinterpret_cast<const float4*>(rec + id_n);
+                q0_n = r4[0];
+                q1_n = r4[1];
+            }
+        } else {
+            const int k = b * SBATCH + lane;
+            q1_n.z = -1.f;
+            if (lane < SBATCH && k < n_proc) {
+                id_n = point_list[range.x + (n_proc - 1 - k)];
+                const float4* r4 = reinterpret_cast<const float4*>(rec + id_n);
+                q0_n = r4[0];
+                q1_n = r4[1];
+            }
         }
     };
-    prefetch(0);
+    prefetch(MASKS ? rounds - 1 : 0);
     int nslot = 0;
 
     auto flush_group = [&](int cnt) {
@@ -149,12 +167,21 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
         __builtin_amdgcn_wave_barrier();
     };
 
-    for (int b = 0; b < rounds; b++) {
+    for (int bi = 0; bi < rounds; bi++) {
+        const int b = MASKS ? rounds - 1 - bi : bi;
         const uint32_t id = id_n;
         const float4 q0 = q0_n, q1 = q1_n;  // (this kernel needs nothing else of a record)
-        const bool hit = ellipse_hits_quadrant(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, t.QX0, t.QY0);
-        if (b + 1 < rounds) prefetch(b + 1);
-        unsigned long long m = __ballot(hit);
+        bool hit;
+        unsigned long long m;
+        if constexpr (MASKS) {
+            m = mem_n;
+            hit = lane < SBATCH && ((mem_n >> lane) & 1u);
+            if (bi + 1 < rounds) prefetch(b - 1);
+        } else {
+            hit = ellipse_hits_quadrant(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, t.QX0, t.QY0);
+            if (bi + 1 < rounds) prefetch(b + 1);
+            m = __ballot(hit);
+        }
         if (m == 0) continue;
         if (hit) {
             int x0, y0, x1, y1;
@@ -169,20 +196,24 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
         // the next candidate's coefficients are requested one trip ahead: a member costs ~20 VALU instructions here, the
         // LDS round trip at the head of every trip was most of it (in the full backward the same prefetch lost: it is
         // register-bound)
-        int j_n = __builtin_ctzll(m);
+        auto next_slot = [&](unsigned long long mm_) {  // MASKS: back to front = the batch's highest member first
+            return MASKS ? 31 - __builtin_clz((uint32_t)mm_) : __builtin_ctzll(mm_);
+        };
+        int j_n = next_slot(m);
         f32x4 g_n = s_geo[j_n], g2_n = s_geo2[j_n];
         while (m) {
             const int j = j_n;
-            m &= m - 1;
-            const int pos0 = n_proc - 1 - (b * SBATCH + j);
+            m &= ~(1ull << j);
+            const int pos0 = MASKS ? b * SBATCH + j : n_proc - 1 - (b * SBATCH + j);
             const f32x4 g = g_n;
             const f32x4 g2 = g2_n;
-            j_n = m ? __builtin_ctzll(m) : j;
+            j_n = m ? next_slot(m) : j;
             g_n = s_geo[j_n];
             g2_n = s_geo2[j_n];
             const PairEval e = eval_poly(g.xy, g.zw, g2.x, g2.y, g2.z, uv);
             const bool live = pos0 < last_contributor;
-            if (!any_all(live, e.below, e.seen)) continue;
+            if constexpr (!MASKS)  // (a member contributes somewhere by construction)
+                if (!any_all(live, e.below, e.seen)) continue;
             const bool c = live && e.hit;
             const float one_m_a = 1.f - e.alpha;
             const float inv = __builtin_amdgcn_rcpf(one_m_a);
@@ -208,17 +239,22 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
 template <int S4>
 void launch_bwd_sem_s4(const GoiRasterScene& sc, const GeomView& g, const ImageView& im, const uint32_t* point_list,
                        const int* radii, const float* out_alpha, const float* dL_dsem, float* rows, uint8_t* flags,
-                       int row_floats, hipStream_t s) {
+                       int row_floats, hipStream_t s, const unsigned long long* qmask) {
     const int gx = (sc.W + TILE - 1) / TILE, gy = (sc.H + TILE - 1) / TILE;
     const int n_quads = gx * gy * 4;
-    if ((g_options.bwd_variant & 15) == 2)  // exact-fp32 flush, as in the full backward
-        render_bwd_sem_k<S4, false><<<dim3(quad_grid(n_quads)), dim3(64), 0, s>>>(
-            im.ranges, point_list, sc.W, sc.H, gx, gy, n_quads, sc.S, g.rec, radii, g.aux, out_alpha, im.n_contrib, dL_dsem,
-            rows, flags, row_floats, g.counters, quad_order_enabled(sc.W, sc.H) ? im.qorder : nullptr);
-    else
-        render_bwd_sem_k<S4, true><<<dim3(quad_grid(n_quads)), dim3(64), 0, s>>>(
-            im.ranges, point_list, sc.W, sc.H, gx, gy, n_quads, sc.S, g.rec, radii, g.aux, out_alpha, im.n_contrib, dL_dsem,
-            rows, flags, row_floats, g.counters, quad_order_enabled(sc.W, sc.H) ? im.qorder : nullptr);
+#define GOI_LAUNCH_SEM(SP, MK)                                                                                         \
+    render_bwd_sem_k<S4, SP, MK><<<dim3(quad_grid(n_quads)), dim3(64), 0, s>>>(                                          \
+        im.ranges, point_list, sc.W, sc.H, gx, gy, n_quads, sc.S, g.rec, radii, g.aux, out_alpha, im.n_contrib, dL_dsem, \
+        rows, flags, row_floats, g.counters, quad_order_enabled(sc.W, sc.H) ? im.qorder : nullptr, im.qmask0, qmask)
+    const bool masks = qmask != nullptr && g_options.bwd_masks != 0;
+    if ((g_options.bwd_variant & 15) == 2) {  // exact-fp32 flush, as in the full backward
+        if (masks) GOI_LAUNCH_SEM(false, true);
+        else GOI_LAUNCH_SEM(false, false);
+    } else {
+        if (masks) GOI_LAUNCH_SEM(true, true);
+        else GOI_LAUNCH_SEM(true, false);
+    }
+#undef GOI_LAUNCH_SEM
 }
 
 }  // namespace
@@ -226,8 +262,8 @@ void launch_bwd_sem_s4(const GoiRasterScene& sc, const GeomView& g, const ImageV
 // rows: [4N][row_floats] with row_floats = 16 * ceil(4*ceil(S/4) / 16); flags [4N] zeroed by the caller
 void launch_render_bwd_sem(const GoiRasterScene& sc, const GeomView& g, const ImageView& im, const uint32_t* point_list,
                            const int* radii, const float* out_alpha, const float* dL_dsem, float* rows, uint8_t* flags,
-                           int row_floats, hipStream_t s) {
-#define GOI_CALL(N) launch_bwd_sem_s4<N>(sc, g, im, point_list, radii, out_alpha, dL_dsem, rows, flags, row_floats, s)
+                           int row_floats, hipStream_t s, const unsigned long long* qmask) {
+#define GOI_CALL(N) launch_bwd_sem_s4<N>(sc, g, im, point_list, radii, out_alpha, dL_dsem, rows, flags, row_floats, s, qmask)
     GOI_DISPATCH_S4(sc.S, GOI_CALL)
 #undef GOI_CALL
 }

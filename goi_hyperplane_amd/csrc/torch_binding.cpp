@@ -19,9 +19,11 @@
 #include <c10/hip/HIPGuard.h>
 #include <c10/hip/HIPStream.h>
 
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <tuple>
+#include <vector>
 
 #include "goi_raster.h"
 
@@ -222,11 +224,59 @@ void* backward_scratch(size_t bytes, const c10::Device& dev, void* stream, const
     return it->second.data_ptr();
 }
 
+// ---- gradient-buffer pool (goi_raster_backward2: rows that already hold zeros are not written again) -------------------------
+// The reference hands autograd eleven freshly zero-filled [P, ..] tensors per backward (rasterize_points.cu:252-262); on the
+// headline scene half of the Gaussians are invisible in any one view: 170 MB of zeros per step.  The binding keeps the ONE
+// allocation all outputs of a backward are views of, together with that frame's radii, and hands it out again once (a) nobody
+// else holds it any more (the storage's reference count is back to the pool's own) and (b) nothing has written to it in place
+// (the version counter its views share is where the backward left it: an in-place collective, a gradient clip, zero_() all
+// bump it -- such a buffer is reused as if it were fresh).  The kernel then skips the rows of Gaussians that were invisible
+// then and are invisible now.  Keyed by device, stream and layout; a few buffers per key (a loop that keeps the gradients of
+// step k alive while step k + 1 runs alternates between two).  GOI_GRAD_POOL=0 / set_grad_pool(false) turns it off.
+struct PoolEntry {
+    Tensor all;         // every output of one backward is a view of this
+    Tensor prev_radii;  // radii of the backward that last wrote it
+    int64_t version;    // version counter of `all` when that backward returned
+};
+struct PoolKey {
+    int dev;
+    void* stream;
+    long long total;
+    int P, M, S;
+    bool operator<(const PoolKey& o) const {
+        return std::tie(dev, stream, total, P, M, S) < std::tie(o.dev, o.stream, o.total, o.P, o.M, o.S);
+    }
+};
+std::mutex g_pool_mu;
+std::map<PoolKey, std::vector<PoolEntry>> g_pool;
+bool g_pool_on = []() {
+    const char* e = std::getenv("GOI_GRAD_POOL");
+    return !(e && (e[0] == '0' || e[0] == 'n' || e[0] == 'f'));
+}();
+long long g_pool_hits = 0, g_pool_dirty = 0, g_pool_fresh = 0;
+constexpr size_t POOL_BUFFERS_PER_KEY = 3;
+
+void set_grad_pool(bool on) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_pool_on = on;
+    if (!on) g_pool.clear();
+}
+std::tuple<long long, long long, long long> grad_pool_stats() {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    return std::make_tuple(g_pool_hits, g_pool_dirty, g_pool_fresh);
+}
+
 long long release_scratch() {
-    std::lock_guard<std::mutex> lk(g_scratch_mu);
     long long freed = 0;
-    for (auto& kv : g_scratch) freed += kv.second.numel();
-    g_scratch.clear();
+    {
+        std::lock_guard<std::mutex> lk(g_scratch_mu);
+        for (auto& kv : g_scratch) freed += kv.second.numel();
+        g_scratch.clear();
+    }
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (auto& kv : g_pool)
+        for (auto& e : kv.second) freed += e.all.numel() * 4;
+    g_pool.clear();
     return freed;
 }
 
@@ -249,13 +299,41 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tenso
     const int M = (sh.defined() && sh.numel()) ? (int)sh.size(1) : 0;
     const bool sh_factored = sh_factored_in && M > 0;
     auto f32 = means3D.options().dtype(torch::kFloat32);
-    const long long sizes[6] = {3ll * P, sh_factored ? 0ll : 3ll * M * P, (long long)S * P, (long long)P, 3ll * P, 4ll * P};
-    long long offs[6], total = 0;
-    for (int i = 0; i < 6; i++) {
+    // sections of ONE allocation: the six parameter gradients first (the span a data-parallel exchange reduces), then the other
+    // per-Gaussian outputs of the call
+    const long long sizes[11] = {3ll * P, sh_factored ? 0ll : 3ll * M * P, (long long)S * P, (long long)P, 3ll * P, 4ll * P,
+                                 3ll * P, 3ll * P, (long long)P, 4ll * P, 6ll * P};
+    long long offs[11], total = 0;
+    for (int i = 0; i < 11; i++) {
         offs[i] = total;
         total += (sizes[i] + 63) / 64 * 64;
     }
-    Tensor flat = torch::empty({total}, f32);
+    void* stream = stream_of(dev);
+    // a pooled buffer nobody else holds any more (see the pool's comment), or a fresh one
+    Tensor flat, prev_radii;
+    const PoolKey key{(int)dev.index(), stream, total, P, sh_factored ? -M : M, S};
+    if (P != 0) {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        if (g_pool_on) {
+            auto& v = g_pool[key];
+            for (size_t i = 0; i < v.size(); i++) {
+                if (v[i].all.storage().use_count() != 1 || v[i].all.use_count() != 1) continue;  // still somebody's gradient
+                flat = v[i].all;
+                if ((int64_t)flat._version() == v[i].version) {
+                    prev_radii = v[i].prev_radii;
+                    g_pool_hits++;
+                } else {
+                    g_pool_dirty++;  // written to in place since: every row is written again
+                }
+                v.erase(v.begin() + i);
+                break;
+            }
+        }
+    }
+    if (!flat.defined()) {
+        flat = torch::empty({total}, f32);
+        g_pool_fresh++;
+    }
     auto view = [&](int i, at::IntArrayRef shape) { return flat.narrow(0, offs[i], sizes[i]).view(shape); };
     Tensor dL_dmeans3D = view(0, {P, 3});
     Tensor dL_dsh = sh_factored ? Tensor() : view(1, {P, M, 3});
@@ -263,9 +341,9 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tenso
     Tensor dL_dopacity = view(3, {P, 1});
     Tensor dL_dscales = view(4, {P, 3});
     Tensor dL_drotations = view(5, {P, 4});
-    Tensor dL_dmeans2D = torch::empty({P, 3}, f32), dL_dcolors = torch::empty({P, 3}, f32);
-    Tensor dL_ddepths = torch::empty({P, 1}, f32), dL_dconic = torch::empty({P, 2, 2}, f32);
-    Tensor dL_dcov3D = torch::empty({P, 6}, f32);
+    Tensor dL_dmeans2D = view(6, {P, 3}), dL_dcolors = view(7, {P, 3});
+    Tensor dL_ddepths = view(8, {P, 1}), dL_dconic = view(9, {P, 2, 2});
+    Tensor dL_dcov3D = view(10, {P, 6});
     if (P != 0) {
         Arg bg = arg(background, "background", dev), m3 = arg(means3D, "means3D", dev), shs = arg(sh, "sh", dev);
         Arg col = arg(colors, "colors_precomp", dev), sem = arg(semantics, "semantics", dev);
@@ -278,18 +356,27 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tenso
         Tensor rad = radii.contiguous();
         GoiRasterScene sc = scene_of(P, degree, sh, S, W, H, bg, m3, shs, col, sem, Arg(), sca, scale_modifier, rot, cov, vm,
                                      pm, cp, tan_fovx, tan_fovy, false, debug);
-        void* stream = stream_of(dev);
         void* scratch = backward_scratch(goi_raster_backward_scratch_bytes(R, S), dev, stream,
                                          means3D.options().dtype(torch::kByte));
-        const int r = goi_raster_backward(
+        const int r = goi_raster_backward2(
             &sc, R, geomBuffer.data_ptr(), binningBuffer.numel() ? binningBuffer.data_ptr() : nullptr,
             imageBuffer.data_ptr(), rad.data_ptr<int>(), al.p, gc.p, gs.p, gd.p, ga.p, dL_dmeans2D.data_ptr<float>(),
             dL_dconic.data_ptr<float>(), dL_dopacity.data_ptr<float>(), dL_dcolors.data_ptr<float>(),
             dL_dsemantics.data_ptr<float>(), dL_ddepths.data_ptr<float>(), dL_dmeans3D.data_ptr<float>(),
             dL_dcov3D.data_ptr<float>(), dL_dsh.defined() && dL_dsh.numel() ? dL_dsh.data_ptr<float>() : nullptr,
-            dL_dscales.data_ptr<float>(), dL_drotations.data_ptr<float>(), scratch, stream);
+            dL_dscales.data_ptr<float>(), dL_drotations.data_ptr<float>(), scratch,
+            prev_radii.defined() ? prev_radii.data_ptr<int>() : nullptr, stream);
         if (r < 0) raise_last();
+        // the buffer goes (back) into the pool with this frame's radii; it is handed out again only when every view the
+        // caller got has been released and nothing has written to it in place
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        if (g_pool_on && !debug) {
+            auto& v = g_pool[key];
+            if (v.size() >= POOL_BUFFERS_PER_KEY) v.erase(v.begin());
+            v.push_back(PoolEntry{flat, rad, (int64_t)flat._version()});
+        }
     }
+    flat = Tensor();  // (the pool's reference is the only one besides the views returned below)
     return std::make_tuple(dL_dmeans2D, dL_dcolors, dL_dsemantics, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh,
                            dL_dscales, dL_drotations);
 }
@@ -399,6 +486,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("backward_ex", &backward_ex);
     m.def("backward_semantics", &backward_semantics);
     m.def("release_scratch", &release_scratch);
+    m.def("set_grad_pool", &set_grad_pool);
+    m.def("grad_pool_stats", &grad_pool_stats);
     // the header this binding was COMPILED against (a stale _goi_C.so next to a newer library must be detectable) ...
     m.def("abi_version", []() { return (int)GOI_RASTER_ABI_VERSION; });
     // ... and what the library it is linked with reports at run time

@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-/* 5: + goi_raster_forward_async_cut, goi_raster_ticket_result2 (speculative depth cut-off of the tile lists); the binning and
+/* 5: + goi_raster_forward_async_cut, goi_raster_ticket_result2 (speculative depth cut-off of the tile lists), goi_raster_backward2; the binning and
  *    backward-scratch workspaces grew (member masks; descriptors of big Gaussians): sizes come from goi_raster_*_bytes as ever
  * 4: + goi_raster_truncated_flag, goi_adam_step_guarded; a truncated speculative frame back-propagates ZERO gradients
  * (3: + goi_raster_forward_reblend, goi_codebook_sim, goi_codebook_fused; 2: + the asynchronous forward; additions only) */
@@ -197,6 +197,21 @@ int goi_raster_backward(const GoiRasterScene* scene, int R,
                         void* scratch /* goi_raster_backward_scratch_bytes(R, S) bytes, uninitialised; NULL selects
                                          the float-atomic accumulation path (not bit-reproducible) */,
                         void* stream);
+
+/* goi_raster_backward with one more pointer (ABI 5).  prev_radii (or NULL = goi_raster_backward): the radii array of the
+ * backward that LAST WROTE these very output buffers -- all eleven of them, e.g. views of one allocation a binding keeps and
+ * reuses once its consumers have let go of it -- provided nothing else has written to them since.  A Gaussian with
+ * prev_radii == 0 that is invisible in this frame as well already has zeros in every output row, and nothing is written for it:
+ * on the headline scene half of the Gaussians are invisible in any one view and the dense gradient tensors of the reference's
+ * interface (rasterize_points.cu:252-262: eleven zero-filled [P, ..] tensors per call) are 170 MB of zeros per step.  The
+ * results are those of goi_raster_backward bit for bit.  (Honoured on the default path -- row records; the other backward
+ * variants write every row.)  csrc/torch_binding.cpp keeps such a pool and checks refcount and version counter before a reuse. */
+int goi_raster_backward2(const GoiRasterScene* scene, int R, const void* geom_buffer, const void* binning_buffer,
+                         const void* image_buffer, const int* radii, const float* out_alpha, const float* dL_dout_color,
+                         const float* dL_dout_semantic, const float* dL_dout_depth, const float* dL_dout_alpha,
+                         float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dsemantic,
+                         float* dL_ddepth, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
+                         float* dL_drot, void* scratch, const int* prev_radii, void* stream);
 
 /* Feature-gradient-only backward: dL/dsemantics [P,S] from dL/d(semantic map) alone, bit-identical to
  * the dL_dsemantic of goi_raster_backward and about 3x cheaper.  For the reference's default training
