@@ -683,7 +683,7 @@ int goi_raster_backward2(const GoiRasterScene* scene, int R, const void* geom_bu
     image_layout(sc.W, sc.H, const_cast<char*>(static_cast<const char*>(image_buffer)), &im);
     const int fin = tile_sort_result_index(sc.W, sc.H, R);
     if (R > 0) binning_layout(R, const_cast<char*>(static_cast<const char*>(binning_buffer)), &bv);
-    const bool rows_path = scratch != nullptr && ((g_options.bwd_variant & 15) == 0 || (g_options.bwd_variant & 15) == 2);
+    const bool rows_path = scratch != nullptr && (g_options.bwd_variant & 15) != 1;
     if (rows_path) {
         // atomic-free path: (quadrant, Gaussian) partial rows + validity bytes, then a fixed-order sum
         BwdScratchView scr;

@@ -153,6 +153,104 @@ constexpr int TS_SPLIT = 80;
 __device__ __forceinline__ constexpr int split_row(int r) { return r * TS_SPLIT + 4 * ((r >> 3) & 1); }
 constexpr int SPLIT_FLOATS = 16 * TS_SPLIT + 4;
 
+// split-f16 flush (render_bwd.hip): rows 0..7 = w, rows 8..15 = h of the group's members; lane (kq, mm) reads member row
+// 2 (mm >> 2) + (mm & 1) of either set at pixels 32 c + 8 kq (c = (mm >> 1) & 1 for w, the other chunk for h) with
+// ds_read_b128: a stride of 72 floats plus 4 for odd rows keeps the 16 lanes of every service group on 16 different
+// bank quads (searched exhaustively over strides and per-bit offsets).
+__device__ __forceinline__ constexpr int f16_row(int r) { return (r & 7) * 72 + 4 * (r & 1) + (r >> 3) * 572; }
+constexpr int F16_FLOATS = 2 * 572;
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// eight consecutive K values -> f16 hi = rne(x) and lo = rne(x - hi): |x - hi - lo| <= 2^-22 |x| while lo stays a normal
+// f16 number (|x| >= 2^-2), 2^-25 absolute below -- the caller scales x towards 2^15
+__device__ __forceinline__ void split16_pack8(const float (&y)[8], f16x8& h, f16x8& l) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    uint32_t hw[4], lw[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const f16x2 hh = __builtin_convertvector(f32x2{y[2 * i], y[2 * i + 1]}, f16x2);  // v_cvt_pk_f16_f32
+        // x - hi as ONE mixed-precision FMA per value (the compiler expands the f16 halves with two conversions first)
+        const uint32_t hb = __builtin_bit_cast(uint32_t, hh);
+        float r0, r1;
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hb), "v"(y[2 * i]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hb), "v"(y[2 * i + 1]));
+        const f16x2 ll = __builtin_convertvector(f32x2{r0, r1}, f16x2);
+        hw[i] = __builtin_bit_cast(uint32_t, hh);
+        lw[i] = __builtin_bit_cast(uint32_t, ll);
+    }
+    h = __builtin_bit_cast(f16x8, u32x4{hw[0], hw[1], hw[2], hw[3]});
+    l = __builtin_bit_cast(f16x8, u32x4{lw[0], lw[1], lw[2], lw[3]});
+}
+
+// B operand of the split-f16 flush for ONE 16-column block: y[chunk][i] = dL[pixel 32 chunk + 8 kq + i][column mm] of lane
+// (kq, mm).  The column is scaled by 2^k = 2^(14 - exponent(largest |y| of the column over the quadrant's 64 pixels)) (k
+// clamped to <= 99: upstream gradients below 2^-85 keep fewer bits; largest = Inf: k = -114 and Inf stays Inf; a NaN is
+// not seen by fmaxf and comes out of the products as NaN) and split into planes; `unscale` = 2^-15 / 2^k undoes it and the
+// 2^15 of the weights (f16_a_operands).  render_bwd_rows_k and render_bwd_sem_k share this function, the A operands and
+// the instruction order of the products: their dL/dsemantics are bit-identical.
+__device__ __forceinline__ void f16_b_operand(float (&y)[2][8], f16x8 (&hi)[2], f16x8 (&lo)[2], float& unscale) {
+    float big = 0.f;
+#pragma unroll
+    for (int c2 = 0; c2 < 2; c2++)
+#pragma unroll
+        for (int i = 0; i < 8; i++) big = fmaxf(big, fabsf(y[c2][i]));
+    big = fmaxf(big, __shfl_xor(big, 16, 64));  // the column's other pixels: lanes mm + 16 kq
+    big = fmaxf(big, __shfl_xor(big, 32, 64));
+    const int e = (int)((__float_as_uint(big) >> 23) & 0xFFu);
+    const int fs = min(268 - e, 226);
+    const float scale = __uint_as_float((uint32_t)fs << 23);
+    unscale = __uint_as_float((uint32_t)(239 - fs) << 23);
+#pragma unroll
+    for (int c2 = 0; c2 < 2; c2++) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) y[c2][i] *= scale;
+        split16_pack8(y[c2], hi[c2], lo[c2]);
+    }
+}
+
+// A operands of the split-f16 flush for eight members (rows r0 .. r0 + 7 of the transposition buffer at f16_row()).
+// A[row mm] = plane (mm >> 1) & 1 (f16 hi / lo) of the weights of member 2 (mm >> 2) + (mm & 1), so that lane (kq, mm) of
+// D = A B holds, for column mm, the hi products of members 2 kq and 2 kq + 1 in elements 0, 1 and their lo products in
+// elements 2, 3.  A lane reads and splits 8 pixels of ONE row -- chunk = its plane: f16_lane_offset() -- and takes the
+// plane it needs of the other chunk from its partner lane mm ^ 2:
+//   A0 (pixels 0..31)  = plane-0 lanes: own hi,          plane-1 lanes: the partner's lo;
+//   A1 (pixels 32..63) = plane-0 lanes: the partner's hi, plane-1 lanes: own lo.
+// The partner exchange is quad_perm [2, 3, 0, 1] fused into the select (v_cndmask_b32_dpp: D = vcc ? src1 : dpp(src0));
+// the leading s_nop covers the two wait states a DPP read needs after a VALU write of its source.
+// The weights, in (0, 1], are split as w 2^15: two f16 planes then carry 22 bits of every weight above 2^-17 and the
+// smallest ones (alpha T ~ 2^-21) to 18.
+__device__ __forceinline__ int f16_lane_offset(int mm, int kq) {
+    return f16_row(2 * (mm >> 2) + (mm & 1)) + (((mm >> 1) & 1) ? 32 : 0) + 8 * kq;
+}
+__device__ __forceinline__ void f16_a_operands(const f32x4* src, f16x8& A0, f16x8& A1) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const f32x4 b0 = src[0] * 32768.f, b1 = src[1] * 32768.f;
+    const float y[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    f16x8 wh, wl;
+    split16_pack8(y, wh, wl);
+    const u32x4 whu = __builtin_bit_cast(u32x4, wh), wlu = __builtin_bit_cast(u32x4, wl);
+    constexpr unsigned long long plane0_mask = 0x3333333333333333ull, plane1_mask = ~plane0_mask;  // lanes with bit 1 clear / set
+    u32x4 P0, P1;
+    asm volatile(
+        "s_nop 1\n"
+        "s_mov_b64 vcc, %16\n"
+        "v_cndmask_b32_dpp %0, %12, %8, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+        "v_cndmask_b32_dpp %1, %13, %9, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+        "v_cndmask_b32_dpp %2, %14, %10, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+        "v_cndmask_b32_dpp %3, %15, %11, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+        "s_mov_b64 vcc, %17\n"
+        "v_cndmask_b32_dpp %4, %8, %12, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+        "v_cndmask_b32_dpp %5, %9, %13, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+        "v_cndmask_b32_dpp %6, %10, %14, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+        "v_cndmask_b32_dpp %7, %11, %15, vcc quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+        : "=&v"(P0[0]), "=&v"(P0[1]), "=&v"(P0[2]), "=&v"(P0[3]), "=&v"(P1[0]), "=&v"(P1[1]), "=&v"(P1[2]), "=&v"(P1[3])
+        : "v"(whu[0]), "v"(whu[1]), "v"(whu[2]), "v"(whu[3]), "v"(wlu[0]), "v"(wlu[1]), "v"(wlu[2]), "v"(wlu[3]),
+          "s"(plane0_mask), "s"(plane1_mask)
+        : "vcc");
+    A0 = __builtin_bit_cast(f16x8, P0);
+    A1 = __builtin_bit_cast(f16x8, P1);
+}
+
 // (a, b) -> packed bf16 pairs: hi = rne(a), rne(b) (a in the low half), lo = rne(a - hi_a), rne(b - hi_b)
 __device__ __forceinline__ void split_pair(float a, float b, uint32_t& hi, uint32_t& lo) {
     hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, bf16x2));  // v_cvt_pk_bf16_f32

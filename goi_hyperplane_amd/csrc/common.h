@@ -92,8 +92,8 @@ size_t binning_layout(int N, char* base, BinView* v);
 // Tuning / experiment switches (goi_raster_set_option); defaults are the shipped configuration.
 struct Options {
     int fwd_variant = 1;  // 0: one candidate per loop trip, 1: two candidates per trip (default)
-    int bwd_variant = 0;  // low 4 bits: 0 atomic-free wave-per-quadrant backward (needs scratch) with the split-bf16
-                          // MFMA flush, 2 the same with the exact-fp32 flush, 1 workgroup-per-tile + atomics
+    int bwd_variant = 0;  // low 4 bits: 0 atomic-free wave-per-quadrant backward (needs scratch) with the split-f16
+                          // MFMA flush (fp32-grade), 2 the same with the exact-fp32 flush, 1 workgroup-per-tile + atomics
     int sort_variant = 1;  // 0: histogram / scan / scatter per pass, 1: onesweep (decoupled look-back, default)
     int decode_variant = 1;  // semantic decode, S <= 16: 1 split-bf16 MFMA contraction, 2 pixel blocks per operand fetch (2: 4 blocks, 3: 1 block; bit-identical), 0 fp32 MFMA
     int cull_variant = 2;  // 0: a Gaussian is listed in every tile of its 3-sigma rectangle (the reference's lists),

@@ -36,19 +36,29 @@
 //
 // Two flushes.  fp32 MFMA (v_mfma_f32_16x16x4_f32) runs at the vector rate (32 clocks per instruction per SIMD)
 // and its time ADDS to the VALU time of the co-resident waves (tools/mfma_mix_probe.hip): the 32 instructions of
-// one group flush were ~20 % of this kernel.  The default flush (MODE 0) therefore uses the bf16 matrix rate with
-// SPLIT operands: every fp32 value x is carried as two bf16 numbers, hi = rne(x) and lo = rne(x - hi)
-// (|x - hi - lo| <= 2^-17 |x|) -- the A operand (w / h) right after it is read from LDS, the B operand (dL / basis;
-// the basis values are exact in bf16) once per kernel in registers -- and a product is formed as  hi*hi + lo*hi + hi*lo  by three
-// v_mfma_f32_16x16x32_bf16 per 32 pixels, accumulated in fp32: 12 instructions of ~20 clocks per flush instead
-// of 32 of ~35.  The dropped lo*lo term is <= 2^-16 of the product; the feature / colour / depth sums differ from
-// exact fp32 by ~1e-5 relative in the worst case (the reference's own float atomicAdd order noise is ~1e-6), still
-// bit-reproducible.  The six MOMENTS get a third plane of h (+2 instructions per flush): the basis is exact in bf16,
-// so they come out fp32-grade.  They are sums over pixels that can cancel to a small fraction of their terms: the
-// opacity gradient of an isolated Gaussian under a +- upstream gradient (|sum| ~ sum|.|/600) was 2.1e-3 off with two
-// planes and is 5.9e-5 off with three (soak case 8102/201, tests/test_gpu_fuzz.py).  (Needle-shaped Gaussians, the
-// original motivation, are NOT helped: their residue is guard flips and the fp32 conditioning of either side.)
-// MODE 1 (bwd_variant = 2) keeps the exact-fp32 flush (an fmaf chain per output) for users who want it.
+// one group flush were ~20 % of this kernel.  The default flush therefore runs at the 16-bit matrix rate on SPLIT
+// operands and is still fp32-grade:
+//   * w (= alpha T, in (0, 1]) and dL are carried as TWO f16 planes, hi = rne(s x), lo = rne(s x - hi), after an exact
+//     power-of-two scaling s that puts them where f16 is densest: w 2^15, and every channel of dL times the 2^k that
+//     brings the channel's largest |dL| of the quadrant to [2^14, 2^15).  |s x - hi - lo| <= 2^-22 |s x| for every value
+//     within 2^17 of the top of the range (2^-25 of the top below that: for w that is alpha T < 2^-17, kept to >= 18
+//     bits).  A product is  hi hi + hi lo + lo hi + lo lo  -- all four terms, each EXACT in the fp32 accumulator of
+//     v_mfma_f32_16x16x32_f16 -- so a sum differs from the exact-fp32 chain by the roundings of the accumulation only.
+//     The four terms cost TWO instructions per 32 pixels: rows 0..7 of A are not the eight members and rows 8..15 idle
+//     weight, they are (member, plane) pairs -- A[4 i + r] = plane r >> 1 of member 2 i + (r & 1) -- so one instruction
+//     forms  hi B  and  lo B  of eight members, and the two land in the SAME lane of D (elements r and r + 2): one add.
+//     Colour / depth (4 channels) ride in one more block whose columns 0..3 hold their hi plane and 4..7 their lo plane.
+//   * h (= opacity G dL/dalpha: any sign, any magnitude) is carried as THREE bf16 planes against the moment basis,
+//     which is exact in bf16: hi + lo + t carries h to 2^-25, three v_mfma_f32_16x16x32_bf16 per flush (one per plane:
+//     the lanes of rows 0..7 / 8..15 hold the two 32-pixel chunks against ONE chunk-centred basis, and the member's
+//     lane shifts either chunk's moments to the Gaussian's centre).  The moments are sums that can cancel to a small
+//     fraction of their terms: the opacity gradient of an isolated Gaussian under a +- upstream gradient
+//     (|sum| ~ sum|.| / 600) was 2.1e-3 off with two bf16 planes and is 5.9e-5 off with three (soak case 8102/201).
+//   9 matrix instructions per flush of 8 members (S <= 16).  Measured against the exact-fp32 flush on 1200 random
+//   configurations (tools/flush_soak.py, profiles/r04_flush_equivalence*.json): the two differ by less than two legal
+//   builds of the reference do; rounds 2-3 used two bf16 planes for w and dL (3 of 4 terms, 2^-17 per product), which
+//   that soak showed to be ~6x noisier than fp32 on dL/dsh and dL/dsemantics -- replaced.
+// F16 = false (bwd_variant 2) keeps the exact-fp32 flush (one fp32 FMA chain per output) for comparison.
 #include "blend_common.h"
 
 namespace goi {
@@ -78,14 +88,14 @@ struct BwdCfg {
     static constexpr int NB = (NSEM + 15) / 16;  // 16-column MFMA blocks of semantic channels (+ 1 mixed block)
 };
 
-// MODE 0: split-bf16 flush (default).  MODE 1: exact-fp32 flush.
+// F16: split-f16 flush (default); otherwise the exact-fp32 flush.
 // MASKS (default): the forward blend has left the MEMBER mask of every (quadrant, 64 list positions) -- which Gaussians
 // contributed to some pixel of the quadrant (render_fwd.hip, member_mask_ptr).  The wave then walks its list in 32-entry
 // batches ALIGNED with the forward's rounds, fetches and stages members only, and evaluates members only: no candidate is
 // tested against the quadrant (ellipse_hits_quadrant: ~45 lane-parallel instructions per batch and a 32-byte gather per
 // candidate) and no hit that contributes nowhere is evaluated.  The member set is exactly the set of pairs the
 // candidate-testing form (MASKS = false, bwd_masks 0) ends up flushing, in the same order: same rows, same bits.
-template <int S4, int MODE, bool MASKS>
+template <int S4, bool F16, bool MASKS>
 __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int gx, int gy,
     int n_quads, int S, const GaussRec* __restrict__ rec, const float* __restrict__ semantics,
@@ -104,12 +114,12 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
     __shared__ f32x4 s_geo2[BATCH + GROUP];  // (A0, A4, lim, slot index (bits))
     __shared__ float2 s_cen[BATCH + GROUP];  // Gaussian centre - quadrant centre (the flush expands the moments around it)
     __shared__ float4 s_feat[BATCH * NF4];  // (r,g,b,depth), semantics...
-    constexpr bool SPLIT = MODE == 0;
-    // [row][pixel]: rows 0..7 = w of slot, rows 8..15 = h of slot.  fp32 flush: floats, row stride TSTRIDE.
-    // Split flush: floats as well (row stride TS_SPLIT, 16-byte aligned rows); the flush splits them into bf16
-    // hi / lo after reading its A operand (two dword stores per member cost the LDS half of four 16-bit ones).
+    // [row][pixel] floats.  fp32 flush: rows 0..7 = w, rows 8..15 = h of the group's members, row stride TSTRIDE.
+    // Split-f16 flush: the same rows at f16_row() (blend_common.h: 16-byte aligned, conflict-free for its reads); the
+    // flush splits them into planes after reading its A operand (two dword stores per member cost the LDS half of
+    // four 16-bit ones).
     constexpr int TS = TSTRIDE;  // (fp32 flush)
-    constexpr int T_BYTES = SPLIT ? SPLIT_FLOATS * 4 : 2 * GROUP * TSTRIDE * 4;
+    constexpr int T_BYTES = F16 ? F16_FLOATS * 4 : 2 * GROUP * TSTRIDE * 4;
     __shared__ __attribute__((aligned(16))) char s_traw[T_BYTES];
     float* const s_t = reinterpret_cast<float*>(s_traw);
 
@@ -159,11 +169,17 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
     // ---- MFMA B operands (fixed for the whole kernel), built once through LDS:
     //      bfrag[nb][s] = dL[pixel 4s + (lane>>4)][channel 16 nb + (lane&15)]
     const int kq = lane >> 4, mm = lane & 15;
-    float bfrag[SPLIT ? 1 : NB][SPLIT ? 1 : 16];  // semantic blocks (fp32 flush)
-    float bmix[SPLIT ? 1 : 16];  // mixed block: columns 0..3 = dL/d(r, g, b, depth), 4..9 = moment basis
-    // split flush: Bh/Bl[block][chunk] = bf16 hi / lo of B[pixel 32 chunk + 8 kq + i][column mm], i = 0..7
-    // (block NB = the mixed block)
-    bf16x8 Bh[SPLIT ? NB + 1 : 1][2], Bl[SPLIT ? NB + 1 : 1][2];
+    float bfrag[F16 ? 1 : NB][F16 ? 1 : 16];  // semantic blocks (fp32 flush)
+    float bmix[F16 ? 1 : 16];  // mixed block: columns 0..3 = dL/d(r, g, b, depth), 4..9 = moment basis
+    // split-f16 flush: Wh/Wl[block][chunk] = f16 hi / lo of  dL[pixel 32 chunk + 8 kq + i][semantic channel 16 block + mm]
+    // * 2^k(channel)  (the channel's largest |dL| of this quadrant brought to [2^14, 2^15): two f16 planes then carry 22
+    // bits of every value within 2^17 of that largest one); unscale[block] = 2^-15 / 2^k (the 2^15 is the scale of the
+    // weights, see the staging store).  The four colour / depth channels share ONE operand: columns 0..3 their hi plane,
+    // columns 4..7 their lo plane.  The moment basis is one bf16 operand for BOTH 32-pixel chunks:
+    // (1, u, v', u^2, u v', v'^2) with v' = v -+ 2 centred on the chunk.
+    f16x8 Wh[F16 ? NB : 1][2], Wl[F16 ? NB : 1][2], Cc[2];
+    float unscale[F16 ? NB : 1], unscale_c = 0.f;
+    bf16x8 Bas;
     static_assert(64 * 16 * 4 <= T_BYTES, "staging region too small");
     // basis_m(pixel p) in quadrant-centred coordinates u, v in [-3.5, 3.5] (pixel p = column p & 7, row p >> 3);
     // m = mm - 4: 1, u, v, u^2, uv, v^2
@@ -173,7 +189,57 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
         const float u = (float)(p & 7) - 3.5f, v = (float)(p >> 3) - 3.5f;
         return k1 + ku * u + kv * v + kuu * (u * u) + kuv * (u * v) + kvv * (v * v);
     };
-    if constexpr (!SPLIT) {
+    if constexpr (F16) {
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++) {
+#pragma unroll
+            for (int c = 0; c < 16; c++) {
+                const int ch = nb * 16 + c;
+                s_t[lane * 16 + c] = ch < NSEM ? dLch[ch] : 0.f;
+            }
+            __builtin_amdgcn_wave_barrier();
+            float y[2][8];
+#pragma unroll
+            for (int c2 = 0; c2 < 2; c2++)
+#pragma unroll
+                for (int i = 0; i < 8; i++) y[c2][i] = s_t[(32 * c2 + 8 * kq + i) * 16 + mm];
+            f16_b_operand(y, Wh[nb], Wl[nb], unscale[nb]);
+            __builtin_amdgcn_wave_barrier();
+        }
+        {
+#pragma unroll
+            for (int c = 0; c < 4; c++) s_t[lane * 4 + c] = dLch[NSEM + c];
+            __builtin_amdgcn_wave_barrier();
+            float y[2][8];
+#pragma unroll
+            for (int c2 = 0; c2 < 2; c2++)
+#pragma unroll
+                for (int i = 0; i < 8; i++) y[c2][i] = s_t[(32 * c2 + 8 * kq + i) * 4 + (mm & 3)];
+            f16x8 hi[2], lo[2];
+            f16_b_operand(y, hi, lo, unscale_c);
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int c2 = 0; c2 < 2; c2++) {
+                const u32x4 hu = __builtin_bit_cast(u32x4, hi[c2]), lu = __builtin_bit_cast(u32x4, lo[c2]);
+                u32x4 cu;
+#pragma unroll
+                for (int i = 0; i < 4; i++) cu[i] = mm < 4 ? hu[i] : mm < 8 ? lu[i] : 0u;
+                Cc[c2] = __builtin_bit_cast(f16x8, cu);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        {
+            float y[8];
+            const float vb = (float)kq - 1.5f;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const float u = (float)i - 3.5f;
+                y[i] = mm == 0 ? 1.f : mm == 1 ? u : mm == 2 ? vb : mm == 3 ? u * u : mm == 4 ? u * vb : mm == 5 ? vb * vb : 0.f;
+            }
+            bf16x8 unused;
+            split_pack8(y, Bas, unused);  // (exact: multiples of 1/4 up to 12.25)
+        }
+    } else {
 #pragma unroll
         for (int nb = 0; nb < NB; nb++) {
 #pragma unroll
@@ -192,42 +258,12 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
 #pragma unroll
         for (int s = 0; s < 16; s++) bmix[s] = mm < 4 ? s_t[(4 * s + kq) * 4 + mm] : basis(4 * s + kq);
         __builtin_amdgcn_wave_barrier();
-    } else {
-#pragma unroll
-        for (int nb = 0; nb < NB; nb++) {
-#pragma unroll
-            for (int c = 0; c < 16; c++) {
-                const int ch = nb * 16 + c;
-                s_t[lane * 16 + c] = ch < NSEM ? dLch[ch] : 0.f;
-            }
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int c2 = 0; c2 < 2; c2++) {
-                float y[8];
-#pragma unroll
-                for (int i = 0; i < 8; i++) y[i] = s_t[(32 * c2 + 8 * kq + i) * 16 + mm];
-                split_pack8(y, Bh[nb][c2], Bl[nb][c2]);
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-#pragma unroll
-        for (int c = 0; c < 4; c++) s_t[lane * 4 + c] = dLch[NSEM + c];
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int c2 = 0; c2 < 2; c2++) {
-            float y[8];
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const int p = 32 * c2 + 8 * kq + i;
-                y[i] = mm < 4 ? s_t[p * 4 + mm] : basis(p);
-            }
-            split_pack8(y, Bh[NB][c2], Bl[NB][c2]);
-        }
-        __builtin_amdgcn_wave_barrier();
     }
-    const float QCX = t.QX0 + 3.5f, QCY = t.QY0 + 3.5f;  // quadrant centre (pixel coordinates)
-    const f32x2 uv = {t.pxf - QCX, t.pyf - QCY};         // this lane's pixel, quadrant-centred
-    const float half_W = 0.5f * W, half_H = 0.5f * H;
+    // (wave-uniform values, pinned to SGPRs: the kernel sits at its VGPR limit and spilled them to scratch otherwise)
+    auto uniform = [](float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); };
+    const float QCX = uniform(t.QX0 + 3.5f), QCY = uniform(t.QY0 + 3.5f);  // quadrant centre (pixel coordinates)
+    const f32x2 uv = {t.pxf - QCX, t.pyf - QCY};                           // this lane's pixel, quadrant-centred
+    const float half_W = uniform(0.5f * W), half_H = uniform(0.5f * H);
 
     // software prefetch of the next batch's id / position / box (one list entry per lane)
     // MASKS: batch kb covers list positions [32 kb, 32 kb + 32), lane l position 32 kb + l, and is walked from its highest
@@ -243,12 +279,9 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
             const unsigned long long w = *member_mask_ptr(const_cast<unsigned long long*>(qmask0),
                                                           const_cast<unsigned long long*>(qmask), tile_u, q_u, x0_u, b >> 1);
             mem_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(w >> (32 * (b & 1))));
-            if (lane < BATCH && ((mem_n >> lane) & 1u)) {
-                id_n = point_list[range.x + (uint32_t)(b * BATCH + lane)];
-                const float4* r4 = reinterpret_cast<const float4*>(rec + id_n);
-                q0_n = r4[0];
-                q1_n = r4[1];
-            }
+            // (the id only: a member's record is fetched when it is staged, together with the other gathers that wait there
+            // anyway -- its first two words, held across the batch, were eight VGPRs of a kernel that sits at its limit)
+            if (lane < BATCH && ((mem_n >> lane) & 1u)) id_n = point_list[range.x + (uint32_t)(b * BATCH + lane)];
         } else {
             const int k = b * BATCH + lane;  // list position n_proc-1-k, walking back to front
             q1_n.z = -1.f;
@@ -269,13 +302,80 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
     unsigned long long jpack = 0;
 
     // flushes `cnt` filled slots: D = [w]^T dL (NB blocks) and [h]^T basis, then one row per member
+    // exchange area of the split-f16 flush: row rho of the moment product (8 floats); rows 8..15 start 16 floats later, so
+    // that the four 16-lane groups of a store (rows 4 kq + r) fall on different banks
+    auto xrow = [](int rho) { return rho * 8 + 16 * (rho >> 3); };
     auto flush_group = [&](int cnt) {
         f32x4 acc[NB];
         f32x4 accx = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int nb = 0; nb < NB; nb++) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
         __builtin_amdgcn_wave_barrier();
-        if constexpr (!SPLIT) {
+        if constexpr (F16) {
+            // A[row mm] = plane (mm >> 1) & 1 (f16 hi / lo) of the weights of member 2 (mm >> 2) + (mm & 1): ONE instruction
+            // forms  hi * B  and  lo * B, and lane (kq, mm) of D holds for column mm the hi products of members 2 kq and
+            // 2 kq + 1 in elements 0, 1 and their lo products in elements 2, 3 -- one add each, in registers.  A lane reads
+            // and splits 8 pixels of ONE w row (chunk = its plane) and takes the plane it needs of the other chunk from its
+            // partner lane mm ^ 2 (one quad-permute DPP per register).  The h row of the same member, the same chunk,
+            // goes to the moment product as three bf16 planes: row mm of that D is the member's moments over one 32-pixel
+            // chunk in chunk-centred coordinates, and the member's lane shifts both chunks to the Gaussian's centre.
+            const f32x4* wsrc = reinterpret_cast<const f32x4*>(s_t + f16_lane_offset(mm, kq));
+            // (two phases, fenced for the instruction scheduler: interleaved, the planes of both live at once and the
+            // kernel, already at its register limit, spills)
+            {
+                const f32x4* src = wsrc + (f16_row(GROUP) - f16_row(0)) / 4;  // (same lane address as the w row + a constant)
+                const f32x4 a0 = src[0], a1 = src[1];
+                const float y[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                bf16x8 Hh, Hl, Ht;
+                split3_pack8(y, Hh, Hl, Ht);
+                accx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ht, Bas, accx, 0, 0, 0);
+                accx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Hl, Bas, accx, 0, 0, 0);
+                accx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Hh, Bas, accx, 0, 0, 0);
+            }
+            f32x4 accc = {0.f, 0.f, 0.f, 0.f};
+            {
+                f16x8 A0, A1;
+                f16_a_operands(wsrc, A0, A1);
+#pragma unroll
+                for (int nb = 0; nb < NB; nb++) {
+                    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A0, Wl[nb][0], acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A1, Wl[nb][1], acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A0, Wh[nb][0], acc[nb], 0, 0, 0);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A1, Wh[nb][1], acc[nb], 0, 0, 0);
+                }
+                accc = __builtin_amdgcn_mfma_f32_16x16x32_f16(A0, Cc[0], accc, 0, 0, 0);
+                accc = __builtin_amdgcn_mfma_f32_16x16x32_f16(A1, Cc[1], accc, 0, 0, 0);
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (mm < 8) {  // moments -> exchange area (16 rows of 8): rows 4 kq + r, one base address + immediates
+                float* xb = s_t + xrow(4 * kq) + mm;
+#pragma unroll
+                for (int r = 0; r < 4; r++) xb[8 * r] = accx[r];
+            }
+            // members 2 kq (element 0) and 2 kq + 1 (element 1): hi products + lo products, unscaled -- as register pairs
+            f32x2 sem[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; nb++) sem[nb] = (acc[nb].xy + acc[nb].zw) * unscale[nb];
+            // colour / depth: columns 0..3 = (hi + lo of the weights) x hi of dL, columns 4..7 = x lo of dL
+            f32x2 col = accc.xy + accc.zw;
+            col.x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(col.x), 0x104, 0xF, 0xF, true));  // row_shl:4 = lane mm + 4
+            col.y += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(col.y), 0x104, 0xF, 0xF, true));
+            col *= unscale_c;
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const int j = 2 * kq + e;
+                if (j < cnt) {
+                    const int idx = (int)((jpack >> (8 * j)) & 0xFF);
+                    float* dst = rows + (size_t)__float_as_uint(s_geo2[idx].w) * row_floats;
+#pragma unroll
+                    for (int nb = 0; nb < NB; nb++) {
+                        const int ch = nb * 16 + mm;
+                        if (ch < NSEM) dst[ch] = sem[nb][e];
+                    }
+                    if (mm < 4) dst[NSEM + mm] = col[e];
+                }
+            }
+        } else {
 #pragma unroll
             for (int s = 0; s < 16; s++) {
                 const float a = s_t[mm * TS + 4 * s + kq];
@@ -284,37 +384,11 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
                     acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bfrag[nb][s], acc[nb], 0, 0, 0);
                 accx = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bmix[s], accx, 0, 0, 0);
             }
-        } else {
-            // A[row = mm][pixel 32 c + 8 kq + i]: two ds_read_b128 per 32-pixel chunk, split in registers
-            // (hi, lo for every product; a third plane for the MOMENTS only: their B operand, the basis, is exact in
-            // bf16, so h = hi + lo + t makes them fp32-grade -- a moment is a sum over pixels that may cancel to 1/600
-            // of its terms, which turns 1e-5 per product into > 1e-3 of the result)
-            bf16x8 Ah[2], Al[2], At[2];
-#pragma unroll
-            for (int c2 = 0; c2 < 2; c2++) {
-                const f32x4* src = reinterpret_cast<const f32x4*>(s_t + split_row(mm) + 32 * c2 + 8 * kq);
-                const f32x4 a0 = src[0], a1 = src[1];
-                const float y[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-                split3_pack8(y, Ah[c2], Al[c2], At[c2]);
-            }
-#pragma unroll
-            for (int c2 = 0; c2 < 2; c2++) {
-#pragma unroll
-                for (int nb = 0; nb < NB; nb++) {
-                    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al[c2], Bh[nb][c2], acc[nb], 0, 0, 0);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[c2], Bl[nb][c2], acc[nb], 0, 0, 0);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[c2], Bh[nb][c2], acc[nb], 0, 0, 0);
-                }
-                accx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(At[c2], Bh[NB][c2], accx, 0, 0, 0);
-                accx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al[c2], Bh[NB][c2], accx, 0, 0, 0);
-                accx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[c2], Bl[NB][c2], accx, 0, 0, 0);
-                accx = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah[c2], Bh[NB][c2], accx, 0, 0, 0);
-            }
         }
         // D[row = 4*kq + r][col = mm]: rows 0..7 = w of slot `row` (x dL), rows 8..15 = h of slot row-8 (x basis)
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
+        for (int r = 0; r < 4 && !F16; r++) {
             const int row = 4 * kq + r;
             if (row >= GROUP && mm >= 4 && mm < 12) s_t[(row - GROUP) * 8 + (mm - 4)] = accx[r];  // moments -> exchange area
             if (row < cnt) {
@@ -341,12 +415,26 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
             const float Dx = cen.x, Dy = cen.y;           // centre - quadrant centre: dx = Dx - u, dy = Dy - v
             float ca, cb, cc, inv_o;  // the conic and 1 / opacity, back from the staged words
             coef_decode(g, g2, ca, cb, cc, inv_o);
-            const float m0 = m03.x, mu = m03.y, mv = m03.z, muu = m03.w, muv = m45.x, mvv = m45.y;
-            const float sx = Dx * m0 - mu;                             // sum h dx
-            const float sy = Dy * m0 - mv;                             // sum h dy
-            const float sxx = Dx * Dx * m0 - 2.f * Dx * mu + muu;      // sum h dx^2
-            const float sxy = Dx * Dy * m0 - Dx * mv - Dy * mu + muv;  // sum h dx dy
-            const float syy = Dy * Dy * m0 - 2.f * Dy * mv + mvv;      // sum h dy^2
+            float m0, sx, sy, sxx, sxy, syy;
+            // moments (1, u, v, uu, uv, vv) of h about a point (Dx, Dy) away from the Gaussian's centre -> sums of h dx^k dy^l
+            auto shift = [&](const float4& a, const float2& b, float DX, float DY) {
+                m0 += a.x;
+                sx += DX * a.x - a.y;                                  // sum h dx
+                sy += DY * a.x - a.z;                                  // sum h dy
+                sxx += DX * DX * a.x - 2.f * DX * a.y + a.w;           // sum h dx^2
+                sxy += DX * DY * a.x - DX * a.z - DY * a.y + b.x;      // sum h dx dy
+                syy += DY * DY * a.x - 2.f * DY * a.z + b.y;           // sum h dy^2
+            };
+            m0 = sx = sy = sxx = sxy = syy = 0.f;
+            if constexpr (F16) {
+                // rows 4 (l >> 1) + (l & 1) and + 2 of the exchange area: the member's moments over pixel rows 0..3 (centre
+                // 2 above the quadrant's) and over pixel rows 4..7 (2 below)
+                const int r1 = 4 * (lane >> 1) + (lane & 1);
+                shift(*reinterpret_cast<const float4*>(&s_t[xrow(r1)]), *reinterpret_cast<const float2*>(&s_t[xrow(r1) + 4]), Dx, Dy + 2.f);
+                shift(*reinterpret_cast<const float4*>(&s_t[xrow(r1 + 2)]), *reinterpret_cast<const float2*>(&s_t[xrow(r1 + 2) + 4]), Dx, Dy - 2.f);
+            } else {
+                shift(m03, m45, Dx, Dy);
+            }
             float* dst = rows + (size_t)slot * row_floats + NCH;
             // (the moments already carry the factor `opacity` of dL/dG = opacity dL/dalpha)
             dst[0] = -half_W * (ca * sx + cb * sy);  // dL/dmean2D.x (NDC units)
@@ -363,7 +451,7 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
     for (int bi = 0; bi < rounds; bi++) {
         const int b = MASKS ? rounds - 1 - bi : bi;
         const uint32_t id = id_n;
-        const float4 q0 = q0_n, q1 = q1_n;
+        float4 q0 = q0_n, q1 = q1_n;
         bool hit;
         unsigned long long m;
         if constexpr (MASKS) {
@@ -379,6 +467,10 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
         // ---- stage the hits (slot = lane)
         if (hit) {
             const float4* r4 = reinterpret_cast<const float4*>(rec + id);
+            if constexpr (MASKS) {
+                q0 = r4[0];
+                q1 = r4[1];
+            }
             const float4 q2 = r4[2];  // r, g, b, depth: the one thing only a hit needs of its record
             int x0, y0, x1, y1;
             const uint4 ax = aux[id];  // first slot, radius, tile mask: one 16-byte gather (three scattered ones before)
@@ -454,8 +546,16 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
                 wgt = e.alpha * Tn;
                 hval = e.E * dL_dopa;  // opacity * G * dL/dalpha: the moments carry the factor `opacity`
             }
-            s_t[(SPLIT ? split_row(nslot) : nslot * TS) + lane] = wgt;
-            s_t[(SPLIT ? split_row(GROUP + nslot) : (GROUP + nslot) * TS) + lane] = hval;
+            if constexpr (F16) {
+                // (one wave-uniform row offset: the h row is the w row plus a constant, which the LDS instruction's immediate
+                // offset carries)
+                const int wrow = nslot * 72 + ((nslot & 1) << 2);  // = f16_row(nslot), nslot < 8
+                s_t[wrow + lane] = wgt;
+                s_t[wrow + lane + (f16_row(GROUP) - f16_row(0))] = hval;
+            } else {
+                s_t[nslot * TS + lane] = wgt;
+                s_t[(GROUP + nslot) * TS + lane] = hval;
+            }
             jpack |= (unsigned long long)j << (8 * nslot);
             nslot++;
             if (nslot == GROUP) {
@@ -577,18 +677,18 @@ void launch_bwd_rows_s4(const GoiRasterScene& sc, const GeomView& g, const Image
                         const unsigned long long* qmask) {
     const int gx = (sc.W + TILE - 1) / TILE, gy = (sc.H + TILE - 1) / TILE;
     const int n_quads = gx * gy * 4;
-#define GOI_LAUNCH_ROWS(MODE, MASKS)                                                                                   \
-    render_bwd_rows_k<S4, MODE, MASKS><<<dim3(quad_grid(n_quads)), dim3(64), 0, s>>>(                                    \
+#define GOI_LAUNCH_ROWS(F16, MASKS)                                                                                    \
+    render_bwd_rows_k<S4, F16, MASKS><<<dim3(quad_grid(n_quads)), dim3(64), 0, s>>>(                                     \
         im.ranges, point_list, sc.W, sc.H, gx, gy, n_quads, sc.S, g.rec, sc.semantics, radii, g.aux, sc.bg, out_alpha, \
         im.n_contrib, dL_dpix, dL_dsem, dL_ddepth, dL_dalpha, scr.rows, scr.flags, bwd_row_floats(sc.S),                 \
         g.counters, quad_order_enabled(sc.W, sc.H) ? im.qorder : nullptr, im.qmask0, qmask)
     const bool masks = qmask != nullptr && g_options.bwd_masks != 0;
-    if ((g_options.bwd_variant & 15) == 2) {
-        if (masks) GOI_LAUNCH_ROWS(1, true);
-        else GOI_LAUNCH_ROWS(1, false);
-    } else {
-        if (masks) GOI_LAUNCH_ROWS(0, true);
-        else GOI_LAUNCH_ROWS(0, false);
+    if ((g_options.bwd_variant & 15) == 2) {  // exact-fp32 flush
+        if (masks) GOI_LAUNCH_ROWS(false, true);
+        else GOI_LAUNCH_ROWS(false, false);
+    } else {  // split-f16 flush
+        if (masks) GOI_LAUNCH_ROWS(true, true);
+        else GOI_LAUNCH_ROWS(true, false);
     }
 #undef GOI_LAUNCH_ROWS
 }

@@ -11,9 +11,10 @@
 // T_final / prod(1 - alpha), MFMA reduction over the 64 pixels, one scratch row per (quadrant,
 // Gaussian), no atomics) and drops the rest: no feature rows are staged, there is no <feature, dL>
 // product, no dL/dalpha recurrence, no moments; 16 members form a group and all 16 MFMA rows carry w.
-// The w values, the arithmetic of the MFMA reduction (SPLIT: the split-bf16 flush of render_bwd.hip, same
-// instruction order per output; otherwise the exact-fp32 flush) and the reduce order are those of the full
-// kernel, so the result is bit-identical to the dL/dsemantics of the full backward in the same mode.
+// The w values, the arithmetic of the MFMA reduction (F16: the split-f16 flush of render_bwd.hip -- the same operand
+// construction (blend_common.h: f16_b_operand, f16_a_operands) and the same instruction order per output, two sets of
+// eight members per group; otherwise the exact-fp32 flush) and the reduce order are those of the full kernel, so the
+// result is bit-identical to the dL/dsemantics of the full backward in the same mode.
 #include "blend_common.h"
 
 namespace goi {
@@ -27,7 +28,7 @@ constexpr int STSTRIDE = 66;
 
 // MASKS: the wave walks the member masks the forward blend left instead of testing every list entry against its quadrant
 // (render_bwd.hip, render_bwd_rows_k: same batches, same order, same bits).
-template <int S4, bool SPLIT, bool MASKS>
+template <int S4, bool F16, bool MASKS>
 __global__ __launch_bounds__(64) void render_bwd_sem_k(
     const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int gx, int gy,
     int n_quads, int S, const GaussRec* __restrict__ rec, const int* __restrict__ radii,
@@ -39,9 +40,9 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
     constexpr int NSEM = 4 * S4, NB = (NSEM + 15) / 16;
     __shared__ f32x4 s_geo[SBATCH];           // (A3, A5, A1, A2) of the quadrant-centred log2-alpha polynomial
     __shared__ f32x4 s_geo2[SBATCH];          // (A0, A4, lim, slot index (bits))
-    // w columns, [member][pixel] floats; the split flush wants 16-byte aligned rows
+    // w columns, [member][pixel] floats; the split flush keeps them at f16_row() (blend_common.h)
     constexpr int TS = STSTRIDE;  // (fp32 flush)
-    constexpr int T_BYTES = SPLIT ? SPLIT_FLOATS * 4 : SGROUP * STSTRIDE * 4;
+    constexpr int T_BYTES = F16 ? F16_FLOATS * 4 : SGROUP * STSTRIDE * 4;
     static_assert(64 * 16 * 4 <= T_BYTES, "staging region too small");
     __shared__ __attribute__((aligned(16))) char s_traw[T_BYTES];
     float* const s_t = reinterpret_cast<float*>(s_traw);
@@ -67,8 +68,9 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
 
     // MFMA B operands: bfrag[nb][s] = dL[pixel 4s + (lane>>4)][channel 16 nb + (lane&15)]
     const int kq = lane >> 4, mm = lane & 15;
-    float bfrag[SPLIT ? 1 : NB][SPLIT ? 1 : 16];
-    bf16x8 Bh[SPLIT ? NB : 1][2], Bl[SPLIT ? NB : 1][2];  // split: B[pixel 32 chunk + 8 kq + i][column mm]
+    float bfrag[F16 ? 1 : NB][F16 ? 1 : 16];
+    f16x8 Wh[F16 ? NB : 1][2], Wl[F16 ? NB : 1][2];  // split: planes of dL[pixel 32 chunk + 8 kq + i][column mm] 2^k(column)
+    float unscale[F16 ? NB : 1];
 #pragma unroll
     for (int nb = 0; nb < NB; nb++) {
 #pragma unroll
@@ -77,17 +79,16 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
             s_t[lane * 16 + c] = (t.inside && ch < S) ? dL_dpixsem[ch * HW + pix_id] : 0.f;
         }
         __builtin_amdgcn_wave_barrier();
-        if constexpr (!SPLIT) {
+        if constexpr (!F16) {
 #pragma unroll
             for (int s = 0; s < 16; s++) bfrag[nb][s] = s_t[(4 * s + kq) * 16 + mm];
         } else {
+            float y[2][8];
 #pragma unroll
-            for (int c2 = 0; c2 < 2; c2++) {
-                float y[8];
+            for (int c2 = 0; c2 < 2; c2++)
 #pragma unroll
-                for (int i = 0; i < 8; i++) y[i] = s_t[(32 * c2 + 8 * kq + i) * 16 + mm];
-                split_pack8(y, Bh[nb][c2], Bl[nb][c2]);
-            }
+                for (int i = 0; i < 8; i++) y[c2][i] = s_t[(32 * c2 + 8 * kq + i) * 16 + mm];
+            f16_b_operand(y, Wh[nb], Wl[nb], unscale[nb]);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -102,12 +103,8 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
             const unsigned long long w = *member_mask_ptr(const_cast<unsigned long long*>(qmask0),
                                                           const_cast<unsigned long long*>(qmask), tile_u, q_u, x0_u, b >> 1);
             mem_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(w >> (32 * (b & 1))));
-            if (lane < SBATCH && ((mem_n >> lane) & 1u)) {
-                id_n = point_list[range.x + (uint32_t)(b * SBATCH + lane)];
-                const float4* r4 = reinterpret_cast<const float4*>(rec + id_n);
-                q0_n = r4[0];
-                q1_n = r4[1];
-            }
+            // (the id only: the record is fetched when the member is staged, with the gather that waits there anyway)
+            if (lane < SBATCH && ((mem_n >> lane) & 1u)) id_n = point_list[range.x + (uint32_t)(b * SBATCH + lane)];
         } else {
             const int k = b * SBATCH + lane;
             q1_n.z = -1.f;
@@ -123,11 +120,11 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
     int nslot = 0;
 
     auto flush_group = [&](int cnt) {
-        f32x4 acc[NB];
+        f32x4 acc[F16 ? 1 : NB];
 #pragma unroll
-        for (int nb = 0; nb < NB; nb++) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int nb = 0; nb < (F16 ? 1 : NB); nb++) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
         __builtin_amdgcn_wave_barrier();
-        if constexpr (!SPLIT) {
+        if constexpr (!F16) {
 #pragma unroll
             for (int s = 0; s < 16; s++) {
                 const float a = s_t[mm * TS + 4 * s + kq];
@@ -135,31 +132,41 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
                 for (int nb = 0; nb < NB; nb++)
                     acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bfrag[nb][s], acc[nb], 0, 0, 0);
             }
-        } else {
 #pragma unroll
-            for (int c2 = 0; c2 < 2; c2++) {
-                const f32x4* src = reinterpret_cast<const f32x4*>(s_t + split_row(mm) + 32 * c2 + 8 * kq);
-                const f32x4 a0 = src[0], a1 = src[1];
-                const float y[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-                bf16x8 Ah, Al;
-                split_pack8(y, Ah, Al);
+            for (int r = 0; r < 4; r++) {
+                const int row = 4 * kq + r;  // D[row = member][col = channel]
+                if (row < cnt) {
+                    float* dst = rows + (size_t)s_slot[row] * row_floats;
 #pragma unroll
-                for (int nb = 0; nb < NB; nb++) {  // same order of terms as render_bwd_rows_k
-                    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bh[nb][c2], acc[nb], 0, 0, 0);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bl[nb][c2], acc[nb], 0, 0, 0);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh[nb][c2], acc[nb], 0, 0, 0);
+                    for (int nb = 0; nb < NB; nb++) {
+                        const int ch = nb * 16 + mm;
+                        if (ch < NSEM) dst[ch] = acc[nb][r];
+                    }
                 }
             }
-        }
+        } else {
+            // two sets of eight members; per set the operands, the four products per block and their order are those of
+            // render_bwd_rows_k (rows of D are independent: what the other rows hold does not matter)
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int row = 4 * kq + r;  // D[row = member][col = channel]
-            if (row < cnt) {
-                float* dst = rows + (size_t)s_slot[row] * row_floats;
+            for (int set = 0; set < 2; set++) {
+                if (8 * set >= cnt) break;  // (wave-uniform)
+                const f32x4* wsrc = reinterpret_cast<const f32x4*>(s_t + f16_lane_offset(mm, kq) + set * (f16_row(8) - f16_row(0)));
+                f16x8 A0, A1;
+                f16_a_operands(wsrc, A0, A1);
 #pragma unroll
                 for (int nb = 0; nb < NB; nb++) {
+                    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_f16(A0, Wl[nb][0], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_f16(A1, Wl[nb][1], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_f16(A0, Wh[nb][0], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_f16(A1, Wh[nb][1], a, 0, 0, 0);
+                    const f32x2 sem = (a.xy + a.zw) * unscale[nb];  // members 8 set + 2 kq (+ 1): hi products + lo products
                     const int ch = nb * 16 + mm;
-                    if (ch < NSEM) dst[ch] = acc[nb][r];
+#pragma unroll
+                    for (int e = 0; e < 2; e++) {
+                        const int j = 8 * set + 2 * kq + e;
+                        if (j < cnt && ch < NSEM) rows[(size_t)s_slot[j] * row_floats + ch] = sem[e];
+                    }
                 }
             }
         }
@@ -170,7 +177,7 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
     for (int bi = 0; bi < rounds; bi++) {
         const int b = MASKS ? rounds - 1 - bi : bi;
         const uint32_t id = id_n;
-        const float4 q0 = q0_n, q1 = q1_n;  // (this kernel needs nothing else of a record)
+        float4 q0 = q0_n, q1 = q1_n;  // (this kernel needs nothing else of a record)
         bool hit;
         unsigned long long m;
         if constexpr (MASKS) {
@@ -184,6 +191,11 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
         }
         if (m == 0) continue;
         if (hit) {
+            if constexpr (MASKS) {
+                const float4* r4 = reinterpret_cast<const float4*>(rec + id);
+                q0 = r4[0];
+                q1 = r4[1];
+            }
             int x0, y0, x1, y1;
             const uint4 ax = aux[id];  // first slot, radius, tile mask: one 16-byte gather (three scattered ones before)
             listed_rect(q0.x, q0.y, (int)ax.y, q1.z, q1.w, cull, gx, gy, x0, y0, x1, y1);
@@ -223,7 +235,7 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
                 T = Tn;
                 wgt = e.alpha * Tn;
             }
-            s_t[(SPLIT ? split_row(nslot) : nslot * TS) + lane] = wgt;
+            s_t[(F16 ? f16_row(nslot) : nslot * TS) + lane] = wgt;
             if (lane == 0) s_slot[nslot] = __float_as_uint(g2.w);
             nslot++;
             if (nslot == SGROUP) {

@@ -267,9 +267,12 @@ int goi_raster_profile_collect(double* ms, int* calls);
 
 /* Tuning / experiment switches; the defaults are the shipped configuration.
  *   "fwd_variant"  1 (default) two candidates per loop trip in the forward blend, 0 one
- *   "bwd_variant"  0 (default) atomic-free backward, MFMA reductions at the bf16 rate with split (hi + lo) operands
- *                  (within ~1e-5 relative of exact fp32, bit-reproducible); 2 the same with exact-fp32 MFMA (an fmaf chain
- *                  per output); 1 workgroup-per-tile backward with float atomics (what scratch = NULL selects)
+ *   "bwd_variant"  0 (default) atomic-free backward; the per-Gaussian sums over pixels run at the 16-bit matrix rate on
+ *                  split operands that keep fp32 accuracy (two f16 planes of exactly scaled values, all four partial
+ *                  products, fp32 accumulation: indistinguishable from the fp32 chain at the noise level of two builds of
+ *                  the reference -- profiles/r04_flush_equivalence*.json; bit-reproducible); 2 the same with exact-fp32
+ *                  MFMA (one fp32 FMA chain per output); 1 workgroup-per-tile backward with float atomics (what
+ *                  scratch = NULL selects)
  *   "sort_variant" 1 (default) onesweep radix sort, 0 histogram / scan / scatter per pass
  *   "cull_variant" 2 (default) a Gaussian is listed only in the tiles its contribution ellipse (alpha >= 1/255) reaches,
  *                  1 in the tiles its axis-aligned contribution box touches, 0 in the reference's 3-sigma squares.

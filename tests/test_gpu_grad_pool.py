@@ -75,7 +75,7 @@ def test_a_buffer_somebody_holds_is_not_reused_and_a_modified_one_counts_as_fres
     ext = _ext()
     pc, cams, ups = _setup(dev)
     ext.set_grad_pool(False)
-    ref = [_grads(c, pc, ups)[0] for c in cams[:3]]
+    ref = [_grads(c, pc, ups)[0] for c in cams[:4]]
     ext.set_grad_pool(True)
     held = []
     g0, _ = _grads(cams[0], pc, ups, hold=held)          # the caller keeps the gradients of view 0 ...
@@ -86,13 +86,15 @@ def test_a_buffer_somebody_holds_is_not_reused_and_a_modified_one_counts_as_fres
     for a, b in zip(g1, ref[1]):
         assert torch.equal(a, b)
     # in-place modification (a gradient clip, an in-place all-reduce): the version counter says so, every row is rewritten
-    held.clear()
+    held.clear()                                          # view 0's buffer is free again, untouched
     s0 = ext.grad_pool_stats()
     for p in pc.parameters():
-        p.grad.add_(1.0)                                  # rows of invisible Gaussians are no longer zero
+        p.grad.add_(1.0)                                  # view 1's buffer: rows of invisible Gaussians are no longer zero
         p.grad = None
-    g2, _ = _grads(cams[2], pc, ups)
+    g2, _ = _grads(cams[2], pc, ups, hold=held)           # takes one of the two free buffers and keeps it ...
+    g3, _ = _grads(cams[3], pc, ups)                      # ... so this one takes the other
     s1 = ext.grad_pool_stats()
-    assert s1[1] > s0[1]                                  # counted as dirty
-    for a, b in zip(g2, ref[2]):
-        assert torch.equal(a, b)
+    assert s1[1] > s0[1]                                  # the modified one was counted as dirty
+    for g, r in ((g2, ref[2]), (g3, ref[3])):
+        for a, b in zip(g, r):
+            assert torch.equal(a, b)

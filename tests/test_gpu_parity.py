@@ -367,7 +367,7 @@ def test_full_size_properties(dev):
 def test_metric_configuration_matches_oracle(oracle_mod, dev, P, yaw):
     """BASELINE.json's own metric configuration -- 1 M Gaussians, 1600x1056, S = 16, SH degree 3 (and the 3 M size of
     configs 2 / 3 with a non-zero dL/dcolour) -- through the DEFAULT HIP path (culled tile lists, speculative forward,
-    split-bf16 flush) against the CPU oracle on all host threads (CR/forward.cu:261-386, CR/backward.cu:415-625), with a
+    split-f16 flush) against the CPU oracle on all host threads (CR/forward.cu:261-386, CR/backward.cu:415-625), with a
     dense random upstream gradient on colour, semantics, depth AND alpha: forward 1e-4 outside the fragile mask, every
     gradient tensor 1e-3 of its scale, element-wise statistics recorded (gpurun_out/parity_stats.json)."""
     from goi_hyperplane_amd import _C, rasterizer
@@ -714,7 +714,7 @@ def test_semantics_only_backward_is_bit_identical_to_the_full_one(dev, P, W, H, 
 
     from goi_hyperplane_amd import _lib
     by_variant = {}
-    for variant in (0, 2):  # split-bf16 MFMA flush (default) and exact-fp32 flush: bit-identical within a mode
+    for variant in (0, 2):  # split-f16 MFMA flush (default) and exact-fp32 flush: bit-identical within a mode
         _lib.set_option("bwd_variant", variant)
         try:
             full, vs_full = sem_grad(False, False)
@@ -728,9 +728,10 @@ def test_semantics_only_backward_is_bit_identical_to_the_full_one(dev, P, W, H, 
             by_variant[variant] = full
         finally:
             _lib.set_option("bwd_variant", 0)
-    # the two flushes agree to the precision of the split operands (16 significant bits per factor)
+    # the two flushes agree at fp32 level: the split operands carry 22 bits per factor and all four partial products are
+    # formed (rounds 2-3, two bf16 planes and three products: 3e-5)
     scale = float(by_variant[2].abs().max())
-    assert float((by_variant[0] - by_variant[2]).abs().max()) <= 3e-5 * scale
+    assert float((by_variant[0] - by_variant[2]).abs().max()) <= 3e-6 * scale
 
 
 @pytest.mark.parametrize("P,W,H,S,mu", [(4000, 200, 152, 16, -2.6), (1500, 123, 77, 10, -1.8), (300_000, 800, 528, 16, -3.8)])
