@@ -14,8 +14,9 @@ import json
 import os
 import sys
 
-STAGE_KERNEL_PREFIX = {"blend_bwd": "render_bwd_rows_k<4, 0>", "blend_fwd": "render_fwd_k<4, false, true>",
-                       "preprocess": "preprocess_fwd_k", "emit": "emit_k<true>"}
+# (template arguments as rocprofv3 prints them: round 4's backward is <S4, F16 = true, MASKS>, its forward <S4, TRACE, UNROLL2, MASKS, LEARN>)
+STAGE_KERNEL_PREFIX = {"blend_bwd": ("render_bwd_rows_k<4, true", "render_bwd_rows_k<4, 0"),
+                       "blend_fwd": ("render_fwd_k<4, false, true",), "preprocess": ("preprocess_fwd_k",), "emit": ("emit_k<true>",)}
 
 
 def main():
@@ -37,8 +38,8 @@ def main():
         kernels[k] = {"FETCH_SIZE_KB": round(fs, 1), "WRITE_SIZE_KB": round(ws, 1),
                       "hbm_bytes_corrected": (2 * fs + ws) * 1024}
     stage_kernel = {}
-    for stage, prefix in STAGE_KERNEL_PREFIX.items():
-        hits = [k for k in kernels if k.startswith(prefix)]
+    for stage, prefixes in STAGE_KERNEL_PREFIX.items():
+        hits = [k for k in kernels if k.startswith(prefixes)]
         if hits:
             stage_kernel[stage] = max(hits, key=lambda k: kernels[k]["hbm_bytes_corrected"])
     out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/pmc_passes.sh) on the " + label +
