@@ -681,6 +681,68 @@ def test_member_mask_backward_is_bit_identical_to_the_candidate_testing_backward
         assert torch.equal(x, y)
 
 
+@pytest.mark.parametrize("flush", [0, 2])
+def test_backward_is_exactly_homogeneous_in_powers_of_two(dev, flush):
+    """The split-f16 flush scales its operands by exact powers of two (csrc/render_bwd.hip: the weights by 2^15, every channel
+    of the upstream gradient by the 2^k that brings the channel's largest value of the quadrant to [2^14, 2^15)) and unscales
+    the sums exactly, so -- like the fp32 chain -- the whole backward is EXACTLY homogeneous under power-of-two scalings of the
+    upstream gradient: bit-identical gradients times 2^k, for all of them or for one semantic channel alone (whose
+    dL/dsemantics column then scales alone: the weights do not depend on the upstream gradient)."""
+    from goi_hyperplane_amd import _lib
+    S, W, H = 16, 200, 152
+    sc = make_scene(3000, S=S, sh_degree=3, seed=7, log_scale_mean=-2.5)
+    cam = make_camera(W, H)
+    bg = np.array([0.1, 0.2, 0.3], np.float32)
+    grads = upstream_grads(S, H, W, seed=3)
+    _lib.set_option("bwd_variant", flush)
+    try:
+        base = run_hip(sc, cam, bg, dev, grads=grads)["grads"]
+        for k in (-20, 17):
+            f = np.float32(2.0 ** k)
+            got = run_hip(sc, cam, bg, dev, grads=[g * f for g in grads])["grads"]
+            for name, b in base.items():
+                assert np.array_equal(got[name], b * f), (name, k)
+        ch, f = 5, np.float32(2.0 ** 12)
+        g2 = [g.copy() for g in grads]
+        g2[1][ch] *= f
+        got = run_hip(sc, cam, bg, dev, grads=g2)["grads"]
+        want = base["semantics"].copy()
+        want[:, ch] *= f
+        assert np.array_equal(got["semantics"], want)
+        assert np.array_equal(got["sh"], base["sh"])
+    finally:
+        _lib.set_option("bwd_variant", 0)
+
+
+def test_split_flush_with_upstream_gradients_of_mixed_magnitude(dev):
+    """Dynamic range inside a quadrant: a few pixels of every channel carry an upstream gradient 2^20 times the rest (the f16
+    planes of the default flush keep 22 bits of whatever is within 2^17 of the channel's largest value in the quadrant and
+    2^-25 of that largest value below).  Against the exact-fp32 flush the sums must still agree to 1e-6 of the tensor's scale,
+    and a channel whose upstream gradient is identically zero must come out as exact zeros."""
+    from goi_hyperplane_amd import _lib
+    S, W, H = 12, 168, 120
+    sc = make_scene(2500, S=S, sh_degree=2, seed=11, log_scale_mean=-2.3)
+    cam = make_camera(W, H, yaw=0.2)
+    bg = np.zeros(3, np.float32)
+    grads = [g.copy() for g in upstream_grads(S, H, W, seed=5)]
+    rng = np.random.default_rng(17)
+    for g in grads[:2]:
+        spikes = rng.random(g.shape) < 0.01
+        g[spikes] *= np.float32(2.0 ** 20)
+    grads[1][3] = 0.0  # a semantic channel nobody differentiates
+    res = {}
+    for flush in (0, 2):
+        _lib.set_option("bwd_variant", flush)
+        try:
+            res[flush] = run_hip(sc, cam, bg, dev, grads=grads)["grads"]
+        finally:
+            _lib.set_option("bwd_variant", 0)
+    for name in ("sh", "semantics", "opacity", "means2D"):
+        scale = float(np.abs(res[2][name]).max())
+        assert float(np.abs(res[0][name] - res[2][name]).max()) <= 1e-6 * scale, name
+    assert not res[0]["semantics"][:, 3].any() and not res[2]["semantics"][:, 3].any()
+
+
 @pytest.mark.parametrize("P,W,H,S", [(4000, 200, 152, 16), (2500, 97, 61, 10), (1500, 64, 48, 3), (200_000, 800, 528, 16),
                                      (400, 1280, 720, 16)])
 def test_semantics_only_backward_is_bit_identical_to_the_full_one(dev, P, W, H, S):
