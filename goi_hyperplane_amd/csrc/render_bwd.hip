@@ -104,7 +104,8 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
     const float* __restrict__ dL_dpixsem, const float* __restrict__ dL_dpixdepth, const float* __restrict__ dL_dalphas,
     float* __restrict__ rows, uint8_t* __restrict__ flags, int row_floats,
     const uint32_t* __restrict__ counters, const uint32_t* __restrict__ qorder,
-    const unsigned long long* __restrict__ qmask0, const unsigned long long* __restrict__ qmask) {
+    const unsigned long long* __restrict__ qmask0, const unsigned long long* __restrict__ qmask,
+    const uint32_t* __restrict__ qcost) {
     using Cfg = BwdCfg<S4>;
     const bool cull = counters[COUNTER_CULL] != 0;  // the rectangles the forward listed
     constexpr int NF4 = Cfg::NF4, NSEM = Cfg::NSEM, NCH = Cfg::NCH, NB = Cfg::NB;
@@ -131,33 +132,42 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
     const uint2 range = ranges[t.tile];
     const size_t HW = (size_t)W * H;
     const size_t pix_id = (size_t)W * t.py + t.px;
-    const int last_contributor = t.inside ? (int)n_contrib[pix_id] : 0;
+    // Every per-pixel input of the wave is REQUESTED here, before anything waits: lanes outside the image read pixel 0 and
+    // discard it (no divergent load blocks, each with its own wait), and the wave's own trip count comes from a scalar load.
+    // The head of a wave used to be five dependent memory round trips (order -> n_contrib -> reduction -> out_alpha -> dL);
+    // with 26 400 waves per launch that was a tenth of the kernel.
+    const size_t pix_ld = t.inside ? pix_id : 0;
+    const uint32_t nc_ld = n_contrib[pix_ld];
+    const float oa_ld = out_alpha[pix_ld];
+    float dLch[NCH];
+    // an absent upstream gradient (NULL) is zero
+    if (dL_dpixsem && S == NSEM) {  // (wave-uniform; the common case without a test per channel)
+#pragma unroll
+        for (int ch = 0; ch < NSEM; ch++) dLch[ch] = dL_dpixsem[ch * HW + pix_ld];
+    } else {
+#pragma unroll
+        for (int ch = 0; ch < NSEM; ch++) dLch[ch] = (dL_dpixsem && ch < S) ? dL_dpixsem[ch * HW + pix_ld] : 0.f;
+    }
+    dLch[NSEM + 0] = dL_dpix ? dL_dpix[0 * HW + pix_ld] : 0.f;
+    dLch[NSEM + 1] = dL_dpix ? dL_dpix[1 * HW + pix_ld] : 0.f;
+    dLch[NSEM + 2] = dL_dpix ? dL_dpix[2 * HW + pix_ld] : 0.f;
+    dLch[NSEM + 3] = dL_dpixdepth ? dL_dpixdepth[pix_ld] : 0.f;
+    float dLa = dL_dalphas ? dL_dalphas[pix_ld] : 0.f;
 
     // ---- this wave's last contributor: list positions [0, n_proc) are all it has to look at
-    int n_proc = last_contributor;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) n_proc = max(n_proc, __shfl_xor(n_proc, d, 64));
-    n_proc = __builtin_amdgcn_readfirstlane(n_proc);
+    // (the forward blend left it per quadrant for the launch order: one scalar load instead of a wave reduction)
+    const int last_contributor = t.inside ? (int)nc_ld : 0;
+    const int n_proc = qcost ? (int)qcost[__builtin_amdgcn_readfirstlane(4 * t.tile + t.q)] : wave_max_i32(last_contributor);
     if (n_proc == 0) return;  // nothing was composited in this quadrant
     const int rounds = (n_proc + BATCH - 1) / BATCH;
 
     // ---- per-pixel upstream gradients, channel order (sem0.., r, g, b, depth)
-    const float T_final = t.inside ? (1.f - out_alpha[pix_id]) : 0.f;
+    const float T_final = t.inside ? (1.f - oa_ld) : 0.f;
     float T = T_final;
-    float dLch[NCH];
-    float dLa = 0.f;
-    if (t.inside) {
-#pragma unroll
-        // an absent upstream gradient (NULL) is zero
-        for (int ch = 0; ch < NSEM; ch++) dLch[ch] = (dL_dpixsem && ch < S) ? dL_dpixsem[ch * HW + pix_id] : 0.f;
-        dLch[NSEM + 0] = dL_dpix ? dL_dpix[0 * HW + pix_id] : 0.f;
-        dLch[NSEM + 1] = dL_dpix ? dL_dpix[1 * HW + pix_id] : 0.f;
-        dLch[NSEM + 2] = dL_dpix ? dL_dpix[2 * HW + pix_id] : 0.f;
-        dLch[NSEM + 3] = dL_dpixdepth ? dL_dpixdepth[pix_id] : 0.f;
-        dLa = dL_dalphas ? dL_dalphas[pix_id] : 0.f;
-    } else {
+    if (!t.inside) {
 #pragma unroll
         for (int ch = 0; ch < NCH; ch++) dLch[ch] = 0.f;
+        dLa = 0.f;
     }
     const float bg_dot = bg[0] * dLch[NSEM] + bg[1] * dLch[NSEM + 1] + bg[2] * dLch[NSEM + 2];
     float R = 0.f;
@@ -180,7 +190,12 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
     f16x8 Wh[F16 ? NB : 1][2], Wl[F16 ? NB : 1][2], Cc[2];
     float unscale[F16 ? NB : 1], unscale_c = 0.f;
     bf16x8 Bas;
-    static_assert(64 * 16 * 4 <= T_BYTES, "staging region too small");
+    // (the operands are transposed through s_t once per kernel: lane = pixel writes [pixel][channel], lane (kq, mm) reads
+    // [pixel 8 kq + i][channel mm].  A row stride of 17 floats makes the writes conflict-free and the reads 2-way; the stride
+    // of 16 it replaced cost 16-way writes and 4-way reads -- ~300 LDS cycles per block and wave, a fifth of this kernel's
+    // LDS time in the counters; 5 instead of 4 for the four colour / depth channels: both conflict-free)
+    constexpr int BT = 17;
+    static_assert(64 * BT * 4 <= F16_FLOATS * 4 && 64 * 16 * 4 <= T_BYTES, "staging region too small");
     // basis_m(pixel p) in quadrant-centred coordinates u, v in [-3.5, 3.5] (pixel p = column p & 7, row p >> 3);
     // m = mm - 4: 1, u, v, u^2, uv, v^2
     const float k1 = mm == 4 ? 1.f : 0.f, ku = mm == 5 ? 1.f : 0.f, kv = mm == 6 ? 1.f : 0.f;
@@ -195,26 +210,26 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
 #pragma unroll
             for (int c = 0; c < 16; c++) {
                 const int ch = nb * 16 + c;
-                s_t[lane * 16 + c] = ch < NSEM ? dLch[ch] : 0.f;
+                s_t[lane * BT + c] = ch < NSEM ? dLch[ch] : 0.f;
             }
             __builtin_amdgcn_wave_barrier();
             float y[2][8];
 #pragma unroll
             for (int c2 = 0; c2 < 2; c2++)
 #pragma unroll
-                for (int i = 0; i < 8; i++) y[c2][i] = s_t[(32 * c2 + 8 * kq + i) * 16 + mm];
+                for (int i = 0; i < 8; i++) y[c2][i] = s_t[(32 * c2 + 8 * kq + i) * BT + mm];
             f16_b_operand(y, Wh[nb], Wl[nb], unscale[nb]);
             __builtin_amdgcn_wave_barrier();
         }
         {
 #pragma unroll
-            for (int c = 0; c < 4; c++) s_t[lane * 4 + c] = dLch[NSEM + c];
+            for (int c = 0; c < 4; c++) s_t[lane * 5 + c] = dLch[NSEM + c];
             __builtin_amdgcn_wave_barrier();
             float y[2][8];
 #pragma unroll
             for (int c2 = 0; c2 < 2; c2++)
 #pragma unroll
-                for (int i = 0; i < 8; i++) y[c2][i] = s_t[(32 * c2 + 8 * kq + i) * 4 + (mm & 3)];
+                for (int i = 0; i < 8; i++) y[c2][i] = s_t[(32 * c2 + 8 * kq + i) * 5 + (mm & 3)];
             f16x8 hi[2], lo[2];
             f16_b_operand(y, hi, lo, unscale_c);
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -681,7 +696,7 @@ void launch_bwd_rows_s4(const GoiRasterScene& sc, const GeomView& g, const Image
     render_bwd_rows_k<S4, F16, MASKS><<<dim3(quad_grid(n_quads)), dim3(64), 0, s>>>(                                     \
         im.ranges, point_list, sc.W, sc.H, gx, gy, n_quads, sc.S, g.rec, sc.semantics, radii, g.aux, sc.bg, out_alpha, \
         im.n_contrib, dL_dpix, dL_dsem, dL_ddepth, dL_dalpha, scr.rows, scr.flags, bwd_row_floats(sc.S),                 \
-        g.counters, quad_order_enabled(sc.W, sc.H) ? im.qorder : nullptr, im.qmask0, qmask)
+        g.counters, quad_order_enabled(sc.W, sc.H) ? im.qorder : nullptr, im.qmask0, qmask, im.qcost)
     const bool masks = qmask != nullptr && g_options.bwd_masks != 0;
     if ((g_options.bwd_variant & 15) == 2) {  // exact-fp32 flush
         if (masks) GOI_LAUNCH_ROWS(false, true);

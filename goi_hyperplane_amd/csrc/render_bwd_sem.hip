@@ -35,7 +35,8 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
     const uint4* __restrict__ aux, const float* __restrict__ out_alpha, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dpixsem, float* __restrict__ rows, uint8_t* __restrict__ flags, int row_floats,
     const uint32_t* __restrict__ counters, const uint32_t* __restrict__ qorder,
-    const unsigned long long* __restrict__ qmask0, const unsigned long long* __restrict__ qmask) {
+    const unsigned long long* __restrict__ qmask0, const unsigned long long* __restrict__ qmask,
+    const uint32_t* __restrict__ qcost) {
     const bool cull = counters[COUNTER_CULL] != 0;  // the rectangles the forward listed
     constexpr int NSEM = 4 * S4, NB = (NSEM + 15) / 16;
     __shared__ f32x4 s_geo[SBATCH];           // (A3, A5, A1, A2) of the quadrant-centred log2-alpha polynomial
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
     // w columns, [member][pixel] floats; the split flush keeps them at f16_row() (blend_common.h)
     constexpr int TS = STSTRIDE;  // (fp32 flush)
     constexpr int T_BYTES = F16 ? F16_FLOATS * 4 : SGROUP * STSTRIDE * 4;
-    static_assert(64 * 16 * 4 <= T_BYTES, "staging region too small");
+    static_assert(64 * (F16 ? 17 : 16) * 4 <= T_BYTES, "staging region too small");
     __shared__ __attribute__((aligned(16))) char s_traw[T_BYTES];
     float* const s_t = reinterpret_cast<float*>(s_traw);
     __shared__ uint32_t s_slot[SGROUP];
@@ -57,14 +58,24 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
     const f32x2 uv = {t.pxf - QCX, t.pyf - QCY};         // this lane's pixel, quadrant-centred
     const size_t HW = (size_t)W * H;
     const size_t pix_id = (size_t)W * t.py + t.px;
-    const int last_contributor = t.inside ? (int)n_contrib[pix_id] : 0;
-    int n_proc = last_contributor;
+    // (all per-pixel inputs are requested before anything waits, lanes outside the image read pixel 0: render_bwd.hip)
+    const size_t pix_ld = t.inside ? pix_id : 0;
+    const uint32_t nc_ld = n_contrib[pix_ld];
+    const float oa_ld = out_alpha[pix_ld];
+    float dLsem[NSEM];
+    if (S == NSEM) {
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) n_proc = max(n_proc, __shfl_xor(n_proc, d, 64));
-    n_proc = __builtin_amdgcn_readfirstlane(n_proc);
+        for (int ch = 0; ch < NSEM; ch++) dLsem[ch] = dL_dpixsem[ch * HW + pix_ld];
+    } else {
+#pragma unroll
+        for (int ch = 0; ch < NSEM; ch++) dLsem[ch] = ch < S ? dL_dpixsem[ch * HW + pix_ld] : 0.f;
+    }
+    const int last_contributor = t.inside ? (int)nc_ld : 0;
+    // (the forward blend left it per quadrant for the launch order: one scalar load instead of a wave reduction)
+    const int n_proc = qcost ? (int)qcost[__builtin_amdgcn_readfirstlane(4 * t.tile + t.q)] : wave_max_i32(last_contributor);
     if (n_proc == 0) return;
     const int rounds = (n_proc + SBATCH - 1) / SBATCH;
-    float T = t.inside ? (1.f - out_alpha[pix_id]) : 0.f;
+    float T = t.inside ? (1.f - oa_ld) : 0.f;
 
     // MFMA B operands: bfrag[nb][s] = dL[pixel 4s + (lane>>4)][channel 16 nb + (lane&15)]
     const int kq = lane >> 4, mm = lane & 15;
@@ -76,7 +87,7 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
 #pragma unroll
         for (int c = 0; c < 16; c++) {
             const int ch = nb * 16 + c;
-            s_t[lane * 16 + c] = (t.inside && ch < S) ? dL_dpixsem[ch * HW + pix_id] : 0.f;
+            s_t[lane * (F16 ? 17 : 16) + c] = (t.inside && ch < NSEM) ? dLsem[ch] : 0.f;  // (row stride: render_bwd.hip, BT)
         }
         __builtin_amdgcn_wave_barrier();
         if constexpr (!F16) {
@@ -87,7 +98,7 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
 #pragma unroll
             for (int c2 = 0; c2 < 2; c2++)
 #pragma unroll
-                for (int i = 0; i < 8; i++) y[c2][i] = s_t[(32 * c2 + 8 * kq + i) * 16 + mm];
+                for (int i = 0; i < 8; i++) y[c2][i] = s_t[(32 * c2 + 8 * kq + i) * 17 + mm];
             f16_b_operand(y, Wh[nb], Wl[nb], unscale[nb]);
         }
         __builtin_amdgcn_wave_barrier();
@@ -257,7 +268,7 @@ void launch_bwd_sem_s4(const GoiRasterScene& sc, const GeomView& g, const ImageV
 #define GOI_LAUNCH_SEM(SP, MK)                                                                                         \
     render_bwd_sem_k<S4, SP, MK><<<dim3(quad_grid(n_quads)), dim3(64), 0, s>>>(                                          \
         im.ranges, point_list, sc.W, sc.H, gx, gy, n_quads, sc.S, g.rec, radii, g.aux, out_alpha, im.n_contrib, dL_dsem, \
-        rows, flags, row_floats, g.counters, quad_order_enabled(sc.W, sc.H) ? im.qorder : nullptr, im.qmask0, qmask)
+        rows, flags, row_floats, g.counters, quad_order_enabled(sc.W, sc.H) ? im.qorder : nullptr, im.qmask0, qmask, im.qcost)
     const bool masks = qmask != nullptr && g_options.bwd_masks != 0;
     if ((g_options.bwd_variant & 15) == 2) {  // exact-fp32 flush, as in the full backward
         if (masks) GOI_LAUNCH_SEM(false, true);

@@ -234,10 +234,7 @@ __global__ __launch_bounds__(64) void render_fwd_k(const uint2* __restrict__ ran
             } else {
                 // every pixel has stopped: what the tile needs of its list ends at the LAST stopping entry (a pixel that has
                 // not met its stopping entry keeps walking: the cut must contain it); lanes outside the image never started
-                int seen = (int)stop_pos;
-#pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) seen = max(seen, __shfl_xor(seen, d, 64));
-                seen = min(len, seen);
+                int seen = min(len, wave_max_i32((int)stop_pos));
                 (void)b_end;
                 const int pos = seen + (seen >> 3) + 32;  // margin: an eighth + 32 list positions
                 if (pos < len)
@@ -250,9 +247,7 @@ __global__ __launch_bounds__(64) void render_fwd_k(const uint2* __restrict__ ran
     }
 
     {   // how far the backward's wave of this quadrant has to walk: the largest last contributor of its 64 pixels
-        int qc = (int)last_contributor;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) qc = max(qc, __shfl_xor(qc, d, 64));
+        const int qc = wave_max_i32((int)last_contributor);
         if (qcost && lane == 0) qcost[tq] = (uint32_t)qc;
     }
     if (t.inside) {
