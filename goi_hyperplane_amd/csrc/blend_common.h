@@ -182,6 +182,15 @@ __device__ __forceinline__ void split16_pack8(const float (&y)[8], f16x8& h, f16
     l = __builtin_bit_cast(f16x8, u32x4{lw[0], lw[1], lw[2], lw[3]});
 }
 
+// LDS-DMA: 16 bytes per active lane straight from global memory to LDS, lane l's at lds_base + 16 l (lds_base wave-uniform; the
+// instruction takes it in M0), tracked by vmcnt like any load (tools/probes/lds_dma_probe.hip checks the addressing).  The
+// builtin exists in the device pass only: hipcc's host pass, which parses kernel bodies too, drops a kernel that names it.
+__device__ __forceinline__ void lds_dma16(const void* global_src, void* lds_base) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_global_load_lds(global_src, lds_base, 16, 0, 0);
+#endif
+}
+
 // Largest value of a wave's 64 lanes, as a scalar.  (__shfl_xor compiles to ds_bpermute: six dependent LDS round trips.  A
 // DPP butterfly inside the 16-lane rows + four v_readlane, and v_permlane16/32_swap for the column maximum below, avoid
 // the LDS altogether and were measured 4-5 us SLOWER on the backward blend, same box, two runs each: 0.532 vs 0.527 ms.)

@@ -114,7 +114,11 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
     __shared__ f32x4 s_geo[BATCH + GROUP];   // (A3, A5, A1, A2) of the quadrant-centred log2-alpha polynomial (blend_common.h)
     __shared__ f32x4 s_geo2[BATCH + GROUP];  // (A0, A4, lim, slot index (bits))
     __shared__ float2 s_cen[BATCH + GROUP];  // Gaussian centre - quadrant centre (the flush expands the moments around it)
-    __shared__ float4 s_feat[BATCH * NF4];  // (r,g,b,depth), semantics...
+    // staged features, word-major: s_feat[i * BATCH + slot], i = 0: (r, g, b, depth), i >= 1: the semantic row's float4 words.
+    // That is the layout LDS-DMA writes (global_load_lds_dwordx4: lane l's 16 bytes land at base + 16 l, inactive lanes write
+    // nothing -- tools/probes/lds_dma_probe.hip): slot = lane, so a member's words travel from memory to LDS without passing
+    // through registers.
+    __shared__ __attribute__((aligned(16))) float4 s_feat[BATCH * NF4];
     // [row][pixel] floats.  fp32 flush: rows 0..7 = w, rows 8..15 = h of the group's members, row stride TSTRIDE.
     // Split-f16 flush: the same rows at f16_row() (blend_common.h: 16-byte aligned, conflict-free for its reads); the
     // flush splits them into planes after reading its A operand (two dword stores per member cost the LDS half of
@@ -482,11 +486,22 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
         // ---- stage the hits (slot = lane)
         if (hit) {
             const float4* r4 = reinterpret_cast<const float4*>(rec + id);
+            // (r, g, b, depth) and the semantic row go to LDS by DMA, requested FIRST: no registers (the row alone would be 16
+            // in a kernel at its limit), no ds_write, and -- unlike loads placed where their data is stored, after the
+            // arithmetic on the record -- in flight together with the record and aux: one memory round trip per batch
+            // instead of two.  Loads return in order: when the record has arrived, so have these.
+            const float* srow = semantics + (size_t)id * S;
+            const bool rows_of_float4 = (S & 3) == 0;  // (wave-uniform)
+            lds_dma16(r4 + 2, &s_feat[0]);
+            if (rows_of_float4) {
+#pragma unroll
+                for (int i = 0; i < S4; i++)
+                    lds_dma16(reinterpret_cast<const float4*>(srow) + i, &s_feat[(1 + i) * BATCH]);
+            }
             if constexpr (MASKS) {
                 q0 = r4[0];
                 q1 = r4[1];
             }
-            const float4 q2 = r4[2];  // r, g, b, depth: the one thing only a hit needs of its record
             int x0, y0, x1, y1;
             const uint4 ax = aux[id];  // first slot, radius, tile mask: one 16-byte gather (three scattered ones before)
             listed_rect(q0.x, q0.y, (int)ax.y, q1.z, q1.w, cull, gx, gy, x0, y0, x1, y1);
@@ -499,13 +514,7 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
             s_geo[sl] = f32x4{pc.A35.x, pc.A35.y, pc.A12.x, pc.A12.y};
             s_geo2[sl] = f32x4{pc.A0, pc.A4, pc.lim, __uint_as_float(inst * 4u + (uint32_t)t.q)};
             s_cen[sl] = make_float2(q0.x - QCX, q0.y - QCY);
-            float4* fdst = &s_feat[sl * NF4];
-            fdst[0] = q2;
-            const float* srow = semantics + (size_t)id * S;
-            if ((S & 3) == 0) {
-#pragma unroll
-                for (int i = 0; i < S4; i++) fdst[1 + i] = reinterpret_cast<const float4*>(srow)[i];
-            } else {
+            if (!rows_of_float4) {  // a row that is not a whole number of float4 words: through registers
 #pragma unroll
                 for (int i = 0; i < S4; i++) {
                     float4 v;
@@ -513,10 +522,11 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
                     v.y = (4 * i + 1 < S) ? srow[4 * i + 1] : 0.f;
                     v.z = (4 * i + 2 < S) ? srow[4 * i + 2] : 0.f;
                     v.w = (4 * i + 3 < S) ? srow[4 * i + 3] : 0.f;
-                    fdst[1 + i] = v;
+                    s_feat[(1 + i) * BATCH + sl] = v;
                 }
             }
         }
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the DMA words are in LDS before any lane reads them
         __builtin_amdgcn_wave_barrier();
 
         while (m) {
@@ -539,12 +549,12 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
             const bool c = live && e.hit;
 
             // <feature, dL/dpixel> as packed fp32 FMAs (v_pk_fma_f32: two channels per instruction)
-            const f32x4 f0 = s_feat4[j * NF4];  // r, g, b, depth
+            const f32x4 f0 = s_feat4[j];  // r, g, b, depth
             f32x2 da = f0.xy * dL2[NSEM / 2];
             f32x2 db = f0.zw * dL2[NSEM / 2 + 1];
 #pragma unroll
             for (int i = 0; i < S4; i++) {
-                const f32x4 f = s_feat4[j * NF4 + 1 + i];
+                const f32x4 f = s_feat4[(1 + i) * BATCH + j];
                 da = __builtin_elementwise_fma(f.xy, dL2[2 * i], da);
                 db = __builtin_elementwise_fma(f.zw, dL2[2 * i + 1], db);
             }
