@@ -289,18 +289,21 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
     // position down; its members are bits [32 (kb & 1), +32) of the forward's mask word kb >> 1 (wave-uniform, SGPRs).
     // Otherwise: batch b covers positions n_proc-1-32b downwards, lane l position n_proc-1-(32 b + l), every lane a candidate.
     uint32_t id_n = 0;
-    uint32_t mem_n = 0;
+    unsigned long long w_n = 0;  // (MASKS) the forward's member word that holds the next batch's 32 bits
     float4 q0_n = make_float4(0, 0, 0, 0), q1_n = make_float4(1.f, 0.f, -1.f, -1.f);  // (conic c, opacity, hx, hy)
     const int tile_u = __builtin_amdgcn_readfirstlane(t.tile), q_u = __builtin_amdgcn_readfirstlane(t.q);
     const uint32_t x0_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)range.x);
     auto prefetch = [&](int b) {
         if constexpr (MASKS) {
-            const unsigned long long w = *member_mask_ptr(const_cast<unsigned long long*>(qmask0),
-                                                          const_cast<unsigned long long*>(qmask), tile_u, q_u, x0_u, b >> 1);
-            mem_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(w >> (32 * (b & 1))));
-            // (the id only: a member's record is fetched when it is staged, together with the other gathers that wait there
-            // anyway -- its first two words, held across the batch, were eight VGPRs of a kernel that sits at its limit)
-            if (lane < BATCH && ((mem_n >> lane) & 1u)) id_n = point_list[range.x + (uint32_t)(b * BATCH + lane)];
+            // the batch's member word and its 32 ids (one line, whoever is a member) are requested TOGETHER, a batch ahead, and
+            // neither is waited for here: the ids used to be fetched for the members only, i.e. behind a wait for the word --
+            // a scalar-memory round trip at the top of every batch before its staging could begin.  (The id only: a member's
+            // record is fetched when it is staged, together with the other gathers that wait there anyway -- its first two
+            // words, held across the batch, were eight VGPRs of a kernel that sits at its limit.)
+            w_n = *member_mask_ptr(const_cast<unsigned long long*>(qmask0), const_cast<unsigned long long*>(qmask), tile_u, q_u,
+                                   x0_u, b >> 1);
+            const int pos = b * BATCH + lane;
+            if (lane < BATCH && pos < n_proc) id_n = point_list[range.x + (uint32_t)pos];
         } else {
             const int k = b * BATCH + lane;  // list position n_proc-1-k, walking back to front
             q1_n.z = -1.f;
@@ -474,8 +477,9 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
         bool hit;
         unsigned long long m;
         if constexpr (MASKS) {
-            m = mem_n;  // (wave-uniform)
-            hit = lane < BATCH && ((mem_n >> lane) & 1u);
+            const uint32_t mem = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(w_n >> (32 * (b & 1))));
+            m = mem;  // (wave-uniform)
+            hit = lane < BATCH && ((mem >> lane) & 1u);
             if (bi + 1 < rounds) prefetch(b - 1);
         } else {
             hit = ellipse_hits_quadrant(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, t.QX0, t.QY0);  // hx < 0 for absent lanes

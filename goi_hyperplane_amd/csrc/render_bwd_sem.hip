@@ -105,17 +105,18 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
     }
 
     uint32_t id_n = 0;
-    uint32_t mem_n = 0;
+    unsigned long long w_n = 0;  // (MASKS) the forward's member word that holds the next batch's 32 bits
     float4 q0_n = make_float4(0, 0, 0, 0), q1_n = make_float4(1.f, 0.f, -1.f, -1.f);  // (conic c, opacity, hx, hy)
     const int tile_u = __builtin_amdgcn_readfirstlane(t.tile), q_u = __builtin_amdgcn_readfirstlane(t.q);
     const uint32_t x0_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)range.x);
     auto prefetch = [&](int b) {
         if constexpr (MASKS) {  // batch b = list positions [32 b, 32 b + 32), lane l position 32 b + l; members only
-            const unsigned long long w = *member_mask_ptr(const_cast<unsigned long long*>(qmask0),
-                                                          const_cast<unsigned long long*>(qmask), tile_u, q_u, x0_u, b >> 1);
-            mem_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(w >> (32 * (b & 1))));
-            // (the id only: the record is fetched when the member is staged, with the gather that waits there anyway)
-            if (lane < SBATCH && ((mem_n >> lane) & 1u)) id_n = point_list[range.x + (uint32_t)(b * SBATCH + lane)];
+            // (member word and the batch's 32 ids requested together, a batch ahead, neither waited for here; the record is
+            // fetched when the member is staged, with the gather that waits there anyway: render_bwd.hip)
+            w_n = *member_mask_ptr(const_cast<unsigned long long*>(qmask0), const_cast<unsigned long long*>(qmask), tile_u, q_u,
+                                   x0_u, b >> 1);
+            const int pos = b * SBATCH + lane;
+            if (lane < SBATCH && pos < n_proc) id_n = point_list[range.x + (uint32_t)pos];
         } else {
             const int k = b * SBATCH + lane;
             q1_n.z = -1.f;
@@ -192,8 +193,9 @@ __global__ __launch_bounds__(64) void render_bwd_sem_k(
         bool hit;
         unsigned long long m;
         if constexpr (MASKS) {
-            m = mem_n;
-            hit = lane < SBATCH && ((mem_n >> lane) & 1u);
+            const uint32_t mem = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(w_n >> (32 * (b & 1))));
+            m = mem;
+            hit = lane < SBATCH && ((mem >> lane) & 1u);
             if (bi + 1 < rounds) prefetch(b - 1);
         } else {
             hit = ellipse_hits_quadrant(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, t.QX0, t.QY0);
