@@ -120,6 +120,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void compact_listed_k(int P, const uint3
 // removes the sort's histogram pass over the 8 M keys and the ranges pass over the sorted keys.
 constexpr int EMIT_ROUNDS = 4;
 
+constexpr int EMIT_BIG_TILES = 1024;  // rectangles above this are written by the big-rectangle loop of emit_k
 template <bool COUNT>
 __global__ __launch_bounds__(256) void emit_k(int P, int gx, int gy, const GaussRec* __restrict__ rec,
                                               const int* __restrict__ radii, const uint32_t* __restrict__ order,
@@ -203,6 +204,34 @@ __global__ __launch_bounds__(256) void emit_k(int P, int gx, int gy, const Gauss
         // instance belongs to rectangle (rectangles that ended before the trip) + (marks below its own position).  Two
         // dependent LDS round trips per trip; the binary search in the scanned counts this replaces had seven, and with
         // two waves per SIMD (emit is a small kernel) their latency was the kernel: 59 -> 3x us.
+        // A BIG rectangle (a frame-filling blob, a long needle: thousands of tiles) is taken out of the wave's common
+        // expansion -- one such rectangle kept its wave in the loop below for a hundred trips of ~80 instructions and two LDS
+        // round trips each while the rest of the chip had finished (clustered workload: emit 0.16 ms against 0.085 for its
+        // instance count) -- and written by a loop that needs none of that: all 64 lanes walk ITS instances, a division per
+        // instance.  Same keys, same values, same positions (a big rectangle is always a full one: the ellipse masks cover
+        // rectangles of at most 64 tiles).
+        const int cnt_own = cnt;
+        const unsigned long long big_lanes = __ballot(cnt > EMIT_BIG_TILES);
+        if (cnt > EMIT_BIG_TILES) cnt = 0;
+        for (unsigned long long bl = big_lanes; bl; bl &= bl - 1) {
+            const int l = __builtin_ctzll(bl);
+            const int bx0 = __builtin_amdgcn_readlane(x0, l), by0 = __builtin_amdgcn_readlane(y0, l);
+            const int bw = __builtin_amdgcn_readlane(w, l), bcnt = __builtin_amdgcn_readlane(cnt_own, l);
+            const uint32_t boff = (uint32_t)__builtin_amdgcn_readlane((int)off, l), bg = (uint32_t)__builtin_amdgcn_readlane((int)g, l);
+            const float inv_w = __builtin_amdgcn_rcpf((float)bw);
+            for (int k = lane; k < bcnt; k += 64) {
+                int row = (int)((float)k * inv_w);  // k / bw, off by at most one
+                row -= (row * bw > k);
+                row += ((row + 1) * bw <= k);
+                const uint32_t key = (uint32_t)((by0 + row) * gx + bx0 + (k - row * bw));
+                const uint32_t pos = boff + (uint32_t)k;
+                if (pos < cap) {
+                    keys[pos] = key;
+                    vals[pos] = bg;
+                    if (COUNT) atomicAdd(&s_cnt[key], 1u);
+                }
+            }
+        }
         int incl = cnt;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {

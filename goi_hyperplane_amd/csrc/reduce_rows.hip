@@ -49,10 +49,15 @@ constexpr uint32_t BIG_INST = 1024;
 // Sums the rows of `cnt` consecutive instances starting at instance `inst0` (their validity words at flags32[inst0 ..]) into
 // sum[] -- the lane's elements of the row -- in slot order.  Wave-synchronous: the four quarter waves of a wave call it
 // together, each for its own (inst0, cnt); w_first = the validity word of instance inst0 + e (prefetched by the caller).
-template <int K>
+// COMPENSATED (reduce_big_k): Kahan summation -- the lost low bits of every addition are carried in comp[] and fed back.  A big
+// Gaussian's sum runs over ten thousand rows of both signs: the plain fp32 sum's error grows with their number and depends on
+// how the rows are split over quarter waves (one component of one needle's dL/dscale moved by 2e-3 of the tensor's scale
+// between a 16- and a 64-part split: clustered workload, tools/diag_blown.py); the compensated sum is good to an ulp or two of
+// the result whatever the split.  Four additions instead of one, on the few hundred Gaussians that take this path.
+template <int K, bool COMPENSATED = false>
 __device__ __forceinline__ void sum_instances(const float* __restrict__ rows, const uint32_t* __restrict__ flags32,
                                               size_t inst0, uint32_t cnt, uint32_t w_first, int quarter, int e,
-                                              float (&sum)[K]) {
+                                              float (&sum)[K], float (&comp)[K]) {
     constexpr int RF = 16 * K;
     constexpr int INFLIGHT = GOI_REDUCE_INFLIGHT;
     auto load_flags = [&](uint32_t c) { return (c + e < cnt) ? flags32[inst0 + c + e] : 0u; };
@@ -114,7 +119,16 @@ __device__ __forceinline__ void sum_instances(const float* __restrict__ rows, co
 #pragma unroll
                 for (int i = 0; i < NF; i++)
 #pragma unroll
-                    for (int kk = 0; kk < K; kk++) sum[kk] += v[i][kk];
+                    for (int kk = 0; kk < K; kk++) {
+                        if constexpr (COMPENSATED) {
+                            const float y = v[i][kk] - comp[kk];
+                            const float t = sum[kk] + y;
+                            comp[kk] = (t - sum[kk]) - y;
+                            sum[kk] = t;
+                        } else {
+                            sum[kk] += v[i][kk];
+                        }
+                    }
             };
             int left = __popcll(m);  // rows this quarter still has to fetch; the wave's largest decides the trip
 #pragma unroll
@@ -267,7 +281,7 @@ __global__ __launch_bounds__(256) void reduce_rows_k(int P, int S, int nch, uint
         float sum[K];
 #pragma unroll
         for (int kk = 0; kk < K; kk++) sum[kk] = 0.f;
-        sum_instances<K>(rows, flags32, inst0, cnt, w_cur, quarter, e, sum);
+        sum_instances<K>(rows, flags32, inst0, cnt, w_cur, quarter, e, sum, sum);  // (comp unused)
         if (live && !big && (!RECORD || cnt > 0)) store_sums<K, RECORD>(sum, rows, inst0, cur.g, e, S, nch, out);
         cur = nxt;
         nxt = nn;
@@ -275,39 +289,47 @@ __global__ __launch_bounds__(256) void reduce_rows_k(int P, int S, int nch, uint
     }
 }
 
-// One WORKGROUP per big Gaussian (persistent: the grid is fixed, the count lives on the device): quarter wave p of the 16 sums
-// part p of the Gaussian's instances -- contiguous, a multiple of 64 instances long -- and quarter wave 0 adds the 16 partial
-// rows in part order and writes what reduce_rows_k writes for a Gaussian.
+// One WORKGROUP per big Gaussian (persistent: the grid is fixed, the count lives on the device): quarter wave p of the
+// BIG_PARTS sums part p of the Gaussian's instances -- contiguous, a multiple of 64 instances long -- and quarter wave 0 adds
+// the partial rows in part order and writes what reduce_rows_k writes for a Gaussian.  (64 parts, a 1024-thread workgroup: with
+// 16 the kernel's time was that of its largest Gaussian -- a frame-filling blob's 6 600 instances were 400 per quarter wave,
+// one row trip after the other.)
+constexpr int BIG_PARTS = 64;
 template <int K, bool RECORD>
-__global__ __launch_bounds__(256) void reduce_big_k(const uint32_t* __restrict__ big_ctl, const uint4* __restrict__ big_desc,
-                                                    float* rows, const uint8_t* __restrict__ flags, int S, int nch,
-                                                    ReduceOut out) {
+__global__ __launch_bounds__(16 * BIG_PARTS) void reduce_big_k(const uint32_t* __restrict__ big_ctl,
+                                                              const uint4* __restrict__ big_desc, float* rows,
+                                                              const uint8_t* __restrict__ flags, int S, int nch, ReduceOut out) {
     constexpr int RF = 16 * K;
-    __shared__ float s_part[16][RF];
+    __shared__ float s_part[BIG_PARTS][RF];
     const uint32_t nbig = big_ctl[1];
     const int lane = threadIdx.x & 63, quarter = lane >> 4, e = lane & 15, part = threadIdx.x >> 4;
     const uint32_t* flags32 = reinterpret_cast<const uint32_t*>(flags);
     for (uint32_t b = blockIdx.x; b < nbig; b += gridDim.x) {  // (block-uniform)
         const uint4 d = big_desc[b];  // (first instance, instances, -, Gaussian id)
-        const uint32_t per = ((d.y + 15u) / 16u + 63u) & ~63u;  // instances per part
+        const uint32_t per = ((d.y + BIG_PARTS - 1u) / BIG_PARTS + 63u) & ~63u;  // instances per part
         const uint32_t p0 = min(d.y, (uint32_t)part * per), p1 = min(d.y, (uint32_t)(part + 1) * per);
         const uint32_t cnt = p1 - p0;
         const size_t inst0 = (size_t)d.x + p0;
         const uint32_t w0 = ((uint32_t)e < cnt) ? flags32[inst0 + e] : 0u;
-        float sum[K];
+        float sum[K], comp[K];
 #pragma unroll
-        for (int kk = 0; kk < K; kk++) sum[kk] = 0.f;
-        sum_instances<K>(rows, flags32, inst0, cnt, w0, quarter, e, sum);
+        for (int kk = 0; kk < K; kk++) sum[kk] = comp[kk] = 0.f;
+        sum_instances<K, true>(rows, flags32, inst0, cnt, w0, quarter, e, sum, comp);
 #pragma unroll
         for (int kk = 0; kk < K; kk++) s_part[part][K == 2 ? 2 * e + kk : e + 16 * kk] = sum[kk];
         __syncthreads();
         if (part == 0) {
-            float tot[K];
+            float tot[K], c[K];
 #pragma unroll
-            for (int kk = 0; kk < K; kk++) tot[kk] = 0.f;
-            for (int pp = 0; pp < 16; pp++)
+            for (int kk = 0; kk < K; kk++) tot[kk] = c[kk] = 0.f;
+            for (int pp = 0; pp < BIG_PARTS; pp++)
 #pragma unroll
-                for (int kk = 0; kk < K; kk++) tot[kk] += s_part[pp][K == 2 ? 2 * e + kk : e + 16 * kk];
+                for (int kk = 0; kk < K; kk++) {  // (compensated as well: the parts' sums cancel like their rows do)
+                    const float y = s_part[pp][K == 2 ? 2 * e + kk : e + 16 * kk] - c[kk];
+                    const float t = tot[kk] + y;
+                    c[kk] = (t - tot[kk]) - y;
+                    tot[kk] = t;
+                }
             store_sums<K, RECORD>(tot, rows, (size_t)d.x, d.w, e, S, nch, out);
         }
         __syncthreads();
@@ -320,6 +342,12 @@ __global__ __launch_bounds__(256) void reduce_big_k(const uint32_t* __restrict__
 #define GOI_REDUCE_GPQ 2
 #endif
 constexpr int REDUCE_GPQ = GOI_REDUCE_GPQ;  // Gaussians per quarter wave of reduce_rows_k
+#ifndef GOI_REDUCE_BIG_GRID
+#define GOI_REDUCE_BIG_GRID 512
+#endif
+// persistent workgroups of reduce_big_k: two 1024-thread workgroups per CU (the kernel waits on memory: with one 256-thread
+// workgroup per CU it ran the clustered workload's big Gaussians at an eighth of the memory-level parallelism the chip has)
+constexpr size_t REDUCE_BIG_GRID = GOI_REDUCE_BIG_GRID;
 
 template <int K, bool RECORD>
 static void launch_reduce_k(const GoiRasterScene& sc, const GeomView& g, int N, int nch, float* rows, const uint8_t* flags,
@@ -332,7 +360,7 @@ static void launch_reduce_k(const GoiRasterScene& sc, const GeomView& g, int N, 
     // the big Gaussians: a fixed, small grid of persistent workgroups (their number is on the device; N == 0: no blend ran,
     // nothing cleared the counter and nothing can be registered)
     if (N > 0)
-        reduce_big_k<K, RECORD><<<dim3((unsigned)std::min<size_t>(256, scr.cap_big)), dim3(256), 0, s>>>(
+        reduce_big_k<K, RECORD><<<dim3((unsigned)std::min<size_t>(REDUCE_BIG_GRID, scr.cap_big)), dim3(16 * BIG_PARTS), 0, s>>>(
             scr.big_ctl, scr.big_desc, rows, flags, sc.S, nch, out);
 }
 
