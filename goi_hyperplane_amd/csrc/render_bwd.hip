@@ -7,9 +7,12 @@
 //  1. ONE WAVE = ONE WORKGROUP = one 8x8 quadrant (as in the forward): no workgroup barriers, no
 //     cross-wave imbalance.  Each wave starts at ITS OWN last contributor (max over its 64 pixels of
 //     n_contrib): the saturated tail of a tile list is never touched.
-//  2. Lane-parallel staging: per batch of 64 list entries every lane fetches one Gaussian's position
-//     and exact contribution box and tests it against the quadrant; only hits fetch the rest of the
-//     record + semantic row into LDS.  The hit mask lives in SGPRs (scalar bit scan).
+//  2. Lane-parallel staging in batches of 32 list entries.  The forward blend has left, per quadrant and 64 list positions,
+//     the mask of the Gaussians that contributed to some pixel of the quadrant (MASKS): the wave stages and evaluates those
+//     MEMBERS only -- mask word and ids requested a batch ahead; a member's record and `aux` word fetched when it is staged,
+//     its colour / depth word and semantic row sent from memory to LDS by DMA at the same moment (no registers, one round
+//     trip per batch).  Without the masks (bwd_masks 0) every lane tests one candidate's contribution ellipse against the
+//     quadrant.  The member / hit mask lives in SGPRs (scalar bit scan).
 //  3. The per-channel "accum_rec" recurrences (backward.cu:557,571,583,589) collapse into ONE scalar
 //     recurrence per pixel: with d_i = <feature_i, dL/dpixel> (+ depth and alpha terms),
 //         dL/dalpha_i = (d_i - R_i) * T_i - T_final/(1-alpha_i) * <bg, dL/dcolour>,
