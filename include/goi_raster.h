@@ -35,6 +35,9 @@
  *   - return value: >= 0 on success (forward/trace: num_rendered), < 0 on error with the message
  *     available from goi_raster_last_error() (thread-local).
  *   - supported S (semantic channels): any 1..32; fast paths are instantiated for 10 and 16.
+ *   - alignment: device pointers as torch / hipMalloc hand them out (256 bytes) are always fine.  What the kernels actually
+ *     assume: `semantics` 16-byte aligned when S is a multiple of 4 (its rows are moved as 16-byte words, by LDS-DMA in the
+ *     backward), the workspaces 256-byte aligned, everything else 4 bytes.
  */
 #ifndef GOI_RASTER_H
 #define GOI_RASTER_H
