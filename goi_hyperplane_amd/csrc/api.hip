@@ -104,6 +104,8 @@ int validate(const GoiRasterScene* sc, bool need_sem, bool need_opacity = true) 
     if (!sc->means3D || !sc->viewmatrix || !sc->projmatrix || !sc->campos || !sc->bg)
         return fail("a required input pointer is NULL");
     if (need_sem && !sc->semantics) return fail("semantics is required (the reference dereferences it unconditionally)");
+    if (sc->semantics && (sc->S & 3) == 0 && (reinterpret_cast<uintptr_t>(sc->semantics) & 15u) != 0)
+        return fail("semantics must be 16-byte aligned when S is a multiple of 4 (its rows are moved as 16-byte words)");
     if ((sc->shs == nullptr) == (sc->colors_precomp == nullptr))
         return fail("Please provide excatly one of either SHs or precomputed colors!");
     if (((sc->scales == nullptr || sc->rotations == nullptr) && sc->cov3D_precomp == nullptr) ||

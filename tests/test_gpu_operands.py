@@ -226,3 +226,19 @@ def test_gradient_gating_is_automatic(dev):  # noqa: F811
         rasterizer.set_backward_mode(semantics_only="auto")
         for p in pc.parameters():
             p.requires_grad_(True)
+
+
+def test_misaligned_semantics_are_refused(dev):  # noqa: F811
+    """S a multiple of 4: the kernels move a Gaussian's semantic row as 16-byte words (by LDS-DMA in the backward); a [P, S]
+    view that starts one float into its storage is contiguous, so nothing would copy it -- the C ABI refuses it by name."""
+    P, S = 64, 16
+    sc = make_scene(P, S=S, seed=5, log_scale_mean=-2.0)
+    cam = make_camera(64, 48)
+    means3D, opac = _leaf(sc.means3D, dev), _leaf(sc.opacities, dev)
+    shs, scales, rots = _leaf(sc.shs, dev), _leaf(sc.scales, dev), _leaf(sc.rotations, dev)
+    storage = torch.zeros(P * S + 4, device=dev)
+    sem = storage[1:1 + P * S].view(P, S)
+    assert sem.is_contiguous() and sem.data_ptr() % 16 != 0
+    m2d = torch.zeros(P, 3, device=dev)
+    with pytest.raises(Exception, match="16-byte aligned"):
+        _raster(dev, cam, np.zeros(3, np.float32))(means3D, m2d, opac, shs=shs, scales=scales, rotations=rots, semantics=sem)
