@@ -142,21 +142,16 @@ __device__ __forceinline__ PairEval eval_poly(f32x2 A35, f32x2 A12, float A0, fl
 }
 #endif  // GOI_ALPHA_DIRECT
 
-// ---- split-bf16 operands of the backward kernels' MFMA reductions (render_bwd.hip, "Two flushes")
+// ---- split operands of the backward kernels' MFMA reductions (render_bwd.hip, "Two flushes"; the bf16 helpers also serve
+// the loss kernels, codebook_loss.hip)
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-// [member row][pixel] transposition buffer of the split flush: row r starts at float split_row(r).  The flush reads
-// it with ds_read_b128 (lane (kq, mm): row mm, pixels 32 c + 8 kq ..), which the LDS serves in the lane groups
-// {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ...: a stride of 80 floats plus 4 floats for rows 8..15 puts the 16
-// lanes of every group on 16 different bank quads (no conflicts; a plain stride of 68 gives 2-way conflicts).
-constexpr int TS_SPLIT = 80;
-__device__ __forceinline__ constexpr int split_row(int r) { return r * TS_SPLIT + 4 * ((r >> 3) & 1); }
-constexpr int SPLIT_FLOATS = 16 * TS_SPLIT + 4;
 
-// split-f16 flush (render_bwd.hip): rows 0..7 = w, rows 8..15 = h of the group's members; lane (kq, mm) reads member row
-// 2 (mm >> 2) + (mm & 1) of either set at pixels 32 c + 8 kq (c = (mm >> 1) & 1 for w, the other chunk for h) with
-// ds_read_b128: a stride of 72 floats plus 4 for odd rows keeps the 16 lanes of every service group on 16 different
-// bank quads (searched exhaustively over strides and per-bit offsets).
+// [member row][pixel] transposition buffer of the split-f16 flush (render_bwd.hip): rows 0..7 = w, rows 8..15 = h of the
+// group's members (render_bwd_sem.hip: 16 w rows); lane (kq, mm) reads member row 2 (mm >> 2) + (mm & 1) of either set at
+// pixels 32 c + 8 kq, c = (mm >> 1) & 1, with ds_read_b128, which the LDS serves in the lane groups {0-3, 12-15, 20-27},
+// {4-11, 16-19, 28-31}, ...: a stride of 72 floats plus 4 for odd rows keeps the 16 lanes of every group on 16 different
+// bank quads (searched exhaustively over strides and per-bit offsets, then timed on the device: tools/probes/lds_probe.hip).
 __device__ __forceinline__ constexpr int f16_row(int r) { return (r & 7) * 72 + 4 * (r & 1) + (r >> 3) * 572; }
 constexpr int F16_FLOATS = 2 * 572;
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
