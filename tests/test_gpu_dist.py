@@ -84,3 +84,49 @@ def test_single_rank_rccl_path_runs_on_hardware(exchange):
     assert isinstance(d["per_rank"], list) and len(d["per_rank"]) == 1 and d["per_rank"][0]["rank"] == 0
     assert d["per_rank"][0]["gpu_stage_ms_sum"] > 0 and d["per_rank"][0]["dominant_stage"] in d["stages"]
     assert d["speculation"]["overflows"] == 0
+
+
+def test_direct_exchange_runs_on_rccl_in_place():
+    """allreduce_gradients_direct on the RCCL backend itself (one rank: all this box has): reduce_scatter_tensor with
+    `output = input[rank]` and all_gather_into_tensor back into the same span, both queued at once, blocking and in flight,
+    with the gradients the rasterizer's backward leaves (views of ONE flat buffer) and with separately allocated ones.  With a
+    single rank the sum is the identity: the gradients must come back bit for bit.  (What more ranks do is tested on gloo,
+    tests/test_dist_cpu.py; RCCL with more than one rank needs more than one GPU.)"""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    code = r'''
+import os, sys, torch
+sys.path.insert(0, os.environ["GOI_ROOT"])
+import torch.distributed as dist
+from goi_hyperplane_amd.dist import allreduce_gradients_direct
+dist.init_process_group("nccl", rank=0, world_size=1, init_method="tcp://127.0.0.1:%s" % os.environ["GOI_PORT"])
+dev = torch.device("cuda:0")
+g = torch.Generator(device=dev).manual_seed(0)
+flat = torch.randn(8 * 1000 + 3, device=dev, generator=g)
+shapes = [(1000, 3), (1000, 4), (1003,)]
+params, off = [], 0
+for shp in shapes:  # gradients that are views of one flat buffer, as the rasterizer's backward returns them
+    n = 1
+    for d_ in shp: n *= d_
+    p = torch.zeros(shp, device=dev, requires_grad=True)
+    p.grad = flat[off:off + n].view(shp)
+    off += n
+    params.append(p)
+extra = torch.zeros(257, 5, device=dev, requires_grad=True)  # and one of its own
+extra.grad = torch.randn(257, 5, device=dev, generator=g)
+params.append(extra)
+want = [p.grad.clone() for p in params]
+allreduce_gradients_direct(params, dist)
+torch.cuda.synchronize()
+assert all(torch.equal(p.grad, w) for p, w in zip(params, want)), "blocking"
+h = allreduce_gradients_direct(params, dist, async_op=True)
+h.wait()
+torch.cuda.synchronize()
+assert all(torch.equal(p.grad, w) for p, w in zip(params, want)), "in flight"
+dist.destroy_process_group()
+print("OK")
+'''
+    env = dict(os.environ, GOI_ROOT=ROOT, GOI_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "OK" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
