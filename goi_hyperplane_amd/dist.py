@@ -61,6 +61,17 @@ def coalesce_shared_storage(grads, max_waste: float = 0.25):
     return out
 
 
+def _touch(t):
+    """Marks `t` as written in place.  c10d collectives write their output tensors WITHOUT bumping the autograd version
+    counter (checked on torch 2.10: all_reduce on an as_strided view leaves `_version` unchanged, blocking or async), and the
+    compiled binding's gradient-buffer pool (torch_binding.cpp, backward_ex) hands a buffer out again as "rows of invisible
+    Gaussians still hold zeros" exactly when that counter has not moved.  A buffer another rank's rows were summed into is
+    NOT such a buffer: every helper here therefore bumps the counter of every tensor it passes to an in-place collective
+    (views share their base's counter), so the pool rewrites the buffer in full.  No kernel, no sync."""
+    torch.autograd.graph.increment_version(t)
+    return t
+
+
 def allreduce_gradients(params, dist, bucket_bytes: int = 0):
     """Sum-all-reduce `.grad` of every parameter in place.
 
@@ -76,7 +87,7 @@ def allreduce_gradients(params, dist, bucket_bytes: int = 0):
     if not grads:
         return
     if bucket_bytes <= 0:
-        works = [dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True) for g in coalesce_shared_storage(grads)]
+        works = [dist.all_reduce(_touch(g), op=dist.ReduceOp.SUM, async_op=True) for g in coalesce_shared_storage(grads)]
         for w in works:
             w.wait()
         return
@@ -151,7 +162,7 @@ def allreduce_gradients_visible(params, visible, dist, dense_above: float = 0.9,
     if n >= dense_above * P or not rows:
         (allreduce_gradients_direct if direct else allreduce_gradients)(with_grad, dist)
         return P
-    works = [dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True)
+    works = [dist.all_reduce(_touch(g), op=dist.ReduceOp.SUM, async_op=True)
              for g in coalesce_shared_storage([p.grad for p in rest])] if rest else []
     views = []
     for p in rows:
@@ -210,7 +221,7 @@ def _issue_sum(grads, dist, direct: bool):
         return [], None, None
     if not direct:
         spans = coalesce_shared_storage(grads)
-        return [dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True) for g in spans], None, spans
+        return [dist.all_reduce(_touch(g), op=dist.ReduceOp.SUM, async_op=True) for g in spans], None, spans
     h = allreduce_gradients_direct([_G(g) for g in grads], dist, async_op=True)
     return h.works, h._finish, h.keep
 
@@ -243,13 +254,13 @@ def allreduce_gradients_direct(params, dist, async_op: bool = False):
     # RCCL runs the collectives of one communicator in issue order on its stream: both can be queued at once.  Other
     # backends (gloo in the CPU tests: a pool of worker threads) give no such order between asynchronous collectives, so
     # there the all-gathers are issued once the reduce-scatters have completed (in wait()).
-    ordered = str(dist.get_backend()).lower() == "nccl"
+    ordered = "nccl" in str(dist.get_backend()).lower() and all(f.is_cuda for _s, f, _p in spans)  # (composite strings: 'cuda:nccl,cpu:gloo')
     shards, works, copies = [], [], []
     for span, flat, padded in spans:
         shard = flat.numel() // world
         mine = flat[rank * shard:(rank + 1) * shard]
         shards.append((flat, mine))
-        works.append(dist.reduce_scatter_tensor(mine, flat, op=dist.ReduceOp.SUM, async_op=True))
+        works.append(dist.reduce_scatter_tensor(mine, _touch(flat), op=dist.ReduceOp.SUM, async_op=True))
         if ordered:
             works.append(dist.all_gather_into_tensor(flat, mine, async_op=True))
         if padded:

@@ -68,6 +68,7 @@ def _worker(rank, world, port, bucket_bytes, q):
         off += (g[n].size + 63) // 64 * 64
         params.append(p)
     local = [p.grad.clone() for p in params]
+    version_before = flat._version  # (the binding's gradient pool reuses a buffer whose counter has not moved)
     if bucket_bytes == -1:  # the exchange left in flight: the handle owns the gradients, the parameters move on
         from goi_hyperplane_amd.dist import allreduce_gradients_async
         held = [p.grad for p in params]
@@ -101,6 +102,10 @@ def _worker(rank, world, port, bucket_bytes, q):
             p.grad = g_
     else:
         allreduce_gradients(params, dist, bucket_bytes=bucket_bytes)
+    # every exchange that summed other ranks' rows into the flat gradient buffer must have marked it as written: c10d
+    # collectives do not bump the autograd version counter themselves, and the compiled binding's gradient-buffer pool would
+    # otherwise hand the buffer out again as "rows of invisible Gaussians still hold zeros" (torch_binding.cpp, backward_ex)
+    assert flat._version > version_before, (bucket_bytes, flat._version, version_before)
     q.put((rank, views[0], [x.numpy() for x in local], [p.grad.numpy() for p in params]))
     dist.barrier()
     dist.destroy_process_group()
@@ -258,6 +263,7 @@ def _worker_factored(rank, world, port, q, in_flight=False, direct=False):
     rest = torch.nn.Parameter(torch.zeros(dsh.shape[0], 15, 3))
     local = [p.grad.clone().numpy() for p in params]
     means = torch.tensor(np.asarray(sc.means3D, np.float32))
+    versions = [p.grad._version for p in params]
     if in_flight:
         from goi_hyperplane_amd.dist import allreduce_gradients_sh_factored_async
         h = allreduce_gradients_sh_factored_async(params, (dc, rest), means, factor, dist, reconstruct=sh_grad_from_views,
@@ -266,6 +272,7 @@ def _worker_factored(rank, world, port, q, in_flight=False, direct=False):
         dc.grad, rest.grad = h.sh_grads[id(dc)], h.sh_grads[id(rest)]
     else:
         allreduce_gradients_sh_factored(params, (dc, rest), means, factor, dist, reconstruct=sh_grad_from_views, direct=direct)
+    assert all(p.grad._version > v for p, v in zip(params, versions))  # (marked as written in place: see _worker)
     q.put((rank, local, dsh.numpy(), [p.grad.numpy() for p in params],
            torch.cat([dc.grad, rest.grad], dim=1).numpy()))
     dist.barrier()
