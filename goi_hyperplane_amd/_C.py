@@ -386,9 +386,12 @@ class LazyCount:
             ce = _DEPTH_CUTS["entries"].get(self.cam_key)
             if ce is not None:
                 ce["n"] = self._n  # (the camera's most recent count: sizes its next frame)
-        if (fl.value & 4) and self.cut_key is not None and self._n <= self.capacity:
+        if self.cut_key is not None and ((fl.value & 4) or self._n > self.capacity):
             # The depth cut this frame's lists were built with was TOO TIGHT: some pixel reached the end of a cut list
-            # unsaturated.  The device has already made the frame harmless (zero gradients); the camera forgets its cut.
+            # unsaturated, or looked at an entry beyond its tile's cut.  The device has already made the frame harmless (zero
+            # gradients); the camera forgets its cut.  A cut frame that OVERFLOWED its (cut-sized) capacity is treated the same
+            # way: the redo of an overflowed frame re-bins from the cut geometry workspace and blends WITHOUT the cut check, so
+            # a too-tight cut would come back as "exact"  -- such a frame is rendered again whole and uncut instead.
             self.cut_failed = True
             SPECULATION_STATS["cut_failures"] += 1
             _DEPTH_CUTS["entries"].pop(self.cut_key, None)
@@ -633,7 +636,9 @@ def _depth_cut_for(dev, P, H, W, viewmatrix, projmatrix, campos, tan_fovx, tan_f
         ents.move_to_end(key)
         z_in = e["z"]
     n_prev = e.get("n", 0) if e is not None else 0
-    z_out = torch.empty(_tiles(H, W), dtype=torch.float32, device=dev)  # (cleared by the frame's first kernel)
+    # (+inf = "no cut": the array is registered as the camera's cut before the frame is enqueued, and a launch that raises
+    # must not leave uninitialised memory behind as the next frame's zcut_in; the frame's first kernel clears it for learning)
+    z_out = torch.full((_tiles(H, W),), float("inf"), dtype=torch.float32, device=dev)
     # what this frame learns is the camera's cut from now on: the next frame of the camera runs behind this one on the same
     # stream.  (A too-tight frame learns +inf for the tiles that failed: the array is conservative whatever became of the frame.)
     ents[key] = {"z": z_out, "keyed": (viewmatrix, projmatrix, campos), "n": n_prev}
@@ -1165,6 +1170,39 @@ def mark_visible(means3D, viewmatrix, projmatrix):
                                            _stream(dev)) < 0:
                 raise RuntimeError(_lib.last_error())
     return present
+
+
+BLEND_STATS_FIELDS = ("quadrants", "rounds", "positions", "forward_pairs", "member_pairs", "live_lanes", "pairs_8x4",
+                      "pairs_4x4", "pairs_2x2", "dead_member_pairs", "pixels", "sum_n_contrib")
+
+
+def blend_stats(P, W, H, R, geomBuffer, binningBuffer, imgBuffer) -> dict:
+    """Lane utilisation of the blend kernels for the frame whose forward filled the three workspaces
+    (goi_raster_blend_stats; diagnostic).  Returns the raw counters by name plus the derived ratios:
+    lane_utilisation_backward = live lanes / (64 x member pairs), lane_utilisation_forward = live lanes / (64 x the pairs
+    the forward evaluates), and what a split of the wave into 8x4 / 4x4 / 2x2 blocks would reach at best (live lanes /
+    (block size x (block, Gaussian) pairs): perfect balance between the blocks of a wave assumed)."""
+    lib = _lib.load()
+    dev = geomBuffer.device
+    R, lazy_binning = _layout_of(R)
+    if lazy_binning is not None:
+        binningBuffer = lazy_binning
+    with torch.cuda.device(dev):
+        out = torch.zeros(16, dtype=torch.int64, device=dev)
+        if lib.goi_raster_blend_stats(P, W, H, R, _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imgBuffer), _ptr(out),
+                                      _stream(dev)) < 0:
+            raise RuntimeError(_lib.last_error())
+        v = [int(x) for x in out.cpu().tolist()]
+    d = dict(zip(BLEND_STATS_FIELDS, v))
+    live = float(d["live_lanes"])
+    d["lane_utilisation_backward"] = live / max(64.0 * d["member_pairs"], 1.0)
+    d["lane_utilisation_forward"] = live / max(64.0 * d["forward_pairs"], 1.0)
+    d["lane_utilisation_8x4_blocks"] = live / max(32.0 * d["pairs_8x4"], 1.0)
+    d["lane_utilisation_4x4_blocks"] = live / max(16.0 * d["pairs_4x4"], 1.0)
+    d["lane_utilisation_2x2_blocks"] = live / max(4.0 * d["pairs_2x2"], 1.0)
+    d["live_lanes_per_member_pair"] = live / max(float(d["member_pairs"]), 1.0)
+    d["contributions_per_pixel"] = live / max(float(d["pixels"]), 1.0)
+    return d
 
 
 def debug_views(P, W, H, R, geomBuffer, binningBuffer, imgBuffer):

@@ -83,6 +83,7 @@ SYMBOLS = {
     "goi_semantic_decode": (C.c_int, [C.c_void_p, C.c_int, C.c_longlong, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                       C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "goi_raster_set_option": (C.c_int, [C.c_char_p, C.c_int]),
+    "goi_raster_blend_stats": (C.c_int, [C.c_int] * 4 + [C.c_void_p] * 5),
     "goi_raster_debug_views": (C.c_int, [C.c_int] * 4 + [C.c_void_p] * 3 + [C.c_void_p] * 8 + [C.c_void_p]),
 }
 

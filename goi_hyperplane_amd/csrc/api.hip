@@ -958,6 +958,24 @@ int goi_raster_profile_collect(double* ms, int* calls) {
     return 0;
 }
 
+int goi_raster_blend_stats(int P, int W, int H, int R, const void* geom_buffer, const void* binning_buffer,
+                           const void* image_buffer, unsigned long long* counters, void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (P <= 0 || W <= 0 || H <= 0 || R < 0) return fail("goi_raster_blend_stats: bad P/W/H/R");
+    if (!geom_buffer || !image_buffer || !counters || (R > 0 && !binning_buffer)) return fail("workspace pointer is NULL");
+    GOI_HIP(hipMemsetAsync(counters, 0, GOI_BLEND_STATS_WORDS * sizeof(unsigned long long), s));
+    if (R == 0) return 0;
+    GeomView g;
+    ImageView im;
+    BinView bv;
+    geom_layout(P, const_cast<char*>(static_cast<const char*>(geom_buffer)), &g);
+    image_layout(W, H, const_cast<char*>(static_cast<const char*>(image_buffer)), &im);
+    binning_layout(R, const_cast<char*>(static_cast<const char*>(binning_buffer)), &bv);
+    launch_blend_stats(W, H, g, im, bv.vals[tile_sort_result_index(W, H, R)], bv.qmask, counters, s);
+    GOI_HIP(hipGetLastError());
+    return 0;
+}
+
 int goi_raster_debug_views(int P, int W, int H, int R, const void* geom_buffer, const void* binning_buffer,
                            const void* image_buffer, float* depths, float* means2D, float* conic_opacity, float* rgb,
                            uint32_t* tiles_touched, uint32_t* point_list, uint32_t* ranges, uint32_t* n_contrib,

@@ -163,6 +163,9 @@ void launch_render_fwd(const GoiRasterScene& sc, const GeomView& g, const ImageV
                        float* out_color, float* out_sem, float* out_depth, float* out_alpha, hipStream_t s,
                        unsigned long long* qmask = nullptr, const float* zcut = nullptr, uint32_t* zlearn = nullptr,
                        uint32_t* host_words = nullptr);  // host_words: pinned, device-mapped words that get counters[0 .. 32)
+// lane utilisation of the blend kernels counted from a forward's member masks / n_contrib (blend_stats.hip): out[GOI_BLEND_STATS_WORDS]
+void launch_blend_stats(int W, int H, const GeomView& g, const ImageView& im, const uint32_t* point_list,
+                        const unsigned long long* qmask, unsigned long long* out, hipStream_t s);
 void launch_trace_fwd(const GoiRasterScene& sc, const float* img_sem, const GeomView& g, const ImageView& im,
                       const uint32_t* point_list, float* out_color, float* gau_sem, int* num_gsem, hipStream_t s);
 // launch order of the backward's quadrant waves (render_bwd.hip): im.qcost -> im.qorder

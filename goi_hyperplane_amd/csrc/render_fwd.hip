@@ -236,13 +236,22 @@ __global__ __launch_bounds__(64) void render_fwd_k(const uint2* __restrict__ ran
                 // not met its stopping entry keeps walking: the cut must contain it); lanes outside the image never started
                 int seen = min(len, wave_max_i32((int)stop_pos));
                 (void)b_end;
+                // A cut list is NOT a prefix of the uncut one: the cut lives in the ellipse tile masks, and a rectangle of
+                // more than 64 tiles has none -- such a Gaussian stays listed at every depth.  A pixel that passes zcut
+                // unsaturated and then stops on a deeper (big) entry has skipped the small Gaussians that were dropped in
+                // between.  Up to zcut the list is exact, so the frame is exact iff no pixel looked beyond it: the deepest
+                // entry any pixel of this wave looked at is its last stopping entry (the list is in depth order).
+                if (zc_in < 3.0e38f && seen > 0) {
+                    const float z_last = rec[point_list[range.x + (uint32_t)(seen - 1)]].q2.w;
+                    if (z_last > zc_in && lane == 0) atomicOr(frame_flags, OVF_CUT_TOO_TIGHT);
+                }
                 const int pos = seen + (seen >> 3) + 32;  // margin: an eighth + 32 list positions
                 if (pos < len)
                     zc = rec[point_list[range.x + (uint32_t)pos]].q2.w;  // (depth of that entry: the list is in depth order)
                 else
                     zc = zc_in;  // the margin runs past the end of the list: keep the cut the list was built with (or none)
             }
-            if (lane == 0) atomicMax(&zlearn[tile_u], __float_as_uint(zc));  // (depths are positive: their bits order like uints)
+            if (zlearn && lane == 0) atomicMax(&zlearn[tile_u], __float_as_uint(zc));  // (depths are positive: their bits order like uints)
         }
     }
 
@@ -274,7 +283,7 @@ void launch_fwd_s4(const GoiRasterScene& sc, const GeomView& g, const ImageView&
     const int n_quads = gx * gy * 4;
 #define GOI_LAUNCH_FWD(U2, MK)                                                                                         \
     do {                                                                                                               \
-        if (zlearn)                                                                                                    \
+        if (zlearn || zcut) /* a cut that is applied is always CHECKED, whether or not the frame learns a new one */    \
             render_fwd_k<S4, false, U2, MK, true><<<dim3(quad_grid(n_quads)), dim3(64), 0, s>>>(                        \
                 im.ranges, point_list, sc.W, sc.H, gx, n_quads, sc.S, g.rec, sc.semantics, sc.bg, out_color, out_sem,   \
                 out_depth, out_alpha, im.n_contrib, nullptr, nullptr, nullptr, im.qcost, im.qmask0, qmask, zcut,        \

@@ -13,10 +13,11 @@ Inference (`compute_similarity`) is the hot part at GUI frame rate: it runs as O
 (csrc/semantic_head.hip: fp32 MFMA contraction + argmax + per-code score lookup) that reads the
 rasterizer's [S, H, W] output directly.  The training losses exist twice: `codebook_losses` restates
 train.py line by line in PyTorch (the parity reference: ~40 kernels over [HW,300] tensors, 109 ms
-and 21 GB at 1600x1056 on MI355X); `fused_codebook_losses` is the product path (8 ms, 8 GB): a library
-GEMM for sim (hipBLASLt through torch.matmul, on a transposed view of the [256,H,W] map), ONE HIP row
-kernel producing the four loss terms and every per-pixel gradient, and a split-K MFMA GEMM for
-dL/dLUT (both in csrc/codebook_loss.hip).
+and 21 GB at 1600x1056 on MI355X); `fused_codebook_losses` is the product path.  For the reference's shapes (256-d
+features, 289..304 codes, S <= 16) that is `goi_codebook_fused`: five hand-written kernels of csrc/codebook_loss.hip,
+no [HW, C] fp32 matrix in memory (the similarity and its gradient exist as MFMA tiles and two bf16 planes), ~3.5 ms and
+8.6 GB at 1600x1056.  Other shapes take the three-kernel path (similarity kernel or library GEMM, one row kernel, a
+split-K MFMA GEMM for dL/dLUT), which is also the cross-check of tests/test_gpu_losses.py; LOSS_PATH_COUNTS says which ran.
 """
 from __future__ import annotations
 
@@ -170,6 +171,9 @@ def codebook_losses(sem_feature_chw: torch.Tensor, semantic_mlp: SemanticModel, 
     return loss, {"lab": lab, "sl": sl, "sl1": sl1, "recc": recc}
 
 
+# which implementation the last loss evaluations took, counted (tests assert on it: the product path for the reference's shapes
+# is "fused"; "three_kernel" / "library_gemm" are the paths for other shapes)
+LOSS_PATH_COUNTS = {"fused": 0, "three_kernel": 0, "library_gemm": 0}
 _SIM_KERNEL = {"on": True}  # False: the library fp32 GEMM for sim (A/B and a fallback for other shapes)
 _FUSED_KERNELS = {"on": True}  # False: the three-kernel path (sim, rows, dLUT) -- kept for other shapes and as a cross-check
 
@@ -208,6 +212,7 @@ class _FusedCodebookLoss(torch.autograd.Function):
                                           p(ws), stream) < 0:
                     raise RuntimeError(_lib.last_error())
                 del ws
+                LOSS_PATH_COUNTS["fused"] += 1
                 return _FusedCodebookLoss._finish(ctx, sem_chw, bias, partials, dsem, part.sum(dim=0)[:C].contiguous(), HW, C, S)
             sim_raw = inv_gnorm = None
             if D == 256 and C <= 304 and C % 4 == 0 and _SIM_KERNEL["on"]:
@@ -217,7 +222,9 @@ class _FusedCodebookLoss(torch.autograd.Function):
                 ws = torch.empty((int(lib.goi_codebook_sim_workspace_bytes()),), dtype=torch.uint8, device=dev)
                 if lib.goi_codebook_sim(p(g), p(l1), HW, C, D, p(sim_raw), p(inv_gnorm), p(ws), stream) < 0:
                     raise RuntimeError(_lib.last_error())
+                LOSS_PATH_COUNTS["three_kernel"] += 1
             else:
+                LOSS_PATH_COUNTS["library_gemm"] += 1
                 inv_gnorm = torch.linalg.vector_norm(g, dim=0).reciprocal_()        # [HW]
                 sim_raw = torch.matmul(g.t(), l1.t())                                 # [HW, C]  (library GEMM, fp32)
             dsim = torch.empty_like(sim_raw)

@@ -378,6 +378,22 @@ int goi_adam_step(const GoiAdamGroup* groups, int n_groups, double beta1, double
 int goi_adam_step_guarded(const GoiAdamGroup* groups, int n_groups, double beta1, double beta2, double eps,
                           const unsigned char* nograd_mask /*[P] or NULL*/, const uint32_t* skip_flag, void* stream);
 
+/* Lane utilisation of the blend kernels, counted on the device from what the forward of a frame left in its workspaces
+ * (member masks, n_contrib, per-quadrant walk lengths): a diagnostic of the execution mapping, not part of the reference's
+ * interface (its blend loops, one thread per pixel: CR/forward.cu:330-372, CR/backward.cu:523-589).  R / the three buffers:
+ * as for goi_raster_backward of the same frame.  counters: DEVICE array of GOI_BLEND_STATS_WORDS 64-bit words, cleared
+ * and filled on `stream`:
+ *   0 quadrants (8x8 pixels = one wave) that composited anything      1 rounds of 64 list positions they walk
+ *   2 list positions in those rounds up to the quadrant's last contributor
+ *   3 of those, candidates passing the forward's quadrant hit test (the pairs the forward blend evaluates)
+ *   4 MEMBER pairs: (quadrant, Gaussian) with a contribution to some pixel (the pairs the backward evaluates and flushes)
+ *   5 live lanes: (pixel, Gaussian) contributions = lanes doing useful work, summed over the member pairs
+ *   6 / 7 / 8 (block, Gaussian) pairs with a live lane were a wave split into 8x4 / 4x4 / 2x2 pixel blocks
+ *   9 member pairs without a live lane (0 by construction)   10 pixels inside the image   11 sum of n_contrib */
+#define GOI_BLEND_STATS_WORDS 16
+int goi_raster_blend_stats(int P, int W, int H, int R, const void* geom_buffer, const void* binning_buffer,
+                           const void* image_buffer, unsigned long long* counters, void* stream);
+
 /* Inspection of the opaque workspaces (tests only): copies device -> caller DEVICE buffers.
  * Any pointer may be NULL.  point_list is in final sorted order. */
 int goi_raster_debug_views(int P, int W, int H, int R, const void* geom_buffer, const void* binning_buffer,

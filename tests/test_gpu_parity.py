@@ -144,6 +144,31 @@ CASES = [
 ]
 
 
+def test_config1_exact_shape_forward_matches_oracle(oracle_mod, dev):
+    """BASELINE.json configs[0] as written -- 10 k random Gaussians, one camera at 400 x 300, forward only, S = 10 with an
+    all-zero feature channel (the reference's default sem_dim and what an un-trained scene holds: "RGB-only") -- through the
+    HIP path, against the oracle run of the same scene (tests/test_oracle_pins.py pins that oracle run to the reference
+    probe's statistics).  Integer stages bit-exact, maps within 1e-4, the feature map exactly zero."""
+    sc = make_scene(10000, S=10, sh_degree=3, seed=0)  # extent (2, 1.5, 1), log-scale mean -3.5: SURVEY.md 8(d)
+    sc.semantics[:] = 0.0
+    cam = make_camera(400, 300, fovx=1.0)
+    bg = np.zeros(3, np.float32)
+    o = oracle_mod.from_scene(sc, cam, bg=bg)
+    f = o.forward()
+    res = run_hip(sc, cam, bg, dev, grads=None, debug_views=True)
+    st = o.state()
+    assert res["N"] == f.num_rendered
+    assert int((res["radii"] > 0).sum()) == 10000
+    v = res["views"]
+    assert (v["point_list"].astype(np.uint32) == st["point_list"]).all()
+    assert (v["ranges"].astype(np.uint32) == st["ranges"]).all()
+    check_forward(res, f, "config1")
+    assert not res["semantics"].any()
+    # the reference probe's figures (SURVEY.md Appendix A.5), at the distribution level like the oracle's own pin
+    assert abs(float(res["alpha"].astype(np.float64).sum()) - 84752.95) <= 0.03 * 84752.95
+    assert abs(float(res["render"].astype(np.float64).sum()) - 129836.92) <= 0.03 * 129836.92
+
+
 @pytest.mark.parametrize("P,S,W,H,mu,deg", CASES)
 def test_forward_backward_match_oracle(oracle_mod, dev, P, S, W, H, mu, deg):
     sc = make_scene(P, S=S, sh_degree=deg, seed=3, log_scale_mean=mu)

@@ -72,3 +72,72 @@ def test_the_loop_learns():
     losses, *_ = run(dev, True, 60)
     first, last = sum(losses[:3]) / 3, sum(losses[-3:]) / 3
     assert last < 0.8 * first, (first, last)
+
+
+def test_training_loop_at_the_reference_shapes_takes_the_fused_kernels():
+    """the loop above uses 40 codes x 64-d, which semantic.py routes to the library-GEMM path.  The
+    reference's own shapes -- tab_len 300, 256-d ground-truth features (arguments/__init__.py, train.py:133-148), S = 16 --
+    at 400 x 304 must run `goi_codebook_fused` (asserted through LOSS_PATH_COUNTS) inside the same render -> losses ->
+    backward -> three Adam steps loop, and track the PyTorch pieces around the same rasterizer."""
+    from goi_hyperplane_amd import rasterizer, semantic
+    from goi_hyperplane_amd.optim import FusedAdam
+    from goi_hyperplane_amd.render import GaussianSet, PipelineParams, TorchCamera, render
+    from goi_hyperplane_amd.scene import make_camera, make_scene
+    from goi_hyperplane_amd.semantic import SemanticModel, codebook_losses, fused_codebook_losses
+    dev = torch.device("cuda")
+    W, H, C, D = 400, 304, 300, 256
+
+    def build():
+        sc = make_scene(20000, S=16, sh_degree=3, seed=1, log_scale_mean=-3.2)
+        pc = GaussianSet.from_scene(sc, dev)
+        for p in pc.parameters():
+            p.requires_grad_(False)
+        pc._semantics.requires_grad_(True)
+        cams = [TorchCamera(make_camera(W, H, yaw=0.1 * i), dev) for i in range(2)]
+        torch.manual_seed(1)
+        mlp = SemanticModel(dim_in=16, dim_out=C, num_layer=1, use_bias=True, device=dev)
+        g = torch.Generator(device=dev).manual_seed(1)
+        lut = torch.nn.Parameter(torch.rand(C, D, device=dev, generator=g) * 0.03)
+        protos = torch.randn(12, D, device=dev, generator=g)
+        ys, xs = torch.meshgrid(torch.arange(H, device=dev), torch.arange(W, device=dev), indexing="ij")
+        noise = 0.05 * torch.randn(H, W, D, device=dev, generator=g)
+        gtl = [(protos[((xs // 100) + 4 * (ys // 76) + v) % 12] + noise).permute(2, 0, 1).contiguous() for v in range(2)]
+        return pc, cams, mlp, lut, gtl
+
+    def run(fused, iters):
+        pc, cams, mlp, lut, gtl = build()
+        Adam = FusedAdam if fused else torch.optim.Adam
+        opts = [Adam([{"params": [pc._semantics], "lr": 5e-3, "name": "semantics"}], lr=0.0, eps=1e-15),
+                Adam(mlp.parameters(), lr=0.003), Adam([lut], lr=0.001)]
+        loss_fn = fused_codebook_losses if fused else codebook_losses
+        rasterizer.set_backward_mode(semantics_only=fused)
+        losses = []
+        try:
+            for it in range(iters):
+                out = render(cams[it % 2], pc, PipelineParams(), torch.zeros(3, device=dev))
+                loss, _ = loss_fn(out["semantics"], mlp, lut, gtl[it % 2], it)
+                loss.backward()
+                for o in opts:
+                    o.step()
+                    o.zero_grad(set_to_none=True)
+                losses.append(float(loss.detach()))
+        finally:
+            rasterizer.set_backward_mode(semantics_only="auto")
+        return losses, pc._semantics.detach().clone(), mlp.layers[0].weight.detach().clone(), lut.detach().clone()
+
+    before = dict(semantic.LOSS_PATH_COUNTS)
+    la, sa, wa, ta = run(True, 4)
+    after = dict(semantic.LOSS_PATH_COUNTS)
+    assert after["fused"] - before["fused"] == 4, (before, after)
+    assert after["three_kernel"] == before["three_kernel"] and after["library_gemm"] == before["library_gemm"]
+    lb, sb, wb, tb = run(False, 4)
+    for x, y in zip(la, lb):
+        assert abs(x - y) <= 2e-4 * abs(y), (la, lb)
+    # Adam with eps = 1e-15 turns a gradient into a step of ~lr whatever its size: an element whose gradient is rounding noise
+    # around zero (a feature of a Gaussian that barely touches a pixel) can step either way in the two runs.  With 320 k
+    # feature elements there are always a few: the bound is on the 99.9 % quantile, and the mean must be far inside it.
+    def q999(x):
+        return float(torch.quantile(x.abs().flatten().float()[: 1 << 22], 0.999))
+    assert q999(sa - sb) <= 0.05 * 5e-3 * 4 and float((sa - sb).abs().mean()) <= 0.005 * 5e-3 * 4
+    assert q999(wa - wb) <= 0.05 * 3e-3 * 4
+    assert q999(ta - tb) <= 0.05 * 1e-3 * 4
