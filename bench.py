@@ -149,6 +149,26 @@ def cpu_baseline(args, n_full_per_view, gpu_view=None):
     }
 
 
+def lane_utilisation(st: dict) -> dict:
+    """The bench line's `blend_lane_utilisation` object from the device counters of goi_raster_blend_stats (_C.blend_stats): how
+    many of a wave's 64 lanes (= the pixels of an 8x8 quadrant) do useful work per loop trip (= per (quadrant, Gaussian) pair)
+    of the two blend kernels, and what a split of the wave into smaller pixel blocks, each with its own list, could reach."""
+    return {
+        "backward": round(st["lane_utilisation_backward"], 4), "forward": round(st["lane_utilisation_forward"], 4),
+        "live_lanes_per_pair": round(st["live_lanes_per_member_pair"], 2),
+        "pairs_backward": st["member_pairs"], "pairs_forward": st["forward_pairs"], "live_lanes": st["live_lanes"],
+        "contributions_per_pixel": round(st["contributions_per_pixel"], 2),
+        "upper_bound_if_split_into": {"8x4": round(st["lane_utilisation_8x4_blocks"], 4),
+                                      "4x4": round(st["lane_utilisation_4x4_blocks"], 4),
+                                      "2x2": round(st["lane_utilisation_2x2_blocks"], 4)},
+        "what": "live lanes / (64 x pairs) of the metric view, counted on the device from the forward's member masks and n_contrib "
+                "(csrc/blend_stats.hip); backward = over the member pairs it walks, forward = over the pairs that pass its quadrant "
+                "hit test; upper_bound_if_split_into = live lanes / (block pixels x (block, Gaussian) pairs with a live lane): "
+                "what a wave of 2 / 4 / 16 independent pixel blocks would reach with perfect balance between its blocks and an "
+                "exact per-block hit test (tools/lane_util_sim.py models the imbalance: 0.84 / 0.77 of today's trips for 4x4 / "
+                "2x2 blocks on the headline view)"}
+
+
 def main():
     from goi_hyperplane_amd.scene import HEADLINE
     ap = argparse.ArgumentParser()
@@ -409,6 +429,8 @@ def main():
                     stats["views"] += 1
                 else:
                     stats["N_listed"] += n
+                    if "lane" not in stats:  # lane utilisation of the blend kernels on this view, counted on the device
+                        stats["lane"] = lane_utilisation(_C.blend_stats(args.P, args.W, args.H, n, *_r[-3:]))
                 del _r
         _C._SPEC.clear()
         _C._SPEC.update(spec_saved)
@@ -809,6 +831,8 @@ def main():
                         nstat["views"] += 1
                     else:
                         nstat["N_listed"] += n_
+                        if "lane" not in nstat:
+                            nstat["lane"] = lane_utilisation(_C.blend_stats(spec2["P"], spec2["W"], spec2["H"], n_, *_r[-3:]))
                     del _r
             _C._SPEC.clear()
             _C._SPEC.update(spec_saved2)
@@ -837,7 +861,7 @@ def main():
                      "speculation": {k: sp1[k] - sp0[k] for k in sp1}, "binning_capacity": cap2,
                      "backward_scratch_bytes": int(_lib.load().goi_raster_backward_scratch_bytes(cap2, spec2["S"])) if cap2 else None,
                      "binning_bytes": int(_lib.load().goi_raster_binning_bytes(cap2)) if cap2 else None,
-                     "stages_ms": st2,
+                     "stages_ms": st2, "blend_lane_utilisation": nstat.get("lane"),
                      "what": "the same step (forward + backward, all gradients, dense upstream gradients) on "
                              "scene.make_clustered_scene: mixture-of-clusters positions, log-normal scales (sigma 1.1) with 2 % "
                              "needles and frame-filling blobs, bimodal opacity, opaque foreground sheets; 16 cameras"}
@@ -938,6 +962,7 @@ def main():
             "gui_frame_ms": gui_ms,  # render + fused semantic decode (300 codes)
             "step_enqueue_ms": step_enqueue_ms,  # host-side, informational (stall detector; not used for value)
             "workload_clustered": clustered,
+            "blend_lane_utilisation": stats.get("lane"),
             "semantic_finetune": sem_only,
             "value_fp32_flush": None if fp32_flush is None else fp32_flush["views_per_s"],
             "value_with_depth_cut": None if with_cut is None else with_cut["views_per_s"],

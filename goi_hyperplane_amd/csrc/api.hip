@@ -404,8 +404,8 @@ size_t bwd_scratch_layout(int N, int S, char* base, BwdScratchView* v) {
     BwdScratchView& b = v ? *v : tmp;
     carve(p, b.rows, n * (size_t)bwd_row_floats(S));
     carve(p, b.flags, n);
-    // big Gaussians (more than 1024 instances each): at most N / 1024 of them
-    b.cap_big = n / 4 / 1024 + 2;
+    // big Gaussians (more than REDUCE_BIG_INST instances each): at most N / REDUCE_BIG_INST of them
+    b.cap_big = n / 4 / REDUCE_BIG_INST + 2;
     carve(p, b.big_ctl, 8);
     carve(p, b.big_desc, b.cap_big);
     return (size_t)(p - base) + 256;

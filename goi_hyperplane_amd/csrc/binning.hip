@@ -118,10 +118,25 @@ __global__ __launch_bounds__(PRE_BLOCK) void compact_listed_k(int P, const uint3
 // (stride 2: the .y words of the ranges array).  The per-tile counts are the tile ranges before their
 // prefix sum AND, folded by digit, the global histograms the onesweep tile sort needs: counting here
 // removes the sort's histogram pass over the 8 M keys and the ranges pass over the sorted keys.
+// Rounds of 256 Gaussians per workgroup of the counting variant: 4 amortise zeroing and flushing the per-tile histogram (T
+// words of LDS, up to T global atomics per workgroup) on a frame of thousands of tiles; a small tile grid (a 512 x 512 close-up:
+// 1024 tiles) flushes next to nothing, and what it needs is workgroups: with 240 k listed Gaussians four rounds left 235
+// workgroups for 256 CUs (emit 261 us for 4.4 M instances; one round: see profiles/README.md)
+#ifndef GOI_EMIT_SMALL_T
+#define GOI_EMIT_SMALL_T 2048
+#endif
 constexpr int EMIT_ROUNDS = 4;
+constexpr int emit_rounds_for(int T) { return T <= GOI_EMIT_SMALL_T ? 1 : EMIT_ROUNDS; }
 
-constexpr int EMIT_BIG_TILES = 1024;  // rectangles above this are written by the big-rectangle loop of emit_k
-template <bool COUNT>
+// Rectangles above this are written by the big-rectangle loop of emit_k.  (1024 until round 5; the depth order puts the near --
+// large -- Gaussians at the front, so the first waves of a close-up hold nothing but rectangles of several hundred tiles and ran
+// two hundred trips of the common expansion while the rest of the chip had finished: emit 171 -> 90 us on the 512 x 512
+// close-up of a 3 M scene with 128, 99 -> 93 on the clustered scene, unchanged on the headline; same-box A/B.)
+#ifndef GOI_EMIT_BIG_TILES
+#define GOI_EMIT_BIG_TILES 128
+#endif
+constexpr int EMIT_BIG_TILES = GOI_EMIT_BIG_TILES;
+template <bool COUNT, int ROUNDS_COUNTING = EMIT_ROUNDS>
 __global__ __launch_bounds__(256) void emit_k(int P, int gx, int gy, const GaussRec* __restrict__ rec,
                                               const int* __restrict__ radii, const uint32_t* __restrict__ order,
                                               const uint32_t* __restrict__ offsets, uint4* __restrict__ aux,
@@ -140,7 +155,7 @@ __global__ __launch_bounds__(256) void emit_k(int P, int gx, int gy, const Gauss
     // COUNT: the blocks also zero the control words of the tile sort that follows (its own memset launch otherwise)
     if (COUNT)
         for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < clear_words; i += gridDim.x * 256u) clear[i] = 0u;
-    constexpr int ROUNDS_PER_BLOCK = COUNT ? EMIT_ROUNDS : 1;
+    constexpr int ROUNDS_PER_BLOCK = COUNT ? ROUNDS_COUNTING : 1;
     if ((int)blockIdx.x * ROUNDS_PER_BLOCK * 256 >= P) return;  // (block-uniform) nothing listed left for this block
     extern __shared__ uint32_t s_cnt[];  // [gx * gy] when COUNT
     __shared__ unsigned long long s_mask[4][64];  // the rectangles' tile masks (cull_variant 2)
@@ -154,7 +169,7 @@ __global__ __launch_bounds__(256) void emit_k(int P, int gx, int gy, const Gauss
     }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // the counting variant amortises zeroing and flushing its tile histogram over EMIT_ROUNDS x 256 Gaussians
-    constexpr int ROUNDS = COUNT ? EMIT_ROUNDS : 1;
+    constexpr int ROUNDS = COUNT ? ROUNDS_COUNTING : 1;
     // a round's Gaussian: id -> radius, position and box are dependent gathers (two DRAM round trips); the next round's
     // are requested before this round's instances are written, or every round would start with both exposed (emit is a
     // small kernel: two waves per SIMD have nothing to hide them behind)
@@ -384,9 +399,14 @@ void launch_emit_counting(int P, int W, int H, const GeomView& g, const uint32_t
                           uint32_t* vals, uint2* ranges, uint32_t* clear, size_t clear_words, uint32_t cap, hipStream_t s) {
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     // `ranges` was zeroed by preprocess_fwd_k
-    emit_k<true><<<dim3((P + 256 * EMIT_ROUNDS - 1) / (256 * EMIT_ROUNDS)), dim3(256), (size_t)gx * gy * sizeof(uint32_t), s>>>(
-        P, gx, gy, g.rec, radii, order, g.offsets, g.aux, keys, vals, reinterpret_cast<uint32_t*>(ranges) + 1, g.counters,
-        clear, (uint32_t)clear_words, cap);
+    if (emit_rounds_for(gx * gy) == 1)
+        emit_k<true, 1><<<dim3((P + 255) / 256), dim3(256), (size_t)gx * gy * sizeof(uint32_t), s>>>(
+            P, gx, gy, g.rec, radii, order, g.offsets, g.aux, keys, vals, reinterpret_cast<uint32_t*>(ranges) + 1, g.counters,
+            clear, (uint32_t)clear_words, cap);
+    else
+        emit_k<true, EMIT_ROUNDS><<<dim3((P + 256 * EMIT_ROUNDS - 1) / (256 * EMIT_ROUNDS)), dim3(256), (size_t)gx * gy * sizeof(uint32_t), s>>>(
+            P, gx, gy, g.rec, radii, order, g.offsets, g.aux, keys, vals, reinterpret_cast<uint32_t*>(ranges) + 1, g.counters,
+            clear, (uint32_t)clear_words, cap);
 }
 
 // per-tile counts -> ranges and the two digit histograms (written to ghist[0..511]) of a sort on

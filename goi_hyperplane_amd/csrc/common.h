@@ -57,12 +57,26 @@ struct ImageView {
 // (emit-order instance, quadrant) and one validity byte per row.
 // row = [sem 0..4*ceil(S/4)) | r g b depth | mean2D.x .y conic.a .b .c opacity | pad], 64-byte multiple
 inline int bwd_row_floats(int S) { return ((4 * ((S + 3) / 4) + 4 + 6 + 15) / 16) * 16; }
+#ifndef GOI_REDUCE_BIG_INST
+#define GOI_REDUCE_BIG_INST 384
+#endif
+#ifndef GOI_REDUCE_HUGE_INST
+#define GOI_REDUCE_HUGE_INST 2048
+#endif
+#ifndef GOI_REDUCE_DENSE_RATIO
+#define GOI_REDUCE_DENSE_RATIO 10
+#endif
+// Instances above which a Gaussian's rows are summed by a workgroup (part) of its own (reduce_rows.hip, "BIG Gaussians"):
+// REDUCE_BIG_INST on a frame with more than REDUCE_DENSE_RATIO instances per listed Gaussian, 1024 otherwise (the frame decides
+// on the device, from its own counters); 64 quarter waves beyond REDUCE_HUGE_INST instances, 16 up to there.
+constexpr uint32_t REDUCE_BIG_INST = GOI_REDUCE_BIG_INST, REDUCE_HUGE_INST = GOI_REDUCE_HUGE_INST,
+                   REDUCE_DENSE_RATIO = GOI_REDUCE_DENSE_RATIO;
 struct BwdScratchView {
     float* rows;     // [4N][bwd_row_floats(S)]: slot = (emit-order instance) * 4 + quadrant
     uint8_t* flags;  // [4N] validity bytes
     // Gaussians with more than 1024 instances get a workgroup of their own (reduce_rows.hip, "BIG Gaussians"):
-    uint32_t* big_ctl;  // [8]: word 1 = big Gaussians registered (zeroed with the validity bytes)
-    uint4* big_desc;    // [cap_big] (first instance, instances, -, Gaussian id)
+    uint32_t* big_ctl;  // [8]: word 1 = HUGE Gaussians registered, word 2 = the other big ones (zeroed with the validity bytes)
+    uint4* big_desc;    // [cap_big] (first instance, instances, -, Gaussian id): huge ones from the front, the others from the back
     size_t cap_big;
 };
 size_t bwd_scratch_layout(int N, int S, char* base, BwdScratchView* v);

@@ -355,8 +355,23 @@ struct RecArgs {
     float* dL_dopacity;
     float* dL_dsemantic;
 };
+// Rows of the dL/dSH staging tile = visible Gaussians a workgroup takes through the chain at a time: 224 x (3 M + 1) floats =
+// 43.9 KB at M = 16, three workgroups per CU with the index lists (the kernel's 143 VGPRs allow three as well).
+#ifndef GOI_PBWD_ROWS
+#define GOI_PBWD_ROWS 224
+#endif
+#ifndef GOI_PBWD_BLOCKS
+#define GOI_PBWD_BLOCKS 3
+#endif
+#ifndef GOI_PBWD_HOIST
+#define GOI_PBWD_HOIST 1
+#endif
+constexpr int BWD_TILE_ROWS = GOI_PBWD_ROWS;
+constexpr int BWD_BLOCKS_PER_CU = GOI_PBWD_BLOCKS;
+constexpr bool BWD_HOIST = GOI_PBWD_HOIST != 0;
+
 template <bool WITH_DSH, bool FROM_ROWS>
-__global__ __launch_bounds__(256) void preprocess_bwd_k(const BwdArgs args, const int* __restrict__ radii,
+__global__ __launch_bounds__(256, GOI_PBWD_BLOCKS) void preprocess_bwd_k(const BwdArgs args, const int* __restrict__ radii,
                                                         const uint32_t* __restrict__ counters,
                                                         const uint8_t* __restrict__ clamped,
                                                         float* dL_dmean2D,
@@ -366,13 +381,24 @@ __global__ __launch_bounds__(256) void preprocess_bwd_k(const BwdArgs args, cons
                                                         float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D,
                                                         float* __restrict__ dL_dsh, float* __restrict__ dL_dscale,
                                                         float* __restrict__ dL_drot) {
-    // dL/dSH is the widest output (192 B per Gaussian at degree 3).  Written per thread it is 48 stores with a
-    // 192-byte lane stride; instead every thread fills its row of an LDS tile (odd row stride: no bank conflicts)
-    // and the block streams the tile out as full lines.
-    extern __shared__ float s_dsh[];  // [256][3 M + 1] when dL_dsh
-    const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = gtid < args.P;
-    const int idx = live ? gtid : args.P - 1;  // lanes past P redo the last Gaussian and write nothing
+    // The work of this kernel is per VISIBLE Gaussian (~600 instructions of chain rule, a 128-byte record, 192 bytes of SH in and
+    // 368 bytes of gradients out); an invisible one needs zeros in its output rows, or -- when the rows still hold the zeros of
+    // the backward that last wrote the buffers (BwdArgs::prev_radii) -- nothing at all.  With one thread per Gaussian id every wave
+    // ran the whole chain at the scene's visible fraction of its lanes (51 % on the headline view, 8 % on a close-up of a 3 M
+    // scene, where the kernel took 264 us for 242 k visible Gaussians), and every block walked all 256 rows of its dL/dSH tile.
+    // Now a PERSISTENT workgroup walks segments of 256 ids (segment = blockIdx.x, + gridDim.x, ...): it CLASSIFIES a segment's ids
+    // (visible / needs zeros / nothing to do) with ballots and a scan of the wave counts, writes the zeros at once, and APPENDS the
+    // visible ids to a pending list; whenever BWD_TILE_ROWS of them are pending (or the input is exhausted) thread t runs the chain
+    // for the t-th pending id -- dense lanes whatever the visible fraction -- and the block streams out exactly the tile rows
+    // that exist.  Per Gaussian the arithmetic is the statement sequence it always was (-ffp-contract=off): bit-identical
+    // gradients, whichever block and lane a Gaussian lands on.
+    // dL/dSH (192 B per Gaussian at degree 3) still leaves through an LDS tile (odd row stride: no bank conflicts) as
+    // contiguous rows instead of 48 stores at a 192-byte lane stride.
+    extern __shared__ float s_dsh[];  // [BWD_TILE_ROWS][3 M + 1] when dL_dsh
+    __shared__ uint32_t s_vis[BWD_TILE_ROWS + 256];  // pending visible ids
+    __shared__ uint16_t s_zero[256];
+    __shared__ uint32_t s_src[BWD_TILE_ROWS];  // (FROM_ROWS) the tile row's record: first slot of a listed Gaussian, ~0u: none
+    __shared__ int s_wcnt[2][4];
     const Camera cam = load_camera(args.view_p, args.proj_p, args.campos_p);
     struct : BwdArgs {
         const float *view, *proj, *campos;
@@ -381,22 +407,117 @@ __global__ __launch_bounds__(256) void preprocess_bwd_k(const BwdArgs args, cons
     a.view = cam.view;
     a.proj = cam.proj;
     a.campos = cam.campos;
+    const int w = 3 * a.M;
+    const int nseg = (args.P + 255) / 256;
+    const bool truncated = counters[COUNTER_OVF] != 0;  // (a truncated frame is treated as if nothing were visible: all gradients zero)
+    int npend = 0;  // (block-uniform)
+    for (int seg = blockIdx.x; seg < nseg || npend > 0; seg += gridDim.x) {
+    int nzero = 0;
+    const int base = seg * 256;
+    if (seg < nseg) {
+        const int gtid = base + threadIdx.x;
+        const bool live = gtid < args.P;
+        const bool vis_t = live && radii[gtid] > 0 && !truncated;
+        // rows that already hold zeros (see BwdArgs::prev_radii) are not written again
+        const bool keep_t = live && !vis_t && args.prev_radii != nullptr && args.prev_radii[gtid] == 0;
+        const bool zero_t = live && !vis_t && !keep_t;
+        const int wv = threadIdx.x >> 6;
+        const unsigned long long bv = __ballot(vis_t), bz = __ballot(zero_t);
+        if ((threadIdx.x & 63) == 0) {
+            s_wcnt[0][wv] = __popcll(bv);
+            s_wcnt[1][wv] = __popcll(bz);
+        }
+        __syncthreads();
+        int ov = 0, oz = 0;
+        for (int i = 0; i < wv; i++) {
+            ov += s_wcnt[0][i];
+            oz += s_wcnt[1][i];
+        }
+        const int nv = s_wcnt[0][0] + s_wcnt[0][1] + s_wcnt[0][2] + s_wcnt[0][3];
+        nzero = s_wcnt[1][0] + s_wcnt[1][1] + s_wcnt[1][2] + s_wcnt[1][3];
+        const unsigned long long lt = (1ull << (threadIdx.x & 63)) - 1ull;
+        if (vis_t) s_vis[npend + ov + __popcll(bv & lt)] = (uint32_t)gtid;
+        if (zero_t) s_zero[oz + __popcll(bz & lt)] = (uint16_t)threadIdx.x;
+        npend += nv;
+        __syncthreads();
+    }
+    // ---- zeros for the invisible Gaussians whose rows do not hold them yet
+    if (nzero > 0) {
+        if ((int)threadIdx.x < nzero) {
+            const int idx = base + s_zero[threadIdx.x];
+            if constexpr (FROM_ROWS) {
+                ra.dL_dopacity[idx] = 0.f;
+                dL_dmean2D[3 * idx] = dL_dmean2D[3 * idx + 1] = dL_dmean2D[3 * idx + 2] = 0.f;
+                dL_dcolor[3 * idx] = dL_dcolor[3 * idx + 1] = dL_dcolor[3 * idx + 2] = 0.f;
+            }
+            dL_dmean3D[3 * idx] = dL_dmean3D[3 * idx + 1] = dL_dmean3D[3 * idx + 2] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 6; i++) dL_dcov3D[(size_t)6 * idx + i] = 0.f;
+            dL_dscale[3 * idx] = dL_dscale[3 * idx + 1] = dL_dscale[3 * idx + 2] = 0.f;
+            reinterpret_cast<float4*>(dL_drot)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if constexpr (FROM_ROWS) {  // dL/dsemantics: S floats per row
+            for (int i = threadIdx.x; i < nzero * ra.S; i += 256) {
+                const int r = i / ra.S;
+                ra.dL_dsemantic[(size_t)(base + s_zero[r]) * ra.S + (i - r * ra.S)] = 0.f;
+            }
+        }
+        if constexpr (WITH_DSH) {
+            for (int i = threadIdx.x; i < nzero * w; i += 256) {
+                const int r = i / w;
+                dL_dsh[(size_t)(base + s_zero[r]) * w + (i - r * w)] = 0.f;
+            }
+        }
+    }
+    // ---- the pending visible Gaussians, BWD_TILE_ROWS at a time: thread t runs the chain for the t-th of them
+    const bool last_trip = seg + (int)gridDim.x >= nseg;  // no further segment for this block: drain the list
+    while (npend >= BWD_TILE_ROWS || (last_trip && npend > 0)) {
+    const int nrows = min(BWD_TILE_ROWS, npend);
+    const bool visible = (int)threadIdx.x < nrows;
+    const int idx = visible ? (int)s_vis[threadIdx.x] : 0;
+    // Everything a Gaussian's chain reads is REQUESTED here, before anything waits.  The kernel is latency bound: its waves
+    // spent two thirds of their time in s_waitcnt (profiles/r04_c_pmc_summary.txt) walking ~10 dependent round trips -- each
+    // input was fetched where the chain first needs it.  The SH rows (192 B, the widest input) are fetched by the whole block,
+    // consecutive lanes taking consecutive 16-byte pieces of a row, into the tile the dL/dSH rows leave through (a thread reads
+    // its coefficients from its tile row before it overwrites them with their gradients); the small per-Gaussian inputs go to
+    // registers: two round trips per chunk (slot -> record; everything else beside the first).
+    if constexpr (WITH_DSH && BWD_HOIST) {
+        if ((w & 3) == 0) {
+            const int w4 = w >> 2;
+            for (int i = threadIdx.x; i < nrows * w4; i += 256) {
+                const int r = i / w4, q = i - r * w4;
+                const float4 v = reinterpret_cast<const float4*>(a.shs + (size_t)s_vis[r] * w)[q];
+                float* dst = s_dsh + r * (w + 1) + 4 * q;
+                dst[0] = v.x;
+                dst[1] = v.y;
+                dst[2] = v.z;
+                dst[3] = v.w;
+            }
+        } else {
+            for (int i = threadIdx.x; i < nrows * w; i += 256) {
+                const int r = i / w;
+                s_dsh[r * (w + 1) + (i - r * w)] = a.shs[(size_t)s_vis[r] * w + (i - r * w)];
+            }
+        }
+    }
+    const V3 mean_in = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
+    float cov3D_in[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) cov3D_in[i] = a.cov3D[(size_t)6 * idx + i];
+    const float4 rot_in = a.scales ? reinterpret_cast<const float4*>(a.rotations)[idx] : make_float4(1.f, 0.f, 0.f, 0.f);
+    const V3 scale_in = a.scales ? V3{a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]} : V3{0.f, 0.f, 0.f};
+    const uint8_t clamp_in = a.shs ? clamped[idx] : (uint8_t)0;
     V3 gmean = {0, 0, 0};
     float gcov[6] = {0, 0, 0, 0, 0, 0};
     V3 gscale = {0, 0, 0};
     float4 grot = make_float4(0, 0, 0, 0);
-    // (a truncated frame -- COUNTER_OVF -- is treated as if nothing were visible: all gradients zero)
-    const bool visible = radii[idx] > 0 && counters[COUNTER_OVF] == 0;
-    // rows that already hold zeros (see BwdArgs::prev_radii) are not written again
-    const bool keep = live && !visible && args.prev_radii != nullptr && args.prev_radii[idx] == 0;
-    __shared__ uint8_t s_keep[256];
-    if constexpr (WITH_DSH) s_keep[threadIdx.x] = keep ? 1 : 0;
     // ---- the blend gradients: from the per-id arrays, or from the Gaussian's record
     float in_conic[3] = {0.f, 0.f, 0.f}, in_m2d[2] = {0.f, 0.f}, in_depth = 0.f;
     V3 in_col = {0.f, 0.f, 0.f};
     if constexpr (FROM_ROWS) {
         const bool listed = visible && ra.tiles_touched[idx] != 0;
-        const float* rec = ra.rows + (size_t)(listed ? ra.aux[idx].x : 0u) * 4 * ra.row_floats;
+        const uint32_t slot = listed ? ra.aux[idx].x : 0u;
+        const float* rec = ra.rows + (size_t)slot * 4 * ra.row_floats;
         const int nsem = ra.nch - 4;
         float opa = 0.f;
         if (listed) {
@@ -412,7 +533,8 @@ __global__ __launch_bounds__(256) void preprocess_bwd_k(const BwdArgs args, cons
             in_conic[2] = co.x;
             opa = co.y;
         }
-        if (live && !keep) {
+        if (visible) {
+            s_src[threadIdx.x] = listed ? slot : 0xFFFFFFFFu;
             ra.dL_dopacity[idx] = opa;
             dL_dmean2D[3 * idx] = in_m2d[0];
             dL_dmean2D[3 * idx + 1] = in_m2d[1];
@@ -420,33 +542,6 @@ __global__ __launch_bounds__(256) void preprocess_bwd_k(const BwdArgs args, cons
             dL_dcolor[3 * idx] = in_col.x;  // (factored SH mode overwrites it with the clamp-masked gradient below)
             dL_dcolor[3 * idx + 1] = in_col.y;
             dL_dcolor[3 * idx + 2] = in_col.z;
-        }
-        // dL/dsemantics, the widest of them (64 bytes per Gaussian at S = 16).  Per thread it is S / 4 loads and stores with a
-        // 64-byte lane stride; with 4 lanes per Gaussian (one float4 each) an instruction moves 16 Gaussians: 16 x 64-byte
-        // pieces of their records in, ONE contiguous kilobyte of the output out.
-        if ((ra.S & 3) == 0 && ra.S <= 16) {
-            const int lane = threadIdx.x & 63, sub = lane & 3, S4 = ra.S >> 2;
-            const uint32_t my = listed ? ra.aux[idx].x : (keep ? 0xFFFFFFFEu : 0xFFFFFFFFu);  // (..FE: its zeros are there already)
-            const int wave_first = gtid - lane;  // the Gaussian of lane 0
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int src = (lane >> 2) + 16 * k;
-                const uint32_t o = (uint32_t)__shfl((int)my, src, 64);
-                const int id2 = wave_first + src;
-                if (sub < S4 && id2 < args.P && o != 0xFFFFFFFEu) {
-                    const float4 v = o != 0xFFFFFFFFu ? *reinterpret_cast<const float4*>(ra.rows + (size_t)o * 4 * ra.row_floats + 4 * sub)
-                                                      : make_float4(0.f, 0.f, 0.f, 0.f);
-                    *reinterpret_cast<float4*>(ra.dL_dsemantic + (size_t)id2 * ra.S + 4 * sub) = v;
-                }
-            }
-        } else if (live && !keep) {
-            float* ds = ra.dL_dsemantic + (size_t)idx * ra.S;
-            if ((ra.S & 3) == 0) {
-                for (int ch = 0; ch < ra.S; ch += 4)
-                    *reinterpret_cast<float4*>(ds + ch) = listed ? *reinterpret_cast<const float4*>(rec + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
-            } else {
-                for (int ch = 0; ch < ra.S; ch++) ds[ch] = listed ? rec[ch] : 0.f;
-            }
         }
     } else if (visible) {
         in_conic[0] = dL_dconic[4 * idx];
@@ -457,18 +552,20 @@ __global__ __launch_bounds__(256) void preprocess_bwd_k(const BwdArgs args, cons
         in_depth = dL_ddepth[idx];
         in_col = V3{dL_dcolor[3 * idx], dL_dcolor[3 * idx + 1], dL_dcolor[3 * idx + 2]};
     }
+    const bool live = visible;  // (the chain below writes through `live`)
     V3* dsh = WITH_DSH ? reinterpret_cast<V3*>(s_dsh + (size_t)threadIdx.x * (3 * a.M + 1)) : nullptr;
     auto put = [&](int k, const V3& v) {
         if constexpr (WITH_DSH) dsh[k] = v;
     };
 
+    if constexpr (WITH_DSH && BWD_HOIST) __syncthreads();  // the SH rows are in the tile
     if (visible) {
-        const V3 mean = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
+        const V3 mean = mean_in;
         // ---- conic -> cov2D -> cov3D and the covariance path of the mean gradient
         {
             float cov3D[6];
 #pragma unroll
-            for (int i = 0; i < 6; i++) cov3D[i] = a.cov3D[(size_t)6 * idx + i];
+            for (int i = 0; i < 6; i++) cov3D[i] = cov3D_in[i];
             const float dca = in_conic[0], dcb = in_conic[1], dcc = in_conic[2];
             Cov2D c;
             ewa_cov2d(mean, a.focal_x, a.focal_y, a.tan_fovx, a.tan_fovy, cov3D, a.view, c);
@@ -547,8 +644,10 @@ __global__ __launch_bounds__(256) void preprocess_bwd_k(const BwdArgs args, cons
             const V3 campos = {a.campos[0], a.campos[1], a.campos[2]};
             const V3 dir_orig = mean - campos;
             const V3 dir = dir_orig / sqrtf(dot3(dir_orig, dir_orig));
-            const V3* sh = reinterpret_cast<const V3*>(a.shs) + (size_t)idx * a.M;
-            const uint8_t cl = clamped[idx];
+            // (the tile row holds the Gaussian's SH coefficients until the put() pass at the end of this block overwrites them)
+            const V3* sh = (WITH_DSH && BWD_HOIST) ? reinterpret_cast<const V3*>(s_dsh + (size_t)threadIdx.x * (3 * a.M + 1))
+                                    : reinterpret_cast<const V3*>(a.shs) + (size_t)idx * a.M;
+            const uint8_t cl = clamp_in;
             V3 g = in_col;
             g.x *= (cl & 1) ? 0.f : 1.f;
             g.y *= (cl & 2) ? 0.f : 1.f;
@@ -562,36 +661,18 @@ __global__ __launch_bounds__(256) void preprocess_bwd_k(const BwdArgs args, cons
             }
             V3 dRGBdx = {0, 0, 0}, dRGBdy = {0, 0, 0}, dRGBdz = {0, 0, 0};
             const float x = dir.x, y = dir.y, z = dir.z;
-            const int ncoef = (a.D + 1) * (a.D + 1);
-            for (int k = ncoef; k < a.M; k++) put(k, V3{0, 0, 0});
-            put(0, kSH0 * g);
             if (a.D > 0) {
-                put(1, (-kSH1 * y) * g);
-                put(2, (kSH1 * z) * g);
-                put(3, (-kSH1 * x) * g);
                 dRGBdx = -kSH1 * sh[3];
                 dRGBdy = -kSH1 * sh[1];
                 dRGBdz = kSH1 * sh[2];
                 if (a.D > 1) {
                     const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-                    put(4, (kSH2[0] * xy) * g);
-                    put(5, (kSH2[1] * yz) * g);
-                    put(6, (kSH2[2] * (2.f * zz - xx - yy)) * g);
-                    put(7, (kSH2[3] * xz) * g);
-                    put(8, (kSH2[4] * (xx - yy)) * g);
                     dRGBdx = dRGBdx + (kSH2[0] * y * sh[4] + kSH2[2] * 2.f * -x * sh[6] + kSH2[3] * z * sh[7] +
                                        kSH2[4] * 2.f * x * sh[8]);
                     dRGBdy = dRGBdy + (kSH2[0] * x * sh[4] + kSH2[1] * z * sh[5] + kSH2[2] * 2.f * -y * sh[6] +
                                        kSH2[4] * 2.f * -y * sh[8]);
                     dRGBdz = dRGBdz + (kSH2[1] * y * sh[5] + kSH2[2] * 2.f * 2.f * z * sh[6] + kSH2[3] * x * sh[7]);
                     if (a.D > 2) {
-                        put(9, (kSH3[0] * y * (3.f * xx - yy)) * g);
-                        put(10, (kSH3[1] * xy * z) * g);
-                        put(11, (kSH3[2] * y * (4.f * zz - xx - yy)) * g);
-                        put(12, (kSH3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy)) * g);
-                        put(13, (kSH3[4] * x * (4.f * zz - xx - yy)) * g);
-                        put(14, (kSH3[5] * z * (xx - yy)) * g);
-                        put(15, (kSH3[6] * x * (xx - 3.f * yy)) * g);
                         dRGBdx = dRGBdx + (kSH3[0] * sh[9] * 3.f * 2.f * xy + kSH3[1] * sh[10] * yz +
                                            kSH3[2] * sh[11] * -2.f * xy + kSH3[3] * sh[12] * -3.f * 2.f * xz +
                                            kSH3[4] * sh[13] * (-3.f * xx + 4.f * zz - yy) +
@@ -615,14 +696,42 @@ __global__ __launch_bounds__(256) void preprocess_bwd_k(const BwdArgs args, cons
             dm.y = (-v.x * v.y * dL_ddir.x + (sum2 - v.y * v.y) * dL_ddir.y - v.z * v.y * dL_ddir.z) * invsum32;
             dm.z = (-v.x * v.z * dL_ddir.x - v.y * v.z * dL_ddir.y + (sum2 - v.z * v.z) * dL_ddir.z) * invsum32;
             gmean = gmean + dm;
+            if constexpr (WITH_DSH) {
+                // dL/dSH[k] = basis_k(dir) * g into the tile row, AFTER the last read of the coefficients it replaces
+                const int ncoef = (a.D + 1) * (a.D + 1);
+                for (int k = ncoef; k < a.M; k++) put(k, V3{0, 0, 0});
+                put(0, kSH0 * g);
+                if (a.D > 0) {
+                    put(1, (-kSH1 * y) * g);
+                    put(2, (kSH1 * z) * g);
+                    put(3, (-kSH1 * x) * g);
+                    if (a.D > 1) {
+                        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                        put(4, (kSH2[0] * xy) * g);
+                        put(5, (kSH2[1] * yz) * g);
+                        put(6, (kSH2[2] * (2.f * zz - xx - yy)) * g);
+                        put(7, (kSH2[3] * xz) * g);
+                        put(8, (kSH2[4] * (xx - yy)) * g);
+                        if (a.D > 2) {
+                            put(9, (kSH3[0] * y * (3.f * xx - yy)) * g);
+                            put(10, (kSH3[1] * xy * z) * g);
+                            put(11, (kSH3[2] * y * (4.f * zz - xx - yy)) * g);
+                            put(12, (kSH3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy)) * g);
+                            put(13, (kSH3[4] * x * (4.f * zz - xx - yy)) * g);
+                            put(14, (kSH3[5] * z * (xx - yy)) * g);
+                            put(15, (kSH3[6] * x * (xx - 3.f * yy)) * g);
+                        }
+                    }
+                }
+            }
         }
         // ---- cov3D -> scale / rotation
         if (a.scales) {
-            const float4 q = reinterpret_cast<const float4*>(a.rotations)[idx];
+            const float4 q = rot_in;
             const float r = q.x, x = q.y, y = q.z, z = q.w;
             const M3 R = rotation_from_quat(r, x, y, z);
             M3 S = make_m3(1, 0, 0, 0, 1, 0, 0, 0, 1);
-            const V3 s = a.scale_modifier * V3{a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]};
+            const V3 s = a.scale_modifier * scale_in;
             S.c[0][0] = s.x;
             S.c[1][1] = s.y;
             S.c[2][2] = s.z;
@@ -655,10 +764,8 @@ __global__ __launch_bounds__(256) void preprocess_bwd_k(const BwdArgs args, cons
             grot.w = 2 * r * (A[0][1] - A[1][0]) + 2 * x * (A[2][0] + A[0][2]) + 2 * y * (A[1][2] + A[2][1]) -
                      4 * z * (A[1][1] + A[0][0]);
         }
-    } else if (WITH_DSH) {
-        for (int k = 0; k < a.M; k++) put(k, V3{0, 0, 0});
     }
-    if (live && !keep) {
+    if (visible) {
         dL_dmean3D[3 * idx] = gmean.x;
         dL_dmean3D[3 * idx + 1] = gmean.y;
         dL_dmean3D[3 * idx + 2] = gmean.z;
@@ -669,16 +776,52 @@ __global__ __launch_bounds__(256) void preprocess_bwd_k(const BwdArgs args, cons
         dL_dscale[3 * idx + 2] = gscale.z;
         reinterpret_cast<float4*>(dL_drot)[idx] = grot;
     }
-    if constexpr (WITH_DSH) {
-        __syncthreads();
-        const int w = 3 * a.M;
-        const int rows = min(256, a.P - (int)(blockIdx.x * blockDim.x));
-        float* out = dL_dsh + (size_t)blockIdx.x * blockDim.x * w;
-        for (int i = threadIdx.x; i < rows * w; i += 256) {
-            const int row = i / w, col = i - row * w;
-            if (!s_keep[row]) out[i] = s_dsh[row * (w + 1) + col];
+    if constexpr (WITH_DSH || FROM_ROWS) __syncthreads();
+    if constexpr (FROM_ROWS) {
+        // dL/dsemantics of the chunk's rows: S floats from the Gaussian's record (zeros for a visible Gaussian without tiles).
+        // Four lanes per row at S = 16 (one float4 each): an instruction moves 16 records' 64-byte pieces in and 16 rows out.
+        if ((ra.S & 3) == 0) {
+            const int S4 = ra.S >> 2;
+            for (int i = threadIdx.x; i < nrows * S4; i += 256) {
+                const int r = i / S4, sub = i - r * S4;
+                const uint32_t o = s_src[r];
+                const float4 v = o != 0xFFFFFFFFu ? *reinterpret_cast<const float4*>(ra.rows + (size_t)o * 4 * ra.row_floats + 4 * sub)
+                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(ra.dL_dsemantic + (size_t)s_vis[r] * ra.S + 4 * sub) = v;
+            }
+        } else {
+            for (int i = threadIdx.x; i < nrows * ra.S; i += 256) {
+                const int r = i / ra.S, ch = i - r * ra.S;
+                const uint32_t o = s_src[r];
+                ra.dL_dsemantic[(size_t)s_vis[r] * ra.S + ch] = o != 0xFFFFFFFFu ? ra.rows[(size_t)o * 4 * ra.row_floats + ch] : 0.f;
+            }
         }
     }
+    if constexpr (WITH_DSH) {
+        // the tile's rows -> the dL/dSH rows of their Gaussians: consecutive lanes take consecutive floats of a row (conflict-free
+        // LDS reads, 192 contiguous bytes per row in memory); (row, column) advance without a division
+        const int dr = 256 / w, dc = 256 - dr * w;
+        int r = (int)threadIdx.x / w, col = (int)threadIdx.x - r * w;
+        while (r < nrows) {
+            dL_dsh[(size_t)s_vis[r] * w + col] = s_dsh[r * (w + 1) + col];
+            r += dr;
+            col += dc;
+            if (col >= w) {
+                col -= w;
+                r++;
+            }
+        }
+    }
+    // the ids that are still pending move to the front of the list (at most 255 of them: one per thread)
+    __syncthreads();
+    const int rest = npend - nrows;
+    const uint32_t moved = (int)threadIdx.x < rest ? s_vis[nrows + threadIdx.x] : 0u;
+    __syncthreads();
+    if ((int)threadIdx.x < rest) s_vis[threadIdx.x] = moved;
+    npend = rest;
+    __syncthreads();
+    }  // chunks of pending visible Gaussians
+    }  // segments
 }
 
 // dL/dSH of a batch of views from its factors: dL/dSH[g][k] = sum_v basis_k(dir(g, v)) * gcol[v][g], with gcol the
@@ -800,13 +943,20 @@ void launch_preprocess_bwd(const GoiRasterScene& sc, const GeomView& g, const in
     a.focal_x = sc.W / (2.0f * sc.tan_fovx);
     a.view_p = sc.viewmatrix; a.proj_p = sc.projmatrix; a.campos_p = sc.campos;
     const bool with_sh = sc.shs && sc.M > 0 && dL_dsh;  // dL_dsh == NULL with SH colours: factored mode
-    const size_t lds = with_sh ? (size_t)256 * (3 * sc.M + 1) * sizeof(float) : 0;  // 50 KB at M = 16
+    const size_t lds = with_sh ? (size_t)BWD_TILE_ROWS * (3 * sc.M + 1) * sizeof(float) : 0;  // 31 KB at M = 16
     // record_rows: the blend gradients are the records reduce_rows_k<.., RECORD> left in the row scratch
     RecArgs ra;
     ra.rows = record_rows; ra.aux = g.aux; ra.tiles_touched = g.tiles_touched;
     ra.row_floats = bwd_row_floats(sc.S); ra.S = sc.S; ra.nch = 4 * ((sc.S + 3) / 4) + 4;
     ra.dL_dopacity = dL_dopacity; ra.dL_dsemantic = dL_dsemantic;
-    const dim3 grid((sc.P + 255) / 256);
+    // persistent workgroups: every CU gets as many as fit (registers and the staging tile: BWD_BLOCKS_PER_CU), each walks
+    // segments of 256 ids
+    static const int n_cu = []() {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    const dim3 grid((unsigned)std::min((sc.P + 255) / 256, n_cu * BWD_BLOCKS_PER_CU));
     if (with_sh && record_rows)
         preprocess_bwd_k<true, true><<<grid, dim3(256), lds, s>>>(
             a, radii, g.counters, g.clamped, dL_dmean2D, dL_dconic, dL_dcolor, dL_ddepth, ra, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);

@@ -39,12 +39,21 @@ namespace {
 // of a reconstructed scene owns thousands of slots and ten thousand rows (clustered workload: 20 blobs x 6600 tiles, needles
 // with whole-frame rectangles), and ONE quarter wave working through them kept this kernel running for 1.2 ms while the chip
 // idled.  A Gaussian with more than BIG_INST instances is therefore not summed here: its quarter wave registers it (a
-// descriptor in the scratch, slots handed out by an atomic counter), and reduce_big_k gives it a whole WORKGROUP: the sixteen
-// quarter waves sum sixteen contiguous parts of its slot range (same walk, same order inside a part), the partial rows meet
-// in LDS and are added in part order.  Which path a Gaussian takes depends on its instance count alone and every order is
-// fixed: bit-reproducible as before.  (The counter is zeroed with the validity bytes: quad_order_k's extra workgroups, or a
-// memset.  A frame without big Gaussians -- the headline scene has none -- pays one launch that finds nothing to do.)
-constexpr uint32_t BIG_INST = 1024;
+// descriptor in the scratch, slots handed out by an atomic counter), and reduce_big_k gives it a whole WORKGROUP: the quarter
+// waves of the workgroup sum contiguous parts of its slot range (same walk, same order inside a part), the partial rows meet
+// in LDS and are added in part order.  Two sizes (round 5): 16 parts (a quarter of the workgroup) for a Gaussian of up to
+// HUGE_INST instances, 64 parts (the whole workgroup) beyond.  The threshold was 1024 whatever the frame: on a close-up of a
+// 3 M scene (BASELINE config 5's shape: 18 instances per listed Gaussian on average, a long tail of several hundred)
+// reduce_rows_k then took 315 us for 450 k rows -- the duration of its longest serial walks; with 384 it takes 67 (+ 28 for
+// the big ones).  On the headline scene (8 instances per listed Gaussian) the few hundred Gaussians between 384 and 1024
+// instances are NOT the tail of reduce_rows_k, and a workgroup of their own costs 10-20 us more than it saves: so the frame
+// chooses -- BIG_INST when it holds more than REDUCE_DENSE_RATIO instances per listed Gaussian, 1024 otherwise, decided by every
+// block from the frame's device counters (no host involvement; same-box A/B of both, tools/gpu_ab_k.sh, profiles/README.md).
+// Which path a Gaussian takes depends on its instance count and those two frame counts alone and every order is fixed:
+// bit-reproducible as before.  (The counters are zeroed with the validity bytes: quad_order_k's extra workgroups, or a
+// memset.  A frame without big Gaussians pays one launch that finds nothing to do.)
+constexpr uint32_t BIG_INST = REDUCE_BIG_INST;  // (common.h: the scratch layout sizes the descriptor list from it)
+constexpr uint32_t HUGE_INST = REDUCE_HUGE_INST;
 
 // Sums the rows of `cnt` consecutive instances starting at instance `inst0` (their validity words at flags32[inst0 ..]) into
 // sum[] -- the lane's elements of the row -- in slot order.  Wave-synchronous: the four quarter waves of a wave call it
@@ -202,7 +211,8 @@ __global__ __launch_bounds__(256) void reduce_rows_k(int P, int S, int nch, uint
                                                      const uint32_t* __restrict__ offsets,
                                                      const uint32_t* __restrict__ tiles_touched,
                                                      float* rows, const uint8_t* __restrict__ flags, ReduceOut out,
-                                                     uint32_t* __restrict__ big_ctl, uint4* __restrict__ big_desc) {
+                                                     uint32_t* __restrict__ big_ctl, uint4* __restrict__ big_desc,
+                                                     uint32_t cap_big) {
     // N_cap: the slot capacity the scratch was laid out for; n_dev: the forward's instance count on the device (the
     // exact forward passes N_cap = num_rendered; the speculative one a capacity, and an overflowed frame stored only
     // the first N_cap instances)
@@ -259,9 +269,11 @@ __global__ __launch_bounds__(256) void reduce_rows_k(int P, int S, int nch, uint
         return m;
     };
     // the 4 quadrant bytes of instance off0 + e (the first chunk of a Gaussian; a BIG one is not walked here)
+    // this frame's threshold (see "BIG Gaussians" above)
+    const uint32_t big_inst = (N > REDUCE_DENSE_RATIO * (uint32_t)V) ? BIG_INST : 1024u;
     auto load_first = [&](const Meta& m) {
         const uint32_t c = m.off1 - m.off0;
-        return (c <= BIG_INST && (uint32_t)e < c) ? flags32[m.off0 + e] : 0u;
+        return (c <= big_inst && (uint32_t)e < c) ? flags32[m.off0 + e] : 0u;
     };
 
     Meta cur = load_meta(0), nxt = load_meta(1);
@@ -273,10 +285,13 @@ __global__ __launch_bounds__(256) void reduce_rows_k(int P, int S, int nch, uint
         const uint32_t w_nxt = load_first(nxt);  // one ahead: validity bytes of its first 16 instances
         const bool live = i0 + 16 * k < V;
         const uint32_t cnt_all = cur.off1 - cur.off0;
-        const bool big = cnt_all > BIG_INST;
+        const bool big = cnt_all > big_inst;
         const size_t inst0 = cur.off0;
-        if (big && e == 0)  // hand the Gaussian over to reduce_big_k
-            big_desc[atomicAdd(&big_ctl[1], 1u)] = make_uint4((uint32_t)inst0, cnt_all, 0u, cur.g);
+        if (big && e == 0) {  // hand the Gaussian over to reduce_big_k: huge ones from the front of the list, the others from its end
+            const uint4 d = make_uint4((uint32_t)inst0, cnt_all, 0u, cur.g);
+            if (cnt_all > HUGE_INST) big_desc[atomicAdd(&big_ctl[1], 1u)] = d;
+            else big_desc[cap_big - 1u - atomicAdd(&big_ctl[2], 1u)] = d;
+        }
         const uint32_t cnt = big ? 0u : cnt_all;
         float sum[K];
 #pragma unroll
@@ -289,25 +304,27 @@ __global__ __launch_bounds__(256) void reduce_rows_k(int P, int S, int nch, uint
     }
 }
 
-// One WORKGROUP per big Gaussian (persistent: the grid is fixed, the count lives on the device): quarter wave p of the
-// BIG_PARTS sums part p of the Gaussian's instances -- contiguous, a multiple of 64 instances long -- and quarter wave 0 adds
-// the partial rows in part order and writes what reduce_rows_k writes for a Gaussian.  (64 parts, a 1024-thread workgroup: with
-// 16 the kernel's time was that of its largest Gaussian -- a frame-filling blob's 6 600 instances were 400 per quarter wave,
-// one row trip after the other.)
-constexpr int BIG_PARTS = 64;
+// The big Gaussians (persistent workgroups of 1024 threads: the grid is fixed, the counts live on the device).  First the ones of
+// up to HUGE_INST instances, FOUR at a time: each quarter of the workgroup (16 quarter waves = 16 parts) takes one; then the
+// huge ones, the whole workgroup (64 parts) each.  Quarter wave p sums part p of its Gaussian's instances -- contiguous, a
+// multiple of 64 instances long -- and the first quarter wave of the group adds the partial rows in part order and writes what
+// reduce_rows_k writes for a Gaussian.  (With 16 parts for a frame-filling blob the kernel's time was that of its largest
+// Gaussian: 6 600 instances were 400 per quarter wave, one row trip after the other.)
+constexpr int BIG_PARTS = 64, MID_PARTS = 16;
 template <int K, bool RECORD>
 __global__ __launch_bounds__(16 * BIG_PARTS) void reduce_big_k(const uint32_t* __restrict__ big_ctl,
-                                                              const uint4* __restrict__ big_desc, float* rows,
+                                                              const uint4* __restrict__ big_desc, uint32_t cap_big, float* rows,
                                                               const uint8_t* __restrict__ flags, int S, int nch, ReduceOut out) {
     constexpr int RF = 16 * K;
     __shared__ float s_part[BIG_PARTS][RF];
-    const uint32_t nbig = big_ctl[1];
     const int lane = threadIdx.x & 63, quarter = lane >> 4, e = lane & 15, part = threadIdx.x >> 4;
     const uint32_t* flags32 = reinterpret_cast<const uint32_t*>(flags);
-    for (uint32_t b = blockIdx.x; b < nbig; b += gridDim.x) {  // (block-uniform)
-        const uint4 d = big_desc[b];  // (first instance, instances, -, Gaussian id)
-        const uint32_t per = ((d.y + BIG_PARTS - 1u) / BIG_PARTS + 63u) & ~63u;  // instances per part
-        const uint32_t p0 = min(d.y, (uint32_t)part * per), p1 = min(d.y, (uint32_t)(part + 1) * per);
+    // PARTS quarter waves starting at quarter wave `first` sum the Gaussian of descriptor d (active: the group has one)
+    auto one = [&](const uint4 d, bool active, int parts, int first) {
+        const int p = part - first;  // this quarter wave's part
+        const uint32_t n = active ? d.y : 0u;
+        const uint32_t per = ((n + (uint32_t)parts - 1u) / (uint32_t)parts + 63u) & ~63u;  // instances per part
+        const uint32_t p0 = min(n, (uint32_t)p * per), p1 = min(n, (uint32_t)(p + 1) * per);
         const uint32_t cnt = p1 - p0;
         const size_t inst0 = (size_t)d.x + p0;
         const uint32_t w0 = ((uint32_t)e < cnt) ? flags32[inst0 + e] : 0u;
@@ -318,14 +335,14 @@ __global__ __launch_bounds__(16 * BIG_PARTS) void reduce_big_k(const uint32_t* _
 #pragma unroll
         for (int kk = 0; kk < K; kk++) s_part[part][K == 2 ? 2 * e + kk : e + 16 * kk] = sum[kk];
         __syncthreads();
-        if (part == 0) {
+        if (p == 0 && active) {
             float tot[K], c[K];
 #pragma unroll
             for (int kk = 0; kk < K; kk++) tot[kk] = c[kk] = 0.f;
-            for (int pp = 0; pp < BIG_PARTS; pp++)
+            for (int pp = 0; pp < parts; pp++)
 #pragma unroll
                 for (int kk = 0; kk < K; kk++) {  // (compensated as well: the parts' sums cancel like their rows do)
-                    const float y = s_part[pp][K == 2 ? 2 * e + kk : e + 16 * kk] - c[kk];
+                    const float y = s_part[first + pp][K == 2 ? 2 * e + kk : e + 16 * kk] - c[kk];
                     const float t = tot[kk] + y;
                     c[kk] = (t - tot[kk]) - y;
                     tot[kk] = t;
@@ -333,7 +350,16 @@ __global__ __launch_bounds__(16 * BIG_PARTS) void reduce_big_k(const uint32_t* _
             store_sums<K, RECORD>(tot, rows, (size_t)d.x, d.w, e, S, nch, out);
         }
         __syncthreads();
+    };
+    const uint32_t nmid = big_ctl[2], nhuge = big_ctl[1];
+    const int sub = part / MID_PARTS;  // which quarter of the workgroup
+    for (uint32_t b0 = blockIdx.x * 4u; b0 < nmid; b0 += gridDim.x * 4u) {  // (block-uniform trip count)
+        const uint32_t b = b0 + (uint32_t)sub;
+        const bool active = b < nmid;
+        const uint4 d = active ? big_desc[cap_big - 1u - b] : make_uint4(0u, 0u, 0u, 0u);  // (first instance, instances, -, id)
+        one(d, active, MID_PARTS, sub * MID_PARTS);
     }
+    for (uint32_t b = blockIdx.x; b < nhuge; b += gridDim.x) one(big_desc[b], true, BIG_PARTS, 0);
 }
 
 }  // namespace
@@ -356,12 +382,12 @@ static void launch_reduce_k(const GoiRasterScene& sc, const GeomView& g, int N, 
     const uint32_t* order = g.sort_vals[depth_sort_result_index()];
     reduce_rows_k<K, REDUCE_GPQ, RECORD><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order,
                                                                     g.offsets, g.tiles_touched, rows, flags, out, scr.big_ctl,
-                                                                    scr.big_desc);
-    // the big Gaussians: a fixed, small grid of persistent workgroups (their number is on the device; N == 0: no blend ran,
-    // nothing cleared the counter and nothing can be registered)
+                                                                    scr.big_desc, (uint32_t)scr.cap_big);
+    // the big Gaussians: fixed, small grids of persistent workgroups (their numbers are on the device; N == 0: no blend ran,
+    // nothing cleared the counters and nothing can be registered)
     if (N > 0)
         reduce_big_k<K, RECORD><<<dim3((unsigned)std::min<size_t>(REDUCE_BIG_GRID, scr.cap_big)), dim3(16 * BIG_PARTS), 0, s>>>(
-            scr.big_ctl, scr.big_desc, rows, flags, sc.S, nch, out);
+            scr.big_ctl, scr.big_desc, (uint32_t)scr.cap_big, rows, flags, sc.S, nch, out);
 }
 
 // records: the sums stay in the row scratch as per-Gaussian records (see reduce_rows_k); the six arrays are not written
