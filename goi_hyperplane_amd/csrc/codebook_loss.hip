@@ -1195,6 +1195,249 @@ __global__ __launch_bounds__(64 * DF_NW, 1) void decoder_df_k(const FusedArgs a)
     }
 }
 
+// ---- decoder_grad_k and decoder_df_k in ONE pass over z (round 5).  The two kernels above each rebuild the block's logits, its
+// probabilities and dz (57 matrix instructions, an exponential and ~12 vector instructions per (pixel, code)) because held
+// together -- 76 registers of dz, 76 of dL/dW accumulators, the df products and their operands -- they do not fit two waves per
+// SIMD.  What forces all 19 code blocks of dz to exist at once is ONE number per pixel: Pl = sum of P over the pixel's label
+// codes, which enters every dz[p][c] through Dsum.  With the label a single code (arg_s: the only case when no two code-book
+// rows coincide) Pl is P at that code, and its logit is a 16-term dot product the 16 lanes of the pixel's row form from the
+// decoder image in LDS and the feature values the lane already holds -- a few instructions per pixel; for a tie the same dot
+// product runs once per bit of the recorded mask.  With Pl known up front the block STREAMS: two code blocks at a time --
+// logits (6 matrix instructions), dz in place, dL/db sums, the dL/dW products, the transposition tile, the df products -- and
+// what lives across the block is the 76 accumulator registers and a handful of row scalars.  Same wave -> partial-row mapping,
+// same partial layout and the same loss sums as decoder_grad_k (its launch shape is kept), same dL/df as decoder_df_k up to
+// the rounding of Pl (the dot product is an fp32 chain over the decoder's hi + lo planes, the logits it replaces the three
+// split-bf16 products of the same planes: ~1e-6 relative on P).
+constexpr int GD_NW = 8;
+__global__ __launch_bounds__(64 * GD_NW, 1) void decoder_gd_k(const FusedArgs a) {
+    __shared__ __attribute__((aligned(16))) char s_wz[FU_WZ_BYTES];
+    __shared__ __attribute__((aligned(16))) char s_wt[FU_WT_BYTES];
+    __shared__ __attribute__((aligned(16))) char s_tr[GD_NW][2][FU_TBUF];
+    __shared__ float s_bias[SIM_NC];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, kq = lane >> 4, mm = lane & 15;
+    const long long HW = a.HW;
+    const int C = a.C, S = a.S;
+    for (int i = tid; i < FU_WZ_BYTES / 16; i += 64 * GD_NW)
+        reinterpret_cast<uint4*>(s_wz)[i] = reinterpret_cast<const uint4*>(a.wz)[i];
+    for (int i = tid; i < FU_WT_BYTES / 16; i += 64 * GD_NW)
+        reinterpret_cast<uint4*>(s_wt)[i] = reinterpret_cast<const uint4*>(a.wt)[i];
+    for (int i = tid; i < SIM_NC; i += 64 * GD_NW) s_bias[i] = (a.bias && i < a.C) ? a.bias[i] : 0.f;
+    __syncthreads();
+    const bool vlast = 16 * (SIM_NCB - 1) + mm < C;
+    const char* const wz_l = s_wz + 32 * mm + 8 * kq;
+    const float* const bias_l = s_bias + mm;
+    const char* const wt_l = s_wt + 64 * mm + 16 * kq;
+    char* const tw_l = s_tr[w][0] + 2 * mm + FU_TROW * 4 * kq;     // tile writes: this lane's code column, its 4 pixel rows
+    const char* const tr_l = s_tr[w][0] + FU_TROW * mm + 16 * kq;  // tile reads: pixel row mm, codes 8 kq ..
+    const uint16_t* const wz16 = reinterpret_cast<const uint16_t*>(s_wz);
+    f32x4 dWacc[SIM_NCB];  // D[code 16 cb + 4 kq + r][s = mm]
+    float dbr[SIM_NCB];    // lane (kq, mm): sum of dz[pixel rows 4 kq + r][code 16 cb + mm]
+#pragma unroll
+    for (int cb = 0; cb < SIM_NCB; cb++) {
+        dWacc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dbr[cb] = 0.f;
+    }
+    float acc_lab = 0.f;
+    const long long wave = (long long)blockIdx.x * GD_NW + w, n_waves = (long long)gridDim.x * GD_NW;
+    float fvz[4], fvw[4];  // the decoder's two views of the feature: f[s = 4 kq + i][pixel mm], f[s = mm][pixel 4 kq + i]
+    DecIn in;
+    auto fetch = [&](long long blk) {
+        const long long pbase = 16 * min(blk, a.blocks - 1);
+        const long long pz = min(pbase + mm, HW - 1);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            fvz[i] = (4 * kq + i < S) ? a.sem[(size_t)(4 * kq + i) * HW + pz] : 0.f;
+            fvw[i] = mm < S ? a.sem[(size_t)mm * HW + min(pbase + 4 * kq + i, HW - 1)] : 0.f;
+        }
+        decoder_fetch(in, a, pbase, kq);
+    };
+    // P of pixel row r at code c (row-uniform c): the row's 16 lanes hold f[s = mm] of that pixel
+    auto prob_at = [&](int c, float f_mm, float mz, float rZ) {
+        const float wv = __uint_as_float((uint32_t)wz16[c * 16 + mm] << 16) + __uint_as_float((uint32_t)wz16[SIM_NC * 16 + c * 16 + mm] << 16);
+        const float zc = row_sum(wv * f_mm) + s_bias[c];
+        return __expf(zc - mz) * rZ;
+    };
+    fetch(wave);
+    for (long long blk = wave; blk < a.blocks; blk += n_waves) {
+        const long long pbase = 16 * blk;
+        // ---- row scalars: Pl, the label bits of this lane's codes, Dsum
+        float kapr[4], dsum[4], mzr[4], rzr[4];
+        uint32_t labm[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const bool valid = pbase + 4 * kq + r < HW;
+            const float mz = in.mz[r], rZ = in.rzp[r], P2 = in.p2[r], nl = in.nl[r];
+            const int arg_s = (&in.args.x)[r];
+            float Pl;
+            uint32_t lm = 0;
+            if (__builtin_expect(__any(nl > 1.f), 0)) {
+                const uint32_t* wd = a.r_tie + (size_t)(pbase + 4 * kq + r) * FU_TIE_WORDS;
+                if (nl > 1.f) {  // (row-uniform) every maximum of sim is a label: their P, one dot product per bit of the mask
+                    Pl = 0.f;
+                    for (int wi = 0; wi < FU_TIE_WORDS; wi++) {
+                        uint32_t bits = wd[wi];
+                        while (bits) {
+                            const int b = __builtin_ctz(bits);
+                            bits &= bits - 1;
+                            Pl += prob_at(32 * wi + b, fvw[r], mz, rZ);
+                        }
+                    }
+#pragma unroll
+                    for (int cb = 0; cb < SIM_NCB; cb++) lm |= ((wd[cb >> 1] >> (16 * (cb & 1) + mm)) & 1u) ? (1u << cb) : 0u;
+                } else {
+                    Pl = prob_at(arg_s, fvw[r], mz, rZ);
+                    lm = (arg_s & 15) == mm ? 1u << (arg_s >> 4) : 0u;
+                }
+            } else {
+                Pl = prob_at(arg_s, fvw[r], mz, rZ);
+                lm = (arg_s & 15) == mm ? 1u << (arg_s >> 4) : 0u;
+            }
+            acc_lab += (valid && mm == 0) ? (P2 - 2.f * Pl) + nl : 0.f;
+            const float kap = valid ? a.kappa : 0.f;  // a pixel beyond the map has no gradient
+            kapr[r] = kap;
+            dsum[r] = kap * (P2 - Pl);
+            mzr[r] = mz;
+            rzr[r] = rZ;
+            labm[r] = lm;
+        }
+        uint32_t fh[2], fl[2], bh[2], bl[2];
+        split_pair(fvz[0], fvz[1], fh[0], fl[0]);
+        split_pair(fvz[2], fvz[3], fh[1], fl[1]);
+        split_pair(fvw[0], fvw[1], bh[0], bl[0]);
+        split_pair(fvw[2], fvw[3], bh[1], bl[1]);
+        const s16x4 fAh = __builtin_bit_cast(s16x4, uint2{fh[0], fh[1]}), fAl = __builtin_bit_cast(s16x4, uint2{fl[0], fl[1]});
+        const s16x4 fBh = __builtin_bit_cast(s16x4, uint2{bh[0], bh[1]}), fBl = __builtin_bit_cast(s16x4, uint2{bl[0], bl[1]});
+        fetch(blk + n_waves);  // the next block's inputs: they land under this block's products
+        // one K step of the df contraction = code blocks 2 j and 2 j + 1: logits, dz, dL/db, dL/dW products, tile j & 1
+        auto step = [&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            f32x4 z[2];
+            s16x4 Bh[2], Bl[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                constexpr int dummy = 0;
+                (void)dummy;
+                const int cb = 2 * j + h;
+                if (cb < SIM_NCB) {
+                    const float b = bias_l[16 * cb];
+                    Bh[h] = *reinterpret_cast<const s16x4*>(wz_l + 512 * cb);
+                    Bl[h] = *reinterpret_cast<const s16x4*>(wz_l + 512 * cb + FU_WZ_BYTES / 2);
+                    z[h] = f32x4{b, b, b, b};
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+                if (2 * j + h < SIM_NCB) z[h] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(fAl, Bh[h], z[h], 0, 0, 0);
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+                if (2 * j + h < SIM_NCB) z[h] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(fAh, Bl[h], z[h], 0, 0, 0);
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+                if (2 * j + h < SIM_NCB) z[h] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(fAh, Bh[h], z[h], 0, 0, 0);
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int cb = 2 * j + h;
+                char* col = tw_l + FU_TBUF * (j & 1) + 32 * h;
+                uint32_t dh[2] = {0u, 0u}, dl[2] = {0u, 0u};
+                if (cb < SIM_NCB) {
+                    if (cb == SIM_NCB - 1 && !vlast) z[h] = f32x4{-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff()};
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const float P = __expf(z[h][r] - mzr[r]) * rzr[r];
+                        const float lab = (labm[r] >> cb) & 1u ? 1.f : 0.f;
+                        z[h][r] = P * (kapr[r] * (P - lab) - dsum[r]);  // dz
+                    }
+                    split_pair(z[h][0], z[h][1], dh[0], dl[0]);
+                    split_pair(z[h][2], z[h][3], dh[1], dl[1]);
+                    dbr[cb] += (z[h][0] + z[h][1]) + (z[h][2] + z[h][3]);
+                    const s16x4 Ah = __builtin_bit_cast(s16x4, uint2{dh[0], dh[1]}), Al = __builtin_bit_cast(s16x4, uint2{dl[0], dl[1]});
+                    dWacc[cb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(Al, fBh, dWacc[cb], 0, 0, 0);
+                    dWacc[cb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(Ah, fBl, dWacc[cb], 0, 0, 0);
+                    dWacc[cb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(Ah, fBh, dWacc[cb], 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    *reinterpret_cast<uint16_t*>(col + FU_TROW * r) = (uint16_t)((r & 1) ? dh[r >> 1] >> 16 : dh[r >> 1]);
+                    *reinterpret_cast<uint16_t*>(col + FU_TROW * r + FU_TPLANE) = (uint16_t)((r & 1) ? dl[r >> 1] >> 16 : dl[r >> 1]);
+                }
+            }
+            // (one step's operands and logits in flight at a time: left to itself the scheduler hoists all ten steps' loads and
+            // products to the top of the block -- 80 spilled registers)
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        f32x4 df0 = f32x4{0.f, 0.f, 0.f, 0.f}, df1 = df0, df2 = df0;
+        auto consume = [&](int j) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const bf16x8 Ah = *reinterpret_cast<const bf16x8*>(tr_l + FU_TBUF * (j & 1));
+            const bf16x8 Al = *reinterpret_cast<const bf16x8*>(tr_l + FU_TBUF * (j & 1) + FU_TPLANE);
+            const bf16x8 Bh = *reinterpret_cast<const bf16x8*>(wt_l + 1024 * j);
+            const bf16x8 Bl = *reinterpret_cast<const bf16x8*>(wt_l + 1024 * j + FU_WT_BYTES / 2);
+            df0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Al, Bh, df0, 0, 0, 0);
+            df1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bl, df1, 0, 0, 0);
+            df2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ah, Bh, df2, 0, 0, 0);
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // tile j + 1 is written before tile j is read (two tiles): the LDS round trip of a step hides behind the next step's logits
+        static_assert(FU_NJ == 10, "the unrolled step sequence below is written for ten K steps");
+        step(std::integral_constant<int, 0>{});
+        step(std::integral_constant<int, 1>{}); consume(0);
+        step(std::integral_constant<int, 2>{}); consume(1);
+        step(std::integral_constant<int, 3>{}); consume(2);
+        step(std::integral_constant<int, 4>{}); consume(3);
+        step(std::integral_constant<int, 5>{}); consume(4);
+        step(std::integral_constant<int, 6>{}); consume(5);
+        step(std::integral_constant<int, 7>{}); consume(6);
+        step(std::integral_constant<int, 8>{}); consume(7);
+        step(std::integral_constant<int, 9>{}); consume(8);
+        consume(9);
+        // D[pixel 4 kq + r][s = mm]
+        if (mm < S) {
+            float* dst = a.dsem + (size_t)mm * HW + pbase + 4 * kq;
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                if (pbase + 4 * kq + r < HW) dst[r] = (df0[r] + df1[r]) + df2[r];
+        }
+    }
+    // ---- this wave's partial sums (decoder_grad_k's layout)
+    float* out = a.partials + (size_t)wave * ((size_t)C * (S + 1) + 4);
+#pragma unroll
+    for (int cb = 0; cb < SIM_NCB; cb++) {
+        if (mm < S) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int c = 16 * cb + 4 * kq + r;
+                if (c < C) out[(size_t)c * (S + 1) + mm] = dWacc[cb][r];
+            }
+        }
+        float d = dbr[cb];
+        d += __shfl_xor(d, 16, 64);
+        d += __shfl_xor(d, 32, 64);
+        if (kq == 0 && 16 * cb + mm < C) out[(size_t)(16 * cb + mm) * (S + 1) + S] = d;
+    }
+    float t0 = wave_sum_u(acc_lab);
+    float t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    for (long long i = wave + n_waves * lane; i < a.n_sums_a; i += 64 * n_waves) {  // lane partials, then the fixed DPP order
+        const f32x4 v = *reinterpret_cast<const f32x4*>(a.sums_a + 4 * i);
+        t1 += v[1];
+        t2 += v[2];
+        t3 += v[3];
+    }
+    t1 = wave_sum_u(t1);
+    t2 = wave_sum_u(t2);
+    t3 = wave_sum_u(t3);
+    if (lane == 0) {
+        float* lo = out + (size_t)C * (S + 1);
+        lo[0] = t0;
+        lo[1] = t1;
+        lo[2] = t2;
+        lo[3] = t3;
+    }
+}
+
 // ---- dL/dL1 from the dsim planes: partial[wg][304][256]
 constexpr int DL2_NW = 8;
 __global__ __launch_bounds__(64 * DL2_NW, 1) void codebook_dlut2_k(const uint16_t* __restrict__ dplanes, const float* __restrict__ g,
@@ -1329,6 +1572,11 @@ int launch_codebook_dlut(const float* dsim, const float* g, long long HW, int C,
     return 0;
 }
 
+// GOI_DECODER_ONE_PASS=0: the two-kernel decoder backward (decoder_grad_k + decoder_df_k) instead of decoder_gd_k (A/B, cross-check)
+static const bool g_decoder_one_pass = []() {
+    const char* e = getenv("GOI_DECODER_ONE_PASS");
+    return !(e && e[0] == '0');
+}();
 // ---- the training half in one call.  workspace: code-book planes | decoder images | per-pixel records | simgrad wave sums |
 // dsim planes (the only large part: 2 x 2 B per (pixel, code))
 static size_t fu_align(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -1378,9 +1626,14 @@ int launch_codebook_fused(const float* g, const float* l1, const float* sem, con
     const long long stat_wgs = (blocks + DS_NW - 1) / DS_NW;
     decoder_stats_k<<<dim3((unsigned)(stat_wgs < 2048 ? stat_wgs : 2048)), dim3(64 * DS_NW), 0, s>>>(a);
     codebook_simgrad_k<<<dim3((unsigned)fu_simgrad_wgs(HW)), dim3(64 * SG_NW), 0, s>>>(a);
-    decoder_grad_k<<<dim3(codebook_fused_rows() / DG_NW), dim3(64 * DG_NW), 0, s>>>(a);
-    const long long df_wgs = (blocks + DF_NW - 1) / DF_NW;
-    decoder_df_k<<<dim3((unsigned)(df_wgs < 1024 ? df_wgs : 1024)), dim3(64 * DF_NW), 0, s>>>(a);
+    static_assert(GD_NW == DG_NW, "decoder_gd_k writes decoder_grad_k's partial rows");
+    if (g_decoder_one_pass) {
+        decoder_gd_k<<<dim3(codebook_fused_rows() / GD_NW), dim3(64 * GD_NW), 0, s>>>(a);
+    } else {
+        decoder_grad_k<<<dim3(codebook_fused_rows() / DG_NW), dim3(64 * DG_NW), 0, s>>>(a);
+        const long long df_wgs = (blocks + DF_NW - 1) / DF_NW;
+        decoder_df_k<<<dim3((unsigned)(df_wgs < 1024 ? df_wgs : 1024)), dim3(64 * DF_NW), 0, s>>>(a);
+    }
     codebook_dlut2_k<<<dim3(codebook_dlut_blocks()), dim3(64 * DL2_NW), 0, s>>>(dplanes, g, HW, dl1_partial);
     return 0;
 }
