@@ -512,12 +512,13 @@ int goi_raster_forward_async_cut(const GoiRasterScene* scene, void* geom_buffer,
     }
     // The frame's counters reach the host without a copy of their own: a wave of the forward blend stores the 32 head words
     // into the ticket's pinned (device-mapped) words, and the event behind the blend says when (the runtime moved the 128-byte
-    // device-to-host copy as two copy kernels per frame).  A frame that LEARNS a depth cut may still raise its flag inside the
-    // blend, so it keeps the copy behind the kernel.
+    // device-to-host copy as two copy kernels per frame).  A frame whose lists were CUT, or that learns a cut, may still raise
+    // its flag inside the blend (the cut is checked there, whether or not zcut_out was given), so it keeps the copy behind the
+    // kernel: the words a blend wave stores are a snapshot taken when the kernel STARTS.
     uint32_t* host_words = nullptr;
     {
         std::lock_guard<std::mutex> lk(g_ticket_mu);
-        if (!zlearn) host_words = g_tickets[ticket].pinned_dev;
+        if (!zlearn && !zcut_in) host_words = g_tickets[ticket].pinned_dev;
     }
     {
         StageTimer t(GOI_STAGE_BLEND_FWD, s);

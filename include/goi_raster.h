@@ -143,7 +143,9 @@ int goi_raster_ticket_result(int ticket, int wait, int* num_rendered);
  *       64 tiles, cull_variant 2: the cut lives in the ellipse tile masks).  Hand in what an earlier frame of the SAME camera
  *       learnt (never an uninitialised array).
  * A frame whose pixels all saturate inside their cut lists is bit-identical to the uncut frame: outputs, n_contrib, every
- * gradient (the dropped instances were never looked at).  If a pixel of a cut tile reaches the end of its list unsaturated the
+ * gradient (the dropped instances were never looked at).  If a pixel of a cut tile reaches the end of its list unsaturated, or
+ * looks at an entry DEEPER than its tile's cut (a rectangle of more than 64 tiles has no tile mask and stays listed at every
+ * depth: the Gaussians that were dropped in between would have come first), the
  * cut was TOO TIGHT for this frame (the geometry has moved since it was learnt): the forward blend raises bit 2 of the frame's
  * flag word (goi_raster_truncated_flag; bit 0 = the instance list was truncated, bit 1 = a sort timed out), the frame's
  * backward writes ZERO gradients like a truncated frame's, and goi_raster_ticket_result2 hands the word to the host, which
@@ -341,7 +343,7 @@ int goi_codebook_dlut_partial_blocks(void);
 int goi_codebook_dlut(const float* dsim, const float* g, long long HW, int C, int D, float* partial, void* stream);
 
 /* The three steps above as one call with no [HW][C] fp32 matrix in memory (csrc/codebook_loss.hip: decoder_stats_k,
- * codebook_simgrad_k, decoder_grad_k, decoder_df_k, codebook_dlut2_k): g [D][HW], lut1 [C][D] (rows normalised), sem [S][HW], W [C][S], bias [C] or NULL, t as in
+ * codebook_simgrad_k, decoder_gd_k, codebook_dlut2_k): g [D][HW], lut1 [C][D] (rows normalised), sem [S][HW], W [C][S], bias [C] or NULL, t as in
  * goi_codebook_loss_rows.  Writes dsem [S][HW], partials [goi_codebook_fused_partial_rows()][C*(S+1)+4] (same row format
  * as goi_codebook_loss_rows) and dlut_partial [goi_codebook_dlut_partial_blocks()][304][D]; the caller sums both over the
  * first axis.  workspace: goi_codebook_fused_workspace_bytes(HW) device bytes (dL/dsim as two bf16 planes: 4 bytes per

@@ -175,3 +175,67 @@ def test_a_moving_scene_is_rendered_exactly_or_skipped_never_wrongly(dev):
     finally:
         rasterizer.set_forward_mode(depth_cut=False)
         _C.forget_depth_cuts()
+
+
+def test_oversized_gaussians_behind_the_cut_never_hide_dropped_ones(dev):
+    """the cut lives in the ellipse tile masks, and a rectangle of more than 64 tiles has none -- such a Gaussian
+    stays listed at every depth, so a cut list is NOT a prefix of the uncut one.  Scene: an opaque foreground (small Gaussians)
+    in front of a mid layer (small) in front of frame-sized opaque blobs (hundreds of tiles each).  The camera learns a cut just
+    behind the foreground; then the foreground turns transparent: every pixel passes the cut unsaturated and would stop on a
+    blob -- having skipped the mid layer the cut dropped.  The frame must be flagged (zero gradients / rendered again exactly
+    when the count is read), never returned as if it were exact."""
+    from goi_hyperplane_amd import _C, rasterizer
+    from goi_hyperplane_amd.render import GaussianSet, TorchCamera
+    from goi_hyperplane_amd.scene import make_camera, make_scene
+    W, H, S = 640, 480, 16
+    sc = make_scene(60_000, S=S, sh_degree=1, seed=31, extent=(2.0, 1.5, 1.0), log_scale_mean=-3.0)
+    P = sc.means3D.shape[0]
+    rng = np.random.default_rng(5)
+    layer = rng.integers(0, 3, P)                    # 0: foreground, 1: mid layer, 2: far blobs
+    layer[rng.choice(P, 40, replace=False)] = 2
+    layer[(layer == 2) & (np.arange(P) % 50 != 0)] = 1  # only a few dozen blobs
+    sc.means3D[:, 2] = np.where(layer == 0, -0.6, np.where(layer == 1, 0.0, 0.6)) + 0.05 * rng.standard_normal(P)
+    sc.scales[layer == 2] = 0.9                      # frame-sized: rectangles of several hundred tiles
+    sc.opacities[:] = np.where(layer == 2, 0.99, 0.95)[:, None].astype(np.float32)  # opaque everywhere
+    cam = TorchCamera(make_camera(W, H, yaw=0.0, pitch=0.0), dev)
+    pc = GaussianSet.from_scene(sc, dev)
+    gen = torch.Generator(device=dev).manual_seed(9)
+    ups = [torch.randn(shape, device=dev, generator=gen) / (W * H) for shape in ((3, H, W), (S, H, W), (1, H, W), (1, H, W))]
+    fg = torch.tensor(layer == 0, device=dev)
+    _C._SPEC.clear()
+    _C.forget_depth_cuts()
+    rasterizer.set_forward_mode(speculative=True, depth_cut=True)
+    try:
+        for _ in range(4):
+            _step(cam, pc, ups)  # exact frames, then speculative ones that learn the cut behind the foreground
+        with torch.no_grad():
+            pc._opacity[fg] = 0.02  # the foreground turns translucent: the cut no longer holds anywhere
+        # the reference: the same scene without a cut
+        _C._FWD["depth_cut"] = False
+        try:
+            ref_out, ref_n, ref_g = _step(cam, pc, ups, read_count=True)
+        finally:
+            _C._FWD["depth_cut"] = True
+        # (1) nobody reads the count: flagged, zero gradients
+        out, n, g = _step(cam, pc, ups)
+        assert isinstance(n, _C.LazyCount) and n.cut_key is not None
+        torch.cuda.synchronize()
+        assert int(rasterizer.truncated_flag().item()) & 4, "a cut frame that looked beyond its cut was returned as exact"
+        assert all(float(t.abs().max()) == 0.0 for t in g)
+        with warnings.catch_warnings(record=True):
+            warnings.simplefilter("always")
+            _C.poll_counts(dev, wait=True)
+        # (2) learn again on the old geometry, break it again, read the count: rendered again, exact
+        with torch.no_grad():
+            pc._opacity[fg] = 0.95
+        for _ in range(2):
+            _step(cam, pc, ups)
+        with torch.no_grad():
+            pc._opacity[fg] = 0.02
+        out, n, g = _step(cam, pc, ups, read_count=True)
+        assert n.cut_failed and n.redone
+        for k in ("render", "semantics", "depth", "alpha", "radii"):
+            assert torch.equal(out[k], ref_out[k]), k
+    finally:
+        rasterizer.set_forward_mode(depth_cut=False)
+        _C.forget_depth_cuts()
