@@ -130,3 +130,96 @@ print("OK")
     env = dict(os.environ, GOI_ROOT=ROOT, GOI_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "OK" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
+
+
+@pytest.mark.parametrize("mode", ["ring", "direct", "async"])
+def test_pooled_gradient_buffers_stay_correct_across_in_place_exchanges(mode):
+    """the compiled binding's gradient pool hands a buffer out again as "rows of Gaussians invisible then and
+    now still hold zeros" when nothing wrote to it in place -- and c10d collectives write in place WITHOUT bumping the autograd
+    version counter.  Two gloo ranks share the GPU, each renders ITS OWN camera (different visibility) for several steps with
+    `p.grad = None` between them, and sums the gradients in place over the ranks; every step's reduced gradient on every rank
+    must equal the sum of the two single-view gradients computed with the pool OFF (a stale row -- another rank's contribution
+    of an earlier step surviving in a row this rank never rewrites -- shows up from the second step on)."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    code = r'''
+import os, sys, torch
+sys.path.insert(0, os.environ["GOI_ROOT"])
+import torch.distributed as dist
+from goi_hyperplane_amd import _C
+from goi_hyperplane_amd.dist import allreduce_gradients, allreduce_gradients_direct, allreduce_gradients_async
+from goi_hyperplane_amd.render import GaussianSet, PipelineParams, TorchCamera, render
+from goi_hyperplane_amd.scene import make_camera, make_scene
+rank, mode = int(os.environ["RANK"]), os.environ["GOI_MODE"]
+dist.init_process_group("gloo", rank=rank, world_size=2, init_method="tcp://127.0.0.1:%s" % os.environ["GOI_PORT"])
+dev = torch.device("cuda:0")
+assert _C.binding() == "compiled", _C.binding()  # (the pool lives in the compiled binding)
+sc = make_scene(20000, S=16, sh_degree=3, seed=5, log_scale_mean=-3.2)
+pc = GaussianSet.from_scene(sc, dev)
+W, H = 320, 208
+# narrow, well separated views: each rank sees a different third of the scene, and a different one every step
+cams = [[TorchCamera(make_camera(W, H, fovx=0.45, yaw=0.5 * r + 0.17 * i - 0.4), dev) for i in range(4)] for r in range(2)]
+gen = torch.Generator(device=dev).manual_seed(3)
+gc = torch.randn((3, H, W), device=dev, generator=gen) / (W * H)
+gs = torch.randn((16, H, W), device=dev, generator=gen) / (W * H)
+params = list(pc.parameters())
+def view_grads(cam):
+    for p in params:
+        p.grad = None
+    out = render(cam, pc, PipelineParams(), torch.zeros(3, device=dev))
+    torch.autograd.backward((out["render"], out["semantics"]), (gc, gs))
+    return out
+import goi_hyperplane_amd._C as C_
+ext = C_._ext()
+# the references first: both ranks' single-view gradients with the pool OFF, summed locally
+ext.set_grad_pool(False)
+wants = []
+for step in range(4):
+    want = None
+    for r in range(2):
+        view_grads(cams[r][step])
+        g = [p.grad.clone() for p in params]
+        want = g if want is None else [a + b for a, b in zip(want, g)]
+    wants.append(want)
+for p in params:
+    p.grad = None
+ext.set_grad_pool(True)
+for step in range(4):
+    want = wants[step]
+    view_grads(cams[rank][step])
+    if mode == "ring":
+        allreduce_gradients(params, dist)
+    elif mode == "direct":
+        allreduce_gradients_direct(params, dist)
+    else:
+        held = [p.grad for p in params]
+        h = allreduce_gradients_async(params, dist)
+        for p in params:
+            p.grad = None
+        h.wait()
+        for p, g_ in zip(params, held):
+            p.grad = g_
+        del held, h
+    torch.cuda.synchronize()
+    for p, w in zip(params, want):
+        scale = float(w.abs().max()) + 1e-30
+        err = float((p.grad - w).abs().max()) / scale
+        assert err <= 1e-5, (step, tuple(p.shape), err)
+for p in params:
+    p.grad = None
+hits, dirty, fresh = ext.grad_pool_stats()
+assert dirty >= 2, (hits, dirty, fresh)  # the exchanged buffers came back from the pool marked as written
+dist.barrier()
+dist.destroy_process_group()
+print("OK", rank, hits, dirty, fresh)
+'''
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, GOI_ROOT=ROOT, GOI_PORT=str(port), RANK=str(r), GOI_MODE=mode, GOI_GRAD_POOL="1")
+        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, cwd=ROOT, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0 and "OK" in so, (so[-500:], se[-3000:])
