@@ -628,11 +628,23 @@ def main():
             barrier()
             c0 = rasterizer.geometry_cache_stats()
             s0 = time.perf_counter()
+            c_enq = []
             for i in range(nss):
+                e0 = time.perf_counter()
                 sem_step(i)
+                c_enq.append(time.perf_counter() - e0)  # (a clock read per step, no synchronisation)
             barrier()
             c_elapsed = time.perf_counter() - s0
             c1 = rasterizer.geometry_cache_stats()
+            # is this mode bound by the host or by the GPU?  The library's own HIP events around each kernel of a few further
+            # (untimed) steps: their sum per step beside the wall clock per step above
+            _lib.profile_collect()
+            _lib.profile_enable(True)
+            for i in range(8):
+                sem_step(i)
+            torch.cuda.synchronize()
+            _lib.profile_enable(False)
+            c_stage_sum = sum(ms_ / n_ for ms_, n_ in _lib.profile_collect().values() if n_)
         finally:
             rasterizer.set_geometry_cache(0)
         if dist is not None:
@@ -642,6 +654,9 @@ def main():
         sem_only["geometry_cache"] = {"views_per_s": nss * world / c_elapsed, "ms_per_step": c_elapsed / nss * 1e3,
                                       "hits": c1["hits"] - c0["hits"], "misses": c1["misses"] - c0["misses"],
                                       "bytes_per_camera": c1["bytes"] // max(1, c1["entries"]),
+                                      "step_enqueue_ms_median": float(np.median(c_enq)) * 1e3,
+                                      "gpu_stage_sum_ms": c_stage_sum,
+                                      "bound": "gpu" if c_stage_sum >= 0.9 * c_elapsed / nss * 1e3 else "host",
                                       "what": "the same with rasterizer.set_geometry_cache on (opt-in): cameras seen before "
                                               "render with the blend alone"}
         rasterizer.set_backward_mode(semantics_only="auto")
@@ -674,6 +689,10 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             f_elapsed = float(tt.item())
         fp32_flush = {"views_per_s": nf * world / f_elapsed, "ms_per_step": f_elapsed / nf * 1e3, "steps": nf,
+                      "role": "cross-check only, not a product mode: same kernel template as the default (member masks, "
+                              "prologue, LDS-DMA staging included); the whole difference is the flush's 32 fp32 matrix "
+                              "instructions per 8 members, which run at the vector rate and add to the vector time on gfx950. "
+                              "The float64 soak (flush_equivalence) is the yardstick that says the default flush loses nothing",
                       "what": "bwd_variant 2: per-Gaussian sums of the backward on v_mfma_f32_16x16x4_f32 (exact fp32 "
                               "FMA chains) instead of the split-f16 operands of the default flush"}
 
@@ -932,6 +951,20 @@ def main():
                                                   + tj["stage_kernel"][dominant] + ", separate rocprofv3 --pmc passes")
         gpu_ms = sum(v["ms"] for v in stage_out.values())
         ms_per_step = elapsed / args.steps * 1e3
+        # device memory of one view in flight at this workload: the workspaces are sized for the speculative frame's CAPACITY
+        # (headroom x the largest count seen), not for its count -- the count is not on the host when the frame is enqueued
+        _hw = int(_C._spec_state(dev).get("high_water", 0))
+        _cap = max(_C._MIN_CAPACITY, int(_C._FWD["headroom"] * _hw) + 4096) if _hw else 0
+        _l = _lib.load()
+        memory = None if not _cap else {
+            "num_rendered_high_water": _hw, "binning_capacity": _cap, "headroom": _C._FWD["headroom"],
+            "geometry_bytes": int(_l.goi_raster_geom_bytes(args.P)), "image_bytes": int(_l.goi_raster_image_bytes(args.W, args.H)),
+            "binning_bytes": int(_l.goi_raster_binning_bytes(_cap)),
+            "backward_scratch_bytes": int(_l.goi_raster_backward_scratch_bytes(_cap, args.S)),
+            "backward_scratch_bytes_if_sized_by_count": int(_l.goi_raster_backward_scratch_bytes(_hw, args.S)),
+            "what": "per view in flight; the row scratch (4 quadrant rows of 128 B + a validity byte per listed instance) is "
+                    "laid out for the capacity because a speculative frame's count has not reached the host when its backward "
+                    "is enqueued; it is grow-only and shared by all frames of a (device, stream)"}
         res = {
             "metric": "training views/sec (rasterizer fwd+bwd), 1M Gaussians @1600x1056 RGB+16-d feat",
             "value": args.steps * world / elapsed, "unit": "views/s", "n_gpus": world, "steps": args.steps,
@@ -962,6 +995,7 @@ def main():
             "gui_frame_ms": gui_ms,  # render + fused semantic decode (300 codes)
             "step_enqueue_ms": step_enqueue_ms,  # host-side, informational (stall detector; not used for value)
             "workload_clustered": clustered,
+            "memory_per_view": memory,
             "blend_lane_utilisation": stats.get("lane"),
             "semantic_finetune": sem_only,
             "value_fp32_flush": None if fp32_flush is None else fp32_flush["views_per_s"],

@@ -37,7 +37,7 @@ def main():
     m2, co, pl, ranges = st["means2D"].astype(np.float64), st["conic_opacity"].astype(np.float64), st["point_list"], st["ranges"]
     tiles = rng.choice(gx * gy, size=min(n_tiles, gx * gy), replace=False)
     shapes = [(8, 8), (8, 4), (4, 8), (4, 4), (4, 2), (2, 4), (2, 2), (1, 1)]
-    acc = {s: dict(pairs_box=0, pairs_ell=0, members=0, iters_box=0, iters_ell=0, ideal_box=0, ideal_ell=0) for s in shapes}
+    acc = {s: dict(pairs_box=0, pairs_ell=0, members=0, iters_box=0, iters_ell=0, ideal_box=0, ideal_ell=0, hyb_box=0, hyb_ell=0, hyb_mem=0) for s in shapes}
     live_total, listed_total, walked_rounds = 0, 0, 0
     for t in tiles:
         tx, ty = t % gx, t // gx
@@ -109,12 +109,19 @@ def main():
                                 cnt[g] = np.bincount(idx // 64, minlength=n_rounds)
                         A["iters_" + key] += int(cnt.max(0).sum())
                         A["ideal_" + key] += int(cnt.sum())  # / G below
+                        # HYBRID: the wave takes its blocks one after the other, G list entries of ONE block per trip
+                        # (block pixels x G Gaussians in the 64 lanes): per block and round ceil(hits / G) trips
+                        A["hyb_" + key] += int(((cnt + len(groups) - 1) // len(groups)).sum())
             if (bw, bh) == (8, 8):
                 walked_rounds += sum((int(walk_pix[qy * 8:qy * 8 + 8, qx * 8:qx * 8 + 8].max()) + 63) // 64 for qy in range(2) for qx in range(2))
     nt = len(tiles)
     print(f"{sys.argv[1]}: {nt} tiles sampled of {gx * gy}; listed entries/tile {listed_total / nt:.1f}; (pixel, Gaussian) contributions/tile {live_total / nt:.0f}; rounds walked/quadrant {walked_rounds / nt / 4:.2f}")
     print("block  G | pairs(box) pairs(ell) members | live/member-pair util | iters(box) iters(ell) ideal(ell) | lane-util of iters(ell) | rel. iters(ell) vs 8x8")
     base = acc[(8, 8)]["iters_ell"]
+    print("hybrid (block pixels x G Gaussians per trip, blocks in sequence): trips(box) trips(ell) relative to 8x8 iters(ell)")
+    for (bw, bh) in shapes:
+        A = acc[(bw, bh)]
+        print(f"  {bw}x{bh}: {A['hyb_box'] / nt:9.0f} {A['hyb_ell'] / nt:9.0f}  {A['hyb_box'] / base:.3f} {A['hyb_ell'] / base:.3f}")
     for (bw, bh) in shapes:
         A = acc[(bw, bh)]
         G = 64 // (bw * bh)
