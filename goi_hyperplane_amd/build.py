@@ -31,6 +31,7 @@ UNITS = {
     "binning.hip": [],
     "reduce_rows.hip": [],
     "render_fwd.hip": ["-fno-slp-vectorize"],
+    "render_fwd_g4.hip": ["-fno-slp-vectorize"],
     "blend_stats.hip": [],
     "render_bwd.hip": [],
     "render_bwd_tile.hip": [],

@@ -177,6 +177,10 @@ void launch_render_fwd(const GoiRasterScene& sc, const GeomView& g, const ImageV
                        float* out_color, float* out_sem, float* out_depth, float* out_alpha, hipStream_t s,
                        unsigned long long* qmask = nullptr, const float* zcut = nullptr, uint32_t* zlearn = nullptr,
                        uint32_t* host_words = nullptr);  // host_words: pinned, device-mapped words that get counters[0 .. 32)
+// fwd_variant 2 (experiment): the 16 pixels x 4 Gaussians mapping of the forward blend (render_fwd_g4.hip); S <= 16, no depth cut
+void launch_render_fwd_g4(const GoiRasterScene& sc, const GeomView& g, const ImageView& im, const uint32_t* point_list,
+                          float* out_color, float* out_sem, float* out_depth, float* out_alpha, hipStream_t s,
+                          unsigned long long* qmask, uint32_t* host_words);
 // lane utilisation of the blend kernels counted from a forward's member masks / n_contrib (blend_stats.hip): out[GOI_BLEND_STATS_WORDS]
 void launch_blend_stats(int W, int H, const GeomView& g, const ImageView& im, const uint32_t* point_list,
                         const unsigned long long* qmask, unsigned long long* out, hipStream_t s);

@@ -317,6 +317,12 @@ void launch_fwd_s4(const GoiRasterScene& sc, const GeomView& g, const ImageView&
 void launch_render_fwd(const GoiRasterScene& sc, const GeomView& g, const ImageView& im, const uint32_t* point_list,
                        float* out_color, float* out_sem, float* out_depth, float* out_alpha, hipStream_t s,
                        unsigned long long* qmask, const float* zcut, uint32_t* zlearn, uint32_t* host_words) {
+    // fwd_variant 2 (EXPERIMENT, render_fwd_g4.hip): the 16 pixels x 4 Gaussians mapping; frames with a depth cut and S > 16 keep
+    // the default kernel
+    if (g_options.fwd_variant == 2 && !zcut && !zlearn && sc.S <= 16) {
+        launch_render_fwd_g4(sc, g, im, point_list, out_color, out_sem, out_depth, out_alpha, s, qmask, host_words);
+        return;
+    }
 #define GOI_CALL(N) launch_fwd_s4<N>(sc, g, im, point_list, out_color, out_sem, out_depth, out_alpha, s, qmask, zcut, zlearn, host_words)
     GOI_DISPATCH_S4(sc.S, GOI_CALL)
 #undef GOI_CALL

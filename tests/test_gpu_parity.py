@@ -904,7 +904,7 @@ def test_runs_on_a_side_stream_with_identical_results(dev):
         assert torch.equal(x, y)
 
 
-@pytest.mark.parametrize("option,value", [("bwd_variant", 1), ("bwd_variant", 2), ("fwd_variant", 0), ("sort_variant", 0), ("cull_variant", 0), ("bwd_records", 0),
+@pytest.mark.parametrize("option,value", [("bwd_variant", 1), ("bwd_variant", 2), ("fwd_variant", 0), ("fwd_variant", 2), ("sort_variant", 0), ("cull_variant", 0), ("bwd_records", 0),
                                           ("cull_variant", 1), ("bwd_masks", 0)])
 def test_alternative_kernels_stay_correct(oracle_mod, dev, option, value):
     """The non-default variants kept behind goi_raster_set_option (tile + atomics backward, one-candidate forward
@@ -925,3 +925,31 @@ def test_alternative_kernels_stay_correct(oracle_mod, dev, option, value):
         _lib.set_option(option, default)
     check_forward(res, f, f"{option}={value}")
     check_backward(res["grads"], o.backward(*grads), f"{option}={value}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P,S,W,H,mu", [(3000, 16, 123, 77, -2.6), (20000, 16, 400, 300, -3.2), (500, 3, 65, 49, -1.5), (40000, 10, 333, 210, -3.8)])
+def test_pixels_x_gaussians_forward_takes_the_same_decisions(dev, P, S, W, H, mu):
+    """fwd_variant 2 (render_fwd_g4.hip: 16 pixels x 4 list entries per loop trip) against the default forward blend: the
+    transmittance recurrence runs in list order through the four lanes of a pixel, so everything that depends on per-pixel
+    DECISIONS -- alpha (1 - T_final), n_contrib, the member masks and the per-quadrant walk lengths the backward reads -- is
+    bit-identical, hence so is every gradient; the channel sums differ by the association of one fp32 sum."""
+    from goi_hyperplane_amd import _lib
+    sc = make_scene(P, S=S, sh_degree=3, seed=11, log_scale_mean=mu)
+    cam = make_camera(W, H, yaw=-0.15, pitch=0.05)
+    bg = np.array([0.2, 0.1, 0.4], np.float32)
+    grads = upstream_grads(S, H, W, seed=6)
+    a = run_hip(sc, cam, bg, dev, grads=grads)
+    _lib.set_option("fwd_variant", 2)
+    try:
+        b = run_hip(sc, cam, bg, dev, grads=grads)
+    finally:
+        _lib.set_option("fwd_variant", 1)
+    assert np.array_equal(a["radii"], b["radii"])
+    assert np.array_equal(a["alpha"], b["alpha"])
+    for k in ("render", "semantics", "depth"):
+        scale = max(float(np.abs(a[k]).max()), 1e-6)
+        assert float(np.abs(a[k] - b[k]).max()) <= 2e-6 * scale, k
+    for k, ga in a["grads"].items():
+        if ga is not None:
+            assert np.array_equal(ga, b["grads"][k]), k
