@@ -238,9 +238,9 @@ int enqueue_front(const GoiRasterScene& sc, GeomView& g, ImageView& im, int* rad
     const size_t depth_ctrl = g_options.sort_variant == 1 ? radix_sort_control_words((size_t)P, 0, 32) : 0;
     // (sizes rounded up to 256 bytes: the runtime splits a memset of any other size into two fill kernels; the few
     // extra words are scratch that is written before it is read)
-    GOI_HIP(hipMemsetAsync(g.counters, 0,
+    GOI_HIP(hipMemsetAsync(g.blk_coarse, 0,
                            round_up_256((size_t)(reinterpret_cast<char*>(g.scratch + depth_ctrl) -
-                                                 reinterpret_cast<char*>(g.counters))), s));
+                                                 reinterpret_cast<char*>(g.blk_coarse))), s));
     {
         StageTimer t(GOI_STAGE_PREPROCESS, s);
         launch_preprocess_fwd(sc, g, radii, im.ranges, gx * gy, s, zcut, zlearn);  // also zeroes the tile ranges
@@ -378,6 +378,8 @@ size_t geom_layout(int P, char* base, GeomView* v) {
     carve(p, g.offsets, n);
     carve(p, g.aux, n);
     carve(p, g.blk_agg, (n + PRE_BLOCK - 1) / PRE_BLOCK);
+    // (blk_coarse, counters, sort control words: contiguous, ONE memset clears the three)
+    carve(p, g.blk_coarse, (((n + PRE_BLOCK - 1) / PRE_BLOCK + COARSE_BLOCKS - 1) / COARSE_BLOCKS) * (size_t)COARSE_STRIDE);
     carve(p, g.counters, COUNTER_WORDS);  // directly in front of the sort scratch: one memset clears both
     g.scratch_words = sort_scratch_words(n) + scan_scratch_words(n);
     carve(p, g.scratch, g.scratch_words);

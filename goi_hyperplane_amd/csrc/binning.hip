@@ -19,10 +19,13 @@ namespace {
 // sort (which then skips its own histogram pass); 2048 keys per workgroup keep the global atomics of that flush at the
 // level of sweep_hist_k (one flush per 256 keys cost 2.3 M same-line atomics: +45 us).
 // pad (a sort that cannot take its count from the device): the unlisted Gaussians follow with key 0xFFFFFFFF.
-constexpr int COMPACT_ROUNDS = 8;
+// COMPACT_ROUNDS: 8 blocks of preprocess per workgroup up to ~1 M Gaussians, 24 above (the flush of the digit histograms is
+// 4 x 256 global atomics per WORKGROUP whatever its size: 3 M Gaussians in workgroups of 2048 were 1.5 M same-line atomics).
+template <int COMPACT_ROUNDS>
 __global__ __launch_bounds__(PRE_BLOCK) void compact_listed_k(int P, const uint32_t* __restrict__ tiles_touched,
                                                               const uint32_t* __restrict__ raw_key,
                                                               const uint2* __restrict__ blk_agg,
+                                                              const unsigned long long* __restrict__ blk_coarse,
                                                               uint32_t* __restrict__ counters,
                                                               uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
                                                               uint32_t* __restrict__ ghist, int pad) {
@@ -41,14 +44,18 @@ __global__ __launch_bounds__(PRE_BLOCK) void compact_listed_k(int P, const uint3
         t[r] = live ? tiles_touched[i] : 0u;
         key[r] = live ? raw_key[i] : 0xFFFFFFFFu;
     }
-    // ---- base rank (blocks in front) and totals
+    // ---- base rank (blocks in front) and totals: whole groups of COARSE_BLOCKS preprocess blocks from their packed sums, the
+    // blocks of this workgroup's own group one by one
     uint32_t before = 0, all_v = 0, all_t = 0;
-    for (int i = tid; i < nblk; i += PRE_BLOCK) {
-        const uint2 a = blk_agg[i];
-        before += i < blk0 ? a.x : 0u;
-        all_v += a.x;
-        all_t += a.y;
+    const int c0 = blk0 / COARSE_BLOCKS, ncoarse = (nblk + COARSE_BLOCKS - 1) / COARSE_BLOCKS;
+    for (int i = tid; i < ncoarse; i += PRE_BLOCK) {
+        const unsigned long long a = blk_coarse[(size_t)i * COARSE_STRIDE];
+        const uint32_t av = (uint32_t)(a >> 40);
+        before += i < c0 ? av : 0u;
+        all_v += av;
+        all_t += (uint32_t)(a & ((1ull << 40) - 1ull));
     }
+    for (int i = c0 * COARSE_BLOCKS + tid; i < blk0; i += PRE_BLOCK) before += blk_agg[i].x;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         before += (uint32_t)__shfl_xor((int)before, d, 64);
@@ -376,8 +383,12 @@ __global__ __launch_bounds__(256) void ranges_k(int N_cap, const uint32_t* __res
 
 void launch_compact_listed(int P, const GeomView& g, uint32_t* ghist, bool pad, hipStream_t s) {
     const int nblk = (P + PRE_BLOCK - 1) / PRE_BLOCK;
-    compact_listed_k<<<dim3((nblk + COMPACT_ROUNDS - 1) / COMPACT_ROUNDS), dim3(PRE_BLOCK), 0, s>>>(
-        P, g.tiles_touched, g.sort_keys[1], g.blk_agg, g.counters, g.sort_keys[0], g.sort_vals[0], ghist, pad ? 1 : 0);
+    if (nblk <= 6144)
+        compact_listed_k<8><<<dim3((nblk + 7) / 8), dim3(PRE_BLOCK), 0, s>>>(
+            P, g.tiles_touched, g.sort_keys[1], g.blk_agg, g.blk_coarse, g.counters, g.sort_keys[0], g.sort_vals[0], ghist, pad ? 1 : 0);
+    else
+        compact_listed_k<24><<<dim3((nblk + 23) / 24), dim3(PRE_BLOCK), 0, s>>>(
+            P, g.tiles_touched, g.sort_keys[1], g.blk_agg, g.blk_coarse, g.counters, g.sort_keys[0], g.sort_vals[0], ghist, pad ? 1 : 0);
 }
 
 void launch_emit(int P, int W, int H, const GeomView& g, const uint32_t* order, const int* radii, uint32_t* keys,

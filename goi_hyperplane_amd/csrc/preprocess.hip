@@ -93,7 +93,8 @@ __global__ __launch_bounds__(256) void preprocess_fwd_k(const PreArgs args, Gaus
                                                         uint32_t* __restrict__ tiles_touched,
                                                         uint8_t* __restrict__ clamped, uint32_t* __restrict__ raw_key,
                                                         uint4* __restrict__ aux,
-                                                        uint2* __restrict__ blk_agg, int* __restrict__ radii,
+                                                        uint2* __restrict__ blk_agg,
+                                                        unsigned long long* __restrict__ blk_coarse, int* __restrict__ radii,
                                                         uint32_t* __restrict__ counters, uint2* __restrict__ ranges,
                                                         int n_tiles) {
     const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -318,7 +319,10 @@ __global__ __launch_bounds__(256) void preprocess_fwd_k(const PreArgs args, Gaus
         const uint32_t bsum = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
         if (bsum) atomicAdd(&counters[NR_BASE + NR_STRIDE * (blockIdx.x % NR_STRIPES)], bsum);
         // the block's aggregate: compact_listed_k ranks the listed Gaussians with it
-        blk_agg[blockIdx.x] = make_uint2(s_wvis[0] + s_wvis[1] + s_wvis[2] + s_wvis[3], bsum);
+        const uint32_t bvis = s_wvis[0] + s_wvis[1] + s_wvis[2] + s_wvis[3];
+        blk_agg[blockIdx.x] = make_uint2(bvis, bsum);
+        // ... and the sum over COARSE_BLOCKS consecutive blocks (compact_listed_k's base rank), packed: one integer atomic
+        if (bvis) atomicAdd(&blk_coarse[(size_t)(blockIdx.x / COARSE_BLOCKS) * COARSE_STRIDE], ((unsigned long long)bvis << 40) | bsum);
     }
 }
 
@@ -926,7 +930,7 @@ void launch_preprocess_fwd(const GoiRasterScene& sc, const GeomView& g, int* rad
     a.view_p = sc.viewmatrix; a.proj_p = sc.projmatrix; a.campos_p = sc.campos;
     static_assert(PRE_BLOCK == 256, "preprocess_fwd_k is written for 256-thread workgroups");
     preprocess_fwd_k<<<dim3((sc.P + PRE_BLOCK - 1) / PRE_BLOCK), dim3(PRE_BLOCK), 0, s>>>(
-        a, g.rec, g.cov3D, g.tiles_touched, g.clamped, g.sort_keys[1], g.aux, g.blk_agg, radii, g.counters, ranges, n_tiles);
+        a, g.rec, g.cov3D, g.tiles_touched, g.clamped, g.sort_keys[1], g.aux, g.blk_agg, g.blk_coarse, radii, g.counters, ranges, n_tiles);
 }
 
 void launch_preprocess_bwd(const GoiRasterScene& sc, const GeomView& g, const int* radii, float* dL_dmean2D,

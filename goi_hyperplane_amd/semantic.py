@@ -14,8 +14,8 @@ Inference (`compute_similarity`) is the hot part at GUI frame rate: it runs as O
 rasterizer's [S, H, W] output directly.  The training losses exist twice: `codebook_losses` restates
 train.py line by line in PyTorch (the parity reference: ~40 kernels over [HW,300] tensors, 109 ms
 and 21 GB at 1600x1056 on MI355X); `fused_codebook_losses` is the product path.  For the reference's shapes (256-d
-features, 289..304 codes, S <= 16) that is `goi_codebook_fused`: five hand-written kernels of csrc/codebook_loss.hip,
-no [HW, C] fp32 matrix in memory (the similarity and its gradient exist as MFMA tiles and two bf16 planes), ~3.5 ms and
+features, 289..304 codes, S <= 16) that is `goi_codebook_fused`: four hand-written kernels of csrc/codebook_loss.hip,
+no [HW, C] fp32 matrix in memory (the similarity and its gradient exist as MFMA tiles and two bf16 planes), ~3.4 ms and
 8.6 GB at 1600x1056.  Other shapes take the three-kernel path (similarity kernel or library GEMM, one row kernel, a
 split-K MFMA GEMM for dL/dLUT), which is also the cross-check of tests/test_gpu_losses.py; LOSS_PATH_COUNTS says which ran.
 """
