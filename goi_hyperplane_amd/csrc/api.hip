@@ -297,7 +297,7 @@ int enqueue_back(const GoiRasterScene& sc, GeomView& g, ImageView& im, const Bin
     if (counting) {
         {
             StageTimer t(GOI_STAGE_RANGES, s);
-            launch_tile_ranges_hist(sc.W, sc.H, im.ranges, radix_sort_ghist(bv.scratch, (size_t)cap, 0, tile_bits), s);
+            launch_tile_ranges_hist(sc.W, sc.H, im.ranges, radix_sort_ghist(bv.scratch, (size_t)cap, 0, tile_bits), g.counters, s);
         }
         StageTimer t(GOI_STAGE_TILE_SORT, s);
         fin = radix_sort_pairs(bv.keys, bv.vals, (size_t)cap, 0, tile_bits, bv.scratch, s, /*cleared=*/true,
@@ -378,6 +378,7 @@ size_t geom_layout(int P, char* base, GeomView* v) {
     carve(p, g.offsets, n);
     carve(p, g.aux, n);
     carve(p, g.blk_agg, (n + PRE_BLOCK - 1) / PRE_BLOCK);
+    carve(p, g.bigq, n);
     // (blk_coarse, counters, sort control words: contiguous, ONE memset clears the three)
     carve(p, g.blk_coarse, (((n + PRE_BLOCK - 1) / PRE_BLOCK + COARSE_BLOCKS - 1) / COARSE_BLOCKS) * (size_t)COARSE_STRIDE);
     carve(p, g.counters, COUNTER_WORDS);  // directly in front of the sort scratch: one memset clears both

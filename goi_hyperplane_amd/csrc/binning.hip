@@ -149,7 +149,8 @@ __global__ __launch_bounds__(256) void emit_k(int P, int gx, int gy, const Gauss
                                               const uint32_t* __restrict__ offsets, uint4* __restrict__ aux,
                                               uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
                                               uint32_t* __restrict__ tile_count, uint32_t* __restrict__ counters,
-                                              uint32_t* __restrict__ clear, uint32_t clear_words, uint32_t cap) {
+                                              uint32_t* __restrict__ clear, uint32_t clear_words, uint32_t cap,
+                                              uint4* __restrict__ bigq) {
     // cap: number of instances keys[] / vals[] can hold.  The exact forward sizes them for num_rendered, so the
     // guard below never fires; the speculative forward sizes them from a guess, and a frame that overflows must
     // stay memory-safe and self-consistent (the tile counts only count what was stored) until the host notices.
@@ -232,25 +233,45 @@ __global__ __launch_bounds__(256) void emit_k(int P, int gx, int gy, const Gauss
         // instance count) -- and written by a loop that needs none of that: all 64 lanes walk ITS instances, a division per
         // instance.  Same keys, same values, same positions (a big rectangle is always a full one: the ellipse masks cover
         // rectangles of at most 64 tiles).
+        // Round 5: the counting variant for SMALL tile grids does not write its big rectangles at all -- the depth order puts the near Gaussians in
+        // front, so on a close-up the first few waves of the grid held nothing but rectangles of hundreds of tiles and wrote
+        // a third of the frame's instances while the rest of the chip had finished (emit 87 us for 2.6 M instances).  They go to
+        // a queue (one atomic per wave that has any), and emit_big_k, launched behind this kernel, spreads them over the chip:
+        // a workgroup per rectangle.  Same keys, same values, same positions.
+        // Only on SMALL tile grids (ROUNDS_COUNTING == 1: a close-up), where rectangles are large against the frame: on a
+        // 1600 x 1056 frame the second launch costs what it saves (headline +5 us for an empty queue, clustered 96 -> 70 + 33 us:
+        // a frame-filling blob makes its workgroup flush all 6600 tile counters).
+        constexpr bool QUEUE = COUNT && ROUNDS_COUNTING == 1;
         const int cnt_own = cnt;
         const unsigned long long big_lanes = __ballot(cnt > EMIT_BIG_TILES);
         if (cnt > EMIT_BIG_TILES) cnt = 0;
-        for (unsigned long long bl = big_lanes; bl; bl &= bl - 1) {
-            const int l = __builtin_ctzll(bl);
-            const int bx0 = __builtin_amdgcn_readlane(x0, l), by0 = __builtin_amdgcn_readlane(y0, l);
-            const int bw = __builtin_amdgcn_readlane(w, l), bcnt = __builtin_amdgcn_readlane(cnt_own, l);
-            const uint32_t boff = (uint32_t)__builtin_amdgcn_readlane((int)off, l), bg = (uint32_t)__builtin_amdgcn_readlane((int)g, l);
-            const float inv_w = __builtin_amdgcn_rcpf((float)bw);
-            for (int k = lane; k < bcnt; k += 64) {
-                int row = (int)((float)k * inv_w);  // k / bw, off by at most one
-                row -= (row * bw > k);
-                row += ((row + 1) * bw <= k);
-                const uint32_t key = (uint32_t)((by0 + row) * gx + bx0 + (k - row * bw));
-                const uint32_t pos = boff + (uint32_t)k;
-                if (pos < cap) {
-                    keys[pos] = key;
-                    vals[pos] = bg;
-                    if (COUNT) atomicAdd(&s_cnt[key], 1u);
+        if (QUEUE) {
+            if (big_lanes) {
+                uint32_t qbase = 0;
+                if (lane == 0) qbase = atomicAdd(&counters[COUNTER_BIGQ], (uint32_t)__popcll(big_lanes));
+                qbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)qbase);
+                if (cnt_own > EMIT_BIG_TILES)
+                    bigq[qbase + (uint32_t)__popcll(big_lanes & ((1ull << lane) - 1ull))] =
+                        make_uint4((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)w | ((uint32_t)(cnt_own / w) << 16), off, g);
+            }
+        } else {
+            for (unsigned long long bl = big_lanes; bl; bl &= bl - 1) {
+                const int l = __builtin_ctzll(bl);
+                const int bx0 = __builtin_amdgcn_readlane(x0, l), by0 = __builtin_amdgcn_readlane(y0, l);
+                const int bw = __builtin_amdgcn_readlane(w, l), bcnt = __builtin_amdgcn_readlane(cnt_own, l);
+                const uint32_t boff = (uint32_t)__builtin_amdgcn_readlane((int)off, l), bg = (uint32_t)__builtin_amdgcn_readlane((int)g, l);
+                const float inv_w = __builtin_amdgcn_rcpf((float)bw);
+                for (int k = lane; k < bcnt; k += 64) {
+                    int row = (int)((float)k * inv_w);  // k / bw, off by at most one
+                    row -= (row * bw > k);
+                    row += ((row + 1) * bw <= k);
+                    const uint32_t key = (uint32_t)((by0 + row) * gx + bx0 + (k - row * bw));
+                    const uint32_t pos = boff + (uint32_t)k;
+                    if (pos < cap) {
+                        keys[pos] = key;
+                        vals[pos] = bg;
+                        if (COUNT) atomicAdd(&s_cnt[key], 1u);
+                    }
                 }
             }
         }
@@ -309,6 +330,40 @@ __global__ __launch_bounds__(256) void emit_k(int P, int gx, int gy, const Gauss
     }
 }
 
+// The big rectangles emit_k<true> queued (more than EMIT_BIG_TILES tiles: always full rectangles): a workgroup per rectangle,
+// 256 lanes walk its instances, a division per instance; the per-tile counts go through the same LDS histogram.
+__global__ __launch_bounds__(256) void emit_big_k(int gx, int T, const uint4* __restrict__ bigq,
+                                                  const uint32_t* __restrict__ counters, uint32_t* __restrict__ keys,
+                                                  uint32_t* __restrict__ vals, uint32_t* __restrict__ tile_count, uint32_t cap) {
+    const uint32_t nbig = counters[COUNTER_BIGQ];
+    if (blockIdx.x >= nbig) return;  // (block-uniform)
+    extern __shared__ uint32_t s_cnt[];  // [T]
+    for (int t = threadIdx.x; t < T; t += 256) s_cnt[t] = 0;
+    __syncthreads();
+    for (uint32_t j = blockIdx.x; j < nbig; j += gridDim.x) {
+        const uint4 q = bigq[j];
+        const int bx0 = (int)(q.x & 0xFFFFu), by0 = (int)(q.x >> 16), bw = (int)(q.y & 0xFFFFu), bcnt = bw * (int)(q.y >> 16);
+        const float inv_w = __builtin_amdgcn_rcpf((float)bw);
+        for (int k = threadIdx.x; k < bcnt; k += 256) {
+            int row = (int)((float)k * inv_w);  // k / bw, off by at most one
+            row -= (row * bw > k);
+            row += ((row + 1) * bw <= k);
+            const uint32_t key = (uint32_t)((by0 + row) * gx + bx0 + (k - row * bw));
+            const uint32_t pos = q.z + (uint32_t)k;
+            if (pos < cap) {
+                keys[pos] = key;
+                vals[pos] = q.w;
+                atomicAdd(&s_cnt[key], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += 256) {
+        const uint32_t c = s_cnt[t];
+        if (c) atomicAdd(&tile_count[2 * t], c);
+    }
+}
+
 // One workgroup: per-tile counts (in ranges[t].y) -> ranges[t] = [start, end) ((0,0) for an empty tile, as
 // the reference leaves it) and the global digit histograms of the tile sort's passes.  A thread owns IT = ceil(T / 1024)
 // consecutive tiles (IT <= 12: emit only counts grids of at most 12288 tiles), so the prefix sum is ONE block scan
@@ -316,7 +371,8 @@ __global__ __launch_bounds__(256) void emit_k(int P, int gx, int gy, const Gauss
 constexpr int TRH_MAX_IT = 12;
 __global__ __launch_bounds__(1024) void tile_ranges_hist_k(int T, uint2* __restrict__ ranges, int passes, int shift0,
                                                            int nbits0, int shift1, int nbits1,
-                                                           uint32_t* __restrict__ ghist) {
+                                                           uint32_t* __restrict__ ghist, uint32_t* __restrict__ counters) {
+    if (threadIdx.x == 0) counters[COUNTER_BIGQ] = 0u;  // (emit_big_k has run: the next emit from this workspace -- a redo -- starts an empty queue)
     __shared__ uint32_t s_h[2][256];
     __shared__ uint32_t s_wave[16];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -395,7 +451,7 @@ void launch_emit(int P, int W, int H, const GeomView& g, const uint32_t* order, 
                  uint32_t* vals, uint32_t cap, hipStream_t s) {
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     emit_k<false><<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, gx, gy, g.rec, radii, order, g.offsets, g.aux, keys, vals,
-                                                              nullptr, g.counters, nullptr, 0u, cap);
+                                                              nullptr, g.counters, nullptr, 0u, cap, nullptr);
 }
 
 bool emit_can_count_tiles(int W, int H) {
@@ -410,24 +466,27 @@ void launch_emit_counting(int P, int W, int H, const GeomView& g, const uint32_t
                           uint32_t* vals, uint2* ranges, uint32_t* clear, size_t clear_words, uint32_t cap, hipStream_t s) {
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     // `ranges` was zeroed by preprocess_fwd_k
-    if (emit_rounds_for(gx * gy) == 1)
+    if (emit_rounds_for(gx * gy) == 1) {
         emit_k<true, 1><<<dim3((P + 255) / 256), dim3(256), (size_t)gx * gy * sizeof(uint32_t), s>>>(
             P, gx, gy, g.rec, radii, order, g.offsets, g.aux, keys, vals, reinterpret_cast<uint32_t*>(ranges) + 1, g.counters,
-            clear, (uint32_t)clear_words, cap);
-    else
+            clear, (uint32_t)clear_words, cap, g.bigq);
+        // the big rectangles the kernel queued: a workgroup per CU walks the queue (workgroups beyond its length leave at once)
+        emit_big_k<<<dim3(256), dim3(256), (size_t)gx * gy * sizeof(uint32_t), s>>>(gx, gx * gy, g.bigq, g.counters, keys, vals,
+                                                                                  reinterpret_cast<uint32_t*>(ranges) + 1, cap);
+    } else
         emit_k<true, EMIT_ROUNDS><<<dim3((P + 256 * EMIT_ROUNDS - 1) / (256 * EMIT_ROUNDS)), dim3(256), (size_t)gx * gy * sizeof(uint32_t), s>>>(
             P, gx, gy, g.rec, radii, order, g.offsets, g.aux, keys, vals, reinterpret_cast<uint32_t*>(ranges) + 1, g.counters,
-            clear, (uint32_t)clear_words, cap);
+            clear, (uint32_t)clear_words, cap, g.bigq);
 }
 
 // per-tile counts -> ranges and the two digit histograms (written to ghist[0..511]) of a sort on
 // key bits [0, bits) split as radix_sort_pairs splits them
-void launch_tile_ranges_hist(int W, int H, uint2* ranges, uint32_t* ghist, hipStream_t s) {
+void launch_tile_ranges_hist(int W, int H, uint2* ranges, uint32_t* ghist, uint32_t* counters, hipStream_t s) {
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     const int bits = tile_key_bits((uint32_t)(gx * gy));
     const int passes = (bits + 7) / 8;
     const int n0 = (bits + passes - 1) / passes, n1 = bits - n0;
-    tile_ranges_hist_k<<<dim3(1), dim3(1024), 0, s>>>(gx * gy, ranges, passes, 0, n0, n0, n1 > 0 ? n1 : 1, ghist);
+    tile_ranges_hist_k<<<dim3(1), dim3(1024), 0, s>>>(gx * gy, ranges, passes, 0, n0, n0, n1 > 0 ? n1 : 1, ghist, counters);
 }
 
 void launch_ranges(int N, const uint32_t* n_dev, const uint32_t* sorted_keys, uint2* ranges, int T, hipStream_t s) {

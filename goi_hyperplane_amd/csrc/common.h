@@ -43,6 +43,7 @@ struct GeomView {
     // (listed << 40 | tiles touched) in the first word of a 64-byte entry: one integer atomic per preprocess block; lets
     // compact_listed_k find its base rank from ~nblk / 32 + 31 words instead of all nblk pairs (3 M Gaussians: 49 -> 26 us)
     unsigned long long* blk_coarse;
+    uint4* bigq;  // [P] emit's queue of big rectangles: (x0 | y0 << 16, w | h << 16, first instance, Gaussian id) -- binning.hip
     uint32_t* scratch;        // scan partials + radix histograms
     uint32_t* counters;       // [COUNTER_WORDS]: 1 = error flag, 2 = cull_variant of this forward, NR_BASE.. = num_rendered stripes
     size_t scratch_words;
@@ -174,7 +175,7 @@ void launch_emit(int P, int W, int H, const GeomView& g, const uint32_t* order, 
 bool emit_can_count_tiles(int W, int H);
 void launch_emit_counting(int P, int W, int H, const GeomView& g, const uint32_t* order, const int* radii, uint32_t* keys,
                           uint32_t* vals, uint2* ranges, uint32_t* clear, size_t clear_words, uint32_t cap, hipStream_t s);
-void launch_tile_ranges_hist(int W, int H, uint2* ranges, uint32_t* ghist, hipStream_t s);
+void launch_tile_ranges_hist(int W, int H, uint2* ranges, uint32_t* ghist, uint32_t* counters, hipStream_t s);
 void launch_ranges(int N, const uint32_t* n_dev, const uint32_t* sorted_keys, uint2* ranges, int T, hipStream_t s);
 // zcut / zlearn: the speculative depth cut-off (goi_raster_forward_async_cut): per tile, the cut this frame's lists were built
 // with (or NULL) and what the frame learns for the camera's next visit (float bits, max over the tile's quadrants; or NULL)
@@ -329,6 +330,8 @@ constexpr int COUNTER_OVF = 4;   // 1: this frame's instance list was TRUNCATED 
                                  // buffers from the true count, CR/rasterizer_impl.cu:283-289, and cannot truncate)
 
 constexpr uint32_t OVF_TRUNCATED = 1u, OVF_MISSORTED = 2u, OVF_CUT_TOO_TIGHT = 4u;  // bits of counters[COUNTER_OVF]
+constexpr int COUNTER_BIGQ = 7;     // emit: number of BIG rectangles queued for emit_big_k (GeomView::bigq); tile_ranges_hist_k, which
+                                    // runs behind both, puts it back to 0 (a redone frame emits again from the same workspace)
 constexpr int COUNTER_SORTERR = 6;  // != 0: a look-back of the DEPTH sort timed out (scan_sort.hip): emit folds it into
                                     // COUNTER_OVF (the tile sort, which runs behind emit, sets bit 1 of COUNTER_OVF itself), so
                                     // a mis-sorted frame back-propagates zeros like a truncated one, and the read-back fails

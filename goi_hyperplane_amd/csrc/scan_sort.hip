@@ -78,7 +78,10 @@ __device__ __forceinline__ size_t scan_n(size_t n, const uint32_t* __restrict__ 
 __global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_k(const uint32_t* __restrict__ in,
                                                               const uint32_t* __restrict__ gather, size_t n_cap,
                                                               const uint32_t* __restrict__ n_dev,
-                                                              uint32_t* __restrict__ partials) {
+                                                              uint32_t* __restrict__ partials,
+                                                              uint32_t* __restrict__ stash) {
+    // stash (with gather): the gathered values are left there in scan order -- the second kernel then reads them as a stream
+    // instead of gathering them again (3 M Gaussians: scan_apply_k 25 -> 10 us)
     __shared__ uint32_t sm[SCAN_THREADS / WAVE + 1];
     const size_t n = scan_n(n_cap, n_dev);
     const size_t base = (size_t)blockIdx.x * SCAN_CHUNK;
@@ -90,7 +93,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_k(const uint32_t* __
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; k++) {
         size_t i = base + (size_t)k * SCAN_THREADS + threadIdx.x;
-        if (i < n) sum += gather ? in[gather[i]] : in[i];
+        if (i < n) {
+            const uint32_t v = gather ? in[gather[i]] : in[i];
+            if (stash) stash[i] = v;
+            sum += v;
+        }
     }
     uint32_t total;
     (void)block_exclusive_scan<SCAN_THREADS>(sum, sm, &total);
@@ -291,6 +298,12 @@ __global__ __launch_bounds__(SORT_THREADS) void sweep_hist_k(const uint32_t* __r
 // 1 M-key sort is resident at once), and that is set by the ITEMS ranking rounds each thread runs back to back:
 // 1024 x 4 sorts 1 M keys in 89 us (4 passes) where 512 x 16 needs 102; with 5 M keys the larger tile wins
 // (88 vs 96 us for 2 passes: fewer tiles to look back over, fewer partial runs per digit).
+// ADAPTIVE tile (min_items < ITEMS; round 5): the count lives on the device and can be a small fraction of the capacity the grid
+// and the status table were laid out for (a 512 x 512 close-up of a 3 M scene lists 240 k Gaussians: 30 tiles of 8192 keys kept
+// 30 of 256 CUs busy for 24 us per pass).  Every block derives the SAME keys-per-thread from the count -- the smallest power
+// of two between min_items and ITEMS that leaves at most SWEEP_TARGET_TILES tiles -- and blocks beyond the tiles of that shape
+// leave before they take a ticket.  (The status table has a row per tile of the SMALLEST shape: sweep_status_words.)
+constexpr int SWEEP_TARGET_TILES = 512;
 template <int THREADS, int ITEMS>
 __global__ __launch_bounds__(THREADS) void sweep_pass_k(const uint32_t* __restrict__ keys_in,
                                                              const uint32_t* __restrict__ vals_in,
@@ -299,15 +312,19 @@ __global__ __launch_bounds__(THREADS) void sweep_pass_k(const uint32_t* __restri
                                                              const uint32_t* __restrict__ n_dev, int shift,
                                                              int nbits, const uint32_t* __restrict__ ghist,
                                                              uint32_t* status, uint32_t* ticket, uint32_t* error,
-                                                             uint32_t* frame_error) {
-    constexpr int TILE_KEYS = THREADS * ITEMS, WAVES = THREADS / WAVE, WAVE_ITEMS = TILE_KEYS / WAVES;
+                                                             uint32_t* frame_error, int min_items) {
+    constexpr int WAVES = THREADS / WAVE;
     const size_t n = effective_n(n_cap, n_dev);
+    int items = ITEMS;
+    while (items > min_items && n <= (size_t)THREADS * (size_t)(items / 2) * SWEEP_TARGET_TILES) items >>= 1;
+    const int TILE_KEYS = THREADS * items, WAVE_ITEMS = TILE_KEYS / WAVES;
+    if ((size_t)blockIdx.x * TILE_KEYS >= n) return;  // (no ticket taken: exactly the tiles of this shape take one)
     __shared__ uint32_t cnt[WAVES][RADIX_MAX];  // per-wave digit counts -> per-wave local offsets
     __shared__ uint32_t gbase[RADIX_MAX];            // global position of this block's first element of digit d
     __shared__ uint32_t lbase[RADIX_MAX];            // local (in-block) exclusive offset of digit d
-    extern __shared__ uint32_t s_dyn[];  // [2][TILE_KEYS]: the tile's keys and values in digit order
+    extern __shared__ uint32_t s_dyn[];  // [2][THREADS * ITEMS]: the tile's keys and values in digit order
     uint32_t* s_keys = s_dyn;
-    uint32_t* s_vals = s_dyn + TILE_KEYS;
+    uint32_t* s_vals = s_dyn + THREADS * ITEMS;
     __shared__ uint32_t s_bid;
     const uint32_t radix = 1u << nbits, mask = radix - 1u;
     // A TRIVIAL pass: every key has the same digit (the global histogram says so: one bin holds all n) -- the top byte of
@@ -317,7 +334,7 @@ __global__ __launch_bounds__(THREADS) void sweep_pass_k(const uint32_t* __restri
         const uint32_t d0 = (keys_in[0] >> shift) & mask;
         if (ghist[d0] == (uint32_t)n) {
             const size_t base = (size_t)blockIdx.x * TILE_KEYS;
-            for (int r = 0; r < ITEMS; r++) {
+            for (int r = 0; r < items; r++) {
                 const size_t i = base + (size_t)r * THREADS + threadIdx.x;
                 if (i < n) {
                     keys_out[i] = keys_in[i];
@@ -342,12 +359,13 @@ __global__ __launch_bounds__(THREADS) void sweep_pass_k(const uint32_t* __restri
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
         size_t i = wbase + (size_t)r * WAVE + lane;
-        const bool ok = i < n;
+        const bool ok = r < items && i < n;
         key[r] = ok ? keys_in[i] : 0xFFFFFFFFu;
         val[r] = ok ? vals_in[i] : 0u;
     }
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
+        if (r >= items) break;  // (wave-uniform)
         size_t i = wbase + (size_t)r * WAVE + lane;
         const bool ok = i < n;
         const uint32_t d = (key[r] >> shift) & mask;
@@ -461,7 +479,7 @@ __global__ __launch_bounds__(THREADS) void sweep_pass_k(const uint32_t* __restri
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
         size_t i = wbase + (size_t)r * WAVE + lane;
-        if (i < n) {
+        if (r < items && i < n) {
             const uint32_t d = (key[r] >> shift) & mask;
             const uint32_t lp = lbase[d] + cnt[w][d] + rank[r];
             s_keys[lp] = key[r];
@@ -469,7 +487,7 @@ __global__ __launch_bounds__(THREADS) void sweep_pass_k(const uint32_t* __restri
         }
     }
     __syncthreads();
-    const uint32_t count = (uint32_t)(tile_base + TILE_KEYS <= n ? TILE_KEYS : (n > tile_base ? n - tile_base : 0));
+    const uint32_t count = (uint32_t)(tile_base + (size_t)TILE_KEYS <= n ? (size_t)TILE_KEYS : (n > tile_base ? n - tile_base : 0));
     for (uint32_t i = threadIdx.x; i < count; i += THREADS) {
         const uint32_t k = s_keys[i];
         const uint32_t d = (k >> shift) & mask;
@@ -485,11 +503,21 @@ inline size_t div_up(size_t a, size_t b) { return (a + b - 1) / b; }
 
 size_t scan_scratch_words(size_t n) { return div_up(n, SCAN_CHUNK) + 16; }
 
+// the smallest tile the adaptive 512 x 16 kernel may choose for a capacity of n keys: 512 x 2 = 1024 keys, more when that
+// would need more than 2048 rows of status words per pass (the table is cleared every frame: 1 KB per row and pass)
+static int sweep_min_items(size_t n) {
+    if (n <= ((size_t)2 << 20)) return 4;  // (1024 x 4: not adaptive)
+    int items = 2;
+    while (items < 16 && (n + (size_t)512 * items - 1) / ((size_t)512 * items) > 2048) items <<= 1;
+    return items;
+}
+static size_t sweep_min_tile_keys(size_t n) { return n <= ((size_t)2 << 20) ? 4096 : (size_t)512 * sweep_min_items(n); }
+
 size_t sort_scratch_words(size_t n) {
-    size_t nblk = div_up(n, 4096);  // the smallest tile any variant uses
+    size_t nblk = div_up(n, 4096);  // the smallest tile of the three-kernel variant
     size_t table = (size_t)RADIX_MAX * nblk;
     size_t three_kernel = table + scan_scratch_words(table) + 16;
-    size_t onesweep = (size_t)MAX_PASSES * table + (size_t)MAX_PASSES * RADIX_MAX + 64;
+    size_t onesweep = (size_t)MAX_PASSES * RADIX_MAX * div_up(n, sweep_min_tile_keys(n)) + (size_t)MAX_PASSES * RADIX_MAX + 64;
     return three_kernel > onesweep ? three_kernel : onesweep;
 }
 
@@ -500,16 +528,17 @@ void exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* ou
         return;
     }
     const size_t nb = div_up(n, SCAN_CHUNK);
-    scan_reduce_k<<<dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s>>>(in, gather, n, n_dev, scratch);
+    const bool stash = gather != nullptr && out != in;  // the gathered values pass through `out`
+    scan_reduce_k<<<dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s>>>(in, gather, n, n_dev, scratch, stash ? out : nullptr);
     scan_partials_k<<<dim3(1), dim3(1024), 0, s>>>(scratch, nb, total);
-    scan_apply_k<<<dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s>>>(in, gather, out, n, n_dev, scratch);
+    scan_apply_k<<<dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s>>>(stash ? out : in, stash ? nullptr : gather, out, n, n_dev, scratch);
 }
 
 // Control words of the onesweep sort, contiguous at the start of the scratch so that ONE memset clears them:
 // [passes][nblk][256] status | [MAX_PASSES][256] global digit histograms | [MAX_PASSES] tickets | error
 static size_t sweep_tile_keys(size_t n) { return n <= ((size_t)2 << 20) ? 4096 : 8192; }  // 1024 x 4 or 512 x 16
 static size_t sweep_status_words(size_t n, int lo, int hi) {
-    return (size_t)((hi - lo + 7) / 8) * div_up(n, sweep_tile_keys(n)) * RADIX_MAX;
+    return (size_t)((hi - lo + 7) / 8) * div_up(n, sweep_min_tile_keys(n)) * RADIX_MAX;
 }
 size_t radix_sort_control_words(size_t n, int lo, int hi) {
     return n ? sweep_status_words(n, lo, hi) + MAX_PASSES * RADIX_MAX + MAX_PASSES + 1 : 0;
@@ -547,7 +576,9 @@ int radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], size_t n, int lo, int
         for (int p = passes; p < MAX_PASSES; p++) plan.shift[p] = plan.nbits[p] = 0;
         if (!ghist_ready) sweep_hist_k<<<dim3(nblk), dim3(SORT_THREADS), 0, s>>>(keys[0], n, n_dev, plan, ghist);
         const size_t tile = sweep_tile_keys(n);
-        const uint32_t nt = (uint32_t)div_up(n, tile);
+        const int min_items = sweep_min_items(n);
+        // grid and status rows for the SMALLEST tile the kernel may choose (the count is on the device)
+        const uint32_t nt = (uint32_t)div_up(n, sweep_min_tile_keys(n));
         const size_t lds = 2 * tile * sizeof(uint32_t);  // the tile's keys and values in digit order
         // (the attribute is per device: set it once on each device this process sorts on)
         static std::atomic<uint64_t> attr_set{0};
@@ -563,11 +594,12 @@ int radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], size_t n, int lo, int
             if (tile == 4096)
                 sweep_pass_k<1024, 4><<<dim3(nt), dim3(1024), lds, s>>>(
                     keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, n_dev, plan.shift[p], plan.nbits[p],
-                    ghist + (size_t)p * RADIX_MAX, status + (size_t)p * nt * RADIX_MAX, ticket + p, error, frame_error);
+                    ghist + (size_t)p * RADIX_MAX, status + (size_t)p * nt * RADIX_MAX, ticket + p, error, frame_error, 4);
             else
                 sweep_pass_k<512, 16><<<dim3(nt), dim3(512), lds, s>>>(
                     keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, n_dev, plan.shift[p], plan.nbits[p],
-                    ghist + (size_t)p * RADIX_MAX, status + (size_t)p * nt * RADIX_MAX, ticket + p, error, frame_error);
+                    ghist + (size_t)p * RADIX_MAX, status + (size_t)p * nt * RADIX_MAX, ticket + p, error, frame_error,
+                    min_items);
             cur ^= 1;
         }
         return cur;
