@@ -4,7 +4,9 @@
 #include <cstring>
 #include <cstdlib>
 #include <atomic>
+#include <chrono>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -133,7 +135,14 @@ struct Ticket {
     int capacity = 0;  // instances the frame's binning buffer holds (speculative frames); 0: exact frame
     bool head_only = false;  // only the first READBACK_HEAD_WORDS words were copied: num_rendered is counters[COUNTER_N]
     uint32_t* pinned_dev = nullptr;  // the same words as the device sees them (the pinned allocation is mapped)
+    // STAMPED read-back (round 5): no copy and no event -- a wave of the forward blend stores the head words into the pinned
+    // words and then, behind a system-scope fence, this use's sequence number into pinned[STAMP_WORD]; the host compares.
+    // (An event recorded behind the blend cost the stream a ~5.6 us bubble per frame: rocprofv3 shows it as the only idle gap
+    // of a training step, between render_fwd_k and the backward's first kernel.)
+    uint32_t seq = 0;
+    bool stamped = false;
 };
+constexpr int STAMP_WORD = 33;  // (the head is words 0..31; word 32 is a num_rendered stripe of the full copy, which is never stamped)
 // A read-back queued BEHIND the whole frame (speculative forward) finds num_rendered as one word (COUNTER_N, left by the
 // listed-Gaussian compaction / the scan): 128 bytes travel instead of the 4 KB of striped partial counters -- which the
 // runtime moved as three copy kernels per frame.
@@ -151,6 +160,7 @@ int ticket_acquire(int capacity) {
         if (!g_tickets[i].busy && g_tickets[i].dev == dev) {
             g_tickets[i].busy = true;
             g_tickets[i].capacity = capacity;
+            g_tickets[i].stamped = false;
             return (int)i;
         }
     if ((int)g_tickets.size() >= MAX_TICKETS)
@@ -161,6 +171,7 @@ int ticket_acquire(int capacity) {
                           hipHostMallocMapped | hipHostMallocCoherent));  // (coherent: a kernel's stores go straight to the host)
     if (hipHostGetDevicePointer(reinterpret_cast<void**>(&t.pinned_dev), t.pinned, 0) != hipSuccess) t.pinned_dev = nullptr;
     GOI_HIP(hipEventCreateWithFlags(&t.ev, hipEventDisableTiming));
+    t.pinned[STAMP_WORD] = 0u;
     t.busy = true;
     t.capacity = capacity;
     g_tickets.push_back(t);
@@ -181,7 +192,32 @@ int ticket_result(int id, int wait, long long* n, unsigned* frame_flags = nullpt
         if (id < 0 || id >= (int)g_tickets.size() || !g_tickets[id].busy) return fail("invalid or already resolved ticket");
         t = g_tickets[id];
     }
-    if (wait) {
+    if (t.stamped) {
+        // the blend's wave stores the head words, fences at system scope, then stores the stamp: an acquire load that sees
+        // this use's sequence number sees the words
+        auto arrived = [&]() { return __atomic_load_n(&t.pinned[STAMP_WORD], __ATOMIC_ACQUIRE) == t.seq; };
+        if (!arrived()) {
+            if (!wait) return 0;
+            // spin politely; a frame is milliseconds.  After two seconds something is wrong with the device (or the frame
+            // never ran): drain it and look once more -- never hang in here
+            const auto t0 = std::chrono::steady_clock::now();
+            int spins = 0;
+            while (!arrived()) {
+                if (++spins > 2000) std::this_thread::sleep_for(std::chrono::microseconds(20));
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+                    int cur = 0;
+                    (void)hipGetDevice(&cur);
+                    (void)hipSetDevice(t.dev);
+                    const hipError_t e = hipDeviceSynchronize();
+                    (void)hipSetDevice(cur);
+                    if (e != hipSuccess || !arrived()) {
+                        ticket_release(id);
+                        return fail("the frame's counters never arrived (num_rendered read-back)", e);
+                    }
+                }
+            }
+        }
+    } else if (wait) {
         hipError_t e = hipEventSynchronize(t.ev);
         if (e != hipSuccess) {
             ticket_release(id);
@@ -375,10 +411,10 @@ size_t geom_layout(int P, char* base, GeomView* v) {
     carve(p, g.sort_keys[1], n);
     carve(p, g.sort_vals[0], n);
     carve(p, g.sort_vals[1], n);
+    g.bigq = g.sort_keys[1];  // (the raw depth keys are consumed by the compaction, the sort's result is in buffer 0)
     carve(p, g.offsets, n);
     carve(p, g.aux, n);
     carve(p, g.blk_agg, (n + PRE_BLOCK - 1) / PRE_BLOCK);
-    carve(p, g.bigq, n);
     // (blk_coarse, counters, sort control words: contiguous, ONE memset clears the three)
     carve(p, g.blk_coarse, (((n + PRE_BLOCK - 1) / PRE_BLOCK + COARSE_BLOCKS - 1) / COARSE_BLOCKS) * (size_t)COARSE_STRIDE);
     carve(p, g.counters, COUNTER_WORDS);  // directly in front of the sort scratch: one memset clears both
@@ -519,22 +555,24 @@ int goi_raster_forward_async_cut(const GoiRasterScene* scene, void* geom_buffer,
     // its flag inside the blend (the cut is checked there, whether or not zcut_out was given), so it keeps the copy behind the
     // kernel: the words a blend wave stores are a snapshot taken when the kernel STARTS.
     uint32_t* host_words = nullptr;
+    uint32_t stamp = 0;
     {
         std::lock_guard<std::mutex> lk(g_ticket_mu);
-        if (!zlearn && !zcut_in) host_words = g_tickets[ticket].pinned_dev;
+        Ticket& tk = g_tickets[ticket];
+        if (!zlearn && !zcut_in && tk.pinned_dev) {
+            host_words = tk.pinned_dev;
+            tk.seq = tk.seq + 1u ? tk.seq + 1u : 1u;  // (never 0: a fresh ticket's stamp word)
+            stamp = tk.seq;
+            tk.head_only = true;
+            tk.stamped = true;  // no copy, no event: ticket_result compares pinned[STAMP_WORD] with seq
+        }
     }
     {
         StageTimer t(GOI_STAGE_BLEND_FWD, s);
         launch_render_fwd(sc, g, im, plist, out_color, out_semantic, out_depth, out_alpha, s, bv.qmask, zcut_in, zlearn,
-                          host_words);
+                          host_words, stamp);
     }
     if (host_words) {
-        std::lock_guard<std::mutex> lk(g_ticket_mu);
-        g_tickets[ticket].head_only = true;
-        if (hipEventRecord(g_tickets[ticket].ev, s) != hipSuccess) {
-            g_tickets[ticket].busy = false;
-            return fail("goi_raster_forward_async: hipEventRecord failed");
-        }
     } else if (enqueue_readback(g, ticket, s, /*head_only=*/true)) {
         ticket_release(ticket);
         return -1;

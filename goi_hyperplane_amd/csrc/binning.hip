@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void emit_k(int P, int gx, int gy, const Gauss
                                               uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
                                               uint32_t* __restrict__ tile_count, uint32_t* __restrict__ counters,
                                               uint32_t* __restrict__ clear, uint32_t clear_words, uint32_t cap,
-                                              uint4* __restrict__ bigq) {
+                                              uint32_t* __restrict__ bigq) {
     // cap: number of instances keys[] / vals[] can hold.  The exact forward sizes them for num_rendered, so the
     // guard below never fires; the speculative forward sizes them from a guess, and a frame that overflows must
     // stay memory-safe and self-consistent (the tile counts only count what was stored) until the host notices.
@@ -250,9 +250,8 @@ __global__ __launch_bounds__(256) void emit_k(int P, int gx, int gy, const Gauss
                 uint32_t qbase = 0;
                 if (lane == 0) qbase = atomicAdd(&counters[COUNTER_BIGQ], (uint32_t)__popcll(big_lanes));
                 qbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)qbase);
-                if (cnt_own > EMIT_BIG_TILES)
-                    bigq[qbase + (uint32_t)__popcll(big_lanes & ((1ull << lane) - 1ull))] =
-                        make_uint4((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)w | ((uint32_t)(cnt_own / w) << 16), off, g);
+                if (cnt_own > EMIT_BIG_TILES)  // (its rank in the depth order: emit_big_k looks the rest up again)
+                    bigq[qbase + (uint32_t)__popcll(big_lanes & ((1ull << lane) - 1ull))] = (uint32_t)i;
             }
         } else {
             for (unsigned long long bl = big_lanes; bl; bl &= bl - 1) {
@@ -332,30 +331,59 @@ __global__ __launch_bounds__(256) void emit_k(int P, int gx, int gy, const Gauss
 
 // The big rectangles emit_k<true> queued (more than EMIT_BIG_TILES tiles: always full rectangles): a workgroup per rectangle,
 // 256 lanes walk its instances, a division per instance; the per-tile counts go through the same LDS histogram.
-__global__ __launch_bounds__(256) void emit_big_k(int gx, int T, const uint4* __restrict__ bigq,
+__global__ __launch_bounds__(256) void emit_big_k(int gx, int gy, const GaussRec* __restrict__ rec,
+                                                  const uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets,
+                                                  const uint4* __restrict__ aux, const uint32_t* __restrict__ bigq,
                                                   const uint32_t* __restrict__ counters, uint32_t* __restrict__ keys,
                                                   uint32_t* __restrict__ vals, uint32_t* __restrict__ tile_count, uint32_t cap) {
     const uint32_t nbig = counters[COUNTER_BIGQ];
     if (blockIdx.x >= nbig) return;  // (block-uniform)
+    const bool cull = counters[COUNTER_CULL] != 0;
+    const int T = gx * gy;
     extern __shared__ uint32_t s_cnt[];  // [T]
     for (int t = threadIdx.x; t < T; t += 256) s_cnt[t] = 0;
     __syncthreads();
-    for (uint32_t j = blockIdx.x; j < nbig; j += gridDim.x) {
-        const uint4 q = bigq[j];
-        const int bx0 = (int)(q.x & 0xFFFFu), by0 = (int)(q.x >> 16), bw = (int)(q.y & 0xFFFFu), bcnt = bw * (int)(q.y >> 16);
-        const float inv_w = __builtin_amdgcn_rcpf((float)bw);
-        for (int k = threadIdx.x; k < bcnt; k += 256) {
-            int row = (int)((float)k * inv_w);  // k / bw, off by at most one
-            row -= (row * bw > k);
-            row += ((row + 1) * bw <= k);
-            const uint32_t key = (uint32_t)((by0 + row) * gx + bx0 + (k - row * bw));
-            const uint32_t pos = q.z + (uint32_t)k;
-            if (pos < cap) {
-                keys[pos] = key;
-                vals[pos] = q.w;
-                atomicAdd(&s_cnt[key], 1u);
+    // The queue holds ranks in the depth order; the rectangle is formed again exactly as emit_k formed it (a big rectangle is
+    // always a full one: the ellipse masks cover rectangles of at most 64 tiles).  Rank -> id, first instance -> record: three
+    // dependent gathers, so the block looks up 256 of its rectangles at a time, one per thread, and then walks them together
+    // (looked up one by one in front of each rectangle the gathers were the kernel: 19 -> 38 us on the close-up).
+    __shared__ uint4 s_rect[256];   // (x0 | y0 << 16, w, instances, first instance)
+    __shared__ uint32_t s_gid[256];
+    for (uint32_t j0 = blockIdx.x; j0 < nbig; j0 += 256u * gridDim.x) {
+        const uint32_t j = j0 + threadIdx.x * gridDim.x;
+        if (j < nbig) {
+            const uint32_t i = bigq[j];
+            const uint32_t gid = order[i], boff = offsets[i];
+            const uint4 a = aux[gid];
+            const float4 q0 = rec[gid].q0, q1 = rec[gid].q1;
+            int bx0, by0, bx1, by1;
+            listed_rect(q0.x, q0.y, (int)a.y, q1.z, q1.w, cull, gx, gy, bx0, by0, bx1, by1);
+            s_rect[threadIdx.x] = make_uint4((uint32_t)bx0 | ((uint32_t)by0 << 16), (uint32_t)(bx1 - bx0),
+                                             (uint32_t)((bx1 - bx0) * (by1 - by0)), boff);
+            s_gid[threadIdx.x] = gid;
+        }
+        __syncthreads();
+        const uint32_t left = (nbig - j0 + gridDim.x - 1) / gridDim.x;  // rectangles of this block from j0 on
+        const int nb = (int)(left < 256u ? left : 256u);
+        for (int b = 0; b < nb; b++) {
+            const uint4 q = s_rect[b];
+            const uint32_t gid = s_gid[b];
+            const int bx0 = (int)(q.x & 0xFFFFu), by0 = (int)(q.x >> 16), bw = (int)q.y, bcnt = (int)q.z;
+            const float inv_w = __builtin_amdgcn_rcpf((float)bw);
+            for (int k = threadIdx.x; k < bcnt; k += 256) {
+                int row = (int)((float)k * inv_w);  // k / bw, off by at most one
+                row -= (row * bw > k);
+                row += ((row + 1) * bw <= k);
+                const uint32_t key = (uint32_t)((by0 + row) * gx + bx0 + (k - row * bw));
+                const uint32_t pos = q.w + (uint32_t)k;
+                if (pos < cap) {
+                    keys[pos] = key;
+                    vals[pos] = gid;
+                    atomicAdd(&s_cnt[key], 1u);
+                }
             }
         }
+        __syncthreads();
     }
     __syncthreads();
     for (int t = threadIdx.x; t < T; t += 256) {
@@ -471,8 +499,8 @@ void launch_emit_counting(int P, int W, int H, const GeomView& g, const uint32_t
             P, gx, gy, g.rec, radii, order, g.offsets, g.aux, keys, vals, reinterpret_cast<uint32_t*>(ranges) + 1, g.counters,
             clear, (uint32_t)clear_words, cap, g.bigq);
         // the big rectangles the kernel queued: a workgroup per CU walks the queue (workgroups beyond its length leave at once)
-        emit_big_k<<<dim3(256), dim3(256), (size_t)gx * gy * sizeof(uint32_t), s>>>(gx, gx * gy, g.bigq, g.counters, keys, vals,
-                                                                                  reinterpret_cast<uint32_t*>(ranges) + 1, cap);
+        emit_big_k<<<dim3(256), dim3(256), (size_t)gx * gy * sizeof(uint32_t), s>>>(
+            gx, gy, g.rec, order, g.offsets, g.aux, g.bigq, g.counters, keys, vals, reinterpret_cast<uint32_t*>(ranges) + 1, cap);
     } else
         emit_k<true, EMIT_ROUNDS><<<dim3((P + 256 * EMIT_ROUNDS - 1) / (256 * EMIT_ROUNDS)), dim3(256), (size_t)gx * gy * sizeof(uint32_t), s>>>(
             P, gx, gy, g.rec, radii, order, g.offsets, g.aux, keys, vals, reinterpret_cast<uint32_t*>(ranges) + 1, g.counters,

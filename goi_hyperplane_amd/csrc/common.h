@@ -43,7 +43,8 @@ struct GeomView {
     // (listed << 40 | tiles touched) in the first word of a 64-byte entry: one integer atomic per preprocess block; lets
     // compact_listed_k find its base rank from ~nblk / 32 + 31 words instead of all nblk pairs (3 M Gaussians: 49 -> 26 us)
     unsigned long long* blk_coarse;
-    uint4* bigq;  // [P] emit's queue of big rectangles: (x0 | y0 << 16, w | h << 16, first instance, Gaussian id) -- binning.hip
+    uint32_t* bigq;  // [P] emit's queue of big rectangles (ranks in the depth order), binning.hip; ALIASES sort_keys[1], which is
+                     // free between the depth sort and the next frame's preprocess
     uint32_t* scratch;        // scan partials + radix histograms
     uint32_t* counters;       // [COUNTER_WORDS]: 1 = error flag, 2 = cull_variant of this forward, NR_BASE.. = num_rendered stripes
     size_t scratch_words;
@@ -182,11 +183,13 @@ void launch_ranges(int N, const uint32_t* n_dev, const uint32_t* sorted_keys, ui
 void launch_render_fwd(const GoiRasterScene& sc, const GeomView& g, const ImageView& im, const uint32_t* point_list,
                        float* out_color, float* out_sem, float* out_depth, float* out_alpha, hipStream_t s,
                        unsigned long long* qmask = nullptr, const float* zcut = nullptr, uint32_t* zlearn = nullptr,
-                       uint32_t* host_words = nullptr);  // host_words: pinned, device-mapped words that get counters[0 .. 32)
+                       uint32_t* host_words = nullptr,  // host_words: pinned, device-mapped words that get counters[0 .. 32) ...
+                       uint32_t stamp = 0);  // ... and, behind a system-scope fence, `stamp` in word HOST_STAMP_WORD (api.hip: tickets)
+constexpr int HOST_STAMP_WORD = 33;
 // fwd_variant 2 (experiment): the 16 pixels x 4 Gaussians mapping of the forward blend (render_fwd_g4.hip); S <= 16, no depth cut
 void launch_render_fwd_g4(const GoiRasterScene& sc, const GeomView& g, const ImageView& im, const uint32_t* point_list,
                           float* out_color, float* out_sem, float* out_depth, float* out_alpha, hipStream_t s,
-                          unsigned long long* qmask, uint32_t* host_words);
+                          unsigned long long* qmask, uint32_t* host_words, uint32_t stamp);
 // lane utilisation of the blend kernels counted from a forward's member masks / n_contrib (blend_stats.hip): out[GOI_BLEND_STATS_WORDS]
 void launch_blend_stats(int W, int H, const GeomView& g, const ImageView& im, const uint32_t* point_list,
                         const unsigned long long* qmask, unsigned long long* out, hipStream_t s);

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(64) void render_fwd_k(const uint2* __restrict__ ran
                                                    uint32_t* __restrict__ qcost, unsigned long long* __restrict__ qmask0,
                                                    unsigned long long* __restrict__ qmask, const float* __restrict__ zcut,
                                                    uint32_t* __restrict__ zlearn, uint32_t* __restrict__ frame_flags,
-                                                   uint32_t* __restrict__ host_words) {
+                                                   uint32_t* __restrict__ host_words, uint32_t stamp) {
     constexpr int NF4 = TRACE ? 1 : 1 + S4;  // float4 words staged per Gaussian: (r,g,b,depth) + semantics
     constexpr int NSEM = TRACE ? 0 : 4 * S4;
     __shared__ f32x4 s_geo[64];   // (A3, A5, A1, A2) of the quadrant-centred log2-alpha polynomial (blend_common.h)
@@ -48,7 +48,12 @@ __global__ __launch_bounds__(64) void render_fwd_k(const uint2* __restrict__ ran
 
     // the frame's counters for the host (speculative forward): final before this kernel starts (frame_flags - COUNTER_OVF is
     // the counters array); 32 words into pinned, device-mapped memory -- visible to the host once the kernel has completed
-    if (host_words && blockIdx.x == 0 && threadIdx.x < 32) host_words[threadIdx.x] = (frame_flags - COUNTER_OVF)[threadIdx.x];
+    if (host_words && blockIdx.x == 0 && threadIdx.x < 32) {
+        host_words[threadIdx.x] = (frame_flags - COUNTER_OVF)[threadIdx.x];
+        __threadfence_system();  // every lane's word is on its way to the host before ...
+        if (threadIdx.x == 0 && stamp)  // ... this use's sequence number says so (api.hip: STAMP_WORD)
+            __hip_atomic_store(&host_words[HOST_STAMP_WORD], stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     const QuadGeom t = quad_geom(W, H, gx, n_quads);
     if (t.tile < 0) return;
     const int tq = quad_slot();
@@ -278,7 +283,7 @@ __global__ __launch_bounds__(64) void render_fwd_k(const uint2* __restrict__ ran
 template <int S4>
 void launch_fwd_s4(const GoiRasterScene& sc, const GeomView& g, const ImageView& im, const uint32_t* point_list,
                    float* out_color, float* out_sem, float* out_depth, float* out_alpha, hipStream_t s,
-                   unsigned long long* qmask, const float* zcut, uint32_t* zlearn, uint32_t* host_words) {
+                   unsigned long long* qmask, const float* zcut, uint32_t* zlearn, uint32_t* host_words, uint32_t stamp) {
     const int gx = (sc.W + TILE - 1) / TILE, gy = (sc.H + TILE - 1) / TILE;
     const int n_quads = gx * gy * 4;
 #define GOI_LAUNCH_FWD(U2, MK)                                                                                         \
@@ -287,12 +292,12 @@ void launch_fwd_s4(const GoiRasterScene& sc, const GeomView& g, const ImageView&
             render_fwd_k<S4, false, U2, MK, true><<<dim3(quad_grid(n_quads)), dim3(64), 0, s>>>(                        \
                 im.ranges, point_list, sc.W, sc.H, gx, n_quads, sc.S, g.rec, sc.semantics, sc.bg, out_color, out_sem,   \
                 out_depth, out_alpha, im.n_contrib, nullptr, nullptr, nullptr, im.qcost, im.qmask0, qmask, zcut,        \
-                zlearn, g.counters + COUNTER_OVF, host_words);                                                          \
+                zlearn, g.counters + COUNTER_OVF, host_words, stamp);                                                   \
         else                                                                                                           \
             render_fwd_k<S4, false, U2, MK><<<dim3(quad_grid(n_quads)), dim3(64), 0, s>>>(                              \
                 im.ranges, point_list, sc.W, sc.H, gx, n_quads, sc.S, g.rec, sc.semantics, sc.bg, out_color, out_sem,   \
                 out_depth, out_alpha, im.n_contrib, nullptr, nullptr, nullptr, im.qcost, im.qmask0, qmask, zcut,        \
-                zlearn, g.counters + COUNTER_OVF, host_words);                                                          \
+                zlearn, g.counters + COUNTER_OVF, host_words, stamp);                                                   \
     } while (0)
     // The member masks are recorded by EVERY forward (a backward may follow with either setting of bwd_masks, and a frame
     // without masks back-propagated through them would be garbage).  BUILD SWITCH for measuring what recording costs the
@@ -316,14 +321,14 @@ void launch_fwd_s4(const GoiRasterScene& sc, const GeomView& g, const ImageView&
 
 void launch_render_fwd(const GoiRasterScene& sc, const GeomView& g, const ImageView& im, const uint32_t* point_list,
                        float* out_color, float* out_sem, float* out_depth, float* out_alpha, hipStream_t s,
-                       unsigned long long* qmask, const float* zcut, uint32_t* zlearn, uint32_t* host_words) {
+                       unsigned long long* qmask, const float* zcut, uint32_t* zlearn, uint32_t* host_words, uint32_t stamp) {
     // fwd_variant 2 (EXPERIMENT, render_fwd_g4.hip): the 16 pixels x 4 Gaussians mapping; frames with a depth cut and S > 16 keep
     // the default kernel
     if (g_options.fwd_variant == 2 && !zcut && !zlearn && sc.S <= 16) {
-        launch_render_fwd_g4(sc, g, im, point_list, out_color, out_sem, out_depth, out_alpha, s, qmask, host_words);
+        launch_render_fwd_g4(sc, g, im, point_list, out_color, out_sem, out_depth, out_alpha, s, qmask, host_words, stamp);
         return;
     }
-#define GOI_CALL(N) launch_fwd_s4<N>(sc, g, im, point_list, out_color, out_sem, out_depth, out_alpha, s, qmask, zcut, zlearn, host_words)
+#define GOI_CALL(N) launch_fwd_s4<N>(sc, g, im, point_list, out_color, out_sem, out_depth, out_alpha, s, qmask, zcut, zlearn, host_words, stamp)
     GOI_DISPATCH_S4(sc.S, GOI_CALL)
 #undef GOI_CALL
 }
@@ -335,7 +340,7 @@ void launch_trace_fwd(const GoiRasterScene& sc, const float* img_sem, const Geom
     render_fwd_k<1, true, false, false><<<dim3(quad_grid(n_quads)), dim3(64), 0, s>>>(
         im.ranges, point_list, sc.W, sc.H, gx, n_quads, sc.S, g.rec, nullptr, sc.bg, out_color, nullptr, nullptr, nullptr,
         im.n_contrib, img_sem, gau_sem, num_gsem, nullptr, nullptr, nullptr, nullptr, nullptr, g.counters + COUNTER_OVF,
-        nullptr);
+        nullptr, 0u);
 }
 
 }  // namespace goi

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
                                                       uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ qcost,
                                                       unsigned long long* __restrict__ qmask0,
                                                       unsigned long long* __restrict__ qmask, uint32_t* __restrict__ frame_flags,
-                                                      uint32_t* __restrict__ host_words) {
+                                                      uint32_t* __restrict__ host_words, uint32_t stamp) {
     constexpr int NF4 = 1 + S4;
     constexpr int NSEM = 4 * S4;
     __shared__ f32x4 s_geo[64];
@@ -74,7 +74,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     __shared__ uint8_t s_member[64];   // slot contributed to some pixel of the quadrant this round
     const f32x4* s_feat4 = reinterpret_cast<const f32x4*>(s_feat);
 
-    if (host_words && blockIdx.x == 0 && threadIdx.x < 32) host_words[threadIdx.x] = (frame_flags - COUNTER_OVF)[threadIdx.x];
+    if (host_words && blockIdx.x == 0 && threadIdx.x < 32) {
+        host_words[threadIdx.x] = (frame_flags - COUNTER_OVF)[threadIdx.x];
+        __threadfence_system();  // every lane's word is on its way to the host before ...
+        if (threadIdx.x == 0 && stamp)  // ... this use's sequence number says so (api.hip: STAMP_WORD)
+            __hip_atomic_store(&host_words[HOST_STAMP_WORD], stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     const QuadGeom t = quad_geom(W, H, gx, n_quads);
     if (t.tile < 0) return;
     const int tq = quad_slot();
@@ -300,25 +305,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 template <int S4>
 void launch_g4_s4(const GoiRasterScene& sc, const GeomView& g, const ImageView& im, const uint32_t* point_list, float* out_color,
                   float* out_sem, float* out_depth, float* out_alpha, hipStream_t s, unsigned long long* qmask,
-                  uint32_t* host_words) {
+                  uint32_t* host_words, uint32_t stamp) {
     const int gx = (sc.W + TILE - 1) / TILE, gy = (sc.H + TILE - 1) / TILE;
     const int n_quads = gx * gy * 4;
     if (qmask)
         render_fwd_g4_k<S4, true><<<dim3(quad_grid(n_quads)), dim3(64), 0, s>>>(
             im.ranges, point_list, sc.W, sc.H, gx, n_quads, sc.S, g.rec, sc.semantics, sc.bg, out_color, out_sem, out_depth,
-            out_alpha, im.n_contrib, im.qcost, im.qmask0, qmask, g.counters + COUNTER_OVF, host_words);
+            out_alpha, im.n_contrib, im.qcost, im.qmask0, qmask, g.counters + COUNTER_OVF, host_words, stamp);
     else
         render_fwd_g4_k<S4, false><<<dim3(quad_grid(n_quads)), dim3(64), 0, s>>>(
             im.ranges, point_list, sc.W, sc.H, gx, n_quads, sc.S, g.rec, sc.semantics, sc.bg, out_color, out_sem, out_depth,
-            out_alpha, im.n_contrib, im.qcost, im.qmask0, qmask, g.counters + COUNTER_OVF, host_words);
+            out_alpha, im.n_contrib, im.qcost, im.qmask0, qmask, g.counters + COUNTER_OVF, host_words, stamp);
 }
 
 }  // namespace
 
 void launch_render_fwd_g4(const GoiRasterScene& sc, const GeomView& g, const ImageView& im, const uint32_t* point_list,
                           float* out_color, float* out_sem, float* out_depth, float* out_alpha, hipStream_t s,
-                          unsigned long long* qmask, uint32_t* host_words) {
-#define GOI_CALL(N) launch_g4_s4<N>(sc, g, im, point_list, out_color, out_sem, out_depth, out_alpha, s, qmask, host_words)
+                          unsigned long long* qmask, uint32_t* host_words, uint32_t stamp) {
+#define GOI_CALL(N) launch_g4_s4<N>(sc, g, im, point_list, out_color, out_sem, out_depth, out_alpha, s, qmask, host_words, stamp)
     GOI_DISPATCH_S4(sc.S, GOI_CALL)
 #undef GOI_CALL
 }
