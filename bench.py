@@ -806,6 +806,7 @@ def main():
     # Secondary object: the ADVERSARIAL workload -- a scene with the statistics of a reconstruction (clustered density,
     # heavy-tailed anisotropic sizes, opaque foreground with lists thousands deep behind it: scene.make_clustered_scene) at the
     # headline's size and image, through the same step.  Not `value`; its oracle parity is tests/test_gpu_clustered.py.
+    _hw_main = int(_C._spec_state(dev).get("high_water", 0))  # (the main workload's; the clustered scene below raises it)
     clustered = None
     if world == 1 and args.scene == "headline" and not args.no_clustered and not args.ply:
         from goi_hyperplane_amd.scene import make_workload
@@ -953,7 +954,7 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         # device memory of one view in flight at this workload: the workspaces are sized for the speculative frame's CAPACITY
         # (headroom x the largest count seen), not for its count -- the count is not on the host when the frame is enqueued
-        _hw = int(_C._spec_state(dev).get("high_water", 0))
+        _hw = _hw_main
         _cap = max(_C._MIN_CAPACITY, int(_C._FWD["headroom"] * _hw) + 4096) if _hw else 0
         _l = _lib.load()
         memory = None if not _cap else {

@@ -505,19 +505,23 @@ size_t scan_scratch_words(size_t n) { return div_up(n, SCAN_CHUNK) + 16; }
 
 // the smallest tile the adaptive 512 x 16 kernel may choose for a capacity of n keys: 512 x 2 = 1024 keys, more when that
 // would need more than 2048 rows of status words per pass (the table is cleared every frame: 1 KB per row and pass)
-static int sweep_min_items(size_t n) {
-    if (n <= ((size_t)2 << 20)) return 4;  // (1024 x 4: not adaptive)
+static int sweep_min_items_for(size_t n, bool small) {
+    if (n <= ((size_t)2 << 20) && !small) return 4;  // (1024 x 4: not adaptive)
     int items = 2;
     while (items < 16 && (n + (size_t)512 * items - 1) / ((size_t)512 * items) > 2048) items <<= 1;
     return items;
 }
-static size_t sweep_min_tile_keys(size_t n) { return n <= ((size_t)2 << 20) ? 4096 : (size_t)512 * sweep_min_items(n); }
+static bool sweep_adaptive(size_t n) { return n > ((size_t)2 << 20) || g_options.sort_small != 0; }
+static int sweep_min_items(size_t n) { return sweep_min_items_for(n, g_options.sort_small != 0); }
+static size_t sweep_min_tile_keys(size_t n) { return sweep_adaptive(n) ? (size_t)512 * sweep_min_items(n) : 4096; }
 
 size_t sort_scratch_words(size_t n) {
     size_t nblk = div_up(n, 4096);  // the smallest tile of the three-kernel variant
     size_t table = (size_t)RADIX_MAX * nblk;
     size_t three_kernel = table + scan_scratch_words(table) + 16;
-    size_t onesweep = (size_t)MAX_PASSES * RADIX_MAX * div_up(n, sweep_min_tile_keys(n)) + (size_t)MAX_PASSES * RADIX_MAX + 64;
+    // (laid out for the smallest tile ANY setting of sort_small may choose: a workspace outlives the option)
+    const size_t min_tile = (size_t)512 * sweep_min_items_for(n, true);
+    size_t onesweep = (size_t)MAX_PASSES * RADIX_MAX * div_up(n, min_tile < 4096 ? min_tile : 4096) + (size_t)MAX_PASSES * RADIX_MAX + 64;
     return three_kernel > onesweep ? three_kernel : onesweep;
 }
 
@@ -536,7 +540,7 @@ void exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* ou
 
 // Control words of the onesweep sort, contiguous at the start of the scratch so that ONE memset clears them:
 // [passes][nblk][256] status | [MAX_PASSES][256] global digit histograms | [MAX_PASSES] tickets | error
-static size_t sweep_tile_keys(size_t n) { return n <= ((size_t)2 << 20) ? 4096 : 8192; }  // 1024 x 4 or 512 x 16
+static size_t sweep_tile_keys(size_t n) { return sweep_adaptive(n) ? 8192 : 4096; }  // 512 x 16 (adaptive) or 1024 x 4
 static size_t sweep_status_words(size_t n, int lo, int hi) {
     return (size_t)((hi - lo + 7) / 8) * div_up(n, sweep_min_tile_keys(n)) * RADIX_MAX;
 }
