@@ -143,8 +143,12 @@ constexpr int emit_rounds_for(int T) { return T <= GOI_EMIT_SMALL_T ? 1 : EMIT_R
 #define GOI_EMIT_BIG_TILES 128
 #endif
 constexpr int EMIT_BIG_TILES = GOI_EMIT_BIG_TILES;
-template <bool COUNT, int ROUNDS_COUNTING = EMIT_ROUNDS>
-__global__ __launch_bounds__(256) void emit_k(int P, int gx, int gy, const GaussRec* __restrict__ rec,
+// WIDE (round 5, the counting variant with four rounds): the four rounds of a workgroup run SIDE BY SIDE -- 1024 threads, each
+// group of 256 takes one round -- instead of one after the other.  Same per-tile histogram, same number of flushes, four times
+// the waves: with 488 workgroups of four waves the headline frame kept 7 waves per CU busy, and emit is nothing but dependent
+// gathers (rank -> id -> record) in front of its stores.
+template <bool COUNT, int ROUNDS_COUNTING = EMIT_ROUNDS, bool WIDE = false>
+__global__ __launch_bounds__(WIDE ? 1024 : 256) void emit_k(int P, int gx, int gy, const GaussRec* __restrict__ rec,
                                               const int* __restrict__ radii, const uint32_t* __restrict__ order,
                                               const uint32_t* __restrict__ offsets, uint4* __restrict__ aux,
                                               uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
@@ -154,6 +158,8 @@ __global__ __launch_bounds__(256) void emit_k(int P, int gx, int gy, const Gauss
     // cap: number of instances keys[] / vals[] can hold.  The exact forward sizes them for num_rendered, so the
     // guard below never fires; the speculative forward sizes them from a guess, and a frame that overflows must
     // stay memory-safe and self-consistent (the tile counts only count what was stored) until the host notices.
+    constexpr uint32_t NT = WIDE ? 1024u : 256u;  // threads of the workgroup
+    constexpr int NWV = WIDE ? 16 : 4;           // its waves
     const bool cull = counters[COUNTER_CULL] != 0;
     P = min(P, (int)counters[COUNTER_V]);  // order[] / offsets[] hold the LISTED Gaussians only (front of the depth order)
     // the frame's "truncated" flag (COUNTER_OVF): emit is the first kernel that knows both the count and the capacity
@@ -162,22 +168,25 @@ __global__ __launch_bounds__(256) void emit_k(int P, int gx, int gy, const Gauss
         counters[COUNTER_OVF] = (counters[COUNTER_N] > cap ? 1u : 0u) | (counters[COUNTER_SORTERR] ? 2u : 0u);
     // COUNT: the blocks also zero the control words of the tile sort that follows (its own memset launch otherwise)
     if (COUNT)
-        for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < clear_words; i += gridDim.x * 256u) clear[i] = 0u;
+        for (uint32_t i = blockIdx.x * NT + threadIdx.x; i < clear_words; i += gridDim.x * NT) clear[i] = 0u;
     constexpr int ROUNDS_PER_BLOCK = COUNT ? ROUNDS_COUNTING : 1;
     if ((int)blockIdx.x * ROUNDS_PER_BLOCK * 256 >= P) return;  // (block-uniform) nothing listed left for this block
     extern __shared__ uint32_t s_cnt[];  // [gx * gy] when COUNT
-    __shared__ unsigned long long s_mask[4][64];  // the rectangles' tile masks (cull_variant 2)
-    __shared__ unsigned long long s_mark[4];  // per wave and trip: bit p = some rectangle's last instance is at position p
-    __shared__ uint4 s_info[4][64];  // (x0 | y0 << 16, exclusive count, offsets[] - exclusive count, Gaussian id)
-    __shared__ int s_w[4][64];       // rectangle width in tiles
+    __shared__ unsigned long long s_mask[NWV][64];  // the rectangles' tile masks (cull_variant 2)
+    __shared__ unsigned long long s_mark[NWV];  // per wave and trip: bit p = some rectangle's last instance is at position p
+    __shared__ uint4 s_info[NWV][64];  // (x0 | y0 << 16, exclusive count, offsets[] - exclusive count, Gaussian id)
+    __shared__ int s_w[NWV][64];       // rectangle width in tiles
     const int T = gx * gy;
     if (COUNT) {
-        for (int t = threadIdx.x; t < T; t += 256) s_cnt[t] = 0;
+        for (int t = threadIdx.x; t < T; t += (int)NT) s_cnt[t] = 0;
         __syncthreads();
     }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // the counting variant amortises zeroing and flushing its tile histogram over EMIT_ROUNDS x 256 Gaussians
     constexpr int ROUNDS = COUNT ? ROUNDS_COUNTING : 1;
+    // WIDE: this thread's group of 256 takes ONE round (the loop below runs once); otherwise the block walks its rounds
+    const int rnd_first = WIDE ? (int)(threadIdx.x >> 8) : 0, rnd_end = WIDE ? rnd_first + 1 : ROUNDS;
+    const int tid256 = (int)(threadIdx.x & 255u);
     // a round's Gaussian: id -> radius, position and box are dependent gathers (two DRAM round trips); the next round's
     // are requested before this round's instances are written, or every round would start with both exposed (emit is a
     // small kernel: two waves per SIMD have nothing to hide them behind)
@@ -189,8 +198,8 @@ __global__ __launch_bounds__(256) void emit_k(int P, int gx, int gy, const Gauss
     };
     auto fetch = [&](int rnd) {
         Fetched f{0u, 0u, 0, make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, -1.f, -1.f), TMASK_FULL};
-        const int i = (blockIdx.x * ROUNDS + rnd) * 256 + threadIdx.x;
-        if (rnd < ROUNDS && i < P) {
+        const int i = (blockIdx.x * ROUNDS + rnd) * 256 + tid256;
+        if (rnd < rnd_end && i < P) {
             f.g = order[i];
             f.off = offsets[i];
             const uint4 a = aux[f.g];  // radius and tile mask: one gather
@@ -201,10 +210,10 @@ __global__ __launch_bounds__(256) void emit_k(int P, int gx, int gy, const Gauss
         }
         return f;
     };
-    Fetched nxt = fetch(0);
+    Fetched nxt = fetch(rnd_first);
 #pragma unroll 1
-    for (int rnd = 0; rnd < ROUNDS; rnd++) {
-        const int i = (blockIdx.x * ROUNDS + rnd) * 256 + threadIdx.x;
+    for (int rnd = rnd_first; rnd < rnd_end; rnd++) {
+        const int i = (blockIdx.x * ROUNDS + rnd) * 256 + tid256;
         const Fetched cur = nxt;
         nxt = fetch(rnd + 1);
         const uint32_t g = cur.g, off = cur.off;
@@ -322,7 +331,7 @@ __global__ __launch_bounds__(256) void emit_k(int P, int gx, int gy, const Gauss
     }
     if (COUNT) {
         __syncthreads();
-        for (int t = threadIdx.x; t < T; t += 256) {
+        for (int t = threadIdx.x; t < T; t += (int)NT) {
             const uint32_t c = s_cnt[t];
             if (c) atomicAdd(&tile_count[2 * t], c);
         }
@@ -502,7 +511,7 @@ void launch_emit_counting(int P, int W, int H, const GeomView& g, const uint32_t
         emit_big_k<<<dim3(256), dim3(256), (size_t)gx * gy * sizeof(uint32_t), s>>>(
             gx, gy, g.rec, order, g.offsets, g.aux, g.bigq, g.counters, keys, vals, reinterpret_cast<uint32_t*>(ranges) + 1, cap);
     } else
-        emit_k<true, EMIT_ROUNDS><<<dim3((P + 256 * EMIT_ROUNDS - 1) / (256 * EMIT_ROUNDS)), dim3(256), (size_t)gx * gy * sizeof(uint32_t), s>>>(
+        emit_k<true, EMIT_ROUNDS, true><<<dim3((P + 256 * EMIT_ROUNDS - 1) / (256 * EMIT_ROUNDS)), dim3(1024), (size_t)gx * gy * sizeof(uint32_t), s>>>(
             P, gx, gy, g.rec, radii, order, g.offsets, g.aux, keys, vals, reinterpret_cast<uint32_t*>(ranges) + 1, g.counters,
             clear, (uint32_t)clear_words, cap, g.bigq);
 }

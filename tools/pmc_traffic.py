@@ -16,7 +16,7 @@ import sys
 
 # (template arguments as rocprofv3 prints them: round 4's backward is <S4, F16 = true, MASKS>, its forward <S4, TRACE, UNROLL2, MASKS, LEARN>)
 STAGE_KERNEL_PREFIX = {"blend_bwd": ("render_bwd_rows_k<4, true", "render_bwd_rows_k<4, 0"),
-                       "blend_fwd": ("render_fwd_k<4, false, true",), "preprocess": ("preprocess_fwd_k",), "emit": ("emit_k<true>",)}
+                       "blend_fwd": ("render_fwd_k<4, false, true",), "preprocess": ("preprocess_fwd_k",), "emit": ("emit_k<true",)}
 
 
 def main():
