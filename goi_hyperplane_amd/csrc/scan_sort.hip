@@ -123,7 +123,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_k(const uint32_t* in,
                                                              const uint32_t* __restrict__ gather,
                                                              uint32_t* out, size_t n_cap,
                                                              const uint32_t* __restrict__ n_dev,
-                                                             const uint32_t* __restrict__ partials) {
+                                                             const uint32_t* __restrict__ partials, int raw_partials) {
     __shared__ uint32_t sm[SCAN_THREADS / WAVE + 1];
     const size_t n = scan_n(n_cap, n_dev);
     if ((size_t)blockIdx.x * SCAN_CHUNK >= n) return;  // (block-uniform)
@@ -137,8 +137,24 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_apply_k(const uint32_t* in,
         if (i < n) v[k] = gather ? in[gather[i]] : in[i];
         sum += v[k];
     }
+    // RAW partials (the three-kernel scan scanned them with a one-block kernel in between: 4.7 us of launch and latency for a few
+    // hundred words): every block adds up the block sums in front of it itself -- at most n / SCAN_CHUNK words out of L2
+    uint32_t before = 0;
+    if (raw_partials) {
+        for (uint32_t j = threadIdx.x; j < blockIdx.x; j += SCAN_THREADS) before += partials[j];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) before += (uint32_t)__shfl_xor((int)before, d, 64);
+        __shared__ uint32_t s_b[SCAN_THREADS / WAVE];
+        if ((threadIdx.x & 63) == 0) s_b[threadIdx.x >> 6] = before;
+        __syncthreads();
+        before = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < SCAN_THREADS / WAVE; w2++) before += s_b[w2];
+    } else {
+        before = partials[blockIdx.x];
+    }
     uint32_t tot;
-    uint32_t run = block_exclusive_scan<SCAN_THREADS>(sum, sm, &tot) + partials[blockIdx.x];
+    uint32_t run = block_exclusive_scan<SCAN_THREADS>(sum, sm, &tot) + before;
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; k++) {
         size_t i = base + k;
@@ -534,8 +550,11 @@ void exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* ou
     const size_t nb = div_up(n, SCAN_CHUNK);
     const bool stash = gather != nullptr && out != in;  // the gathered values pass through `out`
     scan_reduce_k<<<dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s>>>(in, gather, n, n_dev, scratch, stash ? out : nullptr);
-    scan_partials_k<<<dim3(1), dim3(1024), 0, s>>>(scratch, nb, total);
-    scan_apply_k<<<dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s>>>(stash ? out : in, stash ? nullptr : gather, out, n, n_dev, scratch);
+    // nobody wants the total and the block sums are few: the second kernel sums the ones in front of it itself (one launch less)
+    const bool raw = total == nullptr && nb <= 4096;
+    if (!raw) scan_partials_k<<<dim3(1), dim3(1024), 0, s>>>(scratch, nb, total);
+    scan_apply_k<<<dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s>>>(stash ? out : in, stash ? nullptr : gather, out, n, n_dev, scratch,
+                                                                  raw ? 1 : 0);
 }
 
 // Control words of the onesweep sort, contiguous at the start of the scratch so that ONE memset clears them:
