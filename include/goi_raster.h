@@ -271,7 +271,9 @@ void goi_raster_profile_stages(unsigned stage_mask);
 int goi_raster_profile_collect(double* ms, int* calls);
 
 /* Tuning / experiment switches; the defaults are the shipped configuration.
- *   "fwd_variant"  1 (default) two candidates per loop trip in the forward blend, 0 one
+ *   "fwd_variant"  1 (default) two candidates per loop trip in the forward blend, 0 one; 2 the EXPERIMENTAL 16 pixels x 4 list
+ *                  entries mapping (csrc/render_fwd_g4.hip; S <= 16, frames without a depth cut): same n_contrib, alpha, member
+ *                  masks and gradients bit for bit, channel sums differ by one fp32 association; 1.7x slower
  *   "bwd_variant"  0 (default) atomic-free backward; the per-Gaussian sums over pixels run at the 16-bit matrix rate on
  *                  split operands that keep fp32 accuracy (two f16 planes of exactly scaled values, all four partial
  *                  products, fp32 accumulation: indistinguishable from the fp32 chain at the noise level of two builds of
@@ -279,6 +281,8 @@ int goi_raster_profile_collect(double* ms, int* calls);
  *                  MFMA (one fp32 FMA chain per output); 1 workgroup-per-tile backward with float atomics (what
  *                  scratch = NULL selects)
  *   "sort_variant" 1 (default) onesweep radix sort, 0 histogram / scan / scatter per pass
+ *   "sort_small"   0 (default) sorts of up to 2 M keys use 1024 x 4-key tiles; 1 they take the adaptive 512 x (2..16) tile that
+ *                  larger sorts choose from the device-side count (slower for them: DESIGN.md 8.2); same order either way
  *   "cull_variant" 2 (default) a Gaussian is listed only in the tiles its contribution ellipse (alpha >= 1/255) reaches,
  *                  1 in the tiles its axis-aligned contribution box touches, 0 in the reference's 3-sigma squares.
  *                  Identical images; gradients equal up to the order of one fp32 sum
