@@ -769,6 +769,21 @@ def main():
         train_iter = {"ms_per_iteration": (time.perf_counter() - t0_) / nti * 1e3, "iterations": nti,
                       "what": "render -> fused code-book losses (300 codes, 256-d ground truth) -> backward -> 3 fused Adam "
                               "steps; semantic features, decoder and code book trainable (train.py:112-199)"}
+        # ... and with the opt-in geometry cache (the training cameras repeat every epoch and only the features move: after the
+        # first pass over the cameras a frame is the blend alone)
+        from goi_hyperplane_amd import rasterizer as _rz
+        _rz.set_geometry_cache(64 << 30)
+        try:
+            for i in range(len(cams) + 2):
+                train_it(i)
+            torch.cuda.synchronize(dev)
+            t0_ = time.perf_counter()
+            for i in range(nti):
+                train_it(i)
+            torch.cuda.synchronize(dev)
+            train_iter["ms_per_iteration_geometry_cache"] = (time.perf_counter() - t0_) / nti * 1e3
+        finally:
+            _rz.set_geometry_cache(0)
         del tpc, mlp, lut, gtl, opts
         torch.cuda.empty_cache()
 
