@@ -99,6 +99,31 @@ def test_overflow_is_redone_bit_identically_when_the_count_is_read_first(dev, fr
     assert after["overflows"] == before["overflows"] + 1 and after["redone"] == before["redone"] + 1
 
 
+@pytest.mark.parametrize("frac", [0.3, 0.9, 2.0])
+def test_big_rectangles_through_the_queue_survive_overflow_and_redo(dev, frac):
+    """Small tile grid (<= 2048 tiles) and frame-filling Gaussians: emit_k hands every rectangle above 128 tiles to emit_big_k
+    through its device-side queue (binning.hip, round 5).  Speculative frames with enough capacity equal the exact frame bit for
+    bit, lists included; a truncated one is repaired by the redo (which emits AGAIN from the same workspace: the queue counter
+    must have been put back to zero by the frame's own tile_ranges_hist_k)."""
+    from goi_hyperplane_amd import _C
+    P, S, W, H = 300, 16, 400, 300
+    sc = make_scene(P, S=S, seed=21, log_scale_mean=-0.6)  # most Gaussians cover most of the 475 tiles
+    cam = make_camera(W, H, yaw=0.1)
+    bg = np.array([0.0, 0.2, 0.1], np.float32)
+    n0, o0, w0 = _raw(dev, sc, cam, bg, speculative=False)
+    assert n0 > 128 * 100  # (rectangles of several hundred tiles: the queue is what wrote most of the list)
+    v0 = _C.debug_views(P, W, H, n0, *w0)
+    cap = max(1, int(frac * n0))
+    n1, o1, w1 = _raw(dev, sc, cam, bg, speculative=True, capacity=cap)
+    torch.cuda.synchronize()
+    assert int(n1) == n0 and n1.overflowed == (cap < n0)
+    for a, b in zip(o0, o1):
+        assert torch.equal(a, b)
+    v1 = _C.debug_views(P, W, H, n1, w1[0], n1.binning, w1[2])
+    for k in v0:
+        assert torch.equal(v0[k], v1[k]), k
+
+
 def test_overflow_through_autograd_read_before_use_gives_exact_gradients(dev):
     """The autograd path: an overflowed frame whose count is read (LazyCount.resolve, here through
     rasterizer.last_num_rendered) before the loss is formed has the exact path's outputs AND gradients."""
