@@ -124,6 +124,43 @@ def test_big_rectangles_through_the_queue_survive_overflow_and_redo(dev, frac):
         assert torch.equal(v0[k], v1[k]), k
 
 
+def test_adaptive_sort_tiles_agree_with_the_three_kernel_sort_above_two_million_gaussians(dev):
+    """Above 2 M keys of CAPACITY the onesweep passes choose their tile shape from the device-side count (scan_sort.hip, round 5:
+    512 x 2 .. 16 keys).  2.3 M Gaussians of which a 320 x 240 view lists a small fraction: the exact frame (count known), a
+    speculative frame (count on the device, generous capacity) and the histogram / scan / scatter sort (sort_variant 0, no
+    look-back at all) must produce the same sorted lists bit for bit; a view that sees NOTHING must run (count 0 everywhere)."""
+    from goi_hyperplane_amd import _C, _lib
+    P, S, W, H = 2_300_000, 4, 320, 240
+    sc = make_scene(P, S=S, sh_degree=0, seed=31, log_scale_mean=-4.2)
+    bg = np.zeros(3, np.float32)
+    cam = make_camera(W, H, yaw=0.1)
+    n0, o0, w0 = _raw(dev, sc, cam, bg, speculative=False)
+    assert isinstance(n0, int) and 0 < n0
+    v0 = _C.debug_views(P, W, H, n0, *w0)
+    n1, o1, w1 = _raw(dev, sc, cam, bg, speculative=True, capacity=3 * n0 + 100_000)
+    for a, b in zip(o0, o1):
+        assert torch.equal(a, b)
+    v1 = _C.debug_views(P, W, H, n1, *w1)
+    _lib.set_option("sort_variant", 0)
+    try:
+        n2, o2, w2 = _raw(dev, sc, cam, bg, speculative=False)
+        v2 = _C.debug_views(P, W, H, n2, *w2)
+    finally:
+        _lib.set_option("sort_variant", 1)
+    assert n2 == n0
+    for k in ("point_list", "ranges", "n_contrib"):
+        assert torch.equal(v0[k], v1[k]), k
+        assert torch.equal(v0[k], v2[k]), k
+    # ... and a view that lists NOTHING: the scene reflected through the camera centre lies behind the near plane
+    from goi_hyperplane_amd.render import TorchCamera
+    c = TorchCamera(cam, dev).camera_center.detach().cpu().numpy().reshape(1, 3)
+    sc.means3D[:] = (2.0 * c - sc.means3D).astype(np.float32)
+    n3, o3, _w3 = _raw(dev, sc, cam, bg, speculative=True, capacity=100_000)
+    torch.cuda.synchronize()
+    assert int(n3) == 0 and not n3.overflowed and float(o3[3].abs().max()) == 0.0  # (alpha: nothing was composited)
+    _C.set_forward_mode(speculative=True, capacity=None)
+
+
 def test_overflow_through_autograd_read_before_use_gives_exact_gradients(dev):
     """The autograd path: an overflowed frame whose count is read (LazyCount.resolve, here through
     rasterizer.last_num_rendered) before the loss is formed has the exact path's outputs AND gradients."""
