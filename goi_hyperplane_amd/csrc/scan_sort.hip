@@ -320,6 +320,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sweep_hist_k(const uint32_t* __r
 // of two between min_items and ITEMS that leaves at most SWEEP_TARGET_TILES tiles -- and blocks beyond the tiles of that shape
 // leave before they take a ticket.  (The status table has a row per tile of the SMALLEST shape: sweep_status_words.)
 constexpr int SWEEP_TARGET_TILES = 512;
+constexpr uint32_t SWEEP_GROUPED_MAX_TILES = 640;  // (grouped look-back up to this many tiles, the chained one above)
 template <int THREADS, int ITEMS>
 __global__ __launch_bounds__(THREADS) void sweep_pass_k(const uint32_t* __restrict__ keys_in,
                                                              const uint32_t* __restrict__ vals_in,
@@ -328,41 +329,57 @@ __global__ __launch_bounds__(THREADS) void sweep_pass_k(const uint32_t* __restri
                                                              const uint32_t* __restrict__ n_dev, int shift,
                                                              int nbits, const uint32_t* __restrict__ ghist,
                                                              uint32_t* status, uint32_t* ticket, uint32_t* error,
-                                                             uint32_t* frame_error, int min_items) {
+                                                             uint32_t* frame_error, int min_items, uint32_t* gstat) {
     constexpr int WAVES = THREADS / WAVE;
-    const size_t n = effective_n(n_cap, n_dev);
-    int items = ITEMS;
-    while (items > min_items && n <= (size_t)THREADS * (size_t)(items / 2) * SWEEP_TARGET_TILES) items >>= 1;
-    const int TILE_KEYS = THREADS * items, WAVE_ITEMS = TILE_KEYS / WAVES;
-    if ((size_t)blockIdx.x * TILE_KEYS >= n) return;  // (no ticket taken: exactly the tiles of this shape take one)
     __shared__ uint32_t cnt[WAVES][RADIX_MAX];  // per-wave digit counts -> per-wave local offsets
     __shared__ uint32_t gbase[RADIX_MAX];            // global position of this block's first element of digit d
     __shared__ uint32_t lbase[RADIX_MAX];            // local (in-block) exclusive offset of digit d
+    __shared__ uint32_t s_gh[RADIX_MAX];             // the pass's global digit histogram (final before the pass starts)
     extern __shared__ uint32_t s_dyn[];  // [2][THREADS * ITEMS]: the tile's keys and values in digit order
     uint32_t* s_keys = s_dyn;
     uint32_t* s_vals = s_dyn + THREADS * ITEMS;
     __shared__ uint32_t s_bid;
+    __shared__ uint32_t s_trivial;
     const uint32_t radix = 1u << nbits, mask = radix - 1u;
-    // A TRIVIAL pass: every key has the same digit (the global histogram says so: one bin holds all n) -- the top byte of
-    // the depth keys of a scene whose depths span less than a factor of four, typically.  The pass is then the identity
-    // permutation: the tile is copied across, no ranking, no look-back, no ticket (nobody will look back at this pass).
-    if (n > 0) {
-        const uint32_t d0 = (keys_in[0] >> shift) & mask;
-        if (ghist[d0] == (uint32_t)n) {
-            const size_t base = (size_t)blockIdx.x * TILE_KEYS;
-            for (int r = 0; r < items; r++) {
-                const size_t i = base + (size_t)r * THREADS + threadIdx.x;
-                if (i < n) {
-                    keys_out[i] = keys_in[i];
-                    vals_out[i] = vals_in[i];
-                }
-            }
-            return;
-        }
-    }
-    if (threadIdx.x == 0) s_bid = atomicAdd(ticket, 1u);
+    // THE HEAD OF A BLOCK IS A CHAIN OF MEMORY ROUND TRIPS, and a pass is barely longer than one block: the count, the first
+    // key, the histogram bin of its digit (the trivial-pass test), the ticket and only then the keys used to be FIVE dependent
+    // trips (~4 us of a 14 us depth pass).  Now everything that does not depend on anything is requested at once: the count,
+    // the whole digit histogram (kept in LDS: the digit bases further down need it anyway, and "one bin holds all n keys" is
+    // the trivial-pass test without looking at a key) and -- where every block takes a ticket -- the ticket.
+    const bool adaptive = min_items < ITEMS;
+    uint32_t early_ticket = 0;
+    if (!adaptive && threadIdx.x == 0) early_ticket = atomicAdd(ticket, 1u);
+    const uint32_t gh = threadIdx.x < radix ? ghist[threadIdx.x] : 0u;
+    const size_t n = effective_n(n_cap, n_dev);
+    int items = ITEMS;
+    while (items > min_items && n <= (size_t)THREADS * (size_t)(items / 2) * SWEEP_TARGET_TILES) items >>= 1;
+    const int TILE_KEYS = THREADS * items, WAVE_ITEMS = TILE_KEYS / WAVES;
+    // (adaptive: blocks beyond the tiles of the chosen shape leave WITHOUT a ticket -- exactly the tiles take one; otherwise
+    // every block has taken one above and the ones past the count leave below, as they always did)
+    if (adaptive && (size_t)blockIdx.x * TILE_KEYS >= n) return;
+    if (threadIdx.x == 0) s_trivial = 0u;
     for (int i = threadIdx.x; i < WAVES * RADIX_MAX; i += THREADS) (&cnt[0][0])[i] = 0;
     __syncthreads();
+    if (threadIdx.x < RADIX_MAX) {
+        s_gh[threadIdx.x] = gh;
+        if (n > 0 && gh == (uint32_t)n) s_trivial = 1u;  // (at most one bin can hold all n keys)
+    }
+    if (threadIdx.x == 0) s_bid = adaptive ? atomicAdd(ticket, 1u) : early_ticket;
+    __syncthreads();
+    // A TRIVIAL pass: every key has the same digit (the global histogram says so: one bin holds all n) -- the top byte of
+    // the depth keys of a scene whose depths span less than a factor of four, typically.  The pass is then the identity
+    // permutation: the tile is copied across, no ranking, no look-back (nobody will look back at this pass; its tickets are unused).
+    if (s_trivial) {
+        const size_t base = (size_t)blockIdx.x * TILE_KEYS;
+        for (int r = 0; r < items; r++) {
+            const size_t i = base + (size_t)r * THREADS + threadIdx.x;
+            if (i < n) {
+                keys_out[i] = keys_in[i];
+                vals_out[i] = vals_in[i];
+            }
+        }
+        return;
+    }
     const uint32_t bid = s_bid;
     // the grid covers the capacity: tickets past the last tile of the real count have nothing to rank and nobody
     // looks back at them (tickets are dealt in order, so every tile below is owned by a running block)
@@ -427,40 +444,91 @@ __global__ __launch_bounds__(THREADS) void sweep_pass_k(const uint32_t* __restri
 #endif
         constexpr int LB = GOI_SORT_LB;
         uint32_t excl = 0, spins = 0;
-        int64_t pb = (int64_t)bid - 1;
-        while (pb >= 0) {
-            uint32_t v[LB];
+        const uint32_t ntiles = (uint32_t)((n + (size_t)TILE_KEYS - 1) / (size_t)TILE_KEYS);
+        if (gstat && ntiles <= SWEEP_GROUPED_MAX_TILES) {
+            // GROUPED look-back (round 5).  Measured with timestamps in the kernel: of the ~12 us a 4 096-key tile of a depth
+            // pass lives, the chained look-back above is 3.3-4.6 us -- every tile of a pass is resident and they all publish
+            // at about the same time, so nobody meets a prefix for a dozen round trips.  With all aggregates there at once the
+            // prefix needs no chain: tiles form groups of GS (16 / 32 / 64, ~sqrt of the tile count); a tile adds up the
+            // aggregates of the tiles in front of it IN ITS GROUP (independent loads, one round trip), the last tile of a
+            // group publishes the group's total, and every tile adds up the totals of the groups in front of its own (one more
+            // round trip).  A tile only ever waits for tiles with lower tickets, which are running.  Same-box A/B (per pass):
+            // depth sort 14.5 -> 12.6 us (125 tiles), close-up 12.6 -> 10.9 (236 tiles), 3 M 24.5 -> 22.4 (366 tiles); the tile
+            // sort 33 -> 31 us at 500 tiles, but 83 -> 85 us at 1 465 tiles (63 + 22 words per thread): the chain stays above
+            // SWEEP_GROUPED_MAX_TILES tiles.
+            uint32_t gs_log = 4;
+            while ((1u << (2 * gs_log)) < ntiles && gs_log < 6) gs_log++;
+            const uint32_t G = bid >> gs_log, first = G << gs_log;
+            auto gather = [&](const uint32_t* base, uint32_t lo, uint32_t hi) {
+                uint32_t sum = 0;
+                for (uint32_t r0 = lo; r0 < hi; r0 += 8) {
+                    uint32_t v[8];
+                    bool ok;
+                    do {
+                        ok = true;
 #pragma unroll
-            for (int j = 0; j < LB; j++)
-                v[j] = pb - j >= 0 ? __hip_atomic_load(st + (size_t)(pb - j) * RADIX_MAX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                   : ST_PREFIX;  // (before tile 0: an inclusive prefix of zero)
-            int used = 0;
-            bool found = false;
+                        for (int j = 0; j < 8; j++)
+                            v[j] = r0 + j < hi ? __hip_atomic_load(base + (size_t)(r0 + j) * RADIX_MAX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                               : ST_PREFIX;
 #pragma unroll
-            for (int j = 0; j < LB; j++) {
-                if (found || used < j) continue;  // (past the prefix, or past a tile that has not published yet)
-                if ((v[j] & ST_MASK) == ST_EMPTY) continue;
-                excl += v[j] & ST_VALUE;
-                used = j + 1;
-                found = (v[j] & ST_MASK) == ST_PREFIX;
-            }
-            if (found) break;
-            pb -= used;
-            if (used > 0) spins = 0;  // (the budget is per predecessor that keeps the tile waiting, not per look-back)
-            if (used < LB) {  // tile pb has not published yet: wait for it
-                if (++spins > (1u << 22)) {
-                    // never hang the device: carry on with garbage, but SAY so -- in the sort's own error word and in the
-                    // caller's (the frame's COUNTER_SORTERR / COUNTER_OVF: a frame sorted wrongly is treated as a truncated
-                    // one, its backward writes zero gradients and the host's read-back fails the call)
-                    atomicOr(error, 2u);
-                    if (frame_error) atomicOr(frame_error, 2u);
-                    break;
+                        for (int j = 0; j < 8; j++) ok = ok && (v[j] & ST_MASK) != ST_EMPTY;
+                        if (!ok) {
+                            if (++spins > (1u << 22)) {  // (never hang the device: see the chained look-back below)
+                                atomicOr(error, 2u);
+                                if (frame_error) atomicOr(frame_error, 2u);
+                                ok = true;
+                            } else {
+                                __builtin_amdgcn_s_sleep(1);
+                            }
+                        }
+                    } while (!ok);
+#pragma unroll
+                    for (int j = 0; j < 8; j++) sum += v[j] & ST_VALUE;
                 }
-                __builtin_amdgcn_s_sleep(1);
+                return sum;
+            };
+            const uint32_t local = gather(st, first, bid);
+            uint32_t* gst = gstat + (size_t)d;
+            if ((bid & ((1u << gs_log) - 1u)) == (1u << gs_log) - 1u)
+                __hip_atomic_store(gst + (size_t)G * RADIX_MAX, ST_PREFIX | ((local + my_total) & ST_VALUE), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            excl = gather(gst, 0u, G) + local;
+        } else {
+            int64_t pb = (int64_t)bid - 1;
+            while (pb >= 0) {
+                uint32_t v[LB];
+    #pragma unroll
+                for (int j = 0; j < LB; j++)
+                    v[j] = pb - j >= 0 ? __hip_atomic_load(st + (size_t)(pb - j) * RADIX_MAX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                       : ST_PREFIX;  // (before tile 0: an inclusive prefix of zero)
+                int used = 0;
+                bool found = false;
+    #pragma unroll
+                for (int j = 0; j < LB; j++) {
+                    if (found || used < j) continue;  // (past the prefix, or past a tile that has not published yet)
+                    if ((v[j] & ST_MASK) == ST_EMPTY) continue;
+                    excl += v[j] & ST_VALUE;
+                    used = j + 1;
+                    found = (v[j] & ST_MASK) == ST_PREFIX;
+                }
+                if (found) break;
+                pb -= used;
+                if (used > 0) spins = 0;  // (the budget is per predecessor that keeps the tile waiting, not per look-back)
+                if (used < LB) {  // tile pb has not published yet: wait for it
+                    if (++spins > (1u << 22)) {
+                        // never hang the device: carry on with garbage, but SAY so -- in the sort's own error word and in the
+                        // caller's (the frame's COUNTER_SORTERR / COUNTER_OVF: a frame sorted wrongly is treated as a truncated
+                        // one, its backward writes zero gradients and the host's read-back fails the call)
+                        atomicOr(error, 2u);
+                        if (frame_error) atomicOr(frame_error, 2u);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
             }
+            __hip_atomic_store(st + (size_t)bid * RADIX_MAX, ST_PREFIX | ((excl + my_total) & ST_VALUE), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
         }
-        __hip_atomic_store(st + (size_t)bid * RADIX_MAX, ST_PREFIX | ((excl + my_total) & ST_VALUE), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
         gbase[d] = excl;  // + global digit base, added after the scan below
         lbase[d] = my_total;
     }
@@ -472,7 +540,7 @@ __global__ __launch_bounds__(THREADS) void sweep_pass_k(const uint32_t* __restri
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const uint32_t d = threadIdx.x * 4 + k;
-            g[k] = d < radix ? ghist[d] : 0u;
+            g[k] = d < radix ? s_gh[d] : 0u;
             l[k] = d < radix ? lbase[d] : 0u;
             gs += g[k];
             ls += l[k];
@@ -521,15 +589,21 @@ size_t scan_scratch_words(size_t n) { return div_up(n, SCAN_CHUNK) + 16; }
 
 // the smallest tile the adaptive 512 x 16 kernel may choose for a capacity of n keys: 512 x 2 = 1024 keys, more when that
 // would need more than 2048 rows of status words per pass (the table is cleared every frame: 1 KB per row and pass)
+// rows of group totals behind a pass's status rows (grouped look-back: groups of at least 16 tiles)
+static size_t sweep_group_rows(size_t tile_rows) { return tile_rows / 16 + 2; }
 static int sweep_min_items_for(size_t n, bool small) {
     if (n <= ((size_t)2 << 20) && !small) return 4;  // (1024 x 4: not adaptive)
     int items = 2;
     while (items < 16 && (n + (size_t)512 * items - 1) / ((size_t)512 * items) > 2048) items <<= 1;
     return items;
 }
-static bool sweep_adaptive(size_t n) { return n > ((size_t)2 << 20) || g_options.sort_small != 0; }
-static int sweep_min_items(size_t n) { return sweep_min_items_for(n, g_options.sort_small != 0); }
-static size_t sweep_min_tile_keys(size_t n) { return sweep_adaptive(n) ? (size_t)512 * sweep_min_items(n) : 4096; }
+static bool sweep_adaptive(size_t n) { return n > ((size_t)2 << 20) || g_options.sort_small == 1; }
+static int sweep_min_items(size_t n) { return sweep_min_items_for(n, g_options.sort_small == 1); }
+// (sort_small 2: sorts of up to 2 M keys keep the 1024-thread kernel but may halve its tile -- 1024 x 2 keys -- by the count)
+static bool sweep_half_tile(size_t n) { return n <= ((size_t)2 << 20) && g_options.sort_small == 2; }
+static size_t sweep_min_tile_keys(size_t n) {
+    return sweep_adaptive(n) ? (size_t)512 * sweep_min_items(n) : (sweep_half_tile(n) ? 2048 : 4096);
+}
 
 size_t sort_scratch_words(size_t n) {
     size_t nblk = div_up(n, 4096);  // the smallest tile of the three-kernel variant
@@ -537,7 +611,8 @@ size_t sort_scratch_words(size_t n) {
     size_t three_kernel = table + scan_scratch_words(table) + 16;
     // (laid out for the smallest tile ANY setting of sort_small may choose: a workspace outlives the option)
     const size_t min_tile = (size_t)512 * sweep_min_items_for(n, true);
-    size_t onesweep = (size_t)MAX_PASSES * RADIX_MAX * div_up(n, min_tile < 4096 ? min_tile : 4096) + (size_t)MAX_PASSES * RADIX_MAX + 64;
+    const size_t rows = div_up(n, min_tile < 4096 ? min_tile : 4096);
+    size_t onesweep = (size_t)MAX_PASSES * RADIX_MAX * (rows + sweep_group_rows(rows)) + (size_t)MAX_PASSES * RADIX_MAX + 64;
     return three_kernel > onesweep ? three_kernel : onesweep;
 }
 
@@ -561,7 +636,8 @@ void exclusive_scan_u32(const uint32_t* in, const uint32_t* gather, uint32_t* ou
 // [passes][nblk][256] status | [MAX_PASSES][256] global digit histograms | [MAX_PASSES] tickets | error
 static size_t sweep_tile_keys(size_t n) { return sweep_adaptive(n) ? 8192 : 4096; }  // 512 x 16 (adaptive) or 1024 x 4
 static size_t sweep_status_words(size_t n, int lo, int hi) {
-    return (size_t)((hi - lo + 7) / 8) * div_up(n, sweep_min_tile_keys(n)) * RADIX_MAX;
+    const size_t rows = div_up(n, sweep_min_tile_keys(n));
+    return (size_t)((hi - lo + 7) / 8) * (rows + sweep_group_rows(rows)) * RADIX_MAX;
 }
 size_t radix_sort_control_words(size_t n, int lo, int hi) {
     return n ? sweep_status_words(n, lo, hi) + MAX_PASSES * RADIX_MAX + MAX_PASSES + 1 : 0;
@@ -613,16 +689,18 @@ int radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], size_t n, int lo, int
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8192 * (int)sizeof(uint32_t));
             attr_set.fetch_or(dev_bit, std::memory_order_relaxed);
         }
+        const size_t prow = (size_t)nt + sweep_group_rows(nt);  // status rows of a pass: its tiles, then its groups
         for (int p = 0; p < passes; p++) {
+            uint32_t* st_p = status + (size_t)p * prow * RADIX_MAX;
+            uint32_t* gst_p = g_options.sort_lookback ? st_p + (size_t)nt * RADIX_MAX : nullptr;  // NULL: the chained look-back
             if (tile == 4096)
                 sweep_pass_k<1024, 4><<<dim3(nt), dim3(1024), lds, s>>>(
                     keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, n_dev, plan.shift[p], plan.nbits[p],
-                    ghist + (size_t)p * RADIX_MAX, status + (size_t)p * nt * RADIX_MAX, ticket + p, error, frame_error, 4);
+                    ghist + (size_t)p * RADIX_MAX, st_p, ticket + p, error, frame_error, sweep_half_tile(n) ? 2 : 4, gst_p);
             else
                 sweep_pass_k<512, 16><<<dim3(nt), dim3(512), lds, s>>>(
                     keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, n_dev, plan.shift[p], plan.nbits[p],
-                    ghist + (size_t)p * RADIX_MAX, status + (size_t)p * nt * RADIX_MAX, ticket + p, error, frame_error,
-                    min_items);
+                    ghist + (size_t)p * RADIX_MAX, st_p, ticket + p, error, frame_error, min_items, gst_p);
             cur ^= 1;
         }
         return cur;

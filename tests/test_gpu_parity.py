@@ -905,7 +905,7 @@ def test_runs_on_a_side_stream_with_identical_results(dev):
 
 
 @pytest.mark.parametrize("option,value", [("bwd_variant", 1), ("bwd_variant", 2), ("fwd_variant", 0), ("fwd_variant", 2), ("sort_variant", 0), ("cull_variant", 0), ("bwd_records", 0),
-                                          ("cull_variant", 1), ("bwd_masks", 0), ("sort_small", 1)])
+                                          ("cull_variant", 1), ("bwd_masks", 0), ("sort_small", 1), ("sort_lookback", 0)])
 def test_alternative_kernels_stay_correct(oracle_mod, dev, option, value):
     """The non-default variants kept behind goi_raster_set_option (tile + atomics backward, one-candidate forward
     loop, the exact-fp32 MFMA flush of the backward, histogram/scan/scatter sort, the reference's un-culled lists) against the oracle on one case."""
@@ -917,7 +917,7 @@ def test_alternative_kernels_stay_correct(oracle_mod, dev, option, value):
     grads = upstream_grads(S, H, W, seed=5)
     o = oracle_mod.from_scene(sc, cam, bg=bg)
     f = o.forward()
-    default = {"bwd_variant": 0, "fwd_variant": 1, "sort_variant": 1, "cull_variant": 2, "bwd_records": 1, "bwd_masks": 1, "sort_small": 0}[option]
+    default = {"bwd_variant": 0, "fwd_variant": 1, "sort_variant": 1, "cull_variant": 2, "bwd_records": 1, "bwd_masks": 1, "sort_small": 0, "sort_lookback": 1}[option]
     _lib.set_option(option, value)
     try:
         res = run_hip(sc, cam, bg, dev, grads=grads)

@@ -147,10 +147,17 @@ def test_adaptive_sort_tiles_agree_with_the_three_kernel_sort_above_two_million_
         v2 = _C.debug_views(P, W, H, n2, *w2)
     finally:
         _lib.set_option("sort_variant", 1)
-    assert n2 == n0
+    _lib.set_option("sort_lookback", 0)  # the chained decoupled look-back instead of the grouped one
+    try:
+        n4, o4, w4 = _raw(dev, sc, cam, bg, speculative=False)
+        v4 = _C.debug_views(P, W, H, n4, *w4)
+    finally:
+        _lib.set_option("sort_lookback", 1)
+    assert n2 == n0 and n4 == n0
     for k in ("point_list", "ranges", "n_contrib"):
         assert torch.equal(v0[k], v1[k]), k
         assert torch.equal(v0[k], v2[k]), k
+        assert torch.equal(v0[k], v4[k]), k
     # ... and a view that lists NOTHING: the scene reflected through the camera centre lies behind the near plane
     from goi_hyperplane_amd.render import TorchCamera
     c = TorchCamera(cam, dev).camera_center.detach().cpu().numpy().reshape(1, 3)
