@@ -597,13 +597,9 @@ static int sweep_min_items_for(size_t n, bool small) {
     while (items < 16 && (n + (size_t)512 * items - 1) / ((size_t)512 * items) > 2048) items <<= 1;
     return items;
 }
-static bool sweep_adaptive(size_t n) { return n > ((size_t)2 << 20) || g_options.sort_small == 1; }
-static int sweep_min_items(size_t n) { return sweep_min_items_for(n, g_options.sort_small == 1); }
-// (sort_small 2: sorts of up to 2 M keys keep the 1024-thread kernel but may halve its tile -- 1024 x 2 keys -- by the count)
-static bool sweep_half_tile(size_t n) { return n <= ((size_t)2 << 20) && g_options.sort_small == 2; }
-static size_t sweep_min_tile_keys(size_t n) {
-    return sweep_adaptive(n) ? (size_t)512 * sweep_min_items(n) : (sweep_half_tile(n) ? 2048 : 4096);
-}
+static bool sweep_adaptive(size_t n) { return n > ((size_t)2 << 20) || g_options.sort_small != 0; }
+static int sweep_min_items(size_t n) { return sweep_min_items_for(n, g_options.sort_small != 0); }
+static size_t sweep_min_tile_keys(size_t n) { return sweep_adaptive(n) ? (size_t)512 * sweep_min_items(n) : 4096; }
 
 size_t sort_scratch_words(size_t n) {
     size_t nblk = div_up(n, 4096);  // the smallest tile of the three-kernel variant
@@ -696,7 +692,7 @@ int radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], size_t n, int lo, int
             if (tile == 4096)
                 sweep_pass_k<1024, 4><<<dim3(nt), dim3(1024), lds, s>>>(
                     keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, n_dev, plan.shift[p], plan.nbits[p],
-                    ghist + (size_t)p * RADIX_MAX, st_p, ticket + p, error, frame_error, sweep_half_tile(n) ? 2 : 4, gst_p);
+                    ghist + (size_t)p * RADIX_MAX, st_p, ticket + p, error, frame_error, 4, gst_p);
             else
                 sweep_pass_k<512, 16><<<dim3(nt), dim3(512), lds, s>>>(
                     keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, n_dev, plan.shift[p], plan.nbits[p],
