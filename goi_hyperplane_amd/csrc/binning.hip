@@ -107,10 +107,13 @@ __global__ __launch_bounds__(PRE_BLOCK) void compact_listed_k(int P, const uint3
     }
     if (ghist) {
         __syncthreads();
+        // (one of SORT_GH_COPIES copies of the histograms, by workgroup: 488 workgroups adding into the SAME thousand words
+        // serialise at the L2's atomic units; the sort's passes add the copies up)
+        uint32_t* gh = ghist + (size_t)(blockIdx.x % SORT_GH_COPIES) * SORT_MAX_PASSES * 256;
 #pragma unroll
         for (int p = 0; p < 4; p++) {
             const uint32_t c = s_h[p][tid];
-            if (c) atomicAdd(&ghist[p * 256 + tid], c);
+            if (c) atomicAdd(&gh[p * 256 + tid], c);
         }
     }
 }

@@ -171,6 +171,9 @@ void launch_preprocess_fwd(const GoiRasterScene& sc, const GeomView& g, int* rad
 // that cannot take its count from the device sorts all P).
 void launch_compact_listed(int P, const GeomView& g, uint32_t* ghist, bool pad, hipStream_t s);
 constexpr int COARSE_BLOCKS = 32, COARSE_STRIDE = 8;  // GeomView::blk_coarse
+// the onesweep sort's global digit histograms: [SORT_GH_COPIES][SORT_MAX_PASSES][256] words; writers that flush with atomics
+// spread over the copies (copy = workgroup % SORT_GH_COPIES), a pass adds them up (scan_sort.hip)
+constexpr int SORT_MAX_PASSES = 4, SORT_GH_COPIES = 8;
 constexpr int PRE_BLOCK = 256;  // Gaussians per workgroup of preprocess_fwd_k = granularity of blk_agg / blk_pre
 // cap: instances keys[] / vals[] can hold (instances past it are dropped: only an overflowed speculative frame has any)
 void launch_emit(int P, int W, int H, const GeomView& g, const uint32_t* order, const int* radii, uint32_t* keys,

@@ -266,7 +266,8 @@ __global__ __launch_bounds__(SORT_THREADS) void radix_scatter_k(const uint32_t* 
 // every spin is bounded and reports through an error word instead of hanging the device.
 constexpr uint32_t ST_EMPTY = 0u, ST_AGGREGATE = 1u << 30, ST_PREFIX = 2u << 30, ST_MASK = 3u << 30;
 constexpr uint32_t ST_VALUE = (1u << 30) - 1u;
-constexpr int MAX_PASSES = 4;
+constexpr int MAX_PASSES = SORT_MAX_PASSES;
+constexpr size_t GH_WORDS = (size_t)SORT_GH_COPIES * MAX_PASSES * RADIX_MAX;  // all copies of the global digit histograms
 
 struct SweepPlan {
     int passes;
@@ -304,9 +305,10 @@ __global__ __launch_bounds__(SORT_THREADS) void sweep_hist_k(const uint32_t* __r
         }
     }
     __syncthreads();
+    uint32_t* gh = ghist + (size_t)(blockIdx.x % SORT_GH_COPIES) * MAX_PASSES * RADIX_MAX;  // (one of the copies: common.h)
     for (int i = threadIdx.x; i < plan.passes * RADIX_MAX; i += SORT_THREADS) {
         const uint32_t v = (&h[0][0])[i];
-        if (v) atomicAdd(&ghist[i], v);
+        if (v) atomicAdd(&gh[i], v);
     }
 }
 
@@ -349,7 +351,11 @@ __global__ __launch_bounds__(THREADS) void sweep_pass_k(const uint32_t* __restri
     const bool adaptive = min_items < ITEMS;
     uint32_t early_ticket = 0;
     if (!adaptive && threadIdx.x == 0) early_ticket = atomicAdd(ticket, 1u);
-    const uint32_t gh = threadIdx.x < radix ? ghist[threadIdx.x] : 0u;
+    uint32_t gh = 0;
+    if (threadIdx.x < radix) {
+#pragma unroll
+        for (int c = 0; c < SORT_GH_COPIES; c++) gh += ghist[(size_t)c * MAX_PASSES * RADIX_MAX + threadIdx.x];
+    }
     const size_t n = effective_n(n_cap, n_dev);
     int items = ITEMS;
     while (items > min_items && n <= (size_t)THREADS * (size_t)(items / 2) * SWEEP_TARGET_TILES) items >>= 1;
@@ -608,7 +614,7 @@ size_t sort_scratch_words(size_t n) {
     // (laid out for the smallest tile ANY setting of sort_small may choose: a workspace outlives the option)
     const size_t min_tile = (size_t)512 * sweep_min_items_for(n, true);
     const size_t rows = div_up(n, min_tile < 4096 ? min_tile : 4096);
-    size_t onesweep = (size_t)MAX_PASSES * RADIX_MAX * (rows + sweep_group_rows(rows)) + (size_t)MAX_PASSES * RADIX_MAX + 64;
+    size_t onesweep = (size_t)MAX_PASSES * RADIX_MAX * (rows + sweep_group_rows(rows)) + GH_WORDS + 64;
     return three_kernel > onesweep ? three_kernel : onesweep;
 }
 
@@ -636,7 +642,7 @@ static size_t sweep_status_words(size_t n, int lo, int hi) {
     return (size_t)((hi - lo + 7) / 8) * (rows + sweep_group_rows(rows)) * RADIX_MAX;
 }
 size_t radix_sort_control_words(size_t n, int lo, int hi) {
-    return n ? sweep_status_words(n, lo, hi) + MAX_PASSES * RADIX_MAX + MAX_PASSES + 1 : 0;
+    return n ? sweep_status_words(n, lo, hi) + GH_WORDS + MAX_PASSES + 1 : 0;
 }
 uint32_t* radix_sort_ghist(uint32_t* scratch, size_t n, int lo, int hi) {
     return scratch + sweep_status_words(n, lo, hi);
@@ -657,7 +663,7 @@ int radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], size_t n, int lo, int
         // scratch: [passes][nblk][256] status words | [passes][256] global histograms | tickets | error
         uint32_t* status = scratch;
         uint32_t* ghist = radix_sort_ghist(scratch, n, lo, hi);
-        uint32_t* ticket = ghist + MAX_PASSES * RADIX_MAX;
+        uint32_t* ticket = ghist + GH_WORDS;
         uint32_t* error = ticket + MAX_PASSES;
         if (!cleared) (void)hipMemsetAsync(status, 0, radix_sort_control_words(n, lo, hi) * sizeof(uint32_t), s);
         SweepPlan plan;
