@@ -965,6 +965,7 @@ int goi_raster_set_option(const char* name, int value) {
     else if (!strcmp(name, "sort_variant")) g_options.sort_variant = value;
     else if (!strcmp(name, "sort_small")) g_options.sort_small = value;
     else if (!strcmp(name, "sort_lookback")) g_options.sort_lookback = value;
+    else if (!strcmp(name, "sort_tickets")) g_options.sort_tickets = value;
     else if (!strcmp(name, "cull_variant")) g_options.cull_variant = value;
     else if (!strcmp(name, "bwd_order")) {
         if (value < 0 || value > 8) return fail("bwd_order must be 0 .. 8");

@@ -116,6 +116,7 @@ struct Options {
                           // MFMA flush (fp32-grade), 2 the same with the exact-fp32 flush, 1 workgroup-per-tile + atomics
     int sort_variant = 1;  // 0: histogram / scan / scatter per pass, 1: onesweep (decoupled look-back, default)
     int sort_lookback = 1;  // onesweep: 1 grouped look-back (two round trips: group aggregates, group totals), 0 the chained decoupled look-back
+    int sort_tickets = 1;  // onesweep: 1 tiles are dealt by a ticket counter (a tile only waits for tiles that are running), 0 tile = workgroup index (experiment)
     int sort_small = 0;    // 1: sorts of up to 2 M keys also take the adaptive 512 x (2..16) tile (scan_sort.hip) instead of 1024 x 4
     int decode_variant = 1;  // semantic decode, S <= 16: 1 split-bf16 MFMA contraction, 2 pixel blocks per operand fetch (2: 4 blocks, 3: 1 block; bit-identical), 0 fp32 MFMA
     int cull_variant = 2;  // 0: a Gaussian is listed in every tile of its 3-sigma rectangle (the reference's lists),

@@ -350,7 +350,7 @@ __global__ __launch_bounds__(THREADS) void sweep_pass_k(const uint32_t* __restri
     // the trivial-pass test without looking at a key) and -- where every block takes a ticket -- the ticket.
     const bool adaptive = min_items < ITEMS;
     uint32_t early_ticket = 0;
-    if (!adaptive && threadIdx.x == 0) early_ticket = atomicAdd(ticket, 1u);
+    if (!adaptive && threadIdx.x == 0 && ticket) early_ticket = atomicAdd(ticket, 1u);
     uint32_t gh = 0;
     if (threadIdx.x < radix) {
 #pragma unroll
@@ -370,7 +370,9 @@ __global__ __launch_bounds__(THREADS) void sweep_pass_k(const uint32_t* __restri
         s_gh[threadIdx.x] = gh;
         if (n > 0 && gh == (uint32_t)n) s_trivial = 1u;  // (at most one bin can hold all n keys)
     }
-    if (threadIdx.x == 0) s_bid = adaptive ? atomicAdd(ticket, 1u) : early_ticket;
+    // (ticket == NULL, sort_tickets 0 -- an EXPERIMENT: the tile is the workgroup's own index, which is only safe while the
+    // hardware starts workgroups in index order)
+    if (threadIdx.x == 0) s_bid = !ticket ? blockIdx.x : (adaptive ? atomicAdd(ticket, 1u) : early_ticket);
     __syncthreads();
     // A TRIVIAL pass: every key has the same digit (the global histogram says so: one bin holds all n) -- the top byte of
     // the depth keys of a scene whose depths span less than a factor of four, typically.  The pass is then the identity
@@ -698,11 +700,11 @@ int radix_sort_pairs(uint32_t* keys[2], uint32_t* vals[2], size_t n, int lo, int
             if (tile == 4096)
                 sweep_pass_k<1024, 4><<<dim3(nt), dim3(1024), lds, s>>>(
                     keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, n_dev, plan.shift[p], plan.nbits[p],
-                    ghist + (size_t)p * RADIX_MAX, st_p, ticket + p, error, frame_error, 4, gst_p);
+                    ghist + (size_t)p * RADIX_MAX, st_p, g_options.sort_tickets ? ticket + p : nullptr, error, frame_error, 4, gst_p);
             else
                 sweep_pass_k<512, 16><<<dim3(nt), dim3(512), lds, s>>>(
                     keys[cur], vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, n_dev, plan.shift[p], plan.nbits[p],
-                    ghist + (size_t)p * RADIX_MAX, st_p, ticket + p, error, frame_error, min_items, gst_p);
+                    ghist + (size_t)p * RADIX_MAX, st_p, g_options.sort_tickets ? ticket + p : nullptr, error, frame_error, min_items, gst_p);
             cur ^= 1;
         }
         return cur;

@@ -284,6 +284,10 @@ int goi_raster_profile_collect(double* ms, int* calls);
  *   "sort_lookback" 1 (default) onesweep passes of up to 640 tiles find their prefix with the GROUPED look-back (a tile adds up the
  *                  aggregates of its group, then the totals of the groups in front: two round trips), 0 always the chained
  *                  decoupled look-back; same order either way
+ *   "sort_tickets" 1 (default) a onesweep workgroup takes its tile from a ticket counter, so that a tile only ever waits for tiles
+ *                  that are running whatever order the hardware starts workgroups in; 0 EXPERIMENT: tile = workgroup index
+ *                  (measures what the tickets cost: 5 us of the headline step, 37 us at 3 M Gaussians; NOT safe as a default:
+ *                  HIP promises no dispatch order)
  *   "sort_small"   0 (default) sorts of up to 2 M keys use 1024 x 4-key tiles; 1 they take the adaptive 512 x (2..16) tile that
  *                  larger sorts choose from the device-side count (slower for them: DESIGN.md 8.2); same order either way
  *   "cull_variant" 2 (default) a Gaussian is listed only in the tiles its contribution ellipse (alpha >= 1/255) reaches,
