@@ -354,9 +354,12 @@ __global__ __launch_bounds__(WIDE ? 1024 : 256) void emit_k(int P, int gx, int g
     }  // chunks
     if (COUNT) {
         __syncthreads();
-        for (int t = threadIdx.x; t < T; t += (int)NT) {
-            const uint32_t c = s_cnt[t];
-            if (c) atomicAdd(&tile_count[2 * t], c);
+        // (the counts of tiles 2 k and 2 k + 1 leave as ONE 64-bit atomic on a dense count array -- the first T words of the
+        // ranges array, which tile_ranges_hist_k reads before it writes the ranges: half the atomics; a count is < 2^31)
+        unsigned long long* pair = reinterpret_cast<unsigned long long*>(tile_count);
+        for (int k = threadIdx.x; 2 * k < T; k += (int)NT) {
+            const unsigned long long lo = s_cnt[2 * k], hi = 2 * k + 1 < T ? s_cnt[2 * k + 1] : 0u;
+            if (lo | hi) atomicAdd(&pair[k], lo | (hi << 32));
         }
     }
 }
@@ -418,9 +421,10 @@ __global__ __launch_bounds__(256) void emit_big_k(int gx, int gy, const GaussRec
         __syncthreads();
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < T; t += 256) {
-        const uint32_t c = s_cnt[t];
-        if (c) atomicAdd(&tile_count[2 * t], c);
+    unsigned long long* pair = reinterpret_cast<unsigned long long*>(tile_count);  // (dense counts, two tiles per atomic: emit_k)
+    for (int k = threadIdx.x; 2 * k < T; k += 256) {
+        const unsigned long long lo = s_cnt[2 * k], hi = 2 * k + 1 < T ? s_cnt[2 * k + 1] : 0u;
+        if (lo | hi) atomicAdd(&pair[k], lo | (hi << 32));
     }
 }
 
@@ -443,7 +447,7 @@ __global__ __launch_bounds__(1024) void tile_ranges_hist_k(int T, uint2* __restr
     uint32_t sum = 0;
 #pragma unroll
     for (int k = 0; k < TRH_MAX_IT; k++) {
-        c[k] = (k < IT && t0 + k < T) ? ranges[t0 + k].y : 0u;
+        c[k] = (k < IT && t0 + k < T) ? reinterpret_cast<const uint32_t*>(ranges)[t0 + k] : 0u;  // (dense counts: emit_k's flush)
         sum += c[k];
     }
     uint32_t v = sum;  // inclusive scan of the 1024 per-thread sums
@@ -528,14 +532,14 @@ void launch_emit_counting(int P, int W, int H, const GeomView& g, const uint32_t
     // `ranges` was zeroed by preprocess_fwd_k
     if (emit_rounds_for(gx * gy) == 1) {
         emit_k<true, 1><<<dim3((P + 255) / 256), dim3(256), (size_t)gx * gy * sizeof(uint32_t), s>>>(
-            P, gx, gy, g.rec, radii, order, g.offsets, g.aux, keys, vals, reinterpret_cast<uint32_t*>(ranges) + 1, g.counters,
+            P, gx, gy, g.rec, radii, order, g.offsets, g.aux, keys, vals, reinterpret_cast<uint32_t*>(ranges), g.counters,
             clear, (uint32_t)clear_words, cap, g.bigq);
         // the big rectangles the kernel queued: a workgroup per CU walks the queue (workgroups beyond its length leave at once)
         emit_big_k<<<dim3(256), dim3(256), (size_t)gx * gy * sizeof(uint32_t), s>>>(
-            gx, gy, g.rec, order, g.offsets, g.aux, g.bigq, g.counters, keys, vals, reinterpret_cast<uint32_t*>(ranges) + 1, cap);
+            gx, gy, g.rec, order, g.offsets, g.aux, g.bigq, g.counters, keys, vals, reinterpret_cast<uint32_t*>(ranges), cap);
     } else
         emit_k<true, EMIT_ROUNDS, true><<<dim3(std::min((P + 256 * EMIT_ROUNDS - 1) / (256 * EMIT_ROUNDS), GOI_EMIT_MAX_GRID)), dim3(1024), (size_t)gx * gy * sizeof(uint32_t), s>>>(
-            P, gx, gy, g.rec, radii, order, g.offsets, g.aux, keys, vals, reinterpret_cast<uint32_t*>(ranges) + 1, g.counters,
+            P, gx, gy, g.rec, radii, order, g.offsets, g.aux, keys, vals, reinterpret_cast<uint32_t*>(ranges), g.counters,
             clear, (uint32_t)clear_words, cap, g.bigq);
 }
 
