@@ -127,6 +127,7 @@ static inline size_t round_up_256(size_t n) { return (n + 255) & ~(size_t)255; }
 // event recorded right behind the copy.  A ticket is one such (pinned words, event) pair; they are pooled per DEVICE
 // (events and pinned allocations belong to the device that was current when they were made) under a mutex, so
 // concurrent callers on different streams / threads / GPUs each get their own.
+constexpr int READBACK_HEAD_WORDS_MIN = 32;
 struct Ticket {
     int dev = -1;
     uint32_t* pinned = nullptr;
@@ -142,7 +143,9 @@ struct Ticket {
     uint32_t seq = 0;
     bool stamped = false;
 };
-constexpr int STAMP_WORD = 33;  // (the head is words 0..31; word 32 is a num_rendered stripe of the full copy, which is never stamped)
+constexpr int STAMP_WORD = HOST_STAMP_WORD;  // 33 (common.h: the blend kernels write it); the head is words 0..31, word 32 is a
+                                            // num_rendered stripe of the full copy, which is never stamped
+static_assert(STAMP_WORD >= READBACK_HEAD_WORDS_MIN && STAMP_WORD < COUNTER_WORDS, "stamp word inside the pinned block, outside the head");
 // A read-back queued BEHIND the whole frame (speculative forward) finds num_rendered as one word (COUNTER_N, left by the
 // listed-Gaussian compaction / the scan): 128 bytes travel instead of the 4 KB of striped partial counters -- which the
 // runtime moved as three copy kernels per frame.
