@@ -173,21 +173,40 @@ __global__ __launch_bounds__(256) void preprocess_fwd_k(const PreArgs args, Gaus
             const V3 campos = {a.campos[0], a.campos[1], a.campos[2]};
             V3 dir = p - campos;
             dir = dir / sqrtf(dot3(dir, dir));
-            const V3* sh = reinterpret_cast<const V3*>(a.shs) + (size_t)idx * a.M;
-            V3 res = kSH0 * sh[0];
+            // A degree-3 row (M = 16: 192 bytes, 16-byte aligned) is fetched as TWELVE 16-byte loads instead of sixteen 12-byte ones:
+            // the SH rows are this kernel's bottleneck (every load instruction of a wave touches 64 different lines -- DESIGN.md
+            // 8.2), a quarter fewer of them and none straddling a line: 75.5 -> 69.6 us on the headline frame, 204 -> 199 at 3 M
+            // (same box), although the row in flight costs the kernel its 8 waves per SIMD (64 -> 88 VGPRs).  Same values, same
+            // order of operations: bit-identical.
+            float rowf[48];
+            const bool row16 = a.M == 16;
+            if (row16) {
+                const float4* r4 = reinterpret_cast<const float4*>(a.shs + (size_t)idx * 48);
+#pragma unroll
+                for (int i = 0; i < 12; i++) {
+                    const float4 v = r4[i];
+                    rowf[4 * i] = v.x;
+                    rowf[4 * i + 1] = v.y;
+                    rowf[4 * i + 2] = v.z;
+                    rowf[4 * i + 3] = v.w;
+                }
+            }
+            const V3* shg = reinterpret_cast<const V3*>(a.shs) + (size_t)idx * a.M;
+            auto SHK = [&](int k) { return row16 ? V3{rowf[3 * k], rowf[3 * k + 1], rowf[3 * k + 2]} : shg[k]; };
+            V3 res = kSH0 * SHK(0);
             if (a.D > 0) {
                 const float x = dir.x, y = dir.y, z = dir.z;
-                res = res - kSH1 * y * sh[1] + kSH1 * z * sh[2] - kSH1 * x * sh[3];
+                res = res - kSH1 * y * SHK(1) + kSH1 * z * SHK(2) - kSH1 * x * SHK(3);
                 if (a.D > 1) {
                     const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-                    res = res + kSH2[0] * xy * sh[4] + kSH2[1] * yz * sh[5] + kSH2[2] * (2.0f * zz - xx - yy) * sh[6] +
-                          kSH2[3] * xz * sh[7] + kSH2[4] * (xx - yy) * sh[8];
+                    res = res + kSH2[0] * xy * SHK(4) + kSH2[1] * yz * SHK(5) + kSH2[2] * (2.0f * zz - xx - yy) * SHK(6) +
+                          kSH2[3] * xz * SHK(7) + kSH2[4] * (xx - yy) * SHK(8);
                     if (a.D > 2) {
-                        res = res + kSH3[0] * y * (3.0f * xx - yy) * sh[9] + kSH3[1] * xy * z * sh[10] +
-                              kSH3[2] * y * (4.0f * zz - xx - yy) * sh[11] +
-                              kSH3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * sh[12] +
-                              kSH3[4] * x * (4.0f * zz - xx - yy) * sh[13] + kSH3[5] * z * (xx - yy) * sh[14] +
-                              kSH3[6] * x * (xx - 3.0f * yy) * sh[15];
+                        res = res + kSH3[0] * y * (3.0f * xx - yy) * SHK(9) + kSH3[1] * xy * z * SHK(10) +
+                              kSH3[2] * y * (4.0f * zz - xx - yy) * SHK(11) +
+                              kSH3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * SHK(12) +
+                              kSH3[4] * x * (4.0f * zz - xx - yy) * SHK(13) + kSH3[5] * z * (xx - yy) * SHK(14) +
+                              kSH3[6] * x * (xx - 3.0f * yy) * SHK(15);
                     }
                 }
             }
