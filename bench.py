@@ -200,6 +200,7 @@ def main():
                          "'closeup' = config 5's shape (512x512 close-up of 3 M clustered Gaussians).  The default line also "
                          "carries the clustered scene as a secondary object (--no-clustered skips it)")
     ap.add_argument("--no-clustered", action="store_true", help="skip the secondary clustered-workload object")
+    ap.add_argument("--no-orbit", action="store_true", help="skip the secondary orbit-camera object (workload_orbit)")
     ap.add_argument("--depth-cut", action="store_true",
                     help="turn the opt-in speculative depth cut-off of the tile lists ON for the whole run (default: off, the "
                          "package default; the default line reports the step with it as `value_with_depth_cut`)")
@@ -818,6 +819,71 @@ def main():
                        "what": "two independent views in flight on two HIP streams of one GPU (same work per view)"}
         del pcs, streams
 
+    # Secondary object: the SAME scene from a capture ORBIT instead of 16 cameras within +-0.16 rad of one direction
+    # (scene.make_orbit_cameras: the look-at point travels around the scene, consecutive steps are seven orbit positions apart, as
+    # train.py:118-124 pops its training cameras at random).  The cycle of near-identical views is the friendliest case for the
+    # gradient-buffer pool (rows that already hold zeros are not rewritten), the capacity policy (2 x the high-water count) and
+    # the L2-resident per-Gaussian arrays; this object says what the step costs when consecutive views see different Gaussians.
+    orbit = None
+    if not args.no_orbit and not args.ply:
+        from goi_hyperplane_amd.scene import ORBIT, make_orbit_cameras
+        ocams = [TorchCamera(c_, dev) for c_ in make_orbit_cameras(args.W, args.H, fovx=WL["fovx"])]
+        ext_ = _C._ext()
+
+        def step_o(i):
+            for p_ in params:
+                p_.grad = None
+            o_ = render(ocams[i % len(ocams)], pc, pipe, bg)
+            torch.autograd.backward((o_["render"], o_["semantics"]), (g_color, g_sem))
+            return o_
+        # an untimed pass over the orbit: teaches the capacity policy the orbit's counts, and collects the visibility sets
+        vis_o, n_o = [], []
+        for i in range(len(ocams)):
+            o_ = step_o(i)
+            vis_o.append(o_["radii"] > 0)
+            n_o.append(rasterizer.last_num_rendered())
+        torch.cuda.synchronize(dev)
+        n_o = [int(c_) for c_ in n_o]
+        shared, kept = [], []
+        for a_, b_ in zip(vis_o, vis_o[1:] + vis_o[:1]):  # consecutive steps (a_ then b_)
+            shared.append(float((a_ & b_).sum()) / max(1.0, float(b_.sum())))        # of b_'s visible Gaussians, seen by a_ as well
+            kept.append(float((~a_ & ~b_).sum()) / max(1.0, float((~b_).sum())))     # of b_'s invisible rows, already zero after a_
+        V_o = float(np.mean([float(v_.sum()) for v_ in vis_o]))
+        del vis_o
+        sp0 = rasterizer.speculation_stats()
+        pool0 = ext_.grad_pool_stats() if ext_ is not None else None
+        for i in range(4):
+            step_o(i)
+        barrier()
+        o0 = time.perf_counter()
+        no = max(16, min(args.steps, 48)) // 16 * 16  # whole cycles of the orbit
+        for i in range(no):
+            step_o(i)
+        barrier()
+        o_el = time.perf_counter() - o0
+        sp1 = rasterizer.speculation_stats()
+        pool1 = ext_.grad_pool_stats() if ext_ is not None else None
+        n_last = rasterizer.last_num_rendered()
+        orbit = {"views_per_s": no / o_el, "ms_per_step": o_el / no * 1e3, "steps": no, "cameras": len(ocams),
+                 "relative_to_value": None,  # (filled in below: orbit views/s per GPU / value per GPU)
+                 "orbit": dict(ORBIT), "V": V_o, "N_listed_per_view": float(np.mean(n_o)), "N_listed_min_max": [min(n_o), max(n_o)],
+                 "visible_shared_with_previous_step": {"mean": round(float(np.mean(shared)), 4), "max": round(max(shared), 4)},
+                 "gradient_pool": {"zero_rows_already_zero": {"mean": round(float(np.mean(kept)), 4), "min": round(min(kept), 4)},
+                                   "buffers": (None if pool0 is None else
+                                               dict(zip(("hits", "dirty", "fresh"), (int(b_ - a_) for a_, b_ in zip(pool0, pool1))))),
+                                   "what": "zero_rows_already_zero: of the Gaussians a step does not see, the fraction the previous "
+                                           "step did not see either (their gradient rows hold zeros and are not rewritten); buffers: "
+                                           "pooled gradient buffers handed out again / found modified in place / freshly allocated "
+                                           "during the timed steps"},
+                 "speculation": {k: sp1[k] - sp0[k] for k in sp1}, "binning_capacity": int(getattr(n_last, "capacity", 0) or 0),
+                 "what": "the same step (forward + backward, all gradients, the same dense upstream gradients) on the SAME scene with "
+                         "scene.make_orbit_cameras: 16 cameras whose look-at points travel around the scene, visited seven positions "
+                         "apart; per GPU, no gradient exchange"}
+        del ocams
+        for i in range(4):  # back to the main cameras' steady state for the objects below
+            step(i)
+        drain()
+
     # Secondary object: the ADVERSARIAL workload -- a scene with the statistics of a reconstruction (clustered density,
     # heavy-tailed anisotropic sizes, opaque foreground with lists thousands deep behind it: scene.make_clustered_scene) at the
     # headline's size and image, through the same step.  Not `value`; its oracle parity is tests/test_gpu_clustered.py.
@@ -1010,6 +1076,7 @@ def main():
             "render_ms_per_frame_speculative": render_ms_spec,
             "gui_frame_ms": gui_ms,  # render + fused semantic decode (300 codes)
             "step_enqueue_ms": step_enqueue_ms,  # host-side, informational (stall detector; not used for value)
+            "workload_orbit": orbit,
             "workload_clustered": clustered,
             "memory_per_view": memory,
             "blend_lane_utilisation": stats.get("lane"),
@@ -1083,6 +1150,8 @@ def main():
                         "exceedances without the slack are listed in both directions"}
         else:
             res["parity"], res["cpu_baseline"] = None, None
+        if orbit is not None:
+            orbit["relative_to_value"] = round(orbit["views_per_s"] / (res["value"] / world), 4)
         print(json.dumps(res))
     if dist is not None:
         dist.barrier()

@@ -217,7 +217,7 @@ _FWD = {"mode": _env_forward_mode(), "inference": _env_inference_mode(),
 _SPEC = {}  # device index -> {"high_water": int, "P": int, "pending": deque of LazyCount}
 _SPEC_LOCK = threading.RLock()
 SPECULATION_STATS = {"exact_frames": 0, "speculative_frames": 0, "overflows": 0, "redone": 0, "waits": 0, "cached_frames": 0,
-                     "skipped_views": 0, "cut_frames": 0, "cut_failures": 0}
+                     "skipped_views": 0, "cut_frames": 0, "cut_failures": 0, "cut_overflows": 0}
 _MIN_CAPACITY = 1 << 16
 _KEEP_WORKSPACES = 2  # pending frames per device whose workspaces stay alive for a possible redo
 
@@ -392,9 +392,15 @@ class LazyCount:
             # gradients); the camera forgets its cut.  A cut frame that OVERFLOWED its (cut-sized) capacity is treated the same
             # way: the redo of an overflowed frame re-bins from the cut geometry workspace and blends WITHOUT the cut check, so
             # a too-tight cut would come back as "exact"  -- such a frame is rendered again whole and uncut instead.
+            # The two signals are kept apart: the device's flag says the CUT was too tight -- the camera forgets it;
+            # a count above the capacity alone says the CAPACITY guess was short -- the cut may be fine and is kept (the
+            # capacity policy has just learnt the count: the camera's next frame fits), only this frame is rendered again.
             self.cut_failed = True
-            SPECULATION_STATS["cut_failures"] += 1
-            _DEPTH_CUTS["entries"].pop(self.cut_key, None)
+            if fl.value & 4:
+                SPECULATION_STATS["cut_failures"] += 1
+                _DEPTH_CUTS["entries"].pop(self.cut_key, None)
+            else:
+                SPECULATION_STATS["cut_overflows"] += 1
             if lazy:
                 self._redo = self._hold = self._full_args = None
                 SPECULATION_STATS["skipped_views"] += 1

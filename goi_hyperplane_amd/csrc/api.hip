@@ -110,6 +110,10 @@ int validate(const GoiRasterScene* sc, bool need_sem, bool need_opacity = true) 
         return fail("semantics must be 16-byte aligned when S is a multiple of 4 (its rows are moved as 16-byte words)");
     if ((sc->shs == nullptr) == (sc->colors_precomp == nullptr))
         return fail("Please provide excatly one of either SHs or precomputed colors!");
+    // (an SH row whose 3 M floats are a whole number of 16-byte words -- M = 4, 8, 12, 16 -- is moved as such by both per-Gaussian
+    // kernels: preprocess.hip, row16 / the backward's hoist)
+    if (sc->shs && (3 * sc->M) % 4 == 0 && (reinterpret_cast<uintptr_t>(sc->shs) & 15u) != 0)
+        return fail("shs must be 16-byte aligned when 3 M is a multiple of 4 (its rows are moved as 16-byte words)");
     if (((sc->scales == nullptr || sc->rotations == nullptr) && sc->cov3D_precomp == nullptr) ||
         ((sc->scales != nullptr || sc->rotations != nullptr) && sc->cov3D_precomp != nullptr))
         return fail("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
@@ -142,6 +146,7 @@ struct Ticket {
     // of a training step, between render_fwd_k and the backward's first kernel.)
     uint32_t seq = 0;
     bool stamped = false;
+    hipStream_t stream = nullptr;  // the stream the frame was enqueued on (the slow path of a blocking wait drains IT, nothing else)
 };
 constexpr int STAMP_WORD = HOST_STAMP_WORD;  // 33 (common.h: the blend kernels write it); the head is words 0..31, word 32 is a
                                             // num_rendered stripe of the full copy, which is never stamped
@@ -202,7 +207,8 @@ int ticket_result(int id, int wait, long long* n, unsigned* frame_flags = nullpt
         if (!arrived()) {
             if (!wait) return 0;
             // spin politely; a frame is milliseconds.  After two seconds something is wrong with the device (or the frame
-            // never ran): drain it and look once more -- never hang in here
+            // never ran): drain the FRAME'S STREAM and look once more -- never hang in here.  (Not the device: that would also
+            // wait for every other stream, e.g. an RCCL collective whose peer needs this very host thread to make progress.)
             const auto t0 = std::chrono::steady_clock::now();
             int spins = 0;
             while (!arrived()) {
@@ -211,7 +217,7 @@ int ticket_result(int id, int wait, long long* n, unsigned* frame_flags = nullpt
                     int cur = 0;
                     (void)hipGetDevice(&cur);
                     (void)hipSetDevice(t.dev);
-                    const hipError_t e = hipDeviceSynchronize();
+                    const hipError_t e = hipStreamSynchronize(t.stream);
                     (void)hipSetDevice(cur);
                     if (e != hipSuccess || !arrived()) {
                         ticket_release(id);
@@ -553,8 +559,11 @@ int goi_raster_forward_async_cut(const GoiRasterScene* scene, void* geom_buffer,
         return -1;
     }
     // The frame's counters reach the host without a copy of their own: a wave of the forward blend stores the 32 head words
-    // into the ticket's pinned (device-mapped) words, and the event behind the blend says when (the runtime moved the 128-byte
-    // device-to-host copy as two copy kernels per frame).  A frame whose lists were CUT, or that learns a cut, may still raise
+    // into the ticket's pinned (device-mapped) words and then, behind a system-scope fence, the ticket's sequence number
+    // (STAMP_WORD): the ticket resolves when that wave has run -- i.e. when the blend has STARTED, not when the frame's kernels
+    // have finished (the counters are final before the blend starts; a caller that needs the images synchronises the stream as
+    // for any other kernel).  The runtime moved a 128-byte device-to-host copy as two copy kernels per frame, and an event behind
+    // the blend cost the stream a bubble.  A frame whose lists were CUT, or that learns a cut, may still raise
     // its flag inside the blend (the cut is checked there, whether or not zcut_out was given), so it keeps the copy behind the
     // kernel: the words a blend wave stores are a snapshot taken when the kernel STARTS.
     uint32_t* host_words = nullptr;
@@ -568,6 +577,7 @@ int goi_raster_forward_async_cut(const GoiRasterScene* scene, void* geom_buffer,
             stamp = tk.seq;
             tk.head_only = true;
             tk.stamped = true;  // no copy, no event: ticket_result compares pinned[STAMP_WORD] with seq
+            tk.stream = s;
         }
     }
     {
@@ -968,7 +978,12 @@ int goi_raster_set_option(const char* name, int value) {
     else if (!strcmp(name, "sort_variant")) g_options.sort_variant = value;
     else if (!strcmp(name, "sort_small")) g_options.sort_small = value;
     else if (!strcmp(name, "sort_lookback")) g_options.sort_lookback = value;
-    else if (!strcmp(name, "sort_tickets")) g_options.sort_tickets = value;
+    else if (!strcmp(name, "sort_tickets")) {
+        // 0 is an EXPERIMENT that is only safe while the hardware starts workgroups in index order (HIP promises no such thing: a
+        // tile could wait for a workgroup that never starts): refused unless the process opts in explicitly
+        if (value == 0 && !getenv("GOI_UNSAFE_EXPERIMENTS")) return fail("sort_tickets 0 is an unsafe experiment: set GOI_UNSAFE_EXPERIMENTS=1 to allow it");
+        g_options.sort_tickets = value;
+    }
     else if (!strcmp(name, "cull_variant")) g_options.cull_variant = value;
     else if (!strcmp(name, "bwd_order")) {
         if (value < 0 || value > 8) return fail("bwd_order must be 0 .. 8");

@@ -520,8 +520,12 @@ void launch_emit(int P, int W, int H, const GeomView& g, const uint32_t* order, 
 
 bool emit_can_count_tiles(int W, int H) {
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
-    // (tile_ranges_hist_k: at most TRH_MAX_IT x 1024 tiles; the per-tile LDS counters of emit: 48 KB)
-    return (size_t)gx * gy <= (size_t)TRH_MAX_IT * 1024 && (size_t)gx * gy * sizeof(uint32_t) <= 48 * 1024 &&
+    // (tile_ranges_hist_k: at most TRH_MAX_IT x 1024 tiles; the per-tile LDS counters of emit are DYNAMIC LDS on top of the
+    // kernel's static arrays -- 28.2 KB in the 1024-thread form: masks 8, info 16, widths 4 KB -- and the sum has to stay inside
+    // the 64 KB a workgroup may be given without asking for more: 8 960 tiles, e.g. 2048 x 1120.  Larger grids take the
+    // non-counting emit + ranges_k.)
+    constexpr size_t EMIT_STATIC_LDS = 16 * 64 * (sizeof(unsigned long long) + sizeof(uint4) + sizeof(int)) + 16 * sizeof(unsigned long long);
+    return (size_t)gx * gy <= (size_t)TRH_MAX_IT * 1024 && (size_t)gx * gy * sizeof(uint32_t) + EMIT_STATIC_LDS <= 64 * 1024 &&
            tile_key_bits((uint32_t)(gx * gy)) <= 16;
 }
 

@@ -74,8 +74,8 @@ class Camera:
 
 
 def make_camera(width: int, height: int, fovx: float = 1.0, yaw: float = 0.0, pitch: float = 0.0,
-                distance: float = 5.0) -> Camera:
-    """Camera on a sphere of radius ``distance`` around the origin, looking at the origin.
+                distance: float = 5.0, target=(0.0, 0.0, 0.0)) -> Camera:
+    """Camera on a sphere of radius ``distance`` around ``target`` (default: the origin), looking at it.
     yaw = pitch = 0 is SURVEY 8(d)'s canonical view: camera at (0,0,-5) looking down +z, i.e.
     W2C = [I | (0,0,5)]."""
     tanfovx = math.tan(0.5 * fovx)
@@ -86,7 +86,7 @@ def make_camera(width: int, height: int, fovx: float = 1.0, yaw: float = 0.0, pi
     Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]], dtype=np.float64)
     Rx = np.array([[1, 0, 0], [0, cp, -sp], [0, sp, cp]], dtype=np.float64)
     R_w2c = Rx @ Ry  # world -> camera rotation
-    t = np.array([0.0, 0.0, distance])
+    t = np.array([0.0, 0.0, distance]) - R_w2c @ np.asarray(target, dtype=np.float64)  # x_cam = R (x - target) + (0, 0, d)
     w2c = world_to_view(R_w2c.T, t)  # world_to_view transposes its argument back
     view_T = np.ascontiguousarray(w2c.T)
     proj_T = np.ascontiguousarray(projection_matrix(ZNEAR, ZFAR, fovx, fovy).T)
@@ -266,6 +266,27 @@ HEADLINE = dict(P=1_000_000, S=16, W=1600, H=1056, extent=(4.0, 2.64, 1.0), log_
 CLUSTERED = dict(P=1_000_000, S=16, W=1600, H=1056, extent=(4.0, 2.64, 1.0), log_scale_mean=-5.2, log_scale_std=1.1, fovx=1.0)
 CLOSEUP = dict(P=3_000_000, S=16, W=512, H=512, extent=(4.0, 2.64, 1.0), log_scale_mean=-4.9, log_scale_std=1.1, fovx=0.6,
                distance=3.2, yaw=0.3, pitch=-0.12)
+
+
+ORBIT = dict(views=16, distance=3.0, target_radius=2.6, visit_stride=7)
+
+
+def make_orbit_cameras(width: int, height: int, fovx: float = 1.0, n: int = ORBIT["views"], distance: float = ORBIT["distance"],
+                       target_radius: float = ORBIT["target_radius"], visit_stride: int = ORBIT["visit_stride"]):
+    """A capture orbit instead of one direction: ``n`` cameras whose look-at points travel once around the scene (an ellipse of
+    radius ``target_radius`` in x, with a wobble in y and z) while the viewing direction turns with them, each ``distance`` from
+    its target -- the way the training views of a reconstruction surround their scene (scene/dataset_readers.py).  Returned in
+    VISIT order: step k renders orbit position (k * visit_stride) mod n, so consecutive steps look at different parts of the
+    scene from different sides (train.py:118-124 pops its cameras at random).  On the headline box consecutive views share
+    ~30 % of their visible Gaussians (bench.py measures and reports the figure on the device)."""
+    cams = []
+    for k in range(n):
+        i = (k * visit_stride) % n
+        th = 2.0 * math.pi * i / n
+        target = (target_radius * math.cos(th), 0.6 * math.sin(2.0 * th), 0.3 * math.sin(th))
+        cams.append(make_camera(width, height, fovx=fovx, yaw=th + 0.4 * math.sin(3.0 * th), pitch=0.15 * math.sin(2.0 * th + 1.0),
+                                distance=distance, target=target))
+    return cams
 
 
 def make_workload(name: str, P: int | None = None, S: int | None = None, seed: int = 0):

@@ -63,7 +63,7 @@ typedef struct GoiRasterScene {
     int W, H;                    /* image width, height */
     const float* bg;             /* [3] */
     const float* means3D;        /* [P,3] */
-    const float* shs;            /* [P,M,3] or NULL */
+    const float* shs;            /* [P,M,3] or NULL; 16-byte aligned when 3 M is a multiple of 4 (rows move as 16-byte words) */
     const float* colors_precomp; /* [P,3] or NULL */
     const float* semantics;      /* [P,S] (forward/backward) */
     const float* opacities;      /* [P] */
@@ -125,6 +125,9 @@ int goi_raster_forward(const GoiRasterScene* scene, void* geom_buffer, void* ima
  *
  * goi_raster_forward_redo reads only P, S, W, H, semantics and bg from `scene` (the other fields may be NULL).
  * Nothing here waits for the device unless asked to (wait != 0).  Every ticket must be resolved exactly once.
+ * A resolved ticket means the COUNT has arrived -- it is final before the frame's blend kernel starts -- not that the frame's
+ * kernels have finished: the outputs are ordered on `stream` like any other kernel's.  A blocking wait spins on host memory;
+ * after two seconds it synchronises the frame's stream (not the device) and fails loudly rather than hang.
  * Not available with scene->debug (which synchronises after every stage) or for P == 0. */
 int goi_raster_forward_async(const GoiRasterScene* scene, void* geom_buffer, void* image_buffer, void* binning_buffer,
                              int capacity, float* out_color, float* out_semantic, float* out_depth, float* out_alpha,

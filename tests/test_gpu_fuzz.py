@@ -34,6 +34,10 @@ def configs(n=None, seed=None):
 
 @pytest.mark.parametrize("k,P,S,W,H,mu,deg,yaw,pitch", configs())
 def test_random_configuration(oracle_mod, dev, k, P, S, W, H, mu, deg, yaw, pitch):  # noqa: F811
+    check_configuration(oracle_mod, dev, k, P, S, W, H, mu, deg, yaw, pitch)
+
+
+def check_configuration(oracle_mod, dev, k, P, S, W, H, mu, deg, yaw, pitch):  # noqa: F811
     sc = make_scene(P, S=S, sh_degree=deg, seed=100 + k, log_scale_mean=mu)
     cam = make_camera(W, H, yaw=yaw, pitch=pitch)
     bg = np.random.default_rng(k).random(3).astype(np.float32)
@@ -123,3 +127,23 @@ def test_soak_regression_is_within_the_plain_tolerance(oracle_mod, dev, k, n, se
     tag = f"soak{seed}_{k}_P{P}_S{S}_{W}x{H}"
     check_forward(res, f, tag)
     check_backward(res["grads"], o.backward(*grads), tag)
+
+
+# The KNOWN OUTLIER of the round-5 soak (profiles/r05_soaks.txt): configuration 1185 of GOI_FUZZ_N=1500 GOI_FUZZ_SEED=66001
+# (P = 257, S = 17, 173 x 157) is outside EVERY criterion of check_configuration: ONE of its 1 028 rotation-gradient elements is
+# 3.11e-3 of the tensor's scale from the oracle where the oracle's own plain and FMA-contracted builds differ by 9.1e-4 (three
+# times that, 2.74e-3, is what the sweep allows).  Float64 yardstick (tools/soak_f64.py 1500 66001 2e-3): |hip - f64| 1.28e-2,
+# |oracle - f64| 9.67e-3 -- the reference's own fp32 order is 1e-2 from float64 on that element (an ill-conditioned needle,
+# DESIGN.md section 2), the oracle is the closer one, and the exact-fp32 flush (bwd_variant 2) gives 2.48e-3.  1 of 2 701 soaked
+# configurations in round 5 (rounds 1-4: 4 of 18 200).  The criteria are not widened for it: it sits here as a strict xfail so
+# that the outlier is visible in every `-m gpu` run -- and so that a build on which it starts to pass says so.
+KNOWN_OUTLIERS = [(1185, 1500, 66001)]
+
+
+@pytest.mark.gpu
+@pytest.mark.xfail(strict=True, reason="known ill-conditioned-needle outlier of the round-5 soak: 3.1e-3 on one dL/drotation "
+                                       "element (tolerance 2.74e-3 = 3 x the oracle builds' own spread); float64 figures above")
+@pytest.mark.parametrize("k,n,seed", KNOWN_OUTLIERS)
+def test_known_soak_outlier_stays_visible(oracle_mod, dev, k, n, seed):  # noqa: F811
+    cfg = [c for c in configs(n, seed) if c[0] == k][0]
+    check_configuration(oracle_mod, dev, *cfg)

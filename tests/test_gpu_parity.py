@@ -138,6 +138,9 @@ CASES = [
     (500, 32, 80, 64, -2.5, 3),       # widest supported S
     (20000, 16, 400, 300, -3.5, 3),   # BASELINE config 1 shape at S = 16
     (1500, 4, 3840, 2160, -2.0, 1),   # 32 400 tiles: per-tile counters no longer fit LDS -> separate histogram / ranges passes
+    (1200, 4, 2048, 1104, -2.2, 1),   # 8 832 tiles: the LARGEST grid whose per-tile counters still fit emit's LDS (35.3 KB dynamic
+                                      # + 28.2 KB static of the 1024-thread kernel <= 64 KB: binning.hip, emit_can_count_tiles)
+    (1200, 4, 2048, 1536, -2.2, 1),   # 12 288 tiles: just beyond it (48 KB of counters alone used to be admitted: 76 KB in all)
     (300, 16, 400, 300, -0.6, 2),     # every Gaussian covers most of the 475 tiles: rectangles beyond the 64-tile ellipse masks
     (150, 16, 1280, 720, -0.4, 1),    # ... and most of 3600 tiles: > 1024 instances each -> the row reduction's workgroup-per-
                                       # Gaussian path for BIG Gaussians (reduce_rows.hip)
