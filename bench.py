@@ -818,6 +818,34 @@ def main():
         two_streams = {"views_per_s": n2 / s_elapsed, "ms_per_view": s_elapsed / n2 * 1e3, "views": n2, "streams": 2,
                        "what": "two independent views in flight on two HIP streams of one GPU (same work per view)"}
         del pcs, streams
+    # ... and the same as a PRODUCT path: dist.backward_views renders the K views of a multi-view batch (config 4's "8-view batch" on
+    # fewer than 8 GPUs; --views-per-exchange K) alternating over two streams and leaves the sum of their gradients in p.grad
+    batch_fig = None
+    if world == 1 and not args.no_two_streams:
+        from goi_hyperplane_amd.dist import backward_views
+        batch_fig = {"what": "dist.backward_views: the K views of a batch between two optimiser steps, forward + backward each, their "
+                             "gradients summed into p.grad; `serial` = one after the other on one stream, `two_streams` = alternating "
+                             "over two HIP streams (the product path); views/s"}
+        for K_ in (2, 4, 8):
+            row = {}
+            for label, ns in (("serial", 1), ("two_streams", 2)):
+                def one_batch(b0):
+                    vs = [cams[(b0 * K_ + k_) % len(cams)] for k_ in range(K_)]
+                    backward_views(vs, lambda cam_: render(cam_, pc, pipe, bg),
+                                   lambda o_, k_: ((o_["render"], o_["semantics"]), (g_color, g_sem)), params, streams=ns)
+                for b0 in range(3):
+                    one_batch(b0)
+                torch.cuda.synchronize(dev)
+                q0 = time.perf_counter()
+                nb = max(3, min(args.steps, 32) // K_)
+                for b0 in range(nb):
+                    one_batch(b0)
+                torch.cuda.synchronize(dev)
+                row[label] = round(nb * K_ / (time.perf_counter() - q0), 2)
+            row["gain"] = round(row["two_streams"] / row["serial"], 4)
+            batch_fig[f"K={K_}"] = row
+        for p_ in params:
+            p_.grad = None
 
     # Secondary object: the SAME scene from a capture ORBIT instead of 16 cameras within +-0.16 rad of one direction
     # (scene.make_orbit_cameras: the look-at point travels around the scene, consecutive steps are seven orbit positions apart, as
@@ -1092,6 +1120,7 @@ def main():
             "semantic_train_iteration": train_iter,
             "value_two_views_in_flight": None if two_streams is None else two_streams["views_per_s"],
             "two_views_in_flight": two_streams,
+            "views_in_flight_batch": batch_fig,
             "fp32_flush": fp32_flush,
             # forward mode of the timed region and what the speculation did in it (exact_frames / waits / overflows
             # should all be 0: nothing in the timed steps waited for the device)

@@ -977,6 +977,7 @@ int goi_raster_set_option(const char* name, int value) {
     }
     else if (!strcmp(name, "sort_variant")) g_options.sort_variant = value;
     else if (!strcmp(name, "sort_small")) g_options.sort_small = value;
+    else if (!strcmp(name, "pre_shdma")) g_options.pre_shdma = value;
     else if (!strcmp(name, "sort_lookback")) g_options.sort_lookback = value;
     else if (!strcmp(name, "sort_tickets")) {
         // 0 is an EXPERIMENT that is only safe while the hardware starts workgroups in index order (HIP promises no such thing: a

@@ -111,7 +111,8 @@ size_t binning_layout(int N, char* base, BinView* v);
 
 // Tuning / experiment switches (goi_raster_set_option); defaults are the shipped configuration.
 struct Options {
-    int fwd_variant = 1;  // 0: one candidate per loop trip, 1: two candidates per trip (default)
+    int fwd_variant = 1;  // 0: one candidate per loop trip, 1: two candidates per trip (default); experiments (render_fwd.hip): 2 the
+                          // 16 pixels x 4 Gaussians mapping, 3 scalar-operand features (S = 16), 4 fp32 outer-product MFMA
     int bwd_variant = 0;  // low 4 bits: 0 atomic-free wave-per-quadrant backward (needs scratch) with the split-f16
                           // MFMA flush (fp32-grade), 2 the same with the exact-fp32 flush, 1 workgroup-per-tile + atomics
     int sort_variant = 1;  // 0: histogram / scan / scatter per pass, 1: onesweep (decoupled look-back, default)
@@ -122,6 +123,9 @@ struct Options {
     int cull_variant = 2;  // 0: a Gaussian is listed in every tile of its 3-sigma rectangle (the reference's lists),
                            // 1: only in the tiles its exact contribution box touches, 2: only in the tiles its contribution
                            // ELLIPSE reaches (rectangles of up to 64 tiles).  Same images and gradients, bit for bit.
+    int pre_shdma = 0;     // preprocess_fwd_k, SH colours with M = 16: 1 the wave moves the SH rows of its visible lanes to LDS by
+                           // DMA (EXPERIMENT, measured: 67 vs 63.5 us at 1 M, 190 vs 193 us at 3 M), 0 every lane fetches its own
+                           // row (default).  Bit-identical.
     int bwd_order = 1;     // backward blend: v >= 1 the quadrants of each XCD's band are launched longest-first (their cost is
                            // known from the forward's n_contrib; cost classes of 2^(3+v) list positions), 0 in tile order.
                            // Same rows, same gradients.

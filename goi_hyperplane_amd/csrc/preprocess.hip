@@ -88,7 +88,56 @@ __device__ __forceinline__ Camera load_camera(const float* __restrict__ v, const
     return cam;
 }
 
-__global__ __launch_bounds__(256) void preprocess_fwd_k(const PreArgs args, GaussRec* __restrict__ rec,
+// SH rows by LDS-DMA (SHDMA: SH colours with M = 16, the degree-3 layout).  A lane's colour is a sequential fp32 sum over its
+// own 192-byte row (the reference's order: the clamp bits depend on it), so the arithmetic stays per lane -- but a lane FETCHING
+// its row (sixteen 12-byte or twelve 16-byte loads at a 192-byte lane stride) makes every load instruction of the wave touch 64
+// different lines, and with 20+ waves per CU a line is fetched from L2 again for most of them: SH -> RGB was 6-12 us of a wave's
+// ~20.  Now the WAVE moves the rows of its visible lanes: global_load_lds_dwordx4 sends 16 bytes per lane from
+// memory straight to LDS (no registers), consecutive lanes taking consecutive 16-byte quads of consecutive VISIBLE rows (ranked
+// by a ballot; a culled Gaussian's row is never requested), so an instruction reads ~5 rows as ~10 whole lines; the requests
+// are issued as soon as the visibility is known and travel under the contribution box / ellipse tile mask work; then every
+// visible lane reads its row from LDS (row stride 13 quads = 52 dwords: eight lanes of a ds_read_b128 cover the 32 banks once)
+// and runs the same statement sequence as before: bit-identical colours and clamp bits.  LDS holds SH_ROWS_CAP rows per wave
+// (7.3 KB: five waves per SIMD, what the registers allow); the ~1 in 6 waves with more visible lanes take a second trip.
+#ifndef GOI_PRE_SH_ROWS
+#define GOI_PRE_SH_ROWS 36
+#endif
+constexpr int SH_ROWS_CAP = GOI_PRE_SH_ROWS;
+constexpr int SH_ROW_QUADS = 13;  // 12 quads of coefficients + 1 of padding
+
+template <typename SHK_T>
+__device__ __forceinline__ V3 sh_to_rgb_sum(int D, const V3& dir, SHK_T SHK) {
+    V3 res = kSH0 * SHK(0);
+    if (D > 0) {
+        const float x = dir.x, y = dir.y, z = dir.z;
+        res = res - kSH1 * y * SHK(1) + kSH1 * z * SHK(2) - kSH1 * x * SHK(3);
+        if (D > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            res = res + kSH2[0] * xy * SHK(4) + kSH2[1] * yz * SHK(5) + kSH2[2] * (2.0f * zz - xx - yy) * SHK(6) +
+                  kSH2[3] * xz * SHK(7) + kSH2[4] * (xx - yy) * SHK(8);
+            if (D > 2) {
+                res = res + kSH3[0] * y * (3.0f * xx - yy) * SHK(9) + kSH3[1] * xy * z * SHK(10) +
+                      kSH3[2] * y * (4.0f * zz - xx - yy) * SHK(11) +
+                      kSH3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * SHK(12) +
+                      kSH3[4] * x * (4.0f * zz - xx - yy) * SHK(13) + kSH3[5] * z * (xx - yy) * SHK(14) +
+                      kSH3[6] * x * (xx - 3.0f * yy) * SHK(15);
+            }
+        }
+    }
+    return res + V3{0.5f, 0.5f, 0.5f};
+}
+
+__device__ __forceinline__ void sh_dma16(const void* global_src, void* lds_base) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_global_load_lds(global_src, lds_base, 16, 0, 0);
+#endif
+}
+
+#ifndef GOI_PRE_MINBLOCKS
+#define GOI_PRE_MINBLOCKS 1
+#endif
+template <bool SHDMA>
+__global__ __launch_bounds__(256, GOI_PRE_MINBLOCKS) void preprocess_fwd_k(const PreArgs args, GaussRec* __restrict__ rec,
                                                         float* __restrict__ cov3D_out,
                                                         uint32_t* __restrict__ tiles_touched,
                                                         uint8_t* __restrict__ clamped, uint32_t* __restrict__ raw_key,
@@ -97,6 +146,8 @@ __global__ __launch_bounds__(256) void preprocess_fwd_k(const PreArgs args, Gaus
                                                         unsigned long long* __restrict__ blk_coarse, int* __restrict__ radii,
                                                         uint32_t* __restrict__ counters, uint2* __restrict__ ranges,
                                                         int n_tiles) {
+    __shared__ __attribute__((aligned(16))) float4 s_sh[SHDMA ? 4 : 1][SHDMA ? SH_ROWS_CAP * SH_ROW_QUADS : 1];
+    __shared__ uint8_t s_rank[SHDMA ? 4 : 1][64];  // rank among the wave's visible lanes -> lane
     const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
     // the tile ranges start from zero (emit accumulates per-tile counts into them): cleared here for free
     for (int t = gtid; t < n_tiles; t += gridDim.x * blockDim.x) ranges[t] = make_uint2(0u, 0u);
@@ -121,6 +172,9 @@ __global__ __launch_bounds__(256) void preprocess_fwd_k(const PreArgs args, Gaus
 
     const V3 p = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
     const V3 p_view = xform_point_4x3(p, a.view);
+    // ---- phase A: projection, covariance, conic, radius, 3-sigma rectangle: is the Gaussian rendered at all?
+    bool vis = false;
+    float pix = 0.f, piy = 0.f, con_a = 0.f, con_b = 0.f, con_c = 0.f, my_radius = 0.f;
     do {
         if (p_view.z <= 0.2f) {
             if (a.prefiltered) atomicOr(&counters[1], 1u);  // the reference traps here
@@ -154,72 +208,55 @@ __global__ __launch_bounds__(256) void preprocess_fwd_k(const PreArgs args, Gaus
         const float det = cx * cz - cy * cy;
         if (det == 0.0f) break;
         const float det_inv = 1.f / det;
-        const float con_a = cz * det_inv, con_b = -cy * det_inv, con_c = cx * det_inv;
+        con_a = cz * det_inv;
+        con_b = -cy * det_inv;
+        con_c = cx * det_inv;
         const float mid = 0.5f * (cx + cz);
         const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
         const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
-        const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
-        const float pix = ndc_to_pix(projx, a.W), piy = ndc_to_pix(projy, a.H);
+        my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+        pix = ndc_to_pix(projx, a.W);
+        piy = ndc_to_pix(projy, a.H);
         int x0, y0, x1, y1;
         tile_rect(pix, piy, (int)my_radius, a.gx, a.gy, x0, y0, x1, y1);
         if ((x1 - x0) * (y1 - y0) == 0) break;
+        vis = live;  // (a lane past P has redone the last Gaussian up to here: it must neither rank among the wave's rows -- its
+                     // "row" would lie beyond the array -- nor store anything)
+    } while (false);
 
-        float cr, cg, cb;
-        if (a.colors_precomp) {
-            cr = a.colors_precomp[3 * idx];
-            cg = a.colors_precomp[3 * idx + 1];
-            cb = a.colors_precomp[3 * idx + 2];
-        } else {
-            const V3 campos = {a.campos[0], a.campos[1], a.campos[2]};
-            V3 dir = p - campos;
-            dir = dir / sqrtf(dot3(dir, dir));
-            // A degree-3 row (M = 16: 192 bytes, 16-byte aligned) is fetched as TWELVE 16-byte loads instead of sixteen 12-byte ones:
-            // the SH rows are this kernel's bottleneck (every load instruction of a wave touches 64 different lines -- DESIGN.md
-            // 8.2), a quarter fewer of them and none straddling a line: 75.5 -> 69.6 us on the headline frame, 204 -> 199 at 3 M
-            // (same box), although the row in flight costs the kernel its 8 waves per SIMD (64 -> 88 VGPRs).  Same values, same
-            // order of operations: bit-identical.
-            float rowf[48];
-            const bool row16 = a.M == 16;
-            if (row16) {
-                const float4* r4 = reinterpret_cast<const float4*>(a.shs + (size_t)idx * 48);
+    // ---- (SHDMA) the wave requests the SH rows of its visible lanes: rank r of the visible lanes -> row r of the wave's LDS area
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    unsigned long long vm = 0ull;
+    int nvis = 0, rank = 0;
+    const int wave_first = blockIdx.x * 256 + wv * 64;
+    auto request_rows = [&](int r0) {  // rows of ranks [r0, r0 + SH_ROWS_CAP): quad k of rank r travels to slot 13 r + k
+        const int nslots = min(SH_ROWS_CAP, nvis - r0) * SH_ROW_QUADS;
 #pragma unroll
-                for (int i = 0; i < 12; i++) {
-                    const float4 v = r4[i];
-                    rowf[4 * i] = v.x;
-                    rowf[4 * i + 1] = v.y;
-                    rowf[4 * i + 2] = v.z;
-                    rowf[4 * i + 3] = v.w;
-                }
+        for (int i = 0; i < (SH_ROWS_CAP * SH_ROW_QUADS + 63) / 64; i++) {
+            if (i * 64 >= nslots) break;  // (wave-uniform)
+            const int sl = i * 64 + lane;
+            const int r = (sl * 5042) >> 16, q = sl - SH_ROW_QUADS * r;  // sl / 13 (exact below 1100), sl % 13
+            if (sl < nslots && q < SH_ROW_QUADS - 1) {
+                const int src = s_rank[wv][r0 + r];
+                sh_dma16(a.shs + ((size_t)(wave_first + src) * 48 + 4 * q), &s_sh[wv][i * 64]);
             }
-            const V3* shg = reinterpret_cast<const V3*>(a.shs) + (size_t)idx * a.M;
-            auto SHK = [&](int k) { return row16 ? V3{rowf[3 * k], rowf[3 * k + 1], rowf[3 * k + 2]} : shg[k]; };
-            V3 res = kSH0 * SHK(0);
-            if (a.D > 0) {
-                const float x = dir.x, y = dir.y, z = dir.z;
-                res = res - kSH1 * y * SHK(1) + kSH1 * z * SHK(2) - kSH1 * x * SHK(3);
-                if (a.D > 1) {
-                    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-                    res = res + kSH2[0] * xy * SHK(4) + kSH2[1] * yz * SHK(5) + kSH2[2] * (2.0f * zz - xx - yy) * SHK(6) +
-                          kSH2[3] * xz * SHK(7) + kSH2[4] * (xx - yy) * SHK(8);
-                    if (a.D > 2) {
-                        res = res + kSH3[0] * y * (3.0f * xx - yy) * SHK(9) + kSH3[1] * xy * z * SHK(10) +
-                              kSH3[2] * y * (4.0f * zz - xx - yy) * SHK(11) +
-                              kSH3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * SHK(12) +
-                              kSH3[4] * x * (4.0f * zz - xx - yy) * SHK(13) + kSH3[5] * z * (xx - yy) * SHK(14) +
-                              kSH3[6] * x * (xx - 3.0f * yy) * SHK(15);
-                    }
-                }
-            }
-            res = res + V3{0.5f, 0.5f, 0.5f};
-            clamp_bits = (uint8_t)((res.x < 0 ? 1 : 0) | (res.y < 0 ? 2 : 0) | (res.z < 0 ? 4 : 0));
-            cr = fmaxf(res.x, 0.0f);
-            cg = fmaxf(res.y, 0.0f);
-            cb = fmaxf(res.z, 0.0f);
         }
+    };
+    if constexpr (SHDMA) {
+        vm = __ballot(vis);
+        nvis = __popcll(vm);
+        rank = __popcll(vm & ((1ull << lane) - 1ull));
+        if (vis) s_rank[wv][rank] = (uint8_t)lane;
+        __builtin_amdgcn_wave_barrier();
+        if (nvis > 0) request_rows(0);
+    }
+
+    // ---- phase B: contribution box, listed rectangle, ellipse tile mask (nothing here needs the colour)
+    float hx = -1.f, hy = -1.f, o = 0.f;
+    if (vis) {
         // Box outside which alpha = min(0.99, o*exp(power)) < 1/255 is certain (see DESIGN.md,
         // "exact contribution box"): the ellipse power >= -tau of the COMPUTED conic, tau inflated.
-        const float o = a.opacities[idx];
-        float hx = -1.f, hy = -1.f;
+        o = a.opacities[idx];
         if (o >= 1.0f / 255.0f) {
             // In single precision, every rounding pushed OUTWARD (the box only has to contain the region; its size
             // decides nothing but how many tiles and quadrants are looked at): the double-precision log / sqrt / divide
@@ -238,12 +275,8 @@ __global__ __launch_bounds__(256) void preprocess_fwd_k(const PreArgs args, Gaus
                 hx = hy = __builtin_inff();
             }
         }
-        GaussRec r;
-        r.q0 = make_float4(pix, piy, con_a, con_b);
-        r.q1 = make_float4(con_c, o, hx, hy);       // what the hit test needs beside q0: fetched for every CANDIDATE
-        r.q2 = make_float4(cr, cg, cb, p_view.z);   // what only a HIT needs (r, g, b, depth: the first staged feature quad as it is)
-        rec[idx] = r;
         my_radius_i = (int)my_radius;
+        int x0, y0, x1, y1;
         listed_rect(pix, piy, my_radius_i, hx, hy, a.cull != 0, a.gx, a.gy, x0, y0, x1, y1);
         touched = (uint32_t)((y1 - y0) * (x1 - x0));  // may be 0 for a visible Gaussian (radius stays > 0)
         // cull_variant 2: of that rectangle, only the tiles the contribution ELLIPSE  1/2 d^T C d <= tau  reaches (the
@@ -313,15 +346,83 @@ __global__ __launch_bounds__(256) void preprocess_fwd_k(const PreArgs args, Gaus
             touched = (uint32_t)__popcll(mask);
         }
         key = __float_as_uint(p_view.z);
-    } while (false);
+    }
 
+    // everything that does not depend on the colour leaves NOW: the values are dead while the SH rows are in registers
+    if (vis) {
+        float4* r4 = reinterpret_cast<float4*>(rec + idx);
+        r4[0] = make_float4(pix, piy, con_a, con_b);
+        r4[1] = make_float4(con_c, o, hx, hy);       // what the hit test needs beside q0: fetched for every CANDIDATE
+    }
     if (live) {
         radii[idx] = my_radius_i;
         tiles_touched[idx] = touched;
-        clamped[idx] = clamp_bits;
         raw_key[idx] = key;  // depth bits by Gaussian id; compact_listed_k keeps the listed ones for the depth sort
         aux[idx] = make_uint4(0u, (uint32_t)my_radius_i, (uint32_t)tmask_v, (uint32_t)(tmask_v >> 32));  // (.x: emit)
     }
+
+    // ---- phase C: the colour
+    float cr = 0.f, cg = 0.f, cb = 0.f;
+    V3 dir = {0.f, 0.f, 0.f};
+    if (vis && !a.colors_precomp) {
+        const V3 campos = {a.campos[0], a.campos[1], a.campos[2]};
+        dir = p - campos;
+        dir = dir / sqrtf(dot3(dir, dir));
+    }
+    auto finish_colour = [&](const V3& res) {
+        clamp_bits = (uint8_t)((res.x < 0 ? 1 : 0) | (res.y < 0 ? 2 : 0) | (res.z < 0 ? 4 : 0));
+        cr = fmaxf(res.x, 0.0f);
+        cg = fmaxf(res.y, 0.0f);
+        cb = fmaxf(res.z, 0.0f);
+    };
+    if constexpr (SHDMA) {
+        for (int r0 = 0; r0 < nvis; r0 += SH_ROWS_CAP) {  // (wave-uniform: one trip for five waves in six)
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the rows are in LDS
+            __builtin_amdgcn_wave_barrier();
+            if (vis && rank >= r0 && rank < r0 + SH_ROWS_CAP) {
+                const float4* row = &s_sh[wv][(rank - r0) * SH_ROW_QUADS];
+                float rowf[48];
+#pragma unroll
+                for (int i = 0; i < 12; i++) {
+                    const float4 v = row[i];
+                    rowf[4 * i] = v.x;
+                    rowf[4 * i + 1] = v.y;
+                    rowf[4 * i + 2] = v.z;
+                    rowf[4 * i + 3] = v.w;
+                }
+                finish_colour(sh_to_rgb_sum(a.D, dir, [&](int k) { return V3{rowf[3 * k], rowf[3 * k + 1], rowf[3 * k + 2]}; }));
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (r0 + SH_ROWS_CAP < nvis) request_rows(r0 + SH_ROWS_CAP);
+        }
+    } else if (vis) {
+        if (a.colors_precomp) {
+            cr = a.colors_precomp[3 * idx];
+            cg = a.colors_precomp[3 * idx + 1];
+            cb = a.colors_precomp[3 * idx + 2];
+        } else {
+            // A degree-3 row (M = 16: 192 bytes, 16-byte aligned) is fetched as TWELVE 16-byte loads instead of sixteen 12-byte ones
+            // (this instance only runs when the LDS-DMA path above is switched off, GOI_OPTIONS pre_shdma=0: the A/B of it).
+            float rowf[48];
+            const bool row16 = a.M == 16;
+            if (row16) {
+                const float4* r4 = reinterpret_cast<const float4*>(a.shs + (size_t)idx * 48);
+#pragma unroll
+                for (int i = 0; i < 12; i++) {
+                    const float4 v = r4[i];
+                    rowf[4 * i] = v.x;
+                    rowf[4 * i + 1] = v.y;
+                    rowf[4 * i + 2] = v.z;
+                    rowf[4 * i + 3] = v.w;
+                }
+            }
+            const V3* shg = reinterpret_cast<const V3*>(a.shs) + (size_t)idx * a.M;
+            finish_colour(sh_to_rgb_sum(a.D, dir, [&](int k) { return row16 ? V3{rowf[3 * k], rowf[3 * k + 1], rowf[3 * k + 2]} : shg[k]; }));
+        }
+    }
+    // what only a HIT needs (r, g, b, depth: the first staged feature quad as it is)
+    if (vis) reinterpret_cast<float4*>(rec + idx)[2] = make_float4(cr, cg, cb, p_view.z);
+    if (live) clamped[idx] = clamp_bits;
     // num_rendered = sum of tiles_touched: order-independent, so it is formed HERE (one integer atomic per wave)
     // instead of falling out of the prefix sum after the depth sort -- the host can read it while the sort runs
     __shared__ uint32_t s_wsum[4], s_wvis[4];
@@ -948,8 +1049,13 @@ void launch_preprocess_fwd(const GoiRasterScene& sc, const GeomView& g, int* rad
     a.focal_x = sc.W / (2.0f * sc.tan_fovx);
     a.view_p = sc.viewmatrix; a.proj_p = sc.projmatrix; a.campos_p = sc.campos;
     static_assert(PRE_BLOCK == 256, "preprocess_fwd_k is written for 256-thread workgroups");
-    preprocess_fwd_k<<<dim3((sc.P + PRE_BLOCK - 1) / PRE_BLOCK), dim3(PRE_BLOCK), 0, s>>>(
-        a, g.rec, g.cov3D, g.tiles_touched, g.clamped, g.sort_keys[1], g.aux, g.blk_agg, g.blk_coarse, radii, g.counters, ranges, n_tiles);
+    // SH colours in the degree-3 layout: the wave moves its visible lanes' rows by LDS-DMA (pre_shdma 0: every lane fetches its own)
+    if (sc.shs && !sc.colors_precomp && sc.M == 16 && g_options.pre_shdma)
+        preprocess_fwd_k<true><<<dim3((sc.P + PRE_BLOCK - 1) / PRE_BLOCK), dim3(PRE_BLOCK), 0, s>>>(
+            a, g.rec, g.cov3D, g.tiles_touched, g.clamped, g.sort_keys[1], g.aux, g.blk_agg, g.blk_coarse, radii, g.counters, ranges, n_tiles);
+    else
+        preprocess_fwd_k<false><<<dim3((sc.P + PRE_BLOCK - 1) / PRE_BLOCK), dim3(PRE_BLOCK), 0, s>>>(
+            a, g.rec, g.cov3D, g.tiles_touched, g.clamped, g.sort_keys[1], g.aux, g.blk_agg, g.blk_coarse, radii, g.counters, ranges, n_tiles);
 }
 
 void launch_preprocess_bwd(const GoiRasterScene& sc, const GeomView& g, const int* radii, float* dL_dmean2D,

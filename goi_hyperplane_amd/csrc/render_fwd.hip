@@ -25,7 +25,25 @@ namespace {
 
 // LEARN: the speculative depth cut-off's per-tile learning / checking (opt-in; a template parameter because the pixel's stop
 // position costs the default kernel its fifth wave per SIMD: 82 -> 99 VGPRs)
-template <int S4, bool TRACE, bool UNROLL2, bool MASKS, bool LEARN = false>
+// Two EXPERIMENTS on the channel sums C += w f of the pair loop (10 v_pk_fma_f32 + 5 broadcast ds_read_b128 of the 36 vector
+// instructions per hit pair), both built, parity-tested (tests/test_gpu_parity.py) and MEASURED SLOWER than the packed FMAs
+// (profiles/r06_blend_bounds.txt): a timing build with the sums removed altogether runs in 184 us instead of
+// 284, so that is all there is to win, and the kernel's time follows its vector-pipe cycles to within 2 %:
+//   SFEAT (fwd_variant 3): the row of a contributing Gaussian (80 bytes, the same for all 64 lanes) never enters LDS: the wave
+//     fetches it with SCALAR loads (s_load_dwordx4 / x16; the Gaussian's id by v_readlane from its staging lane) one pair ahead
+//     into one of two SGPR sets, and the packed FMAs take the feature pair as their scalar operand.  Bit-identical images.
+//     308 us against 286: a scalar load's result can only be waited for with lgkmcnt(0), i.e. together with everything else in
+//     flight, so one pair of look-ahead is all two register sets give, and an L2 round trip is longer than a pair.
+//   OUTER (fwd_variant 4): C[pixel][channel] += w[pixel] f[channel] is a rank-one update, and v_mfma_f32_32x32x1_2b_f32 is two
+//     32 x 32 outer products of fp32 vectors (exact fp32 FMAs): block b = the quadrant's pixels 32 b .. 32 b + 31, a lane supplies
+//     its own pixel's weight as A and ONE feature channel (lane % 32; a plain ds_read_b32) as B; the 32 accumulators live in AGPRs
+//     in the matrix layout (register 16 b + r of lane l: pixel 32 b + 8 (r / 4) + 4 (l / 32) + r % 4, channel l % 32 --
+//     tools/probes/mfma_outer_probe.hip) and are transposed through LDS once, at the end of the list.  Decisions and gradients
+//     bit-identical, maps equal to the last bit or two.  328 us against 284: the instruction is 16 passes = 64 clocks of a pipe
+//     that fp32 matrix work SHARES with the vector instructions (tools/mfma_mix_probe.hip), against 40 for the ten packed FMAs it
+//     replaces: (26 x 4 + 64) / (36 x 4) = 1.17, measured 1.16.
+typedef float f32x32 __attribute__((ext_vector_type(32)));
+template <int S4, bool TRACE, bool UNROLL2, bool MASKS, bool LEARN = false, bool SFEAT = false, bool OUTER = false>
 __global__ __launch_bounds__(64) void render_fwd_k(const uint2* __restrict__ ranges,
                                                    const uint32_t* __restrict__ point_list, int W, int H, int gx,
                                                    int n_quads, int S, const GaussRec* __restrict__ rec,
@@ -38,11 +56,16 @@ __global__ __launch_bounds__(64) void render_fwd_k(const uint2* __restrict__ ran
                                                    unsigned long long* __restrict__ qmask, const float* __restrict__ zcut,
                                                    uint32_t* __restrict__ zlearn, uint32_t* __restrict__ frame_flags,
                                                    uint32_t* __restrict__ host_words, uint32_t stamp) {
+    static_assert(!(SFEAT && (TRACE || UNROLL2)), "scalar features: the plain pair loop only");
     constexpr int NF4 = TRACE ? 1 : 1 + S4;  // float4 words staged per Gaussian: (r,g,b,depth) + semantics
     constexpr int NSEM = TRACE ? 0 : 4 * S4;
     __shared__ f32x4 s_geo[64];   // (A3, A5, A1, A2) of the quadrant-centred log2-alpha polynomial (blend_common.h)
     __shared__ f32x4 s_geo2[64];  // (A0, A4, lim, -)
-    __shared__ float4 s_feat[64 * NF4];
+    static_assert(!(OUTER && (TRACE || SFEAT || 4 * NF4 > 32)), "outer-product accumulation: at most 32 channels, staged rows");
+    constexpr int NCH = 4 * NF4;                 // channels of a staged row: r, g, b, depth, semantics
+    constexpr int OSTR = NCH + 1;                // (OUTER) row stride of the final transposition [pixel][channel]
+    constexpr int FEAT4 = SFEAT ? 1 : (OUTER ? (64 * OSTR + 3) / 4 + 8 : 64 * NF4);  // (OUTER: lanes read up to 32 floats of a 20-float row)
+    __shared__ float4 s_feat[FEAT4];
     const f32x4* s_feat4 = reinterpret_cast<const f32x4*>(s_feat);
     __shared__ uint32_t s_id[TRACE ? 64 : 1];
 
@@ -79,6 +102,10 @@ __global__ __launch_bounds__(64) void render_fwd_k(const uint2* __restrict__ ran
     f32x2 Cs2[NSEM > 0 ? NSEM / 2 : 1];
 #pragma unroll
     for (int i = 0; i < NSEM / 2; i++) Cs2[i] = f32x2{0.f, 0.f};
+    f32x32 acc;  // (OUTER) register 16 b + r of lane l: pixel 32 b + 8 (r / 4) + 4 (l / 32) + r % 4, channel l % 32
+#pragma unroll
+    for (int r = 0; r < 32; r++) acc[r] = 0.f;
+    const float* s_featf = reinterpret_cast<const float*>(s_feat) + (lane & 31);  // (OUTER) this lane's channel of a staged row
 
     // software prefetch of the next batch's id / position / box (one Gaussian per lane)
     uint32_t id_n = 0;
@@ -93,7 +120,7 @@ __global__ __launch_bounds__(64) void render_fwd_k(const uint2* __restrict__ ran
             const float4* r4 = reinterpret_cast<const float4*>(rec + id_n);
             q0_n = r4[0];
             q1_n = r4[1];
-            q2_n = r4[2];
+            if constexpr (!SFEAT) q2_n = r4[2];
         }
     };
     if (rounds > 0) prefetch(0);
@@ -129,8 +156,9 @@ __global__ __launch_bounds__(64) void render_fwd_k(const uint2* __restrict__ ran
             const PolyCoef pc = poly_coefs(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, QCX, QCY);
             s_geo[lane] = f32x4{pc.A35.x, pc.A35.y, pc.A12.x, pc.A12.y};
             s_geo2[lane] = f32x4{pc.A0, pc.A4, pc.lim, 0.f};
-            s_feat[lane * NF4] = q2;  // r, g, b, depth
-            if constexpr (TRACE) {
+            if constexpr (!SFEAT) s_feat[lane * NF4] = q2;  // r, g, b, depth
+            if constexpr (SFEAT) {
+            } else if constexpr (TRACE) {
                 s_id[lane] = id;
             } else {
                 const float* srow = semantics + (size_t)id * S;
@@ -164,6 +192,9 @@ __global__ __launch_bounds__(64) void render_fwd_k(const uint2* __restrict__ ran
                 if constexpr (MASKS) asm("s_bitset1_b64 %0, %1" : "+s"(members) : "s"(j));  // members |= 1 << j, pinned to SGPRs
                 const float wgt = c ? e.alpha * T_live : 0.f;
                 const f32x2 w2 = {wgt, wgt};
+                if constexpr (OUTER) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x1f32(wgt, s_featf[j * NCH], acc, 0, 0, 0);
+                } else {
                 const f32x4 f0 = s_feat4[j * NF4];
                 C2[0] = __builtin_elementwise_fma(f0.xy, w2, C2[0]);
                 C2[1] = __builtin_elementwise_fma(f0.zw, w2, C2[1]);
@@ -182,6 +213,7 @@ __global__ __launch_bounds__(64) void render_fwd_k(const uint2* __restrict__ ran
                         atomicAdd(&num_gsem[gid], S);
                     }
                 }
+                }  // (!OUTER)
                 if (c) {
                     T = test_T;
                     last_contributor = (uint32_t)(b * 64 + j + 1);
@@ -191,7 +223,78 @@ __global__ __launch_bounds__(64) void render_fwd_k(const uint2* __restrict__ ran
                 if (c0 && !ok) stop_pos = (uint32_t)(b * 64 + j + 1);  // (the depth cut-off must keep this entry)
             T_live = c0 ? (ok ? test_T : 0.0f) : T_live;
         };
-        if constexpr (UNROLL2) {
+        if constexpr (SFEAT) {
+            // software pipeline, one pair ahead: the coefficients (LDS) and the feature row (scalar loads) of the NEXT hit are
+            // requested before the current one is evaluated; one wait per trip (scalar loads return out of order: any wait for
+            // them is a wait for all, so nothing else may be requested between a wait and its uses)
+            typedef float f32x16 __attribute__((ext_vector_type(16)));
+            static_assert(S4 == 4, "scalar features: S = 16 (one s_load_dwordx16 per row)");
+            struct Feat {
+                f32x4 c;     // r, g, b, depth
+                f32x16 s;    // semantic row
+            };
+            // (inline assembly: the compiler sinks scalar loads it knows about to just in front of their wait -- and then nothing
+            // overlaps; requested here, they are in flight while the current pair is evaluated.  The wait below is the builtin, which
+            // the compiler's own bookkeeping of the LDS reads understands.)
+            auto request = [&](int jj, Feat& F) {
+                const uint32_t gid = (uint32_t)__builtin_amdgcn_readlane((int)id, jj);  // the staging lane's Gaussian
+                const GaussRec* pr = rec + gid;
+                const float* ps = semantics + (size_t)gid * 16;
+                asm volatile("s_load_dwordx4 %0, %1, 0x20" : "=&s"(F.c) : "s"(pr));
+                asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=&s"(F.s) : "s"(ps));
+            };
+            auto arrived = [&](Feat& F) {
+                __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+                asm volatile("" : "+s"(F.c), "+s"(F.s));  // (the uses below stay below)
+            };
+            auto accumulate = [&](int j, const PairEval& e, const Feat& F) {
+                const float test_T = T_live * (1.f - e.alpha);
+                const bool c0 = e.hit;
+                const bool ok = test_T >= kTMin;
+                const bool c = c0 && ok;
+                const bool some = any_all(e.below, e.seen, ok);
+                if (some) {
+                    if constexpr (MASKS) asm("s_bitset1_b64 %0, %1" : "+s"(members) : "s"(j));
+                    const float wgt = c ? e.alpha * T_live : 0.f;
+                    const f32x2 w2 = {wgt, wgt};
+                    C2[0] = __builtin_elementwise_fma(F.c.xy, w2, C2[0]);
+                    C2[1] = __builtin_elementwise_fma(F.c.zw, w2, C2[1]);
+#pragma unroll
+                    for (int i = 0; i < 8; i++)
+                        Cs2[i] = __builtin_elementwise_fma(f32x2{F.s[2 * i], F.s[2 * i + 1]}, w2, Cs2[i]);
+                    if (c) {
+                        T = test_T;
+                        last_contributor = (uint32_t)(b * 64 + j + 1);
+                    }
+                }
+                if constexpr (LEARN)
+                    if (c0 && !ok) stop_pos = (uint32_t)(b * 64 + j + 1);
+                T_live = c0 ? (ok ? test_T : 0.0f) : T_live;
+            };
+            if (m) {
+                int j = __builtin_ctzll(m);
+                Feat Fa, Fb;  // two register sets, used in turn (no copies at the end of a trip)
+                f32x4 ga = s_geo[j], ga2 = s_geo2[j], gb, gb2;
+                request(j, Fa);
+                // one pair: wait for its row, request the next hit's row and coefficients into the OTHER set, evaluate; false = done
+                auto trip = [&](Feat& F, const f32x4& g, const f32x4& g2, Feat& Fn, f32x4& gn, f32x4& gn2) {
+                    arrived(F);
+                    m &= m - 1;
+                    const bool more = m != 0;
+                    const int jn = more ? __builtin_ctzll(m) : j;
+                    request(jn, Fn);
+                    gn = s_geo[jn];
+                    gn2 = s_geo2[jn];
+                    const PairEval e = eval_poly(g.xy, g.zw, g2.x, g2.y, g2.z, uv);
+                    accumulate(j, e, F);
+                    j = jn;
+                    return more && !all_done();
+                };
+                while (trip(Fa, ga, ga2, Fb, gb, gb2) && trip(Fb, gb, gb2, Fa, ga, ga2)) {
+                }
+                __builtin_amdgcn_s_waitcnt(0xC07F);  // (the last request is never used: it must not land in registers that live on)
+            }
+        } else if constexpr (UNROLL2) {
             // two candidates per trip: their alpha evaluations are independent (ILP, half the
             // branches); the state update stays strictly in list order
             while (m) {
@@ -264,6 +367,25 @@ __global__ __launch_bounds__(64) void render_fwd_k(const uint2* __restrict__ ran
         const int qc = wave_max_i32((int)last_contributor);
         if (qcost && lane == 0) qcost[tq] = (uint32_t)qc;
     }
+    if constexpr (OUTER) {
+        // matrix layout -> one pixel per lane: [pixel][channel] through LDS (the staging area is free now), once per wave
+        float* s_out = reinterpret_cast<float*>(s_feat);
+        const int ch = lane & 31;
+        __builtin_amdgcn_wave_barrier();
+        if (ch < NCH) {
+#pragma unroll
+            for (int r = 0; r < 32; r++) {
+                const int pix = 32 * (r >> 4) + 8 * ((r & 15) >> 2) + 4 * (lane >> 5) + (r & 3);
+                s_out[pix * OSTR + ch] = acc[r];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const float* mine = s_out + lane * OSTR;
+        C2[0] = f32x2{mine[0], mine[1]};
+        C2[1] = f32x2{mine[2], mine[3]};
+#pragma unroll
+        for (int i = 0; i < NSEM / 2; i++) Cs2[i] = f32x2{mine[4 + 2 * i], mine[5 + 2 * i]};
+    }
     if (t.inside) {
         n_contrib[pix_id] = last_contributor;
         out_color[0 * HW + pix_id] = C2[0].x + T * bg[0];
@@ -307,7 +429,26 @@ void launch_fwd_s4(const GoiRasterScene& sc, const GeomView& g, const ImageView&
 #else
     const bool masks = qmask != nullptr;
 #endif
-    if (g_options.fwd_variant == 1) {
+    if constexpr (S4 <= 7) {
+        // fwd_variant 4 (EXPERIMENT, measured negative: profiles/r06_blend_bounds.txt): outer-product accumulation on the fp32 matrix
+        // instruction; frames with a depth cut keep the default kernel
+        if (g_options.fwd_variant == 4 && masks && !zlearn && !zcut) {
+            render_fwd_k<S4, false, true, true, false, false, true><<<dim3(quad_grid(n_quads)), dim3(64), 0, s>>>(
+                im.ranges, point_list, sc.W, sc.H, gx, n_quads, sc.S, g.rec, sc.semantics, sc.bg, out_color, out_sem, out_depth,
+                out_alpha, im.n_contrib, nullptr, nullptr, nullptr, im.qcost, im.qmask0, qmask, zcut, zlearn,
+                g.counters + COUNTER_OVF, host_words, stamp);
+            return;
+        }
+    }
+    bool scalar_features = false;
+    if constexpr (S4 == 4) scalar_features = g_options.fwd_variant == 3 && sc.S == 16 && masks && !zlearn && !zcut;
+    if (scalar_features) {
+        if constexpr (S4 == 4)
+            render_fwd_k<S4, false, false, true, false, true><<<dim3(quad_grid(n_quads)), dim3(64), 0, s>>>(
+                im.ranges, point_list, sc.W, sc.H, gx, n_quads, sc.S, g.rec, sc.semantics, sc.bg, out_color, out_sem, out_depth,
+                out_alpha, im.n_contrib, nullptr, nullptr, nullptr, im.qcost, im.qmask0, qmask, zcut, zlearn,
+                g.counters + COUNTER_OVF, host_words, stamp);
+    } else if (g_options.fwd_variant == 1 || g_options.fwd_variant >= 3) {
         if (masks) GOI_LAUNCH_FWD(true, true);
         else GOI_LAUNCH_FWD(true, false);
     } else {

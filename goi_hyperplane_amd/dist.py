@@ -438,3 +438,88 @@ def allreduce_gradients_sh_factored_async(params, sh_leaves, means3D, factor, di
     h = PendingExchange(works, (grads, spans, gcol, campos, all_g, all_c), finish)
     h.sh_grads = result  # id(leaf) -> its reduced dL/dSH part, filled by wait() (the leaves' .grad may have moved on)
     return h
+
+
+# ---- a multi-view batch on ONE rank: the K views of a rank's share of a batch, in flight on several HIP streams -----------------
+_VIEW_STREAMS = {}  # (device index, n) -> list of side streams (created once: a stream owns its allocator pool and its scratch)
+
+
+def _view_streams(dev: torch.device, n: int):
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), n)
+    if key not in _VIEW_STREAMS:
+        _VIEW_STREAMS[key] = [torch.cuda.Stream(device=dev) for _ in range(n)]
+    return _VIEW_STREAMS[key]
+
+
+def backward_views(views, render_view, upstream, params, streams: int = 2, accumulate: bool = False):
+    """Forward + backward of the K views of a multi-view batch (BASELINE config 4's "8-view batch" on fewer than 8 GPUs, or
+    --views-per-exchange K before one gradient exchange) with the views ALTERNATING over `streams` HIP streams of this GPU,
+    and the SUM of their gradients left in `p.grad` of every parameter -- what K serial `loss.backward()` calls leave there.
+
+    Independent views overlap: one view's latency-bound kernels (the sorts and scans of its front end, kernel tails) run
+    beside the other view's blends; on one MI355X two streams render 1.10x the views per second of one (bench.py,
+    `views_in_flight_batch`).  train.py's own loop (one view, optimiser step, next view: train.py:96-198) cannot do this;
+    a batch of views between two optimiser steps can.
+
+      views        sequence of K view descriptors (cameras)
+      render_view  view -> dict of outputs (e.g. lambda cam: render(cam, pc, pipe, bg))
+      upstream     (outputs, k) -> (tensors, grad_tensors): what torch.autograd.grad differentiates for view k
+      params       the leaves whose gradients are wanted (every one must take part in every view's graph, or be unused in all)
+      streams      HIP streams the views alternate over (1 = one after the other on the current stream)
+      accumulate   add to the gradients already in p.grad instead of replacing them
+
+    Stream s sums the gradients of ITS views (views s, s + streams, ...) in view order with torch.autograd.grad -- never through
+    p.grad, which two streams would race on -- and the current stream adds the per-stream sums in stream order once all are
+    done: for K = 2 that is g0 + g1, bit-identical to the serial sum; beyond, (g0 + g2 + ...) + (g1 + g3 + ...): the serial
+    sum up to the association of fp32 additions (tests/test_gpu_dist.py).  Returns the list of per-view outputs (detached)."""
+    params = [p for p in params if p.requires_grad]
+    if not views:
+        return []
+    dev = params[0].device
+    n = max(1, min(int(streams), len(views)))
+    cur = torch.cuda.current_stream(dev)
+    side = [cur] if n == 1 else _view_streams(dev, n)
+    sums = [None] * n
+    outs = [None] * len(views)
+    for s_ in side:
+        if s_ is not cur:
+            s_.wait_stream(cur)  # the parameters' latest values (an optimiser step on the current stream) are visible
+    for k, view in enumerate(views):
+        si = k % n
+        with torch.cuda.stream(side[si]):
+            out = render_view(view)
+            tensors, grads = upstream(out, k)
+            g = torch.autograd.grad(tensors, params, grads, allow_unused=True)
+            if sums[si] is None:
+                sums[si] = [None if t is None else t for t in g]
+            else:
+                for i, t in enumerate(g):
+                    if t is None:
+                        continue
+                    if sums[si][i] is None:
+                        sums[si][i] = t
+                    else:
+                        sums[si][i] = sums[si][i] + t  # (out of place: a gradient may be a view of the rasterizer's pooled buffer)
+            outs[k] = {key: (v.detach() if torch.is_tensor(v) else v) for key, v in out.items()}
+            for t in g:  # the caching allocator must not hand these blocks to another stream before this one is done with them
+                if t is not None and side[si] is not cur:
+                    t.record_stream(side[si])
+    for s_ in side:
+        if s_ is not cur:
+            cur.wait_stream(s_)
+    for i, p in enumerate(params):
+        tot = None
+        for si in range(n):
+            t = None if sums[si] is None else sums[si][i]
+            if t is None:
+                continue
+            if side[si] is not cur:
+                t.record_stream(cur)
+            tot = t if tot is None else tot + t
+        if tot is None:
+            continue
+        if accumulate and p.grad is not None:
+            p.grad = p.grad + tot
+        else:
+            p.grad = tot
+    return outs

@@ -276,7 +276,11 @@ int goi_raster_profile_collect(double* ms, int* calls);
 /* Tuning / experiment switches; the defaults are the shipped configuration.
  *   "fwd_variant"  1 (default) two candidates per loop trip in the forward blend, 0 one; 2 the EXPERIMENTAL 16 pixels x 4 list
  *                  entries mapping (csrc/render_fwd_g4.hip; S <= 16, frames without a depth cut): same n_contrib, alpha, member
- *                  masks and gradients bit for bit, channel sums differ by one fp32 association; 1.7x slower
+ *                  masks and gradients bit for bit, channel sums differ by one fp32 association; 1.7x slower;
+ *                  3 EXPERIMENT (S = 16): a contributing Gaussian's feature row reaches the packed FMAs as scalar operands through
+ *                  scalar loads instead of broadcast LDS reads (bit-identical; 1.08x slower); 4 EXPERIMENT (S <= 28): the channel
+ *                  sums as fp32 outer products on v_mfma_f32_32x32x1_2b_f32 (decisions and gradients bit-identical; 1.16x slower)
+ *                  -- DESIGN.md section 9, profiles/r06_blend_bounds.txt
  *   "bwd_variant"  0 (default) atomic-free backward; the per-Gaussian sums over pixels run at the 16-bit matrix rate on
  *                  split operands that keep fp32 accuracy (two f16 planes of exactly scaled values, all four partial
  *                  products, fp32 accumulation: indistinguishable from the fp32 chain at the noise level of two builds of
@@ -293,6 +297,9 @@ int goi_raster_profile_collect(double* ms, int* calls);
  *                  HIP promises no dispatch order)
  *   "sort_small"   0 (default) sorts of up to 2 M keys use 1024 x 4-key tiles; 1 they take the adaptive 512 x (2..16) tile that
  *                  larger sorts choose from the device-side count (slower for them: DESIGN.md 8.2); same order either way
+ *   "pre_shdma"    0 (default) every lane of the per-Gaussian forward fetches its own degree-3 SH row; 1 EXPERIMENT: the wave moves
+ *                  the rows of its visible Gaussians to LDS by DMA (coalesced, culled rows never requested): measured slower at
+ *                  1 M Gaussians (67 vs 63.5 us), level at 3 M.  Bit-identical
  *   "cull_variant" 2 (default) a Gaussian is listed only in the tiles its contribution ellipse (alpha >= 1/255) reaches,
  *                  1 in the tiles its axis-aligned contribution box touches, 0 in the reference's 3-sigma squares.
  *                  Identical images; gradients equal up to the order of one fp32 sum

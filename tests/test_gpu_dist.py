@@ -223,3 +223,59 @@ print("OK", rank, hits, dirty, fresh)
     outs = [p.communicate(timeout=600) for p in procs]
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0 and "OK" in so, (so[-500:], se[-3000:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,streams", [(2, 2), (4, 2), (5, 3), (3, 1)])
+def test_views_of_a_batch_in_flight_sum_to_the_serial_gradient(K, streams):
+    """dist.backward_views: the K views of a multi-view batch alternate over several HIP streams of one GPU and the sum of their
+    gradients lands in p.grad.  K = 2 on two streams is g0 + g1 -- bit-identical to two serial backward calls accumulating into
+    p.grad; with more views per stream the sum is associated differently ((g0 + g2) + (g1 + g3)): equal to the serial sum to a few
+    ulps of the largest term.  The per-view outputs are those of the serial renders, bit for bit."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from goi_hyperplane_amd.dist import backward_views
+    from goi_hyperplane_amd.render import GaussianSet, PipelineParams, TorchCamera, render
+    from goi_hyperplane_amd.scene import make_camera, make_scene
+    dev = torch.device("cuda:0")
+    sc = make_scene(30000, S=16, sh_degree=3, seed=8, log_scale_mean=-3.3)
+    pc = GaussianSet.from_scene(sc, dev)
+    W, H = 320, 208
+    cams = [TorchCamera(make_camera(W, H, fovx=0.6, yaw=0.3 * k - 0.5, pitch=0.05 * k), dev) for k in range(K)]
+    gen = torch.Generator(device=dev).manual_seed(11)
+    ups = [(torch.randn((3, H, W), device=dev, generator=gen) / (W * H), torch.randn((16, H, W), device=dev, generator=gen) / (W * H))
+           for _ in range(K)]
+    params = list(pc.parameters())
+    bg = torch.zeros(3, device=dev)
+    pipe = PipelineParams()
+    # the serial reference: K backward calls accumulating into p.grad
+    for p in params:
+        p.grad = None
+    ref_out = []
+    for k in range(K):
+        o = render(cams[k], pc, pipe, bg)
+        torch.autograd.backward((o["render"], o["semantics"]), ups[k])
+        ref_out.append({key: o[key].detach().clone() for key in ("render", "semantics", "radii")})
+    torch.cuda.synchronize()
+    want = [p.grad.clone() for p in params]
+    for rep in range(2):  # (twice: the second batch reuses the streams' pooled buffers and scratch)
+        for p in params:
+            p.grad = None
+        outs = backward_views(cams, lambda cam: render(cam, pc, pipe, bg), lambda o, k: ((o["render"], o["semantics"]), ups[k]),
+                              params, streams=streams)
+        torch.cuda.synchronize()
+        for k in range(K):
+            for key in ("render", "semantics", "radii"):
+                assert torch.equal(outs[k][key], ref_out[k][key]), (rep, k, key)
+        for p, w in zip(params, want):
+            if K <= 2 or streams == 1:
+                assert torch.equal(p.grad, w), rep
+            else:
+                scale = float(w.abs().max())
+                assert float((p.grad - w).abs().max()) <= 4e-6 * scale + 1e-12, rep
+    # accumulate=True adds to what is there
+    backward_views(cams[:2], lambda cam: render(cam, pc, pipe, bg), lambda o, k: ((o["render"], o["semantics"]), ups[k]), params,
+                   streams=2, accumulate=True)
+    torch.cuda.synchronize()
+    assert all(not torch.equal(p.grad, w) for p, w in zip(params[:1], want[:1]))

@@ -907,7 +907,7 @@ def test_runs_on_a_side_stream_with_identical_results(dev):
         assert torch.equal(x, y)
 
 
-@pytest.mark.parametrize("option,value", [("bwd_variant", 1), ("bwd_variant", 2), ("fwd_variant", 0), ("fwd_variant", 2), ("sort_variant", 0), ("cull_variant", 0), ("bwd_records", 0),
+@pytest.mark.parametrize("option,value", [("bwd_variant", 1), ("bwd_variant", 2), ("fwd_variant", 0), ("fwd_variant", 2), ("fwd_variant", 3), ("fwd_variant", 4), ("sort_variant", 0), ("cull_variant", 0), ("bwd_records", 0),
                                           ("cull_variant", 1), ("bwd_masks", 0), ("sort_small", 1), ("sort_lookback", 0)])
 def test_alternative_kernels_stay_correct(oracle_mod, dev, option, value):
     """The non-default variants kept behind goi_raster_set_option (tile + atomics backward, one-candidate forward
@@ -944,6 +944,62 @@ def test_pixels_x_gaussians_forward_takes_the_same_decisions(dev, P, S, W, H, mu
     grads = upstream_grads(S, H, W, seed=6)
     a = run_hip(sc, cam, bg, dev, grads=grads)
     _lib.set_option("fwd_variant", 2)
+    try:
+        b = run_hip(sc, cam, bg, dev, grads=grads)
+    finally:
+        _lib.set_option("fwd_variant", 1)
+    assert np.array_equal(a["radii"], b["radii"])
+    assert np.array_equal(a["alpha"], b["alpha"])
+    for k in ("render", "semantics", "depth"):
+        scale = max(float(np.abs(a[k]).max()), 1e-6)
+        assert float(np.abs(a[k] - b[k]).max()) <= 2e-6 * scale, k
+    for k, ga in a["grads"].items():
+        if ga is not None:
+            assert np.array_equal(ga, b["grads"][k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P,S,W,H,mu", [(3000, 16, 123, 77, -2.6), (20000, 16, 400, 300, -3.2), (800, 16, 64, 48, -1.2), (40000, 16, 333, 210, -3.8)])
+def test_scalar_feature_forward_is_bit_identical(dev, P, S, W, H, mu):
+    """fwd_variant 3 (render_fwd.hip, SFEAT: a contributing Gaussian's feature row reaches the packed FMAs through scalar loads and
+    scalar operands instead of five broadcast LDS reads) against the two-candidate loop and the one-candidate loop: the same
+    products are added in the same order, so images, n_contrib, member masks and therefore all gradients are bit-identical."""
+    from goi_hyperplane_amd import _lib
+    sc = make_scene(P, S=S, sh_degree=3, seed=12, log_scale_mean=mu)
+    cam = make_camera(W, H, yaw=-0.15, pitch=0.05)
+    bg = np.array([0.2, 0.1, 0.4], np.float32)
+    grads = upstream_grads(S, H, W, seed=6)
+    res = {}
+    try:
+        for v in (1, 3, 0):
+            _lib.set_option("fwd_variant", v)
+            res[v] = run_hip(sc, cam, bg, dev, grads=grads)
+    finally:
+        _lib.set_option("fwd_variant", 1)
+    for v in (1, 0):
+        for k in ("radii", "alpha", "render", "semantics", "depth"):
+            assert np.array_equal(res[v][k], res[3][k]), (v, k)
+        for k, ga in res[v]["grads"].items():
+            if ga is not None:
+                assert np.array_equal(ga, res[3]["grads"][k]), (v, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", [4])
+@pytest.mark.parametrize("P,S,W,H,mu", [(3000, 16, 123, 77, -2.6), (20000, 16, 400, 300, -3.2), (800, 16, 64, 48, -1.2), (500, 3, 65, 49, -1.5),
+                                        (40000, 10, 333, 210, -3.8), (2000, 24, 160, 120, -2.8)])
+def test_outer_product_forward_takes_the_same_decisions(dev, variant, P, S, W, H, mu):
+    """fwd_variant 4 (render_fwd.hip, OUTER: the channel sums C += w f run on v_mfma_f32_32x32x1_2b_f32, accumulators in the
+    matrix layout, one transposition at the end) against the packed-FMA forward: everything that depends on per-pixel DECISIONS
+    (alpha, n_contrib, member masks -- hence every gradient) is bit-identical; a channel sum is the same sequence of fp32
+    multiply-adds, so the maps agree to the last bit unless the matrix unit rounds a product differently (allowed: 2e-6 of scale)."""
+    from goi_hyperplane_amd import _lib
+    sc = make_scene(P, S=S, sh_degree=3, seed=13, log_scale_mean=mu)
+    cam = make_camera(W, H, yaw=-0.15, pitch=0.05)
+    bg = np.array([0.2, 0.1, 0.4], np.float32)
+    grads = upstream_grads(S, H, W, seed=6)
+    a = run_hip(sc, cam, bg, dev, grads=grads)
+    _lib.set_option("fwd_variant", variant)
     try:
         b = run_hip(sc, cam, bg, dev, grads=grads)
     finally:
