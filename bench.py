@@ -1072,9 +1072,13 @@ def main():
             "binning_bytes": int(_l.goi_raster_binning_bytes(_cap)),
             "backward_scratch_bytes": int(_l.goi_raster_backward_scratch_bytes(_cap, args.S)),
             "backward_scratch_bytes_if_sized_by_count": int(_l.goi_raster_backward_scratch_bytes(_hw, args.S)),
-            "what": "per view in flight; the row scratch (4 quadrant rows of 128 B + a validity byte per listed instance) is "
-                    "laid out for the capacity because a speculative frame's count has not reached the host when its backward "
-                    "is enqueued; it is grow-only and shared by all frames of a (device, stream)"}
+            "row_scratch_layouts_this_process": dict(_C.SCRATCH_STATS),
+            "what": "per view in flight; the row scratch (4 quadrant rows of 128 B + a validity byte per listed instance) is laid out "
+                    "for the frame's COUNT when that has reached the host by the time the backward is enqueued (goi_raster_backward3; "
+                    "a free poll, nothing waits) and for its capacity otherwise -- in this bench the backward follows the forward "
+                    "at once, so most frames are sized by capacity (row_scratch_layouts_this_process counts both cases over the "
+                    "whole run); with a loss between the two (tests/test_gpu_speculative.py) it is the count.  The buffer is "
+                    "grow-only and shared by all frames of a (device, stream)"}
         res = {
             "metric": "training views/sec (rasterizer fwd+bwd), 1M Gaussians @1600x1056 RGB+16-d feat",
             "value": args.steps * world / elapsed, "unit": "views/s", "n_gpus": world, "steps": args.steps,

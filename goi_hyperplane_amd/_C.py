@@ -663,6 +663,22 @@ def _layout_of(R):
     return int(R), None
 
 
+SCRATCH_STATS = {"sized_by_count": 0, "sized_by_capacity": 0}  # full backwards of speculative frames, by how their row scratch was laid out
+
+
+def _scratch_instances(R, layout: int) -> int:
+    """Instances the backward's row scratch is laid out for (goi_raster_backward3).  A speculative frame's workspaces are sized
+    for its CAPACITY; if its count has reached the host by now (the free look of _layout_of: the loss usually sits between the
+    forward and this call) the scratch -- 129 bytes per instance and quadrant, the largest workspace of a step -- only has to
+    hold the COUNT.  0 = as the binning layout."""
+    if isinstance(R, LazyCount) and not R.redone:
+        if R.resolved and R._error is None and R._n is not None and 0 < R._n <= layout and not R.overflowed and not R.cut_failed:
+            SCRATCH_STATS["sized_by_count"] += 1
+            return max(int(R._n), 1)
+        SCRATCH_STATS["sized_by_capacity"] += 1
+    return 0
+
+
 def _scene(P, S, H, W, bg, means3D, sh, colors, semantics, opacity, scales, rotations, scale_modifier, cov3D,
            viewmatrix, projmatrix, tan_fovx, tan_fovy, degree, campos, prefiltered, debug):
     M = 0 if (sh is None or sh.numel() == 0) else int(sh.size(1))
@@ -956,7 +972,7 @@ def _backward_impl(background, means3D, radii, colors, semantics, scales, rotati
                                float(tan_fovy), dL_dout_color, dL_dout_semantic, dL_dout_depth, dL_dout_alpha, _e(sh),
                                int(degree), campos, geomBuffer, R_layout,
                                binningBuffer if lazy_binning is None else lazy_binning, imageBuffer, alphas, bool(debug),
-                               bool(sh_factored))
+                               bool(sh_factored), _scratch_instances(R, R_layout))
     P = int(means3D.size(0))
     # the reference reads H, W off dL_dout_color (rasterize_points.cu:243-244); here any upstream gradient may be
     # None (an output the loss does not use), so the sizes come from tensors that always exist
@@ -1014,13 +1030,14 @@ def _backward_impl(background, means3D, radii, colors, semantics, scales, rotati
             R_layout, lazy_binning = _layout_of(R)
             if lazy_binning is not None:
                 binningBuffer = lazy_binning  # (a redone frame has a new buffer)
-            scratch = _backward_scratch(lib.goi_raster_backward_scratch_bytes(R_layout, S), dev)
-            r = lib.goi_raster_backward(
-                C.byref(sc), R_layout, _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(ten["radii"]),
+            R_scratch = _scratch_instances(R, R_layout)
+            scratch = _backward_scratch(lib.goi_raster_backward_scratch_bytes(R_scratch or R_layout, S), dev)
+            r = lib.goi_raster_backward3(
+                C.byref(sc), R_layout, R_scratch, _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(ten["radii"]),
                 _ptr(ten["alphas"]), _ptr(ten["g_c"]), _ptr(ten["g_s"]), _ptr(ten["g_d"]), _ptr(ten["g_a"]),
                 _ptr(dL_dmeans2D), _ptr(dL_dconic), _ptr(dL_dopacity), _ptr(dL_dcolors), _ptr(dL_dsemantics),
                 _ptr(dL_ddepths), _ptr(dL_dmeans3D), _ptr(dL_dcov3D), _ptr(dL_dsh), _ptr(dL_dscales),
-                _ptr(dL_drotations), _ptr(scratch), _stream(dev))
+                _ptr(dL_drotations), _ptr(scratch), None, _stream(dev))
             if r < 0:
                 raise RuntimeError(_lib.last_error())
     return (dL_dmeans2D, dL_dcolors, dL_dsemantics, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales,

@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libgoi_raster.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 STAGES = ("preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges", "blend_fwd", "blend_bwd",
           "preprocess_bwd")
@@ -54,6 +54,8 @@ SYMBOLS = {
     "goi_raster_backward": (C.c_int, [C.POINTER(GoiRasterScene), C.c_int] + [C.c_void_p] * 3 + [C.c_void_p] * 6
                             + [C.c_void_p] * 11 + [C.c_void_p, C.c_void_p]),
     "goi_raster_backward2": (C.c_int, [C.POINTER(GoiRasterScene), C.c_int] + [C.c_void_p] * 3 + [C.c_void_p] * 6
+                             + [C.c_void_p] * 11 + [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "goi_raster_backward3": (C.c_int, [C.POINTER(GoiRasterScene), C.c_int, C.c_int] + [C.c_void_p] * 3 + [C.c_void_p] * 6
                              + [C.c_void_p] * 11 + [C.c_void_p, C.c_void_p, C.c_void_p]),
     "goi_raster_backward_semantics": (C.c_int, [C.POINTER(GoiRasterScene), C.c_int] + [C.c_void_p] * 9),
     "goi_raster_trace": (C.c_int, [C.POINTER(GoiRasterScene), C.c_void_p, C.c_void_p, C.c_void_p, ALLOC_FN,

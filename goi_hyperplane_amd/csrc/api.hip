@@ -720,12 +720,12 @@ int goi_raster_backward(const GoiRasterScene* scene, int R, const void* geom_buf
                                 stream);
 }
 
-int goi_raster_backward2(const GoiRasterScene* scene, int R, const void* geom_buffer, const void* binning_buffer,
-                         const void* image_buffer, const int* radii, const float* out_alpha, const float* dL_dout_color,
-                         const float* dL_dout_semantic, const float* dL_dout_depth, const float* dL_dout_alpha,
-                         float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dsemantic,
-                         float* dL_ddepth, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
-                         float* dL_drot, void* scratch, const int* prev_radii, void* stream) {
+int goi_raster_backward3(const GoiRasterScene* scene, int R, int scratch_instances, const void* geom_buffer,
+                         const void* binning_buffer, const void* image_buffer, const int* radii, const float* out_alpha,
+                         const float* dL_dout_color, const float* dL_dout_semantic, const float* dL_dout_depth,
+                         const float* dL_dout_alpha, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
+                         float* dL_dsemantic, float* dL_ddepth, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                         float* dL_dscale, float* dL_drot, void* scratch, const int* prev_radii, void* stream) {
     refresh_options();
     if (validate(scene, true, false)) return -1;  // opacity lives in the forward's records
     const GoiRasterScene& sc = *scene;
@@ -741,18 +741,21 @@ int goi_raster_backward2(const GoiRasterScene* scene, int R, const void* geom_bu
     const int fin = tile_sort_result_index(sc.W, sc.H, R);
     if (R > 0) binning_layout(R, const_cast<char*>(static_cast<const char*>(binning_buffer)), &bv);
     const bool rows_path = scratch != nullptr && (g_options.bwd_variant & 15) != 1;
+    if (scratch_instances < 0 || scratch_instances > R) return fail("scratch_instances must be in 0..R (0: the scratch is laid out for R)");
+    // Rs: instances the ROW SCRATCH holds rows for (the binning workspace keeps R); every slot index is below 4 x num_rendered <= 4 Rs
+    const int Rs = scratch_instances > 0 ? scratch_instances : R;
     if (rows_path) {
         // atomic-free path: (quadrant, Gaussian) partial rows + validity bytes, then a fixed-order sum
         BwdScratchView scr;
-        bwd_scratch_layout(R, sc.S, static_cast<char*>(scratch), &scr);
+        bwd_scratch_layout(Rs, sc.S, static_cast<char*>(scratch), &scr);
         {
             StageTimer t(GOI_STAGE_BLEND_BWD, s);
             if (R > 0) {
                 // the validity bytes of the slots this frame can use are cleared by extra workgroups of the quadrant-order
                 // launch (count on the device: 4 x num_rendered bytes, not 4 x capacity) -- or by a memset where that
                 // launch does not exist
-                if (!launch_quad_order(sc, im, s, scr.flags, g.counters + COUNTER_N, (uint32_t)R, scr.big_ctl)) {
-                    GOI_HIP(hipMemsetAsync(scr.flags, 0, round_up_256((size_t)R * 4), s));  // (the layout ends with 256 spare bytes)
+                if (!launch_quad_order(sc, im, s, scr.flags, g.counters + COUNTER_N, (uint32_t)Rs, scr.big_ctl)) {
+                    GOI_HIP(hipMemsetAsync(scr.flags, 0, round_up_256((size_t)Rs * 4), s));  // (the layout ends with 256 spare bytes)
                     GOI_HIP(hipMemsetAsync(scr.big_ctl, 0, 8 * sizeof(uint32_t), s));
                 }
                 launch_render_bwd_rows(sc, g, im, bv.vals[fin], radii, out_alpha, dL_dout_color, dL_dout_semantic,
@@ -761,13 +764,18 @@ int goi_raster_backward2(const GoiRasterScene* scene, int R, const void* geom_bu
         }
         if (check_stage(sc, s, "backward blend")) return -1;
         StageTimer t(GOI_STAGE_PREPROCESS_BWD, s);
-        if (g_options.bwd_records) {
+        if (g_options.bwd_records == 2 && bwd_row_floats(sc.S) == 32 && R > 0) {
+            // the per-Gaussian backward sums its Gaussians' rows itself; only the BIG Gaussians pass through reduce_big_k's records
+            launch_reduce_big_only(sc, g, Rs, scr, s);
+            launch_preprocess_bwd(sc, g, radii, dL_dmean2D, dL_dconic, dL_dcolor, dL_ddepth, dL_dmean3D, dL_dcov3D, dL_dsh,
+                                  dL_dscale, dL_drot, s, scr.rows, dL_dopacity, dL_dsemantic, prev_radii, scr.flags, Rs);
+        } else if (g_options.bwd_records) {
             // the sums stay in the row scratch (one record per listed Gaussian); preprocess_bwd_k writes the per-id outputs
-            launch_reduce_rows(sc, g, R, scr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, s, true);
+            launch_reduce_rows(sc, g, Rs, scr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, s, true);
             launch_preprocess_bwd(sc, g, radii, dL_dmean2D, dL_dconic, dL_dcolor, dL_ddepth, dL_dmean3D, dL_dcov3D, dL_dsh,
                                   dL_dscale, dL_drot, s, scr.rows, dL_dopacity, dL_dsemantic, prev_radii);
         } else {
-            launch_reduce_rows(sc, g, R, scr, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dsemantic, dL_ddepth, s);
+            launch_reduce_rows(sc, g, Rs, scr, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dsemantic, dL_ddepth, s);
             launch_preprocess_bwd(sc, g, radii, dL_dmean2D, dL_dconic, dL_dcolor, dL_ddepth, dL_dmean3D, dL_dcov3D, dL_dsh,
                                   dL_dscale, dL_drot, s);
         }
@@ -793,6 +801,18 @@ int goi_raster_backward2(const GoiRasterScene* scene, int R, const void* geom_bu
     if (check_stage(sc, s, "backward preprocess")) return -1;
     GOI_HIP(hipGetLastError());
     return 0;
+}
+
+int goi_raster_backward2(const GoiRasterScene* scene, int R, const void* geom_buffer, const void* binning_buffer,
+                         const void* image_buffer, const int* radii, const float* out_alpha, const float* dL_dout_color,
+                         const float* dL_dout_semantic, const float* dL_dout_depth, const float* dL_dout_alpha,
+                         float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dsemantic,
+                         float* dL_ddepth, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
+                         float* dL_drot, void* scratch, const int* prev_radii, void* stream) {
+    return goi_raster_backward3(scene, R, 0, geom_buffer, binning_buffer, image_buffer, radii, out_alpha, dL_dout_color,
+                                dL_dout_semantic, dL_dout_depth, dL_dout_alpha, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor,
+                                dL_dsemantic, dL_ddepth, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, scratch, prev_radii,
+                                stream);
 }
 
 int goi_raster_backward_semantics(const GoiRasterScene* scene, int R, const void* geom_buffer, const void* binning_buffer,
@@ -996,7 +1016,7 @@ int goi_raster_set_option(const char* name, int value) {
         g_options.bwd_masks = value;
     }
     else if (!strcmp(name, "bwd_records")) {
-        if (value < 0 || value > 1) return fail("bwd_records must be 0 or 1");
+        if (value < 0 || value > 2) return fail("bwd_records must be 0, 1 or 2");
         g_options.bwd_records = value;
     }
     else return fail(std::string("unknown option ") + name);

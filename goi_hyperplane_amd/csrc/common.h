@@ -132,7 +132,8 @@ struct Options {
     int bwd_masks = 1;     // atomic-free backward blend: 1 walks the MEMBER masks the forward blend left (no candidate tests, no
                            // evaluation of pairs that contribute nowhere; default), 0 tests every candidate of its list against
                            // the quadrant itself.  Same rows, same gradients, bit for bit.
-    int bwd_records = 1;   // atomic-free backward: 1 the per-Gaussian sums stay in the row scratch as records and
+    int bwd_records = 1;   // atomic-free backward: 2 EXPERIMENT the per-Gaussian backward sums its Gaussians' rows itself (no record, no
+                           // reduce_rows_k; 128-byte rows), 1 the per-Gaussian sums stay in the row scratch as records and
                            // preprocess_bwd_k writes every per-id output (default), 0 reduce_rows_k writes six per-id arrays
                            // (and zeros for the unlisted Gaussians) that preprocess_bwd_k reads back.  Same gradients, bit for bit.
 };
@@ -221,6 +222,7 @@ void launch_render_bwd_rows(const GoiRasterScene& sc, const GeomView& g, const I
 void launch_render_bwd_sem(const GoiRasterScene& sc, const GeomView& g, const ImageView& im, const uint32_t* point_list,
                            const int* radii, const float* out_alpha, const float* dL_dsem, float* rows, uint8_t* flags,
                            int row_floats, hipStream_t s, const unsigned long long* qmask = nullptr);
+void launch_reduce_big_only(const GoiRasterScene& sc, const GeomView& g, int N, const BwdScratchView& scr, hipStream_t s);
 void launch_reduce_sem_rows(const GoiRasterScene& sc, const GeomView& g, int N, const BwdScratchView& scr, int row_floats,
                             float* dL_dsemantic, hipStream_t s);
 // sums every Gaussian's partial rows (fixed order) into the six blend-gradient arrays (writes all P rows) -- or, `records`,
@@ -241,7 +243,8 @@ void launch_preprocess_bwd(const GoiRasterScene& sc, const GeomView& g, const in
                            const float* dL_dconic, float* dL_dcolor, const float* dL_ddepth, float* dL_dmean3D,
                            float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, hipStream_t s,
                            const float* record_rows = nullptr, float* dL_dopacity = nullptr, float* dL_dsemantic = nullptr,
-                           const int* prev_radii = nullptr);  // prev_radii: BwdArgs (rows that already hold zeros)
+                           const int* prev_radii = nullptr,  // prev_radii: BwdArgs (rows that already hold zeros)
+                           const uint8_t* row_flags = nullptr, int N_cap = 0);  // row_flags: the kernel sums the rows itself (bwd_records 2)
 int launch_semantic_decode(const float* sem, int S, long long HW, const float* W, const float* bias, int n_codes,
                            const float* code_score, float thresh, float* sim_out, int* idx_out, uint8_t* bg_mask_out,
                            hipStream_t s);

@@ -10,10 +10,12 @@
 //             :20-139 (SH), :278-341 (cov3D)
 // Layout is this library's own: one 48-byte GaussRec per Gaussian instead of five arrays, depth
 // keys for the per-Gaussian depth sort, 3 clamp bits in one byte.
+#include <algorithm>
 #include <type_traits>
 
 #include "common.h"
 #include "gmath.h"
+#include "row_sum.h"
 
 namespace goi {
 
@@ -478,6 +480,10 @@ struct RecArgs {
     int row_floats, S, nch;         // nch = padded semantic channels + 4 (see render_bwd.hip: BwdCfg)
     float* dL_dopacity;
     float* dL_dsemantic;
+    // SRC == 2 (bwd_records 2): the kernel sums the rows itself
+    const uint8_t* flags;           // validity bytes of the row slots
+    const uint32_t* n_dev;          // the frame's counters from COUNTER_N on (instances, listed Gaussians: the BIG threshold)
+    uint32_t N_cap;                 // slot capacity the scratch was laid out for
 };
 // Rows of the dL/dSH staging tile = visible Gaussians a workgroup takes through the chain at a time: 224 x (3 M + 1) floats =
 // 43.9 KB at M = 16, three workgroups per CU with the index lists (the kernel's 143 VGPRs allow three as well).
@@ -490,11 +496,25 @@ struct RecArgs {
 #ifndef GOI_PBWD_HOIST
 #define GOI_PBWD_HOIST 1
 #endif
-constexpr int BWD_TILE_ROWS = GOI_PBWD_ROWS;
+constexpr int BWD_TILE_ROWS_DEFAULT = GOI_PBWD_ROWS;
+#ifndef GOI_PBWD_INFLIGHT
+#define GOI_PBWD_INFLIGHT 16  // rows a quarter wave requests back to back in the in-kernel row sum (reduce_rows_k: 32)
+#endif
+#ifndef GOI_PBWD_ROWS_FUSED
+#define GOI_PBWD_ROWS_FUSED 208
+#endif
+constexpr int BWD_TILE_ROWS_FUSED = GOI_PBWD_ROWS_FUSED;  // (SRC == 2: ten more floats of LDS per row; 208 rows keep three workgroups per CU)
+constexpr int BWD_REC_FLOATS = 10;  // r, g, b, depth, mean2D x, y, conic a, b, c, opacity
 constexpr int BWD_BLOCKS_PER_CU = GOI_PBWD_BLOCKS;
 constexpr bool BWD_HOIST = GOI_PBWD_HOIST != 0;
 
-template <bool WITH_DSH, bool FROM_ROWS>
+// SRC: where the blend gradients of a Gaussian come from -- 0 the six per-id arrays, 1 its RECORD in the row scratch
+// (reduce_rows_k<.., RECORD>), 2 the kernel SUMS THE ROWS ITSELF (bwd_records 2; 128-byte rows): before a tile's chain, the
+// workgroup's sixteen quarter waves walk the tile's Gaussians, each summing one Gaussian's rows exactly as reduce_rows_k does
+// (same function, same slot order: bit-identical sums; slot range two Gaussians ahead, validity bytes one ahead); the 16
+// semantic sums leave for dL/dsemantics at once, the ten values the chain needs go to LDS.  No record is written or read back,
+// no second kernel walks the listed Gaussians; only the BIG ones (reduce_big_k) still pass through a record.
+template <bool WITH_DSH, int SRC>
 __global__ __launch_bounds__(256, GOI_PBWD_BLOCKS) void preprocess_bwd_k(const BwdArgs args, const int* __restrict__ radii,
                                                         const uint32_t* __restrict__ counters,
                                                         const uint8_t* __restrict__ clamped,
@@ -518,10 +538,13 @@ __global__ __launch_bounds__(256, GOI_PBWD_BLOCKS) void preprocess_bwd_k(const B
     // gradients, whichever block and lane a Gaussian lands on.
     // dL/dSH (192 B per Gaussian at degree 3) still leaves through an LDS tile (odd row stride: no bank conflicts) as
     // contiguous rows instead of 48 stores at a 192-byte lane stride.
+    constexpr bool FROM_ROWS = SRC != 0;
+    constexpr int BWD_TILE_ROWS = SRC == 2 ? BWD_TILE_ROWS_FUSED : BWD_TILE_ROWS_DEFAULT;
     extern __shared__ float s_dsh[];  // [BWD_TILE_ROWS][3 M + 1] when dL_dsh
     __shared__ uint32_t s_vis[BWD_TILE_ROWS + 256];  // pending visible ids
     __shared__ uint16_t s_zero[256];
-    __shared__ uint32_t s_src[BWD_TILE_ROWS];  // (FROM_ROWS) the tile row's record: first slot of a listed Gaussian, ~0u: none
+    __shared__ uint32_t s_src[SRC == 1 ? BWD_TILE_ROWS : 1];  // (SRC 1) the tile row's record: first slot of a listed Gaussian, ~0u: none
+    __shared__ float s_rec[SRC == 2 ? BWD_TILE_ROWS * BWD_REC_FLOATS : 1];  // (SRC 2) the chain's ten inputs of every tile row
     __shared__ int s_wcnt[2][4];
     const Camera cam = load_camera(args.view_p, args.proj_p, args.campos_p);
     struct : BwdArgs {
@@ -624,6 +647,65 @@ __global__ __launch_bounds__(256, GOI_PBWD_BLOCKS) void preprocess_bwd_k(const B
             }
         }
     }
+    if constexpr (SRC == 2) {
+        // ---- the tile's rows: quarter wave qw sums the rows of tile rows qw, qw + 16, ... (software pipeline as in reduce_rows_k)
+        constexpr int RF = 32;  // 128-byte rows (the launcher takes this mode for them only)
+        const int qw = threadIdx.x >> 4, e = threadIdx.x & 15, quarter = (threadIdx.x & 63) >> 4;
+        const uint32_t* flags32 = reinterpret_cast<const uint32_t*>(ra.flags);
+        const uint32_t N = min(ra.N_cap, ra.n_dev[0]);  // (a truncated frame has no visible Gaussians: never gets here)
+        const uint32_t Vl = ra.n_dev[COUNTER_V - COUNTER_N];
+        const uint32_t big_inst = (N > REDUCE_DENSE_RATIO * Vl) ? REDUCE_BIG_INST : 1024u;  // (reduce_rows.hip: find_big_k)
+        const int rounds = (nrows + 15) >> 4;  // (block-uniform)
+        struct Meta {
+            uint32_t idx, off0, cnt;
+        };
+        auto load_meta = [&](int k) {
+            const int r = qw + 16 * k;
+            Meta m{0u, 0u, 0u};
+            if (k < rounds && r < nrows) {
+                m.idx = s_vis[r];
+                m.cnt = ra.tiles_touched[m.idx];          // instances = slots / 4 of a listed Gaussian, 0: not listed
+                m.off0 = ra.aux[m.idx].x;                 // its first emit-order instance
+                if (m.cnt == 0u) m.off0 = 0u;
+            }
+            return m;
+        };
+        auto load_first = [&](const Meta& m) { return (m.cnt <= big_inst && (uint32_t)e < m.cnt) ? flags32[m.off0 + e] : 0u; };
+        Meta cur = load_meta(0), nxt = load_meta(1);
+        uint32_t w_cur = load_first(cur);
+#pragma unroll 1
+        for (int k = 0; k < rounds; k++) {
+            const Meta nn = load_meta(k + 2);
+            const uint32_t w_nxt = load_first(nxt);
+            const int r = qw + 16 * k;
+            const bool big = cur.cnt > big_inst;
+            float sum[2] = {0.f, 0.f};
+            sum_instances<2, false, GOI_PBWD_INFLIGHT>(ra.rows, flags32, (size_t)cur.off0, big ? 0u : cur.cnt, w_cur, quarter, e, sum, sum);
+            if (r < nrows) {
+                if (big) {  // its record, left by reduce_big_k over the first slot it owns
+                    const float2 t = reinterpret_cast<const float2*>(ra.rows + (size_t)cur.off0 * 4 * RF)[e];
+                    sum[0] = t.x;
+                    sum[1] = t.y;
+                }
+                const int nsem = ra.nch - 4;  // lane e holds row elements 2 e, 2 e + 1
+                const int el = 2 * e;
+                if (el < nsem) {
+                    float* dst = ra.dL_dsemantic + (size_t)cur.idx * ra.S;
+                    if (el + 1 < ra.S && (ra.S & 1) == 0) *reinterpret_cast<float2*>(dst + el) = make_float2(sum[0], sum[1]);
+                    else {
+                        if (el < ra.S) dst[el] = sum[0];
+                        if (el + 1 < ra.S) dst[el + 1] = sum[1];
+                    }
+                } else if (el < nsem + BWD_REC_FLOATS) {
+                    *reinterpret_cast<float2*>(&s_rec[r * BWD_REC_FLOATS + (el - nsem)]) = make_float2(sum[0], sum[1]);
+                }
+            }
+            cur = nxt;
+            nxt = nn;
+            w_cur = w_nxt;
+        }
+        __syncthreads();
+    }
     const V3 mean_in = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
     float cov3D_in[6];
 #pragma unroll
@@ -638,7 +720,25 @@ __global__ __launch_bounds__(256, GOI_PBWD_BLOCKS) void preprocess_bwd_k(const B
     // ---- the blend gradients: from the per-id arrays, or from the Gaussian's record
     float in_conic[3] = {0.f, 0.f, 0.f}, in_m2d[2] = {0.f, 0.f}, in_depth = 0.f;
     V3 in_col = {0.f, 0.f, 0.f};
-    if constexpr (FROM_ROWS) {
+    if constexpr (SRC == 2) {
+        if (visible) {
+            const float* rc = &s_rec[threadIdx.x * BWD_REC_FLOATS];
+            in_col = V3{rc[0], rc[1], rc[2]};
+            in_depth = rc[3];
+            in_m2d[0] = rc[4];
+            in_m2d[1] = rc[5];
+            in_conic[0] = rc[6];
+            in_conic[1] = rc[7];
+            in_conic[2] = rc[8];
+            ra.dL_dopacity[idx] = rc[9];
+            dL_dmean2D[3 * idx] = in_m2d[0];
+            dL_dmean2D[3 * idx + 1] = in_m2d[1];
+            dL_dmean2D[3 * idx + 2] = 0.f;
+            dL_dcolor[3 * idx] = in_col.x;  // (factored SH mode overwrites it with the clamp-masked gradient below)
+            dL_dcolor[3 * idx + 1] = in_col.y;
+            dL_dcolor[3 * idx + 2] = in_col.z;
+        }
+    } else if constexpr (SRC == 1) {
         const bool listed = visible && ra.tiles_touched[idx] != 0;
         const uint32_t slot = listed ? ra.aux[idx].x : 0u;
         const float* rec = ra.rows + (size_t)slot * 4 * ra.row_floats;
@@ -901,7 +1001,7 @@ __global__ __launch_bounds__(256, GOI_PBWD_BLOCKS) void preprocess_bwd_k(const B
         reinterpret_cast<float4*>(dL_drot)[idx] = grot;
     }
     if constexpr (WITH_DSH || FROM_ROWS) __syncthreads();
-    if constexpr (FROM_ROWS) {
+    if constexpr (SRC == 1) {
         // dL/dsemantics of the chunk's rows: S floats from the Gaussian's record (zeros for a visible Gaussian without tiles).
         // Four lanes per row at S = 16 (one float4 each): an instruction moves 16 records' 64-byte pieces in and 16 rows out.
         if ((ra.S & 3) == 0) {
@@ -1061,7 +1161,8 @@ void launch_preprocess_fwd(const GoiRasterScene& sc, const GeomView& g, int* rad
 void launch_preprocess_bwd(const GoiRasterScene& sc, const GeomView& g, const int* radii, float* dL_dmean2D,
                            const float* dL_dconic, float* dL_dcolor, const float* dL_ddepth, float* dL_dmean3D,
                            float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, hipStream_t s,
-                           const float* record_rows, float* dL_dopacity, float* dL_dsemantic, const int* prev_radii) {
+                           const float* record_rows, float* dL_dopacity, float* dL_dsemantic, const int* prev_radii,
+                           const uint8_t* row_flags, int N_cap) {
     BwdArgs a;
     a.prev_radii = prev_radii;
     a.P = sc.P; a.D = sc.D; a.M = sc.M; a.W = sc.W; a.H = sc.H;
@@ -1072,12 +1173,16 @@ void launch_preprocess_bwd(const GoiRasterScene& sc, const GeomView& g, const in
     a.focal_x = sc.W / (2.0f * sc.tan_fovx);
     a.view_p = sc.viewmatrix; a.proj_p = sc.projmatrix; a.campos_p = sc.campos;
     const bool with_sh = sc.shs && sc.M > 0 && dL_dsh;  // dL_dsh == NULL with SH colours: factored mode
-    const size_t lds = with_sh ? (size_t)BWD_TILE_ROWS * (3 * sc.M + 1) * sizeof(float) : 0;  // 31 KB at M = 16
-    // record_rows: the blend gradients are the records reduce_rows_k<.., RECORD> left in the row scratch
+    // record_rows: the blend gradients are the records reduce_rows_k<.., RECORD> left in the row scratch -- or, with row_flags
+    // (bwd_records 2), the rows themselves: the kernel sums them (128-byte rows only: the caller checks)
+    const bool fused = record_rows != nullptr && row_flags != nullptr;
+    const int tile_rows = fused ? BWD_TILE_ROWS_FUSED : BWD_TILE_ROWS_DEFAULT;
+    const size_t lds = with_sh ? (size_t)tile_rows * (3 * sc.M + 1) * sizeof(float) : 0;  // 43.9 KB at M = 16 (40.8 fused)
     RecArgs ra;
     ra.rows = record_rows; ra.aux = g.aux; ra.tiles_touched = g.tiles_touched;
     ra.row_floats = bwd_row_floats(sc.S); ra.S = sc.S; ra.nch = 4 * ((sc.S + 3) / 4) + 4;
     ra.dL_dopacity = dL_dopacity; ra.dL_dsemantic = dL_dsemantic;
+    ra.flags = row_flags; ra.n_dev = g.counters + COUNTER_N; ra.N_cap = (uint32_t)std::max(N_cap, 0);
     // persistent workgroups: every CU gets as many as fit (registers and the staging tile: BWD_BLOCKS_PER_CU), each walks
     // segments of 256 ids
     static const int n_cu = []() {
@@ -1086,18 +1191,17 @@ void launch_preprocess_bwd(const GoiRasterScene& sc, const GeomView& g, const in
         return n > 0 ? n : 256;
     }();
     const dim3 grid((unsigned)std::min((sc.P + 255) / 256, n_cu * BWD_BLOCKS_PER_CU));
-    if (with_sh && record_rows)
-        preprocess_bwd_k<true, true><<<grid, dim3(256), lds, s>>>(
-            a, radii, g.counters, g.clamped, dL_dmean2D, dL_dconic, dL_dcolor, dL_ddepth, ra, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
-    else if (with_sh)
-        preprocess_bwd_k<true, false><<<grid, dim3(256), lds, s>>>(
-            a, radii, g.counters, g.clamped, dL_dmean2D, dL_dconic, dL_dcolor, dL_ddepth, ra, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
-    else if (record_rows)
-        preprocess_bwd_k<false, true><<<grid, dim3(256), 0, s>>>(
-            a, radii, g.counters, g.clamped, dL_dmean2D, dL_dconic, dL_dcolor, dL_ddepth, ra, dL_dmean3D, dL_dcov3D, nullptr, dL_dscale, dL_drot);
-    else
-        preprocess_bwd_k<false, false><<<grid, dim3(256), 0, s>>>(
-            a, radii, g.counters, g.clamped, dL_dmean2D, dL_dconic, dL_dcolor, dL_ddepth, ra, dL_dmean3D, dL_dcov3D, nullptr, dL_dscale, dL_drot);
+#define GOI_PBWD(DSH, SRC, LDS)                                                                                             \
+    preprocess_bwd_k<DSH, SRC><<<grid, dim3(256), LDS, s>>>(a, radii, g.counters, g.clamped, dL_dmean2D, dL_dconic, dL_dcolor, \
+                                                            dL_ddepth, ra, dL_dmean3D, dL_dcov3D, DSH ? dL_dsh : nullptr,      \
+                                                            dL_dscale, dL_drot)
+    if (with_sh && fused) GOI_PBWD(true, 2, lds);
+    else if (with_sh && record_rows) GOI_PBWD(true, 1, lds);
+    else if (with_sh) GOI_PBWD(true, 0, lds);
+    else if (fused) GOI_PBWD(false, 2, 0);
+    else if (record_rows) GOI_PBWD(false, 1, 0);
+    else GOI_PBWD(false, 0, 0);
+#undef GOI_PBWD
 }
 
 void launch_sh_grad_from_views(int P, int D, int M, int V, const float* means3D, const float* campos, const float* gcol,

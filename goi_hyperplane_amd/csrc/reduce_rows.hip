@@ -6,6 +6,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "row_sum.h"
 
 namespace goi {
 
@@ -31,9 +32,6 @@ namespace {
 // preprocess_bwd_k, which runs over the ids anyway, fetches the line through goff[] and writes every per-id output itself,
 // coalesced.  Measured on the headline view before it was built (timing builds): the zero phase 21 us, the scattered
 // stores 40 us of the kernel's 213; a dense 128-byte store instead 8 us.
-#ifndef GOI_REDUCE_INFLIGHT
-#define GOI_REDUCE_INFLIGHT 32
-#endif
 
 // BIG Gaussians.  A quarter wave sums ITS Gaussian's rows one trip after the other; a frame-filling blob or a long needle
 // of a reconstructed scene owns thousands of slots and ten thousand rows (clustered workload: 20 blobs x 6600 tiles, needles
@@ -54,112 +52,6 @@ namespace {
 // memset.  A frame without big Gaussians pays one launch that finds nothing to do.)
 constexpr uint32_t BIG_INST = REDUCE_BIG_INST;  // (common.h: the scratch layout sizes the descriptor list from it)
 constexpr uint32_t HUGE_INST = REDUCE_HUGE_INST;
-
-// Sums the rows of `cnt` consecutive instances starting at instance `inst0` (their validity words at flags32[inst0 ..]) into
-// sum[] -- the lane's elements of the row -- in slot order.  Wave-synchronous: the four quarter waves of a wave call it
-// together, each for its own (inst0, cnt); w_first = the validity word of instance inst0 + e (prefetched by the caller).
-// COMPENSATED (reduce_big_k): Kahan summation -- the lost low bits of every addition are carried in comp[] and fed back.  A big
-// Gaussian's sum runs over ten thousand rows of both signs: the plain fp32 sum's error grows with their number and depends on
-// how the rows are split over quarter waves (one component of one needle's dL/dscale moved by 2e-3 of the tensor's scale
-// between a 16- and a 64-part split: clustered workload, tools/diag_blown.py); the compensated sum is good to an ulp or two of
-// the result whatever the split.  Four additions instead of one, on the few hundred Gaussians that take this path.
-template <int K, bool COMPENSATED = false>
-__device__ __forceinline__ void sum_instances(const float* __restrict__ rows, const uint32_t* __restrict__ flags32,
-                                              size_t inst0, uint32_t cnt, uint32_t w_first, int quarter, int e,
-                                              float (&sum)[K], float (&comp)[K]) {
-    constexpr int RF = 16 * K;
-    constexpr int INFLIGHT = GOI_REDUCE_INFLIGHT;
-    auto load_flags = [&](uint32_t c) { return (c + e < cnt) ? flags32[inst0 + c + e] : 0u; };
-    // every lane of the wave must reach the ballots: loop to the wave's largest count
-    uint32_t cmax = cnt;
-#pragma unroll
-    for (int d = 32; d >= 16; d >>= 1) cmax = max(cmax, (uint32_t)__shfl_xor((int)cmax, d, 64));
-    // The instances are looked at 64 at a time: four validity words per lane, requested together (and the next 64 under this
-    // block's rows), and a 16-instance chunk in which no quarter of the wave has a row is skipped on one ballot.
-    uint32_t wq[4] = {w_first, 0u, 0u, 0u};
-    if (cmax > 16) {
-#pragma unroll
-        for (int sblk = 1; sblk < 4; sblk++) wq[sblk] = load_flags(16u * sblk);
-    }
-    for (uint32_t c = 0; c < cmax; c += 64) {
-        uint32_t wn[4] = {0u, 0u, 0u, 0u};
-        if (c + 64 < cmax) {
-#pragma unroll
-            for (int sblk = 0; sblk < 4; sblk++) wn[sblk] = load_flags(c + 64 + 16u * sblk);
-        }
-#pragma unroll 1
-        for (int sblk = 0; sblk < 4; sblk++) {  // (not unrolled: the queue is rotated instead of indexed)
-            const uint32_t cc = c + 16u * sblk;
-            if (cc >= cmax) break;                  // (wave-uniform)
-            const uint32_t w = wq[0];               // 4 quadrant bytes of instance cc+e
-            wq[0] = wq[1];
-            wq[1] = wq[2];
-            wq[2] = wq[3];
-            if (__ballot(w != 0u) == 0) continue;   // (wave-uniform) no quarter has a row in this chunk
-            unsigned long long m = 0;  // bit 16q + i: quadrant q of instance cc+i is valid
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const unsigned long long bal = __ballot(((w >> (8 * q)) & 0xFFu) != 0);
-                m |= ((bal >> (16 * quarter)) & 0xFFFFull) << (16 * q);
-            }
-            const float* chunk = rows + (inst0 + cc) * 4 * RF;
-            // NF rows requested back to back, then added in slot order (absent slots add +0: the sums do not depend on
-            // NF).  Most Gaussians own a handful of rows -- 6 on average, half of them at most 4 -- and the 16-slot trip
-            // costs ~160 vector instructions whatever it finds (the kernel issued 60 M of them: 44 % VALU-busy on top
-            // of its memory waits): when no quarter of the wave has more than 4 rows left, a 4-slot trip does.
-            auto trip = [&](auto nf_c) {
-                constexpr int NF = decltype(nf_c)::value;
-                float v[NF][K];
-#pragma unroll
-                for (int i = 0; i < NF; i++) {
-                    const bool have = m != 0;
-                    const int bit = have ? __builtin_ctzll(m) : 0;
-                    if (have) m &= m - 1;
-                    const float* r = chunk + (size_t)((bit & 15) * 4 + (bit >> 4)) * RF;
-                    if (K == 2) {  // one 8-byte load per lane: the quarter wave reads the 128-byte row in one request
-                        const float2 t = have ? reinterpret_cast<const float2*>(r)[e] : make_float2(0.f, 0.f);
-                        v[i][0] = t.x;
-                        v[i][K - 1] = t.y;
-                    } else {
-#pragma unroll
-                        for (int kk = 0; kk < K; kk++) v[i][kk] = have ? r[e + 16 * kk] : 0.f;
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < NF; i++)
-#pragma unroll
-                    for (int kk = 0; kk < K; kk++) {
-                        if constexpr (COMPENSATED) {
-                            const float y = v[i][kk] - comp[kk];
-                            const float t = sum[kk] + y;
-                            comp[kk] = (t - sum[kk]) - y;
-                            sum[kk] = t;
-                        } else {
-                            sum[kk] += v[i][kk];
-                        }
-                    }
-            };
-            int left = __popcll(m);  // rows this quarter still has to fetch; the wave's largest decides the trip
-#pragma unroll
-            for (int d = 32; d >= 16; d >>= 1) left = max(left, __shfl_xor(left, d, 64));
-            left = __builtin_amdgcn_readfirstlane(left);
-            while (left > 0) {
-                if (left <= 4) {
-                    trip(std::integral_constant<int, 4>{});
-                    left -= 4;
-                } else if (left <= 12) {
-                    trip(std::integral_constant<int, 12>{});
-                    left -= 12;
-                } else {
-                    trip(std::integral_constant<int, INFLIGHT>{});
-                    left -= INFLIGHT;
-                }
-            }
-        }
-#pragma unroll
-        for (int sblk = 0; sblk < 4; sblk++) wq[sblk] = wn[sblk];
-    }
-}
 
 struct ReduceOut {
     float *dL_dmean2D, *dL_dconic, *dL_dopacity, *dL_dcolor, *dL_dsemantic, *dL_ddepth;
@@ -304,6 +196,28 @@ __global__ __launch_bounds__(256) void reduce_rows_k(int P, int S, int nch, uint
     }
 }
 
+// bwd_records 2 (the per-Gaussian backward sums its Gaussians' rows itself: preprocess.hip): nobody walks the listed Gaussians
+// in here any more, so the BIG ones are registered by this kernel -- one thread per listed Gaussian in depth order, the same
+// threshold from the same frame counters, the same descriptors -- and reduce_big_k leaves their records in the row scratch as
+// before.  (The order of the descriptors differs from run to run; every Gaussian's sum is its own: bit-reproducible.)
+__global__ __launch_bounds__(256) void find_big_k(uint32_t N_cap, const uint32_t* __restrict__ n_dev,
+                                                  const uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets,
+                                                  uint32_t* __restrict__ big_ctl, uint4* __restrict__ big_desc, uint32_t cap_big) {
+    const bool truncated = n_dev[COUNTER_OVF - COUNTER_N] != 0;
+    const uint32_t N = truncated ? 0u : min(N_cap, *n_dev);
+    const int V = truncated ? 0 : (int)n_dev[COUNTER_V - COUNTER_N];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= V) return;
+    const uint32_t off0 = min(offsets[i], N), off1 = i + 1 < V ? min(offsets[i + 1], N) : N;
+    const uint32_t cnt = off1 - off0;
+    const uint32_t big_inst = (N > REDUCE_DENSE_RATIO * (uint32_t)V) ? BIG_INST : 1024u;
+    if (cnt > big_inst) {
+        const uint4 d = make_uint4(off0, cnt, 0u, order[i]);
+        if (cnt > HUGE_INST) big_desc[atomicAdd(&big_ctl[1], 1u)] = d;
+        else big_desc[cap_big - 1u - atomicAdd(&big_ctl[2], 1u)] = d;
+    }
+}
+
 // The big Gaussians (persistent workgroups of 1024 threads: the grid is fixed, the counts live on the device).  First the ones of
 // up to HUGE_INST instances, FOUR at a time: each quarter of the workgroup (16 quarter waves = 16 parts) takes one; then the
 // huge ones, the whole workgroup (64 parts) each.  Quarter wave p sums part p of its Gaussian's instances -- contiguous, a
@@ -405,6 +319,19 @@ void launch_reduce_rows(const GoiRasterScene& sc, const GeomView& g, int N, cons
     else if (rf == 16) GOI_REDUCE(1);
     else GOI_REDUCE(3);
 #undef GOI_REDUCE
+}
+
+// bwd_records 2: only the BIG Gaussians are summed here (records into the row scratch); everything else is summed by
+// preprocess_bwd_k.  Only laid out for 128-byte rows (K = 2: S = 5 .. 20); the caller checks.
+void launch_reduce_big_only(const GoiRasterScene& sc, const GeomView& g, int N, const BwdScratchView& scr, hipStream_t s) {
+    if (N <= 0) return;
+    const int nch = 4 * ((sc.S + 3) / 4) + 4;
+    const ReduceOut out{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const uint32_t* order = g.sort_vals[depth_sort_result_index()];
+    find_big_k<<<dim3((sc.P + 255) / 256), dim3(256), 0, s>>>((uint32_t)N, g.counters + COUNTER_N, order, g.offsets, scr.big_ctl,
+                                                             scr.big_desc, (uint32_t)scr.cap_big);
+    reduce_big_k<2, true><<<dim3((unsigned)std::min<size_t>(REDUCE_BIG_GRID, scr.cap_big)), dim3(16 * BIG_PARTS), 0, s>>>(
+        scr.big_ctl, scr.big_desc, (uint32_t)scr.cap_big, scr.rows, scr.flags, sc.S, nch, out);
 }
 
 void launch_reduce_sem_rows(const GoiRasterScene& sc, const GeomView& g, int N, const BwdScratchView& scr, int row_floats,

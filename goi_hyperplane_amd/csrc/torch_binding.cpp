@@ -290,7 +290,8 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tenso
     const c10::optional<Tensor>& dL_dout_color, const c10::optional<Tensor>& dL_dout_semantic,
     const c10::optional<Tensor>& dL_dout_depth, const c10::optional<Tensor>& dL_dout_alpha, const Tensor& sh,
     const int degree, const Tensor& campos, const Tensor& geomBuffer, const int R, const Tensor& binningBuffer,
-    const Tensor& imageBuffer, const Tensor& alphas, const bool debug, const bool sh_factored_in) {
+    const Tensor& imageBuffer, const Tensor& alphas, const bool debug, const bool sh_factored_in,
+    const int scratch_instances /* 0: the row scratch is laid out for R (goi_raster_backward3) */) {
     const c10::Device dev = check_device(means3D);
     c10::hip::HIPGuard guard(dev.index());
     const int P = (int)means3D.size(0);
@@ -356,10 +357,10 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tenso
         Tensor rad = radii.contiguous();
         GoiRasterScene sc = scene_of(P, degree, sh, S, W, H, bg, m3, shs, col, sem, Arg(), sca, scale_modifier, rot, cov, vm,
                                      pm, cp, tan_fovx, tan_fovy, false, debug);
-        void* scratch = backward_scratch(goi_raster_backward_scratch_bytes(R, S), dev, stream,
-                                         means3D.options().dtype(torch::kByte));
-        const int r = goi_raster_backward2(
-            &sc, R, geomBuffer.data_ptr(), binningBuffer.numel() ? binningBuffer.data_ptr() : nullptr,
+        void* scratch = backward_scratch(goi_raster_backward_scratch_bytes(scratch_instances > 0 ? scratch_instances : R, S), dev,
+                                         stream, means3D.options().dtype(torch::kByte));
+        const int r = goi_raster_backward3(
+            &sc, R, scratch_instances, geomBuffer.data_ptr(), binningBuffer.numel() ? binningBuffer.data_ptr() : nullptr,
             imageBuffer.data_ptr(), rad.data_ptr<int>(), al.p, gc.p, gs.p, gd.p, ga.p, dL_dmeans2D.data_ptr<float>(),
             dL_dconic.data_ptr<float>(), dL_dopacity.data_ptr<float>(), dL_dcolors.data_ptr<float>(),
             dL_dsemantics.data_ptr<float>(), dL_ddepths.data_ptr<float>(), dL_dmeans3D.data_ptr<float>(),
@@ -391,7 +392,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tenso
     const Tensor& binningBuffer, const Tensor& imageBuffer, const Tensor& alphas, const bool debug) {
     return backward_ex(background, means3D, radii, colors, semantics, scales, rotations, scale_modifier, cov3D_precomp,
                        viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_semantic, dL_dout_depth,
-                       dL_dout_alpha, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, alphas, debug, false);
+                       dL_dout_alpha, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, alphas, debug, false, 0);
 }
 
 // dL/dsemantics only (goi_raster_backward_semantics)

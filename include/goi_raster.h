@@ -49,11 +49,12 @@
 extern "C" {
 #endif
 
-/* 5: + goi_raster_forward_async_cut, goi_raster_ticket_result2 (speculative depth cut-off of the tile lists), goi_raster_backward2; the binning and
+/* 6: + goi_raster_backward3 (row scratch sized by the frame's count instead of its capacity), goi_raster_blend_stats
+ * 5: + goi_raster_forward_async_cut, goi_raster_ticket_result2 (speculative depth cut-off of the tile lists), goi_raster_backward2; the binning and
  *    backward-scratch workspaces grew (member masks; descriptors of big Gaussians): sizes come from goi_raster_*_bytes as ever
  * 4: + goi_raster_truncated_flag, goi_adam_step_guarded; a truncated speculative frame back-propagates ZERO gradients
  * (3: + goi_raster_forward_reblend, goi_codebook_sim, goi_codebook_fused; 2: + the asynchronous forward; additions only) */
-#define GOI_RASTER_ABI_VERSION 5
+#define GOI_RASTER_ABI_VERSION 6
 
 typedef struct GoiRasterScene {
     int P;                       /* number of Gaussians */
@@ -220,6 +221,19 @@ int goi_raster_backward2(const GoiRasterScene* scene, int R, const void* geom_bu
                          float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dsemantic,
                          float* dL_ddepth, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
                          float* dL_drot, void* scratch, const int* prev_radii, void* stream);
+
+/* goi_raster_backward2 with the row scratch laid out for FEWER instances than the binning workspace (ABI 6).  `R` stays what the
+ * binning buffer was laid out for (a speculative frame: its capacity); `scratch_instances` (0 = R) is what the scratch --
+ * goi_raster_backward_scratch_bytes(scratch_instances, S) bytes -- holds rows for.  It must be >= the frame's num_rendered: a
+ * caller that has READ the count of a speculative frame by the time it enqueues the backward (the loss usually sits in between)
+ * passes the count and needs half the scratch of a frame sized by its capacity (headroom 2: 2.1 instead of 4.3 GB on the
+ * headline view, 6.4 instead of 12.9 GB at 3 M Gaussians).  Same results bit for bit. */
+int goi_raster_backward3(const GoiRasterScene* scene, int R, int scratch_instances, const void* geom_buffer,
+                         const void* binning_buffer, const void* image_buffer, const int* radii, const float* out_alpha,
+                         const float* dL_dout_color, const float* dL_dout_semantic, const float* dL_dout_depth,
+                         const float* dL_dout_alpha, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
+                         float* dL_dsemantic, float* dL_ddepth, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                         float* dL_dscale, float* dL_drot, void* scratch, const int* prev_radii, void* stream);
 
 /* Feature-gradient-only backward: dL/dsemantics [P,S] from dL/d(semantic map) alone, bit-identical to
  * the dL_dsemantic of goi_raster_backward and about 3x cheaper.  For the reference's default training

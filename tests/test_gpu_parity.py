@@ -907,7 +907,7 @@ def test_runs_on_a_side_stream_with_identical_results(dev):
         assert torch.equal(x, y)
 
 
-@pytest.mark.parametrize("option,value", [("bwd_variant", 1), ("bwd_variant", 2), ("fwd_variant", 0), ("fwd_variant", 2), ("fwd_variant", 3), ("fwd_variant", 4), ("sort_variant", 0), ("cull_variant", 0), ("bwd_records", 0),
+@pytest.mark.parametrize("option,value", [("bwd_variant", 1), ("bwd_variant", 2), ("fwd_variant", 0), ("fwd_variant", 2), ("fwd_variant", 3), ("fwd_variant", 4), ("sort_variant", 0), ("cull_variant", 0), ("bwd_records", 0), ("bwd_records", 2),
                                           ("cull_variant", 1), ("bwd_masks", 0), ("sort_small", 1), ("sort_lookback", 0)])
 def test_alternative_kernels_stay_correct(oracle_mod, dev, option, value):
     """The non-default variants kept behind goi_raster_set_option (tile + atomics backward, one-candidate forward
@@ -1012,3 +1012,31 @@ def test_outer_product_forward_takes_the_same_decisions(dev, variant, P, S, W, H
     for k, ga in a["grads"].items():
         if ga is not None:
             assert np.array_equal(ga, b["grads"][k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P,S,W,H,mu,deg", [(3000, 16, 123, 77, -2.6, 2), (20000, 16, 400, 300, -3.2, 3), (40000, 10, 333, 210, -3.8, 3),
+                                            (150, 16, 1280, 720, -0.4, 1), (300, 16, 400, 300, -0.6, 2), (2000, 20, 160, 120, -2.8, 0),
+                                            (600, 5, 90, 70, -2.0, 3), (5000, 24, 200, 150, -3.0, 1)])
+def test_row_sums_inside_the_per_gaussian_backward_are_bit_identical(dev, P, S, W, H, mu, deg):
+    """bwd_records 2: preprocess_bwd_k sums its Gaussians' rows itself (no reduce_rows_k, no record round trip; the BIG Gaussians
+    still through reduce_big_k) -- same summation function, same slot order: every gradient bit-identical to the record path
+    (bwd_records 1) and to the six-array path (0).  Shapes: ordinary, S = 10 (the reference's width), Gaussians of several hundred
+    to several thousand instances (the workgroup-per-Gaussian path), 128-byte rows at S = 5 and 20, and S = 24 (192-byte rows: the
+    mode falls back to the records there)."""
+    from goi_hyperplane_amd import _lib
+    sc = make_scene(P, S=S, sh_degree=deg, seed=21, log_scale_mean=mu)
+    cam = make_camera(W, H, yaw=0.1, pitch=-0.05)
+    bg = np.array([0.3, 0.2, 0.1], np.float32)
+    grads = upstream_grads(S, H, W, seed=9)
+    res = {}
+    try:
+        for v in (1, 2, 0):
+            _lib.set_option("bwd_records", v)
+            res[v] = run_hip(sc, cam, bg, dev, grads=grads)
+    finally:
+        _lib.set_option("bwd_records", 1)
+    for v in (1, 0):
+        for k, ga in res[v]["grads"].items():
+            if ga is not None:
+                assert np.array_equal(ga, res[2]["grads"][k]), (v, k)

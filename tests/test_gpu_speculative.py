@@ -513,3 +513,47 @@ def test_a_much_larger_image_starts_the_capacity_policy_over(dev):
     _C.set_forward_mode(speculative=False)
     n_ref, color_ref, *_ = _C.rasterize_gaussians(*_args(sc, large, dev, bg))
     assert int(n_ref) == int(n) and torch.equal(color_ref, color)
+
+
+@pytest.mark.parametrize("P,S,W,H,mu", [(20000, 16, 400, 300, -3.3), (3000, 10, 160, 120, -2.8)])
+def test_row_scratch_is_sized_by_the_count_once_it_has_arrived(dev, P, S, W, H, mu):
+    """goi_raster_backward3: a speculative frame's workspaces are laid out for its CAPACITY, but the backward's row scratch (129
+    bytes per instance and quadrant: the largest workspace of a step) only has to hold the COUNT -- and the count has usually
+    reached the host by the time the backward is enqueued.  The binding polls (no wait) and lays the scratch out for whichever
+    is known: the gradients are bit-identical either way, and identical to those of an exact frame."""
+    from goi_hyperplane_amd import _C, rasterizer
+    from goi_hyperplane_amd.render import GaussianSet, PipelineParams, TorchCamera, render
+    sc = make_scene(P, S=S, seed=4, log_scale_mean=mu)
+    cam = TorchCamera(make_camera(W, H, yaw=0.1), dev)
+    pc = GaussianSet.from_scene(sc, dev)
+    bg = torch.zeros(3, device=dev)
+    gen = torch.Generator(device=dev).manual_seed(5)
+    gc = torch.randn((3, H, W), device=dev, generator=gen) / (W * H)
+    gs = torch.randn((S, H, W), device=dev, generator=gen) / (W * H)
+
+    def step(wait):
+        for p in pc.parameters():
+            p.grad = None
+        out = render(cam, pc, PipelineParams(), bg)
+        if wait:
+            torch.cuda.synchronize()  # the frame has run: its count is in the pinned words (nobody has looked yet)
+        torch.autograd.backward((out["render"], out["semantics"]), (gc, gs))
+        torch.cuda.synchronize()
+        return [p.grad.clone() for p in pc.parameters()]
+    _C.set_forward_mode(speculative=False)
+    want = step(False)
+    n_exact = int(rasterizer.last_num_rendered())
+    _C.set_forward_mode(speculative=True, capacity=3 * n_exact + 999)
+    s0 = dict(_C.SCRATCH_STATS)
+    got_late = step(True)    # count known at the backward: scratch for the count
+    s1 = dict(_C.SCRATCH_STATS)
+    assert s1["sized_by_count"] == s0["sized_by_count"] + 1 and s1["sized_by_capacity"] == s0["sized_by_capacity"]
+    for a, b in zip(want, got_late):
+        assert torch.equal(a, b)
+    lib = __import__("goi_hyperplane_amd._lib", fromlist=["load"]).load()
+    assert lib.goi_raster_backward_scratch_bytes(n_exact, S) * 2 < lib.goi_raster_backward_scratch_bytes(3 * n_exact + 999, S)
+    got_any = step(False)    # whatever is known (usually nothing yet): same gradients
+    s2 = dict(_C.SCRATCH_STATS)
+    assert s2["sized_by_count"] + s2["sized_by_capacity"] == s1["sized_by_count"] + s1["sized_by_capacity"] + 1
+    for a, b in zip(want, got_any):
+        assert torch.equal(a, b)

@@ -11,6 +11,9 @@
 #   bench[:<extra args>]         python bench.py <extra args>  (',' separates arguments)
 #   pmc:<workload>               kernel stats + the five --pmc passes of the step loop (tools/pmc_steps.sh)
 #   timeline:<workload>          per-dispatch timeline of one step
+#   pmcopt:<wl>:<opts>:<regex>   instruction counters (one --pmc pass) of the kernels matching <regex> under GOI_OPTIONS=<opts>
+#   benchprof                    bench.py --steps 20 --warmup 3 under rocprofv3 --kernel-trace --stats
+#   soak:<N>:<seed>              tests/test_gpu_fuzz.py with GOI_FUZZ_N / GOI_FUZZ_SEED
 #   py:<script>[:args]           python tools/<script> args (',' separates arguments)
 cd $GRAFT_REPO_ROOT
 T=$1; shift
@@ -55,6 +58,29 @@ PY
       ;;
     pmc) A1=$(echo $A1 | tr '%' ':'); bash tools/pmc_steps.sh ${T}_pmc_$(echo $A1 | tr ':' '_') $A1 > /dev/null 2>&1; cat gpurun_out/${T}_pmc_$(echo $A1 | tr ':' '_')/kernel_stats.txt ;;
     timeline) bash tools/step_timeline.sh $A1 > gpurun_out/${T}_timeline_$A1.txt 2>&1; tail -40 gpurun_out/${T}_timeline_$A1.txt ;;
+    pmcopt)  # pmcopt:<workload>:<GOI_OPTIONS with + for ,>:<kernel regex>  -- instruction counters of an option variant (one --pmc pass)
+      W=$(echo $A1 | tr '%' ':'); O=$GRAFT_REPO_ROOT/gpurun_out/${T}_pmcopt; rm -rf $O; mkdir -p $O
+      (cd /tmp; export TMPDIR=/tmp; GOI_OPTIONS=$(echo $A2 | tr '+' ',') timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $O -o p -- python $GRAFT_REPO_ROOT/tools/step_loop.py 8 $W > $O/log.txt 2>&1)
+      python - <<PY | tee -a gpurun_out/${T}_pmcopt.txt
+import csv, glob, collections, re
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("$O/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if re.search(r"$A3", r["Kernel_Name"]):
+            k = r["Kernel_Name"].split("(")[0][-60:]
+            agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            agg[k]["VGPR"] = [float(r.get("VGPR_Count", 0) or 0)]; agg[k]["AGPR"] = [float(r.get("Accum_VGPR_Count", 0) or 0)]
+for k, c in agg.items():
+    print("pmc [$W] [$A2]", k, {n: round(sum(v) / len(v) / (1e6 if n not in ("VGPR", "AGPR") else 1), 3) for n, v in sorted(c.items())})
+PY
+      ;;
+    benchprof)  # the driver's own command under the profiler (kernel stats must agree with the bench line's roofline.avg_ms)
+      O=$GRAFT_REPO_ROOT/gpurun_out/${T}_benchprof; rm -rf $O; mkdir -p $O
+      (cd /tmp; export TMPDIR=/tmp; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o b -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/bench.json 2> $O/err.txt; rm -f $O/*kernel_trace.csv $O/*/*kernel_trace.csv)
+      python tools/kernel_stats_top.py $O 12 2>/dev/null | head -16 ;;
+    soak)  # soak:<N>:<seed>  -- the fuzz sweep on a fresh seed
+      GOI_FUZZ_N=${A1:-1200} GOI_FUZZ_SEED=${A2:-9601} timeout 1800 python -m pytest tests/test_gpu_fuzz.py -m gpu -q 2>&1 | tail -4 | tee -a gpurun_out/${T}_soak_fuzz.log
+      cp gpurun_out/parity_stats.json gpurun_out/${T}_soak_parity_stats_${A2:-9601}.json 2>/dev/null ;;
     py) timeout 1200 python tools/$A1 $(echo $A2 | tr ',' ' ') 2>&1 | tee gpurun_out/${T}_$(basename $A1 .py).txt | tail -40 ;;
     *) echo "unknown step $STEP" ;;
   esac
