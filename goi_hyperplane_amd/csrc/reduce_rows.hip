@@ -97,7 +97,10 @@ __device__ __forceinline__ void store_sums(const float (&sum)[K], float* rows, s
     }
 }
 
-template <int K, int GPQ, bool RECORD>  // K = row_floats / 16; GPQ = Gaussians per quarter wave
+// INFLIGHT: rows a quarter wave requests back to back (its registers: 2 K per row).  32 is best up to ~2 M Gaussians; on larger
+// scenes (a 12.9 GB slot space at 3 M: every round trip longer) 16 -- fewer registers, more resident waves -- is, and the launcher
+// picks by P (same-box A/B, profiles/r06_tail.txt: 3 M 282 -> 250 us, 1 M 153 -> 183 us the other way round).  Same sums.
+template <int K, int GPQ, bool RECORD, int INFLIGHT = GOI_REDUCE_INFLIGHT>  // K = row_floats / 16; GPQ = Gaussians per quarter wave
 __global__ __launch_bounds__(256) void reduce_rows_k(int P, int S, int nch, uint32_t N_cap, const uint32_t* __restrict__ n_dev,
                                                      const uint32_t* __restrict__ order,
                                                      const uint32_t* __restrict__ offsets,
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(256) void reduce_rows_k(int P, int S, int nch, uint
         float sum[K];
 #pragma unroll
         for (int kk = 0; kk < K; kk++) sum[kk] = 0.f;
-        sum_instances<K>(rows, flags32, inst0, cnt, w_cur, quarter, e, sum, sum);  // (comp unused)
+        sum_instances<K, false, INFLIGHT>(rows, flags32, inst0, cnt, w_cur, quarter, e, sum, sum);  // (comp unused)
         if (live && !big && (!RECORD || cnt > 0)) store_sums<K, RECORD>(sum, rows, inst0, cur.g, e, S, nch, out);
         cur = nxt;
         nxt = nn;
@@ -289,14 +292,23 @@ constexpr int REDUCE_GPQ = GOI_REDUCE_GPQ;  // Gaussians per quarter wave of red
 // workgroup per CU it ran the clustered workload's big Gaussians at an eighth of the memory-level parallelism the chip has)
 constexpr size_t REDUCE_BIG_GRID = GOI_REDUCE_BIG_GRID;
 
+#ifndef GOI_REDUCE_LARGE_SCENE
+#define GOI_REDUCE_LARGE_SCENE 2000000
+#endif
+constexpr int REDUCE_LARGE_SCENE = GOI_REDUCE_LARGE_SCENE;  // Gaussians from which reduce_rows_k keeps 16 instead of 32 rows in flight
 template <int K, bool RECORD>
 static void launch_reduce_k(const GoiRasterScene& sc, const GeomView& g, int N, int nch, float* rows, const uint8_t* flags,
                             const BwdScratchView& scr, const ReduceOut& out, hipStream_t s) {
     const dim3 grid((sc.P + 16 * REDUCE_GPQ - 1) / (16 * REDUCE_GPQ));
     const uint32_t* order = g.sort_vals[depth_sort_result_index()];
-    reduce_rows_k<K, REDUCE_GPQ, RECORD><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order,
-                                                                    g.offsets, g.tiles_touched, rows, flags, out, scr.big_ctl,
-                                                                    scr.big_desc, (uint32_t)scr.cap_big);
+    if (sc.P >= REDUCE_LARGE_SCENE && GOI_REDUCE_INFLIGHT > 16)
+        reduce_rows_k<K, REDUCE_GPQ, RECORD, 16><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order,
+                                                                            g.offsets, g.tiles_touched, rows, flags, out, scr.big_ctl,
+                                                                            scr.big_desc, (uint32_t)scr.cap_big);
+    else
+        reduce_rows_k<K, REDUCE_GPQ, RECORD><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order,
+                                                                        g.offsets, g.tiles_touched, rows, flags, out, scr.big_ctl,
+                                                                        scr.big_desc, (uint32_t)scr.cap_big);
     // the big Gaussians: fixed, small grids of persistent workgroups (their numbers are on the device; N == 0: no blend ran,
     // nothing cleared the counters and nothing can be registered)
     if (N > 0)

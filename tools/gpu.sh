@@ -57,7 +57,7 @@ except Exception as e:
 PY
       ;;
     pmc) A1=$(echo $A1 | tr '%' ':'); bash tools/pmc_steps.sh ${T}_pmc_$(echo $A1 | tr ':' '_') $A1 > /dev/null 2>&1; cat gpurun_out/${T}_pmc_$(echo $A1 | tr ':' '_')/kernel_stats.txt ;;
-    timeline) bash tools/step_timeline.sh $A1 > gpurun_out/${T}_timeline_$A1.txt 2>&1; tail -40 gpurun_out/${T}_timeline_$A1.txt ;;
+    timeline) A1=$(echo $A1 | tr '%' ':'); F=gpurun_out/${T}_timeline_$(echo $A1 | tr ':' '_').txt; bash tools/step_timeline.sh $A1 > $F 2>&1; tail -30 $F ;;
     pmcopt)  # pmcopt:<workload>:<GOI_OPTIONS with + for ,>:<kernel regex>  -- instruction counters of an option variant (one --pmc pass)
       W=$(echo $A1 | tr '%' ':'); O=$GRAFT_REPO_ROOT/gpurun_out/${T}_pmcopt; rm -rf $O; mkdir -p $O
       (cd /tmp; export TMPDIR=/tmp; GOI_OPTIONS=$(echo $A2 | tr '+' ',') timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $O -o p -- python $GRAFT_REPO_ROOT/tools/step_loop.py 8 $W > $O/log.txt 2>&1)
