@@ -177,9 +177,6 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
         dLa = 0.f;
     }
     const float bg_dot = bg[0] * dLch[NSEM] + bg[1] * dLch[NSEM + 1] + bg[2] * dLch[NSEM + 2];
-    // (a black background -- the reference's default -- or a loss that ignores colour: the background term of dL/dalpha is zero for
-    // every pixel of the wave, and the pair loop skips its two instructions on a scalar branch; x - 0 is x: same bits)
-    const bool any_bg = __builtin_amdgcn_ballot_w64(t.inside && bg_dot != 0.f) != 0;
     float R = 0.f;
     f32x2 dL2[NCH / 2];  // the same gradients as register pairs for the packed dot product
 #pragma unroll
@@ -575,8 +572,7 @@ __global__ GOI_BWD_LAUNCH_BOUNDS void render_bwd_rows_k(
             const float Tn = T * inv;
             float wgt = 0.f, hval = 0.f;
             if (c) {
-                float dL_dopa = (dotv - R) * Tn;
-                if (any_bg) dL_dopa -= (T_final * inv) * bg_dot;
+                const float dL_dopa = (dotv - R) * Tn - (T_final * inv) * bg_dot;
                 R = e.alpha * dotv + one_m_a * R;
                 T = Tn;
                 wgt = e.alpha * Tn;
