@@ -955,9 +955,12 @@ def _rasterize_gaussians_frame(background, means3D, colors, semantics, opacity, 
 def _backward_impl(background, means3D, radii, colors, semantics, scales, rotations, scale_modifier,
                                  cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
                                  dL_dout_semantic, dL_dout_depth, dL_dout_alpha, sh, degree, campos, geomBuffer, R,
-                                 binningBuffer, imageBuffer, alphas, debug, sh_factored=False):
+                                 binningBuffer, imageBuffer, alphas, debug, sh_factored=False, accumulate_into=None):
     """-> (dL_dmeans2D[P,3], dL_dcolors[P,3], dL_dsemantics[P,S], dL_dopacity[P,1], dL_dmeans3D[P,3],
     dL_dcov3D[P,6], dL_dsh[P,M,3], dL_dscales[P,3], dL_drotations[P,4])
+
+    accumulate_into (compiled binding only): the dL_dmeans3D an earlier call of the same batch returned -- this view's gradients
+    are ADDED to that call's tensors (goi_raster_backward3, GOI_BACKWARD_ACCUMULATE) and the same tensors are returned.
 
     sh_factored (not in the reference's pybind module; FACTORED mode of goi_raster_backward): dL_dsh is not formed
     (returned as None) and dL_dcolors is the clamp-masked colour gradient g, the factor of
@@ -972,7 +975,9 @@ def _backward_impl(background, means3D, radii, colors, semantics, scales, rotati
                                float(tan_fovy), dL_dout_color, dL_dout_semantic, dL_dout_depth, dL_dout_alpha, _e(sh),
                                int(degree), campos, geomBuffer, R_layout,
                                binningBuffer if lazy_binning is None else lazy_binning, imageBuffer, alphas, bool(debug),
-                               bool(sh_factored), _scratch_instances(R, R_layout))
+                               bool(sh_factored), _scratch_instances(R, R_layout), accumulate_into)
+    if accumulate_into is not None:
+        raise RuntimeError("accumulate_into needs the compiled binding (python -m goi_hyperplane_amd.build)")
     P = int(means3D.size(0))
     # the reference reads H, W off dL_dout_color (rasterize_points.cu:243-244); here any upstream gradient may be
     # None (an output the loss does not use), so the sizes come from tensors that always exist
@@ -1033,7 +1038,7 @@ def _backward_impl(background, means3D, radii, colors, semantics, scales, rotati
             R_scratch = _scratch_instances(R, R_layout)
             scratch = _backward_scratch(lib.goi_raster_backward_scratch_bytes(R_scratch or R_layout, S), dev)
             r = lib.goi_raster_backward3(
-                C.byref(sc), R_layout, R_scratch, _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(ten["radii"]),
+                C.byref(sc), R_layout, R_scratch, 0, _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(ten["radii"]),
                 _ptr(ten["alphas"]), _ptr(ten["g_c"]), _ptr(ten["g_s"]), _ptr(ten["g_d"]), _ptr(ten["g_a"]),
                 _ptr(dL_dmeans2D), _ptr(dL_dconic), _ptr(dL_dopacity), _ptr(dL_dcolors), _ptr(dL_dsemantics),
                 _ptr(dL_ddepths), _ptr(dL_dmeans3D), _ptr(dL_dcov3D), _ptr(dL_dsh), _ptr(dL_dscales),
@@ -1052,6 +1057,13 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, semantics, 
     dL_dcov3D[P,6], dL_dsh[P,M,3], dL_dscales[P,3], dL_drotations[P,4]) -- the reference's RasterizeGaussiansBackwardCUDA
     (rasterize_points.cu:213-306), same argument list."""
     return _backward_impl(background, means3D, radii, colors, semantics, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_semantic, dL_dout_depth, dL_dout_alpha, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, alphas, debug)
+
+
+def rasterize_gaussians_backward_accumulate(accumulate_into, *args):
+    """rasterize_gaussians_backward(*args) (not in the reference's pybind module) whose gradients are ADDED, on the device, to the
+    tensors an earlier call of the same batch returned: accumulate_into = that call's dL_dmeans3D (None: a plain call, the
+    batch's first).  Returns the same nine tensors.  goi_raster_backward3 / GOI_BACKWARD_ACCUMULATE; compiled binding only."""
+    return _backward_impl(*args, accumulate_into=accumulate_into)
 
 
 def rasterize_gaussians_backward_sh_factored(background, means3D, radii, colors, semantics, scales, rotations, scale_modifier,

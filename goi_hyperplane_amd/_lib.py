@@ -55,7 +55,7 @@ SYMBOLS = {
                             + [C.c_void_p] * 11 + [C.c_void_p, C.c_void_p]),
     "goi_raster_backward2": (C.c_int, [C.POINTER(GoiRasterScene), C.c_int] + [C.c_void_p] * 3 + [C.c_void_p] * 6
                              + [C.c_void_p] * 11 + [C.c_void_p, C.c_void_p, C.c_void_p]),
-    "goi_raster_backward3": (C.c_int, [C.POINTER(GoiRasterScene), C.c_int, C.c_int] + [C.c_void_p] * 3 + [C.c_void_p] * 6
+    "goi_raster_backward3": (C.c_int, [C.POINTER(GoiRasterScene), C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 3 + [C.c_void_p] * 6
                              + [C.c_void_p] * 11 + [C.c_void_p, C.c_void_p, C.c_void_p]),
     "goi_raster_backward_semantics": (C.c_int, [C.POINTER(GoiRasterScene), C.c_int] + [C.c_void_p] * 9),
     "goi_raster_trace": (C.c_int, [C.POINTER(GoiRasterScene), C.c_void_p, C.c_void_p, C.c_void_p, ALLOC_FN,

@@ -720,7 +720,7 @@ int goi_raster_backward(const GoiRasterScene* scene, int R, const void* geom_buf
                                 stream);
 }
 
-int goi_raster_backward3(const GoiRasterScene* scene, int R, int scratch_instances, const void* geom_buffer,
+int goi_raster_backward3(const GoiRasterScene* scene, int R, int scratch_instances, int flags, const void* geom_buffer,
                          const void* binning_buffer, const void* image_buffer, const int* radii, const float* out_alpha,
                          const float* dL_dout_color, const float* dL_dout_semantic, const float* dL_dout_depth,
                          const float* dL_dout_alpha, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
@@ -744,6 +744,10 @@ int goi_raster_backward3(const GoiRasterScene* scene, int R, int scratch_instanc
     if (scratch_instances < 0 || scratch_instances > R) return fail("scratch_instances must be in 0..R (0: the scratch is laid out for R)");
     // Rs: instances the ROW SCRATCH holds rows for (the binning workspace keeps R); every slot index is below 4 x num_rendered <= 4 Rs
     const int Rs = scratch_instances > 0 ? scratch_instances : R;
+    const bool accumulate = (flags & GOI_BACKWARD_ACCUMULATE) != 0;
+    if (accumulate && (!rows_path || g_options.bwd_records != 1 || prev_radii || (sc.shs && !dL_dsh) || sc.debug))
+        return fail("GOI_BACKWARD_ACCUMULATE needs the default backward (scratch given, bwd_variant 0 / 2, bwd_records 1), dL_dsh when "
+                    "the colours are SH, prev_radii NULL and debug off");
     if (rows_path) {
         // atomic-free path: (quadrant, Gaussian) partial rows + validity bytes, then a fixed-order sum
         BwdScratchView scr;
@@ -764,7 +768,7 @@ int goi_raster_backward3(const GoiRasterScene* scene, int R, int scratch_instanc
         }
         if (check_stage(sc, s, "backward blend")) return -1;
         StageTimer t(GOI_STAGE_PREPROCESS_BWD, s);
-        if (g_options.bwd_records == 2 && bwd_row_floats(sc.S) == 32 && R > 0) {
+        if (g_options.bwd_records == 2 && bwd_row_floats(sc.S) == 32 && R > 0 && !accumulate) {
             // the per-Gaussian backward sums its Gaussians' rows itself; only the BIG Gaussians pass through reduce_big_k's records
             launch_reduce_big_only(sc, g, Rs, scr, s);
             launch_preprocess_bwd(sc, g, radii, dL_dmean2D, dL_dconic, dL_dcolor, dL_ddepth, dL_dmean3D, dL_dcov3D, dL_dsh,
@@ -773,7 +777,7 @@ int goi_raster_backward3(const GoiRasterScene* scene, int R, int scratch_instanc
             // the sums stay in the row scratch (one record per listed Gaussian); preprocess_bwd_k writes the per-id outputs
             launch_reduce_rows(sc, g, Rs, scr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, s, true);
             launch_preprocess_bwd(sc, g, radii, dL_dmean2D, dL_dconic, dL_dcolor, dL_ddepth, dL_dmean3D, dL_dcov3D, dL_dsh,
-                                  dL_dscale, dL_drot, s, scr.rows, dL_dopacity, dL_dsemantic, prev_radii);
+                                  dL_dscale, dL_drot, s, scr.rows, dL_dopacity, dL_dsemantic, prev_radii, nullptr, 0, accumulate);
         } else {
             launch_reduce_rows(sc, g, Rs, scr, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dsemantic, dL_ddepth, s);
             launch_preprocess_bwd(sc, g, radii, dL_dmean2D, dL_dconic, dL_dcolor, dL_ddepth, dL_dmean3D, dL_dcov3D, dL_dsh,
@@ -809,7 +813,7 @@ int goi_raster_backward2(const GoiRasterScene* scene, int R, const void* geom_bu
                          float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dsemantic,
                          float* dL_ddepth, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale,
                          float* dL_drot, void* scratch, const int* prev_radii, void* stream) {
-    return goi_raster_backward3(scene, R, 0, geom_buffer, binning_buffer, image_buffer, radii, out_alpha, dL_dout_color,
+    return goi_raster_backward3(scene, R, 0, 0, geom_buffer, binning_buffer, image_buffer, radii, out_alpha, dL_dout_color,
                                 dL_dout_semantic, dL_dout_depth, dL_dout_alpha, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor,
                                 dL_dsemantic, dL_ddepth, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, scratch, prev_radii,
                                 stream);

@@ -244,7 +244,8 @@ void launch_preprocess_bwd(const GoiRasterScene& sc, const GeomView& g, const in
                            float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, hipStream_t s,
                            const float* record_rows = nullptr, float* dL_dopacity = nullptr, float* dL_dsemantic = nullptr,
                            const int* prev_radii = nullptr,  // prev_radii: BwdArgs (rows that already hold zeros)
-                           const uint8_t* row_flags = nullptr, int N_cap = 0);  // row_flags: the kernel sums the rows itself (bwd_records 2)
+                           const uint8_t* row_flags = nullptr, int N_cap = 0,  // row_flags: the kernel sums the rows itself (bwd_records 2)
+                           bool accumulate = false);  // add to the outputs instead of writing them (record path only: BwdArgs::accumulate)
 int launch_semantic_decode(const float* sem, int S, long long HW, const float* W, const float* bias, int n_codes,
                            const float* code_score, float thresh, float* sim_out, int* idx_out, uint8_t* bg_mask_out,
                            hipStream_t s);

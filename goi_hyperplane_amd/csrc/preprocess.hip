@@ -463,6 +463,11 @@ struct BwdArgs {
     // was invisible then and is invisible now already has zeros in every output row -- nothing is written for it (half of the
     // headline scene: 170 MB of zeros per step).  goi_raster_backward2, csrc/torch_binding.cpp: the gradient-buffer pool.
     const int* prev_radii;
+    // ACCUMULATE (goi_raster_backward3, flags bit 0; the record path only): the outputs already hold the gradients of earlier
+    // views of the same batch -- a visible Gaussian's rows are read, added to and written back, an invisible one's are left
+    // alone.  The sum of K views then costs each view its visible rows once more instead of a dense [P, 75 + S] addition
+    // (dist.backward_views).
+    int accumulate;
 };
 
 // WITH_DSH: dL/dSH is formed ([P,M,3], staged through LDS).  Otherwise (the caller passed dL_dsh = NULL with SH
@@ -567,7 +572,7 @@ __global__ __launch_bounds__(256, GOI_PBWD_BLOCKS) void preprocess_bwd_k(const B
         const bool vis_t = live && radii[gtid] > 0 && !truncated;
         // rows that already hold zeros (see BwdArgs::prev_radii) are not written again
         const bool keep_t = live && !vis_t && args.prev_radii != nullptr && args.prev_radii[gtid] == 0;
-        const bool zero_t = live && !vis_t && !keep_t;
+        const bool zero_t = live && !vis_t && !keep_t && !args.accumulate;
         const int wv = threadIdx.x >> 6;
         const unsigned long long bv = __ballot(vis_t), bz = __ballot(zero_t);
         if ((threadIdx.x & 63) == 0) {
@@ -759,13 +764,22 @@ __global__ __launch_bounds__(256, GOI_PBWD_BLOCKS) void preprocess_bwd_k(const B
         }
         if (visible) {
             s_src[threadIdx.x] = listed ? slot : 0xFFFFFFFFu;
-            ra.dL_dopacity[idx] = opa;
-            dL_dmean2D[3 * idx] = in_m2d[0];
-            dL_dmean2D[3 * idx + 1] = in_m2d[1];
-            dL_dmean2D[3 * idx + 2] = 0.f;
-            dL_dcolor[3 * idx] = in_col.x;  // (factored SH mode overwrites it with the clamp-masked gradient below)
-            dL_dcolor[3 * idx + 1] = in_col.y;
-            dL_dcolor[3 * idx + 2] = in_col.z;
+            if (a.accumulate) {
+                ra.dL_dopacity[idx] += opa;
+                dL_dmean2D[3 * idx] += in_m2d[0];
+                dL_dmean2D[3 * idx + 1] += in_m2d[1];
+                dL_dcolor[3 * idx] += in_col.x;
+                dL_dcolor[3 * idx + 1] += in_col.y;
+                dL_dcolor[3 * idx + 2] += in_col.z;
+            } else {
+                ra.dL_dopacity[idx] = opa;
+                dL_dmean2D[3 * idx] = in_m2d[0];
+                dL_dmean2D[3 * idx + 1] = in_m2d[1];
+                dL_dmean2D[3 * idx + 2] = 0.f;
+                dL_dcolor[3 * idx] = in_col.x;  // (factored SH mode overwrites it with the clamp-masked gradient below)
+                dL_dcolor[3 * idx + 1] = in_col.y;
+                dL_dcolor[3 * idx + 2] = in_col.z;
+            }
         }
     } else if (visible) {
         in_conic[0] = dL_dconic[4 * idx];
@@ -990,6 +1004,19 @@ __global__ __launch_bounds__(256, GOI_PBWD_BLOCKS) void preprocess_bwd_k(const B
         }
     }
     if (visible) {
+        if (a.accumulate) {  // (requested together, added, written back)
+            const float m0 = dL_dmean3D[3 * idx], m1 = dL_dmean3D[3 * idx + 1], m2 = dL_dmean3D[3 * idx + 2];
+            float c6[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) c6[i] = dL_dcov3D[(size_t)6 * idx + i];
+            const float s0 = dL_dscale[3 * idx], s1 = dL_dscale[3 * idx + 1], s2 = dL_dscale[3 * idx + 2];
+            const float4 r4 = reinterpret_cast<const float4*>(dL_drot)[idx];
+            gmean = gmean + V3{m0, m1, m2};
+#pragma unroll
+            for (int i = 0; i < 6; i++) gcov[i] += c6[i];
+            gscale = gscale + V3{s0, s1, s2};
+            grot = make_float4(grot.x + r4.x, grot.y + r4.y, grot.z + r4.z, grot.w + r4.w);
+        }
         dL_dmean3D[3 * idx] = gmean.x;
         dL_dmean3D[3 * idx + 1] = gmean.y;
         dL_dmean3D[3 * idx + 2] = gmean.z;
@@ -1011,13 +1038,21 @@ __global__ __launch_bounds__(256, GOI_PBWD_BLOCKS) void preprocess_bwd_k(const B
                 const uint32_t o = s_src[r];
                 const float4 v = o != 0xFFFFFFFFu ? *reinterpret_cast<const float4*>(ra.rows + (size_t)o * 4 * ra.row_floats + 4 * sub)
                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
-                *reinterpret_cast<float4*>(ra.dL_dsemantic + (size_t)s_vis[r] * ra.S + 4 * sub) = v;
+                float4* dst = reinterpret_cast<float4*>(ra.dL_dsemantic + (size_t)s_vis[r] * ra.S + 4 * sub);
+                if (a.accumulate) {
+                    const float4 p = *dst;
+                    *dst = make_float4(p.x + v.x, p.y + v.y, p.z + v.z, p.w + v.w);
+                } else {
+                    *dst = v;
+                }
             }
         } else {
             for (int i = threadIdx.x; i < nrows * ra.S; i += 256) {
                 const int r = i / ra.S, ch = i - r * ra.S;
                 const uint32_t o = s_src[r];
-                ra.dL_dsemantic[(size_t)s_vis[r] * ra.S + ch] = o != 0xFFFFFFFFu ? ra.rows[(size_t)o * 4 * ra.row_floats + ch] : 0.f;
+                const float v = o != 0xFFFFFFFFu ? ra.rows[(size_t)o * 4 * ra.row_floats + ch] : 0.f;
+                float* dst = &ra.dL_dsemantic[(size_t)s_vis[r] * ra.S + ch];
+                *dst = a.accumulate ? *dst + v : v;
             }
         }
     }
@@ -1027,7 +1062,8 @@ __global__ __launch_bounds__(256, GOI_PBWD_BLOCKS) void preprocess_bwd_k(const B
         const int dr = 256 / w, dc = 256 - dr * w;
         int r = (int)threadIdx.x / w, col = (int)threadIdx.x - r * w;
         while (r < nrows) {
-            dL_dsh[(size_t)s_vis[r] * w + col] = s_dsh[r * (w + 1) + col];
+            float* dst = &dL_dsh[(size_t)s_vis[r] * w + col];
+            *dst = a.accumulate ? *dst + s_dsh[r * (w + 1) + col] : s_dsh[r * (w + 1) + col];
             r += dr;
             col += dc;
             if (col >= w) {
@@ -1162,9 +1198,10 @@ void launch_preprocess_bwd(const GoiRasterScene& sc, const GeomView& g, const in
                            const float* dL_dconic, float* dL_dcolor, const float* dL_ddepth, float* dL_dmean3D,
                            float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, hipStream_t s,
                            const float* record_rows, float* dL_dopacity, float* dL_dsemantic, const int* prev_radii,
-                           const uint8_t* row_flags, int N_cap) {
+                           const uint8_t* row_flags, int N_cap, bool accumulate) {
     BwdArgs a;
     a.prev_radii = prev_radii;
+    a.accumulate = accumulate ? 1 : 0;
     a.P = sc.P; a.D = sc.D; a.M = sc.M; a.W = sc.W; a.H = sc.H;
     a.means3D = sc.means3D; a.shs = sc.shs; a.scales = sc.scales; a.rotations = sc.rotations;
     a.cov3D = sc.cov3D_precomp ? sc.cov3D_precomp : g.cov3D;

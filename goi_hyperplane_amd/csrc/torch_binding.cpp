@@ -291,7 +291,9 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tenso
     const c10::optional<Tensor>& dL_dout_depth, const c10::optional<Tensor>& dL_dout_alpha, const Tensor& sh,
     const int degree, const Tensor& campos, const Tensor& geomBuffer, const int R, const Tensor& binningBuffer,
     const Tensor& imageBuffer, const Tensor& alphas, const bool debug, const bool sh_factored_in,
-    const int scratch_instances /* 0: the row scratch is laid out for R (goi_raster_backward3) */) {
+    const int scratch_instances /* 0: the row scratch is laid out for R (goi_raster_backward3) */,
+    const c10::optional<Tensor>& accumulate_into /* the dL_dmeans3D an earlier call of the same batch returned: this view's
+                                                    gradients are ADDED to that call's buffer (GOI_BACKWARD_ACCUMULATE) */) {
     const c10::Device dev = check_device(means3D);
     c10::hip::HIPGuard guard(dev.index());
     const int P = (int)means3D.size(0);
@@ -313,7 +315,18 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tenso
     // a pooled buffer nobody else holds any more (see the pool's comment), or a fresh one
     Tensor flat, prev_radii;
     const PoolKey key{(int)dev.index(), stream, total, P, sh_factored ? -M : M, S};
-    if (P != 0) {
+    const bool accumulate = accumulate_into.has_value() && accumulate_into->defined() && P != 0;
+    if (accumulate) {
+        // the flat buffer of the batch's first backward: its first section is the dL_dmeans3D the caller kept
+        const Tensor& first = *accumulate_into;
+        TORCH_CHECK(!sh_factored, "accumulate_into: not with the factored dL/dSH");
+        TORCH_CHECK(first.is_cuda() && first.device() == dev && first.scalar_type() == torch::kFloat32 && first.storage_offset() == 0 &&
+                        (long long)(first.storage().nbytes() / sizeof(float)) >= total,
+                    "accumulate_into must be the dL_dmeans3D an earlier backward of the same shapes returned");
+        flat = torch::empty({0}, f32).set_(first.storage(), 0, {total}, {1});
+        // the pool may still list this buffer with the FIRST view's radii ("rows invisible then hold zeros"): not after this call
+        first.unsafeGetTensorImpl()->bump_version();
+    } else if (P != 0) {
         std::lock_guard<std::mutex> lk(g_pool_mu);
         if (g_pool_on) {
             auto& v = g_pool[key];
@@ -360,7 +373,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tenso
         void* scratch = backward_scratch(goi_raster_backward_scratch_bytes(scratch_instances > 0 ? scratch_instances : R, S), dev,
                                          stream, means3D.options().dtype(torch::kByte));
         const int r = goi_raster_backward3(
-            &sc, R, scratch_instances, geomBuffer.data_ptr(), binningBuffer.numel() ? binningBuffer.data_ptr() : nullptr,
+            &sc, R, scratch_instances, accumulate ? GOI_BACKWARD_ACCUMULATE : 0, geomBuffer.data_ptr(), binningBuffer.numel() ? binningBuffer.data_ptr() : nullptr,
             imageBuffer.data_ptr(), rad.data_ptr<int>(), al.p, gc.p, gs.p, gd.p, ga.p, dL_dmeans2D.data_ptr<float>(),
             dL_dconic.data_ptr<float>(), dL_dopacity.data_ptr<float>(), dL_dcolors.data_ptr<float>(),
             dL_dsemantics.data_ptr<float>(), dL_ddepths.data_ptr<float>(), dL_dmeans3D.data_ptr<float>(),
@@ -371,7 +384,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tenso
         // the buffer goes (back) into the pool with this frame's radii; it is handed out again only when every view the
         // caller got has been released and nothing has written to it in place
         std::lock_guard<std::mutex> lk(g_pool_mu);
-        if (g_pool_on && !debug) {
+        if (g_pool_on && !debug && !accumulate) {  // (an accumulated buffer is the caller's: its zero rows are no longer this frame's)
             auto& v = g_pool[key];
             if (v.size() >= POOL_BUFFERS_PER_KEY) v.erase(v.begin());
             v.push_back(PoolEntry{flat, rad, (int64_t)flat._version()});
@@ -392,7 +405,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tenso
     const Tensor& binningBuffer, const Tensor& imageBuffer, const Tensor& alphas, const bool debug) {
     return backward_ex(background, means3D, radii, colors, semantics, scales, rotations, scale_modifier, cov3D_precomp,
                        viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_semantic, dL_dout_depth,
-                       dL_dout_alpha, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, alphas, debug, false, 0);
+                       dL_dout_alpha, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, alphas, debug, false, 0, c10::nullopt);
 }
 
 // dL/dsemantics only (goi_raster_backward_semantics)

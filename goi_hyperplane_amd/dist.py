@@ -451,27 +451,41 @@ def _view_streams(dev: torch.device, n: int):
     return _VIEW_STREAMS[key]
 
 
-def backward_views(views, render_view, upstream, params, streams: int = 2, accumulate: bool = False):
+def backward_views(views, render_view, upstream, params, streams: int = 1, accumulate: bool = False, on_device: bool = True):
     """Forward + backward of the K views of a multi-view batch (BASELINE config 4's "8-view batch" on fewer than 8 GPUs, or
     --views-per-exchange K before one gradient exchange) with the views ALTERNATING over `streams` HIP streams of this GPU,
     and the SUM of their gradients left in `p.grad` of every parameter -- what K serial `loss.backward()` calls leave there.
-
-    Independent views overlap: one view's latency-bound kernels (the sorts and scans of its front end, kernel tails) run
-    beside the other view's blends; on one MI355X two streams render 1.10x the views per second of one (bench.py,
-    `views_in_flight_batch`).  train.py's own loop (one view, optimiser step, next view: train.py:96-198) cannot do this;
-    a batch of views between two optimiser steps can.
+    train.py's own loop (one view, optimiser step, next view: train.py:96-198) cannot batch; a batch of views between two
+    optimiser steps can.
 
       views        sequence of K view descriptors (cameras)
       render_view  view -> dict of outputs (e.g. lambda cam: render(cam, pc, pipe, bg))
-      upstream     (outputs, k) -> (tensors, grad_tensors): what torch.autograd.grad differentiates for view k
-      params       the leaves whose gradients are wanted (every one must take part in every view's graph, or be unused in all)
+      upstream     (outputs, k) -> (tensors, grad_tensors): what is differentiated for view k
+      params       the leaves whose gradients are wanted
       streams      HIP streams the views alternate over (1 = one after the other on the current stream)
       accumulate   add to the gradients already in p.grad instead of replacing them
+      on_device    sum the rasterizer's gradients on the device (below); False: K dense sums of leaf gradients
 
-    Stream s sums the gradients of ITS views (views s, s + streams, ...) in view order with torch.autograd.grad -- never through
-    p.grad, which two streams would race on -- and the current stream adds the per-stream sums in stream order once all are
-    done: for K = 2 that is g0 + g1, bit-identical to the serial sum; beyond, (g0 + g2 + ...) + (g1 + g3 + ...): the serial
-    sum up to the association of fp32 additions (tests/test_gpu_dist.py).  Returns the list of per-view outputs (detached)."""
+    MEASURED on one MI355X, headline workload (bench.py `views_in_flight_batch`, round 6): single-view steps 759 views/s; a batch
+    through this function 717-728 (streams 1: a batch's gradients are the caller's until the next batch, so the gradient-buffer
+    pool cannot skip the rows that already hold zeros) and 684-704 with streams 2 -- two views whose gradients need NOT be summed
+    overlap to 824-839 views/s (`two_views_in_flight`), but with one sum the backwards have to take turns and what is left to
+    overlap (a forward beside the other view's backward) does not pay for the joins at the batch's ends.  Hence streams = 1 by
+    default; the parameter stays for GPUs / sizes where the balance differs.
+
+    Two things can make a batch cheaper than K steps.  (1) Independent views overlap: one view's latency-bound kernels (sorts, scans,
+    kernel tails) run beside the other's blends.  (2) on_device: the K views share their operands (the activations of the same
+    parameters), so the rasterizer's backward of view 2, 3, ... ADDS its per-Gaussian gradients to view 1's tensors inside the
+    per-Gaussian kernel (rasterizer.accumulate_gradients -> goi_raster_backward3, GOI_BACKWARD_ACCUMULATE: a view reads and rewrites
+    the rows of the Gaussians it sees -- half of the scene -- instead of a dense [P, 75 + S] addition per view, and no row of an
+    invisible Gaussian is zero-filled or touched), one sum per stream; the per-stream sums are added once and back-propagated
+    through the activations ONCE instead of K times.  The result equals the serial sum up to the association of fp32 additions
+    (tests/test_gpu_dist.py).  Gradients that do not come through the rasterizer, and backward modes that do not accumulate
+    (semantics-only, factored, ctypes binding), are summed as leaf gradients, per stream in view order, then in stream order.
+    Returns the list of per-view outputs (detached)."""
+    import contextlib
+
+    from . import rasterizer
     params = [p for p in params if p.requires_grad]
     if not views:
         return []
@@ -480,6 +494,12 @@ def backward_views(views, render_view, upstream, params, streams: int = 2, accum
     cur = torch.cuda.current_stream(dev)
     side = [cur] if n == 1 else _view_streams(dev, n)
     sums = [None] * n
+    # on_device: ONE sum for all streams.  The backward of view k waits (an event) for the backward of view k - 1, whichever stream
+    # that ran on, so the accumulating kernels never meet -- what overlaps is view k + 1's forward (front end, forward blend) with
+    # view k's backward; no per-stream sums to add at the end, one zero-fill per batch.
+    shared = dict(grads=None, inputs=None, views=0)
+    states = [shared if on_device else dict(grads=None, inputs=None, views=0) for _ in range(n)]
+    bwd_done = None
     outs = [None] * len(views)
     for s_ in side:
         if s_ is not cur:
@@ -487,19 +507,28 @@ def backward_views(views, render_view, upstream, params, streams: int = 2, accum
     for k, view in enumerate(views):
         si = k % n
         with torch.cuda.stream(side[si]):
-            out = render_view(view)
-            tensors, grads = upstream(out, k)
-            g = torch.autograd.grad(tensors, params, grads, allow_unused=True)
+            ctx = rasterizer.accumulate_gradients(states[si]) if on_device else contextlib.nullcontext()
+            with ctx:
+                out = render_view(view)
+                tensors, grads = upstream(out, k)
+                if on_device and n > 1 and bwd_done is not None:
+                    side[si].wait_event(bwd_done)
+                g = torch.autograd.grad(tensors, params, grads, allow_unused=True)
+                if on_device and n > 1:
+                    bwd_done = torch.cuda.Event()
+                    bwd_done.record(side[si])
+                    if shared["grads"] is not None:
+                        for t in shared["grads"]:
+                            if t is not None:
+                                t.record_stream(side[si])
             if sums[si] is None:
-                sums[si] = [None if t is None else t for t in g]
+                sums[si] = list(g)
             else:
                 for i, t in enumerate(g):
                     if t is None:
                         continue
-                    if sums[si][i] is None:
-                        sums[si][i] = t
-                    else:
-                        sums[si][i] = sums[si][i] + t  # (out of place: a gradient may be a view of the rasterizer's pooled buffer)
+                    # (out of place: a gradient may be a view of the rasterizer's pooled buffer)
+                    sums[si][i] = t if sums[si][i] is None else sums[si][i] + t
             outs[k] = {key: (v.detach() if torch.is_tensor(v) else v) for key, v in out.items()}
             for t in g:  # the caching allocator must not hand these blocks to another stream before this one is done with them
                 if t is not None and side[si] is not cur:
@@ -507,8 +536,32 @@ def backward_views(views, render_view, upstream, params, streams: int = 2, accum
     for s_ in side:
         if s_ is not cur:
             cur.wait_stream(s_)
+    # ---- the rasterizer's gradients, summed on the device per stream: add the streams' sums, then through the activations once
+    op_total, op_inputs = None, None
+    for si in range(n):
+        st = states[si]
+        if st["grads"] is None or (on_device and si > 0):  # (on_device: the one shared sum)
+            continue
+        if side[si] is not cur:
+            for t in st["grads"]:
+                if t is not None:
+                    t.record_stream(cur)
+        if op_total is None:
+            op_total, op_inputs = list(st["grads"]), st["inputs"]
+        else:
+            for i, t in enumerate(st["grads"]):
+                if t is not None and op_total[i] is not None:
+                    op_total[i].add_(t)
+    from_op = [None] * len(params)
+    if op_total is not None:
+        # operands (means3D, sh, colors_precomp, semantics, opacities, scales, rotations, cov3Ds_precomp) <- positions of their
+        # gradients in the op's result (dL_dmeans2D, dL_dcolors, dL_dsemantics, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, ...)
+        pairs = [(inp, op_total[j]) for inp, j in zip(op_inputs, (4, 6, 1, 2, 3, 7, 8, 5))
+                 if torch.is_tensor(inp) and inp.requires_grad and op_total[j] is not None and op_total[j].numel() == inp.numel()]
+        if pairs:
+            from_op = torch.autograd.grad([a_ for a_, _b in pairs], params, [b_.view_as(a_) for a_, b_ in pairs], allow_unused=True)
     for i, p in enumerate(params):
-        tot = None
+        tot = from_op[i]
         for si in range(n):
             t = None if sums[si] is None else sums[si][i]
             if t is None:

@@ -220,6 +220,18 @@ class _RasterizeGaussians(torch.autograd.Function):
              grad_scales, grad_rotations) = _C.rasterize_gaussians_backward_sh_factored(*args)
             grad_colors_precomp = None
             _LAST_BACKWARD["kernel"] = "full_no_dsh"
+        elif _ACCUM["state"] is not None and not rs.debug and _C._ext() is not None:
+            # a multi-view batch (accumulate_gradients / dist.backward_views): this view's gradients are ADDED, on the device, to
+            # the tensors the batch's first view returned; autograd gets nothing from here -- the batch back-propagates the sums
+            # through the activations once, at its end
+            st = _ACCUM["state"]
+            first = st.get("grads")
+            res = _C.rasterize_gaussians_backward_accumulate(None if first is None else first[4], *args)
+            if first is None:
+                st["grads"] = res
+            st["views"] = st.get("views", 0) + 1
+            _LAST_BACKWARD["kernel"] = "full_accumulate"
+            return (None,) * 10
         else:
             _LAST_BACKWARD["kernel"] = "full"
             (grad_means2D, grad_colors_precomp, grad_semantics, grad_opacities, grad_means3D, grad_cov3Ds_precomp,
@@ -246,6 +258,8 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, semantics, opaciti
     # (means2D is the caller's gradient SINK -- the reference's harness makes it require a gradient on every call -- so it
     # does not count)
     tensors = (means3D, sh, colors_precomp, semantics, opacities, scales, rotations, cov3Ds_precomp)
+    if _ACCUM["state"] is not None:  # (the operands of the batch's views are the same activations of the same parameters)
+        _ACCUM["state"]["inputs"] = tensors
     _C._CALL.inference = not (torch.is_grad_enabled()
                               and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors))
     # eligible for the opt-in geometry cache: no input but the semantic features (and the sink) can receive a gradient
@@ -257,6 +271,34 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, semantics, opaciti
     finally:
         _C._CALL.inference = False
         _C._CALL.geometry_frozen = False
+
+
+_ACCUM = {"state": None}  # process-wide on purpose: Function.backward runs on autograd's device thread, not the caller's
+
+
+class accumulate_gradients:
+    """Context of a MULTI-VIEW BATCH (dist.backward_views): while it is active, the full backward of every rasterizer call adds
+    its per-Gaussian gradients ON THE DEVICE to the tensors the first such call returned (goi_raster_backward3 with
+    GOI_BACKWARD_ACCUMULATE: a view reads and rewrites the rows of the Gaussians it sees, nothing else) and hands autograd no
+    gradient; `state` collects {"grads": the nine tensors in the op's order (dL_dmeans2D, dL_dcolors, dL_dsemantics, dL_dopacity,
+    dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations), "inputs": the operands of the last call (means3D, sh,
+    colors_precomp, semantics, opacities, scales, rotations, cov3Ds_precomp), "views": how many views are summed}.  The caller
+    back-propagates the sums through whatever produced the operands (the activations), once.  Valid only while the parameters do
+    not change between the views of the batch.  One batch at a time per process; the semantics-only, factored and debug
+    backwards, and the ctypes binding, do not accumulate (they return gradients as usual: state["views"] stays put)."""
+
+    def __init__(self, state: dict):
+        self.state = state
+
+    def __enter__(self):
+        if _ACCUM["state"] is not None and _ACCUM["state"] is not self.state:
+            raise RuntimeError("accumulate_gradients: another batch is being accumulated")
+        _ACCUM["state"] = self.state
+        return self.state
+
+    def __exit__(self, *exc):
+        _ACCUM["state"] = None
+        return False
 
 
 def set_geometry_cache(max_bytes) -> None:

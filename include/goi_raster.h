@@ -227,8 +227,15 @@ int goi_raster_backward2(const GoiRasterScene* scene, int R, const void* geom_bu
  * goi_raster_backward_scratch_bytes(scratch_instances, S) bytes -- holds rows for.  It must be >= the frame's num_rendered: a
  * caller that has READ the count of a speculative frame by the time it enqueues the backward (the loss usually sits in between)
  * passes the count and needs half the scratch of a frame sized by its capacity (headroom 2: 2.1 instead of 4.3 GB on the
- * headline view, 6.4 instead of 12.9 GB at 3 M Gaussians).  Same results bit for bit. */
-int goi_raster_backward3(const GoiRasterScene* scene, int R, int scratch_instances, const void* geom_buffer,
+ * headline view, 6.4 instead of 12.9 GB at 3 M Gaussians).  Same results bit for bit.
+ * `flags` bit 0, ACCUMULATE: the eleven output arrays already hold the gradients of earlier views of the same batch (written by a
+ * call without the bit, then possibly added to by calls with it) and this view's gradients are ADDED: the rows of a Gaussian that
+ * is visible in this view are read, added to and written back, all other rows are left alone -- the sum over the K views of a batch
+ * costs each view its visible rows once more instead of a dense [P, 75 + S] addition per view.  Default (record) path with dL_dsh
+ * formed or no SH at all; prev_radii must be NULL.  (Not in the reference: its loop back-propagates one view per optimiser step,
+ * train.py:96-198; dist.backward_views uses it for multi-view batches.) */
+#define GOI_BACKWARD_ACCUMULATE 1
+int goi_raster_backward3(const GoiRasterScene* scene, int R, int scratch_instances, int flags, const void* geom_buffer,
                          const void* binning_buffer, const void* image_buffer, const int* radii, const float* out_alpha,
                          const float* dL_dout_color, const float* dL_dout_semantic, const float* dL_dout_depth,
                          const float* dL_dout_alpha, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,

@@ -226,12 +226,15 @@ print("OK", rank, hits, dirty, fresh)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("K,streams", [(2, 2), (4, 2), (5, 3), (3, 1)])
-def test_views_of_a_batch_in_flight_sum_to_the_serial_gradient(K, streams):
+@pytest.mark.parametrize("K,streams,on_device", [(2, 2, True), (4, 2, True), (5, 3, True), (3, 1, True), (2, 2, False), (4, 2, False),
+                                                 (3, 1, False)])
+def test_views_of_a_batch_in_flight_sum_to_the_serial_gradient(K, streams, on_device):
     """dist.backward_views: the K views of a multi-view batch alternate over several HIP streams of one GPU and the sum of their
-    gradients lands in p.grad.  K = 2 on two streams is g0 + g1 -- bit-identical to two serial backward calls accumulating into
-    p.grad; with more views per stream the sum is associated differently ((g0 + g2) + (g1 + g3)): equal to the serial sum to a few
-    ulps of the largest term.  The per-view outputs are those of the serial renders, bit for bit."""
+    gradients lands in p.grad.  on_device (default): views 2, 3, ... of a stream ADD their per-Gaussian gradients to view 1's inside
+    the per-Gaussian backward kernel (goi_raster_backward3, GOI_BACKWARD_ACCUMULATE) and the sums go through the activations once:
+    the serial sum up to the association of fp32 additions.  on_device False: K dense sums of leaf gradients -- K = 2 on two
+    streams is g0 + g1, bit-identical to two serial backward calls; with more views per stream (g0 + g2) + (g1 + g3).  The per-view
+    outputs are those of the serial renders, bit for bit, either way."""
     import torch
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
@@ -263,19 +266,76 @@ def test_views_of_a_batch_in_flight_sum_to_the_serial_gradient(K, streams):
         for p in params:
             p.grad = None
         outs = backward_views(cams, lambda cam: render(cam, pc, pipe, bg), lambda o, k: ((o["render"], o["semantics"]), ups[k]),
-                              params, streams=streams)
+                              params, streams=streams, on_device=on_device)
+        if on_device:
+            from goi_hyperplane_amd import _C, rasterizer
+            if _C._ext() is not None:
+                assert rasterizer.last_backward_kernel() == "full_accumulate"
         torch.cuda.synchronize()
         for k in range(K):
             for key in ("render", "semantics", "radii"):
                 assert torch.equal(outs[k][key], ref_out[k][key]), (rep, k, key)
         for p, w in zip(params, want):
-            if K <= 2 or streams == 1:
+            if (K <= 2 or streams == 1) and not on_device:
                 assert torch.equal(p.grad, w), rep
             else:
                 scale = float(w.abs().max())
                 assert float((p.grad - w).abs().max()) <= 4e-6 * scale + 1e-12, rep
     # accumulate=True adds to what is there
     backward_views(cams[:2], lambda cam: render(cam, pc, pipe, bg), lambda o, k: ((o["render"], o["semantics"]), ups[k]), params,
-                   streams=2, accumulate=True)
+                   streams=2, accumulate=True, on_device=on_device)
     torch.cuda.synchronize()
     assert all(not torch.equal(p.grad, w) for p, w in zip(params[:1], want[:1]))
+
+
+@pytest.mark.gpu
+def test_accumulating_backward_adds_exactly_the_visible_rows():
+    """goi_raster_backward3 with GOI_BACKWARD_ACCUMULATE through the binding: the second view's call adds to the first view's
+    tensors -- equal to the sum of two plain calls to an ulp of the larger term, rows of Gaussians neither view sees stay exactly
+    zero, and the pooled-buffer bookkeeping does not hand the accumulated buffer out as "zero rows known" afterwards."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from goi_hyperplane_amd import _C, rasterizer
+    from goi_hyperplane_amd.render import GaussianSet, PipelineParams, TorchCamera, render
+    from goi_hyperplane_amd.scene import make_camera, make_scene
+    if _C._ext() is None:
+        pytest.skip("the compiled binding is not built")
+    dev = torch.device("cuda:0")
+    sc = make_scene(40000, S=16, sh_degree=3, seed=9, extent=(6.0, 4.0, 1.0), log_scale_mean=-3.4)
+    pc = GaussianSet.from_scene(sc, dev)
+    W, H = 320, 208
+    cams = [TorchCamera(make_camera(W, H, fovx=0.5, yaw=y), dev) for y in (-0.6, 0.5)]
+    gen = torch.Generator(device=dev).manual_seed(12)
+    ups = [(torch.randn((3, H, W), device=dev, generator=gen) / (W * H), torch.randn((16, H, W), device=dev, generator=gen) / (W * H))
+           for _ in cams]
+    bg, pipe = torch.zeros(3, device=dev), PipelineParams()
+    params = list(pc.parameters())
+
+    def one(cam, up, state=None):
+        ctx = rasterizer.accumulate_gradients(state) if state is not None else __import__("contextlib").nullcontext()
+        with ctx:
+            o = render(cam, pc, pipe, bg)
+            g = torch.autograd.grad((o["render"], o["semantics"]), params, up, allow_unused=True)
+        return o["radii"] > 0, g
+    vis0, g0 = one(cams[0], ups[0])
+    vis1, g1 = one(cams[1], ups[1])
+    want = [a + b for a, b in zip(g0, g1)]
+    state = dict(grads=None, inputs=None, views=0)
+    one(cams[0], ups[0], state)
+    one(cams[1], ups[1], state)
+    torch.cuda.synchronize()
+    assert state["views"] == 2
+    got = torch.autograd.grad([state["inputs"][i] for i in (0, 1, 3, 4, 5, 6)], params,
+                              [state["grads"][j].view_as(state["inputs"][i]) for i, j in ((0, 4), (1, 6), (3, 2), (4, 3), (5, 7), (6, 8))],
+                              allow_unused=True)
+    unseen = ~(vis0 | vis1)
+    assert int(unseen.sum()) > 1000
+    for a, b in zip(got, want):
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 4e-6 * scale + 1e-12
+        assert float(a[unseen].abs().max()) == 0.0
+    # a plain backward afterwards (pool in play) is still exact
+    _v, g2 = one(cams[0], ups[0])
+    for a, b in zip(g2, g0):
+        assert torch.equal(a, b)
