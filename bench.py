@@ -852,6 +852,7 @@ def main():
     # train.py:118-124 pops its training cameras at random).  The cycle of near-identical views is the friendliest case for the
     # gradient-buffer pool (rows that already hold zeros are not rewritten), the capacity policy (2 x the high-water count) and
     # the L2-resident per-Gaussian arrays; this object says what the step costs when consecutive views see different Gaussians.
+    _hw_main = int(_C._spec_state(dev).get("high_water", 0))  # (the main workload's; the orbit and the clustered scene below raise it)
     orbit = None
     if not args.no_orbit and not args.ply:
         from goi_hyperplane_amd.scene import ORBIT, make_orbit_cameras
@@ -915,7 +916,6 @@ def main():
     # Secondary object: the ADVERSARIAL workload -- a scene with the statistics of a reconstruction (clustered density,
     # heavy-tailed anisotropic sizes, opaque foreground with lists thousands deep behind it: scene.make_clustered_scene) at the
     # headline's size and image, through the same step.  Not `value`; its oracle parity is tests/test_gpu_clustered.py.
-    _hw_main = int(_C._spec_state(dev).get("high_water", 0))  # (the main workload's; the clustered scene below raises it)
     clustered = None
     if world == 1 and args.scene == "headline" and not args.no_clustered and not args.ply:
         from goi_hyperplane_amd.scene import make_workload
