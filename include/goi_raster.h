@@ -332,7 +332,9 @@ int goi_raster_profile_collect(double* ms, int* calls);
  *                  128 positions (closer to tile order: less HBM traffic, less balance), 0 in tile order; same gradients
  *   "bwd_records"  1 (default) the per-Gaussian sums of the atomic-free backward stay in the scratch as one record per
  *                  listed Gaussian and the per-Gaussian pass writes every per-id output; 0 they go through six per-id
- *                  arrays (dL_dconic, dL_ddepth, ... and zeros for the Gaussians that are not listed); same gradients, bit for bit
+ *                  arrays (dL_dconic, dL_ddepth, ... and zeros for the Gaussians that are not listed); same gradients, bit for bit;
+ *                  2 EXPERIMENT (128-byte rows: S = 5 .. 20): the per-Gaussian pass sums its Gaussians' rows itself -- no record,
+ *                  no reduce_rows_k; bit-identical, measured slower (285 -> 437 us on the headline view: DESIGN.md 9.3)
  * Thread safety: the set is changed under a mutex; an entry point snapshots it when it starts. */
 int goi_raster_set_option(const char* name, int value);
 
