@@ -99,7 +99,8 @@ __device__ __forceinline__ void store_sums(const float (&sum)[K], float* rows, s
 
 // INFLIGHT: rows a quarter wave requests back to back (its registers: 2 K per row).  32 is best up to ~2 M Gaussians; on larger
 // scenes (a 12.9 GB slot space at 3 M: every round trip longer) 16 -- fewer registers, more resident waves -- is, and the launcher
-// picks by P (same-box A/B, profiles/r06_tail.txt: 3 M 282 -> 250 us, 1 M 153 -> 183 us the other way round).  Same sums.
+// picks by P (same-box A/B, profiles/r06_tail.txt: 3 M 282 -> 250 us and -> 227 with one Gaussian per quarter wave, 1 M 153 -> 183 us
+// the other way round).  Same sums.
 template <int K, int GPQ, bool RECORD, int INFLIGHT = GOI_REDUCE_INFLIGHT>  // K = row_floats / 16; GPQ = Gaussians per quarter wave
 __global__ __launch_bounds__(256) void reduce_rows_k(int P, int S, int nch, uint32_t N_cap, const uint32_t* __restrict__ n_dev,
                                                      const uint32_t* __restrict__ order,
@@ -301,10 +302,10 @@ static void launch_reduce_k(const GoiRasterScene& sc, const GeomView& g, int N, 
                             const BwdScratchView& scr, const ReduceOut& out, hipStream_t s) {
     const dim3 grid((sc.P + 16 * REDUCE_GPQ - 1) / (16 * REDUCE_GPQ));
     const uint32_t* order = g.sort_vals[depth_sort_result_index()];
-    if (sc.P >= REDUCE_LARGE_SCENE && GOI_REDUCE_INFLIGHT > 16)
-        reduce_rows_k<K, REDUCE_GPQ, RECORD, 16><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order,
-                                                                            g.offsets, g.tiles_touched, rows, flags, out, scr.big_ctl,
-                                                                            scr.big_desc, (uint32_t)scr.cap_big);
+    if (sc.P >= REDUCE_LARGE_SCENE && GOI_REDUCE_INFLIGHT > 16)  // (one Gaussian per quarter wave there as well: 3 M 250 -> 227 us, 6 M 420 -> 377)
+        reduce_rows_k<K, 1, RECORD, 16><<<dim3((sc.P + 15) / 16), dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N,
+                                                                                    order, g.offsets, g.tiles_touched, rows, flags, out,
+                                                                                    scr.big_ctl, scr.big_desc, (uint32_t)scr.cap_big);
     else
         reduce_rows_k<K, REDUCE_GPQ, RECORD><<<grid, dim3(256), 0, s>>>(sc.P, sc.S, nch, (uint32_t)N, g.counters + COUNTER_N, order,
                                                                         g.offsets, g.tiles_touched, rows, flags, out, scr.big_ctl,
